@@ -1,0 +1,126 @@
+/* svb_hip.h -- C ABI of libsvb_hip.so, the MI355X (gfx950) kernel library under the NeuralSVB hot path.
+ *
+ * The reference (MoonInTheRiver/NeuralSVB) has no FFI: every op below replaces a *stock torch op sequence*
+ * inside one of the reference's nn.Modules.  Each entry point cites the reference
+ * interface it sits under.  Conventions:
+ *   - plain pointers + sizes only; all pointers are DEVICE pointers to contiguous fp32 unless noted;
+ *   - activations are [B, C, T] (time contiguous), exactly the reference's Conv1d layout;
+ *   - no allocation inside: workspaces are passed in, sized by the matching *_workspace_* query;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous and re-entrant per stream;
+ *   - return 0 on success, <0 on error (-1 bad argument, -2 launch failure, -3 unsupported shape); never throws.
+ */
+#ifndef SVB_HIP_H
+#define SVB_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVB_ABI_VERSION 1
+int svb_abi_version(void);
+
+/* ---- fused conv epilogue / prologue description ------------------------------------------------------
+ * y = mask * ( residual + out_gate' * act( conv(x * in_gate') + bias ) )
+ *   in_gate'  = 1 where in_gate  > 0 else in_slope        (in_gate == x  -> LeakyReLU(x) fused on the load;
+ *                                                          in_gate == saved y -> activation backward)
+ *   out_gate' = 1 where out_gate > 0 else out_gate_slope  (data-gradient through a fused input LeakyReLU)
+ * Any pointer may be NULL (term skipped).  out_act: 0 none, 1 ReLU, 2 LeakyReLU(out_slope), 3 tanh.
+ * force_cfg: 0 = auto tile choice, 1..5 = force tile configuration (tests).                              */
+typedef struct SvbConvEpilogue {
+    const float* bias;      /* [Cout] */
+    const float* in_gate;   /* same shape as x */
+    const float* out_gate;  /* same shape as y */
+    const float* residual;  /* same shape as y */
+    const float* mask;      /* [B, Tout] */
+    float in_slope, out_slope, out_gate_slope;
+    int out_act;
+    int force_cfg;
+} SvbConvEpilogue;
+
+/* Weight pack (+ WeightNorm forward  w = g * v / ||v||, norm over all dims but 0).
+ * Replaces torch.nn.utils.weight_norm's per-forward recompute (reference modules/fastspeech/fs2_vae.py:42,48,58;
+ * modules/hifigan/hifigan.py:33-50,117,124,140).  v: [d0][d1][k] reference layout (Conv1d: d0=Cout, d1=Cin/groups;
+ * ConvTranspose1d: d0=Cin, d1=Cout).  pa: [k][d1][d0], pb: [k][d0][d1] (either may be NULL).                */
+int svb_weight_pack(const float* v, const float* g, float* pa, float* pb, int d0, int d1, int k, int weight_norm,
+                    void* stream);
+
+/* Conv1d forward: y[b,co,q] = sum_{ci,j} w[co,ci,j] x[b,ci,q*stride + j*dil - pad].
+ * Replaces F.conv1d at reference fs2_vae.py:73,83,109-114,125; vae_models.py:86-94; common_layers.py:739-773;
+ * hifigan.py:33-61,117,140,202-223 (Conv2d (k,1) over period-major layout),261-286.
+ * wp = pa of svb_weight_pack ([k][Cin/groups][Cout]).  Also computes ConvTranspose1d's data gradient.         */
+int svb_conv1d_forward(const float* x, const float* wp, float* y, int B, int Cin, int Cout, int groups, int Tin,
+                       int Tout, int k, int stride, int pad, int dil, const SvbConvEpilogue* epi, void* stream);
+
+/* Transposed conv (gather form): y[b,co,p] = sum_{ci,j : p = t*stride - pad + j*dil} w[ci,co,j] x[b,ci,t].
+ * Replaces F.conv_transpose1d (reference vae_models.py:115-120,126; hifigan.py:122-125,156) and the data
+ * gradient of F.conv1d.  wp: [k][Cin][Cout/groups] (= pb of a ConvTranspose1d weight, = pb of a Conv1d weight
+ * when used as that conv's dgrad with Cin:=conv.Cout, Cout:=conv.Cin).                                       */
+int svb_conv1d_transposed(const float* x, const float* wp, float* y, int B, int Cin, int Cout, int groups, int Tin,
+                          int Tout, int k, int stride, int pad, int dil, const SvbConvEpilogue* epi, void* stream);
+
+/* Weight gradient, stage 1 (split-K partials): part[s][a][b][j] += A[n,a,q] * Bt[n,b,q*sx + j*dil - pad].
+ * Conv1d: A = dy (CA=Cout), Bt = x (CB=Cin); ConvTranspose1d: A = x (CA=Cin), Bt = dy (CB=Cout).
+ * a_gate/b_gate: optional activation-derivative gates (see SvbConvEpilogue).  Workspace = floats returned by
+ * svb_conv1d_wgrad_workspace_floats(), which also returns the split count to pass as `nsplit`.                */
+size_t svb_conv1d_wgrad_workspace_floats(int B, int CA, int CB, int groups, int TA, int k, int sx, int* nsplit_out);
+int svb_conv1d_wgrad(const float* a, const float* b, float* part, int B, int CA, int CB, int groups, int TA, int TB,
+                     int k, int sx, int pad, int dil, const float* a_gate, float a_slope, const float* b_gate,
+                     float b_slope, int nsplit, void* stream);
+/* Stage 2: reduce partials (+ WeightNorm backward: dv, dg from dW).  rows = d0, rowlen = d1*k.              */
+int svb_wgrad_reduce(const float* part, int nsplit, const float* v, const float* g, float* dv, float* dg, int rows,
+                     int rowlen, int weight_norm, int accumulate, void* stream);
+/* db[c] = sum_{b,t} dy[b,c,t] * gate'(gate[b,c,t])                                                          */
+int svb_bias_grad(const float* dy, const float* gate, float slope, float* db, int B, int C, int T, void* stream);
+
+/* ---- WaveNet-style gated layer pieces (reference modules/fastspeech/fs2_vae.py:10-16,61-91) ---------------
+ * gate fwd: acts[b,c,t] = tanh(xin[b,c,t] + g[b,goff+c,t]) * sigmoid(xin[b,C+c,t] + g[b,goff+C+c,t])
+ * gate bwd: d_xin from d_acts; the same values are the gradient of g's slice and are optionally also written
+ * into dg[b, g_off : g_off+2C, t] (dg has g_channels channels; dxin or dg may be NULL).                      */
+int svb_wn_gate_fwd(const float* xin, const float* g, float* acts, int B, int C, int T, int g_channels, int g_off,
+                    void* stream);
+int svb_wn_gate_bwd(const float* xin, const float* g, const float* dacts, float* dxin, float* dg, int B, int C, int T,
+                    int g_channels, int g_off, void* stream);
+/* res/skip update: x_new = (x + rs[:, :C]) * mask ; out_new = out + rs[:, C:]   (last layer: out += rs, x untouched;
+ * rs then has C channels and x/x_new may be NULL).  In-place allowed (x_new == x, out_new == out).            */
+int svb_wn_res_skip(const float* x, const float* rs, const float* mask, const float* out, float* x_new, float* out_new,
+                    int B, int C, int T, int last, void* stream);
+/* backward of the (non-last) res/skip update: drs[:, :C] = dx_new*mask, drs[:, C:] = dout, dxm = dx_new*mask
+ * (dx_new NULL = zeros, dxm may be NULL).                                                                    */
+int svb_wn_res_skip_bwd(const float* dx_new, const float* dout, const float* mask, float* drs, float* dxm, int B, int C,
+                        int T, void* stream);
+
+/* ---- LayerNorm over the channel (last) dim of [rows, C] (reference modules/fastspeech/conformer/layers.py:160-170,
+ * conformer.py:30; torch.nn.LayerNorm eps 1e-5).                                                             */
+int svb_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                      int rows, int C, float eps, void* stream);
+int svb_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* mean, const float* rstd,
+                      float* dx, float* dgamma_part, float* dbeta_part, int rows, int C, int n_part, void* stream);
+
+/* ---- STFT magnitude + mel filterbank + log, one kernel (reference data_gen/tts/data_gen_utils.py:123-134 and
+ * modules/hifigan/mel_utils.py:45-79).  wav: [B, N].  mode 0 = offline front-end: zero-pad n_fft/2 both sides
+ * ("center", pad_mode constant), frames = 1 + N/hop, |X|, log10(max(eps, mel)), out [B, frames, n_mels];
+ * mode 1 = in-graph: clamp to [-1,1], reflect-pad (n_fft-hop)/2, frames = N/hop, sqrt(re^2+im^2+1e-9),
+ * ln(max(1e-5, mel)), out [B, n_mels, frames].  n_fft must be 512 or 1024 (radix-2 in LDS); window [n_fft];
+ * mel_basis [n_mels][n_fft/2+1].                                                                              */
+int svb_stft_mel(const float* wav, const float* window, const float* mel_basis, float* out, int B, int N, int n_fft,
+                 int hop, int n_mels, int n_frames, int mode, float eps, void* stream);
+
+/* ---- NSF harmonic source (reference modules/parallel_wavegan/models/source.py:44-137,385-398 and
+ * modules/hifigan/hifigan.py:145-149): f0 [B, frames] Hz (0 = unvoiced) is held for `upp` samples (nearest upsample);
+ * rand_ini [B, H] initial phases (column 0 must be 0); noise [B, frames*upp, H] standard normal;
+ * sine_waves out [B, frames*upp, H] (may be NULL), merged out [B, frames*upp] = tanh(sum_h w[h]*sine_h + bias),
+ * uv out [B, frames*upp] (may be NULL).  Phase is accumulated in fp32 with the reference's wrap rule.           */
+int svb_nsf_source(const float* f0, const float* rand_ini, const float* noise, const float* lin_w, const float* lin_b,
+                   float* sine_waves, float* merged, float* uv, int B, int frames, int upp, int H, float sample_rate,
+                   float sine_amp, float noise_std, void* stream);
+
+/* ---- pitch-bin quantisation, bit exact (reference utils/pitch_utils.py:130-146).  mode 0: numpy semantics
+ * (f64 input, rint half-to-even) ; mode 1: torch semantics (f32 input, (x+0.5) truncation).                     */
+int svb_f0_to_coarse_f64(const double* f0, int64_t* out, int64_t n, void* stream);
+int svb_f0_to_coarse_f32(const float* f0, int64_t* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVB_HIP_H */

@@ -1,0 +1,89 @@
+"""ctypes binding of libsvb_hip.so (C ABI declared in include/svb_hip.h).
+
+The HIP library is the only compute path of this package: `get_lib()` raises if it has not been
+built (`python -c "import __graft_entry__ as g; g.build()"`); there is no CPU or eager fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvb_hip.so")
+
+c_fp = C.c_void_p  # device pointers are passed as integers
+
+
+class SvbConvEpilogue(C.Structure):
+    _fields_ = [
+        ("bias", C.c_void_p), ("in_gate", C.c_void_p), ("out_gate", C.c_void_p),
+        ("residual", C.c_void_p), ("mask", C.c_void_p),
+        ("in_slope", C.c_float), ("out_slope", C.c_float), ("out_gate_slope", C.c_float),
+        ("out_act", C.c_int), ("force_cfg", C.c_int),
+    ]
+
+
+I, F, P, SZ, I64 = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_int64
+
+# name -> (restype, argtypes)   -- must mirror include/svb_hip.h exactly
+SIGNATURES = {
+    "svb_abi_version": (I, []),
+    "svb_weight_pack": (I, [P, P, P, P, I, I, I, I, P]),
+    "svb_conv1d_forward": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),
+    "svb_conv1d_transposed": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),
+    "svb_conv1d_wgrad_workspace_floats": (SZ, [I, I, I, I, I, I, I, C.POINTER(I)]),
+    "svb_conv1d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, P, F, P, F, I, P]),
+    "svb_wgrad_reduce": (I, [P, I, P, P, P, P, I, I, I, I, P]),
+    "svb_bias_grad": (I, [P, P, F, P, I, I, I, P]),
+    "svb_wn_gate_fwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "svb_wn_gate_bwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "svb_wn_res_skip_bwd": (I, [P, P, P, P, P, I, I, I, P]),
+    "svb_wn_res_skip": (I, [P, P, P, P, P, P, I, I, I, I, P]),
+    "svb_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
+    "svb_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
+    "svb_stft_mel": (I, [P, P, P, P, I, I, I, I, I, I, I, F, P]),
+    "svb_nsf_source": (I, [P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, P]),
+    "svb_f0_to_coarse_f64": (I, [P, P, I64, P]),
+    "svb_f0_to_coarse_f32": (I, [P, P, I64, P]),
+}
+
+_LIB = None
+_LIB_IS_EMU = False  # only ever set by tests/emu (CPU lane emulator, test infrastructure)
+
+
+class SvbLibraryMissing(RuntimeError):
+    pass
+
+
+def bind(path):
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def get_lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise SvbLibraryMissing(
+                f"{LIB_PATH} not built: the HIP extension is the only compute path of neuralsvb_amd "
+                f"(run __graft_entry__.build()).")
+        _LIB = bind(LIB_PATH)
+    return _LIB
+
+
+def lib_is_emulator():
+    return _LIB_IS_EMU
+
+
+class SvbError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "bad argument", -2: "kernel launch failure", -3: "unsupported shape"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SvbError(f"{what} failed: {_ERR.get(rc, rc)}")

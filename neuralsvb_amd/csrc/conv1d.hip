@@ -1,0 +1,521 @@
+// conv1d.hip -- implicit-GEMM 1-D convolution family on the CDNA4 matrix cores (gfx950).
+//
+// One "tap-offset" kernel covers every dense 1-D conv on the NeuralSVB hot path:
+//   * Conv1d forward (dilated / strided / grouped)            reference: modules/fastspeech/fs2_vae.py:44-59 (WN),
+//                                                               modules/hifigan/hifigan.py:33-50,117,261-268 ...
+//   * ConvTranspose1d forward and Conv1d data-gradient         reference: vae_models.py:115-120, hifigan.py:122-125
+//     (decomposed into `stride` output phases, each a stride-1 tap-offset conv -> no zero-insertion work)
+// and a second kernel computes weight gradients (split-K over batch x time, deterministic two-stage reduce).
+//
+// Data layout in HBM: activations [B, C, T] fp32 (time contiguous -- the reference's NCT), weights pre-packed
+// by svb_weight_pack() to [tap][k-channel][m-channel] so that both MFMA operands are read with unit stride.
+// GEMM view: M = out channels, N = output positions of one batch row, K = (in channel, tap).
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  Lane l supplies A[i=l&31][k=l>>5] and
+// B[k=l>>5][j=l&31]; accumulator reg r of lane l is D[(r&3)+8*(r>>2)+4*(l>>5)][l&31].
+// LDS: x tile [kc channels][span] (+ phase-split for strided reads so lanes stay bank-conflict free),
+//      w tile [taps][kc][BM].  Both halves of the wave (k=0/1) read different rows -> conflict free.
+// Block->tile map is XCD-aware: the M tiles that share one x tile run on the same XCD (shared L2).
+#include "svb_common.h"
+#include "conv1d.h"
+
+template <int WM, int WN, int NT, int XS_TOTAL, int WS_TOTAL>
+__global__ __launch_bounds__(256) void svb_conv1d_mfma_kernel(SvbConvArgs a, SvbConvPlan p) {
+    constexpr int BM = 32 * WM, BN = 32 * WN * NT, KCMAX = 16;
+    constexpr int TG = WS_TOTAL / (KCMAX * BM);
+    static_assert(WM * WN == 4, "256 threads = 4 waves");
+    static_assert(TG >= 1, "weight stage too small");
+    __shared__ float xs[XS_TOTAL];
+    __shared__ float ws[WS_TOTAL];
+    __shared__ int tap_lds[SVB_MAX_TAPS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int kk = lane >> 5, l31 = lane & 31;
+
+    // XCD-aware bijective remap (block id b runs on XCD b%8): consecutive work ids stay on one XCD.
+    const int nwg = gridDim.x * gridDim.y;
+    const int orig = blockIdx.y * gridDim.x + blockIdx.x;
+    const int qd = nwg >> 3, rd = nwg & 7, xcd = orig & 7;
+    const int wgid = (xcd < rd ? xcd * (qd + 1) : rd * (qd + 1) + (xcd - rd) * qd) + (orig >> 3);
+    const int mt = wgid % gridDim.x, qt = wgid / gridDim.x;
+
+    const int m_tiles_g = gridDim.x / a.G;
+    const int g = mt / m_tiles_g, mtile = mt % m_tiles_g;
+    const int b = blockIdx.z / p.n_phase, ph = blockIdx.z % p.n_phase;
+    const int nq = p.phase_nq[ph];
+    const int q0 = qt * BN;
+    if (q0 >= nq) return;  // block-uniform
+
+    const int t0 = p.phase_start[ph], ntap = p.phase_start[ph + 1] - t0;
+    const int min_off = p.phase_min_off[ph];
+    const int lo = q0 * a.sx + min_off;
+    const int span = (BN - 1) * a.sx + p.phase_span_off[ph] + 1;
+    if (tid < ntap) {
+        const int rel = p.tap_off[t0 + tid] - min_off;
+        tap_lds[tid] = (a.sx == 1) ? rel : (rel % a.sx) * a.ph_len + rel / a.sx;
+    }
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+    const int m_base = mtile * BM;
+    const int m_valid = min(BM, a.Cout_g - m_base);
+
+    for (int c0 = 0; c0 < a.Cin_g; c0 += a.kc) {
+        const int kc = min(a.kc, a.Cin_g - c0);
+        const int kcp = (kc + 1) & ~1;
+        for (int tg = 0; tg < ntap; tg += TG) {
+            const int nt_here = min(TG, ntap - tg);
+            __syncthreads();
+            if (tg == 0) {
+                for (int r = wave; r < kcp; r += 4) {
+                    const bool rv = r < kc;
+                    const size_t roff = ((size_t)b * a.Cin + (size_t)g * a.Cin_g + c0 + r) * a.Tin;
+                    const float* xr = a.x + roff;
+                    const float* gr = a.in_gate ? a.in_gate + roff : nullptr;
+                    float* xd = xs + r * a.xrow;
+                    for (int i = lane; i < span; i += 64) {
+                        const int pos = lo + i;
+                        float v = 0.f;
+                        if (rv && pos >= 0 && pos < a.Tin) {
+                            v = xr[pos];
+                            if (gr) v *= svb_gate(gr[pos], a.in_slope);
+                        }
+                        const int di = (a.sx == 1) ? i : (i % a.sx) * a.ph_len + i / a.sx;
+                        xd[di] = v;
+                    }
+                }
+            }
+            for (int r = wave; r < nt_here * kcp; r += 4) {
+                const int t = r / kcp, c = r - t * kcp;
+                const int wt = p.tap_w[t0 + tg + t];
+                const float* wr = a.wp + (size_t)wt * a.w_tap_stride +
+                                  (size_t)(g * a.w_goff_k + c0 + c) * a.w_ld + (size_t)g * a.w_goff_m + m_base;
+                float* wd = ws + (t * KCMAX + c) * BM;
+                for (int m = lane; m < BM; m += 64) wd[m] = (c < kc && m < m_valid) ? wr[m] : 0.f;
+            }
+            __syncthreads();
+            for (int t = 0; t < nt_here; ++t) {
+                const float* wsa = ws + (t * KCMAX + kk) * BM + wm * 32 + l31;
+                const float* xsb = xs + kk * a.xrow + tap_lds[tg + t] + (wn * NT) * 32 + l31;
+                for (int c2 = 0; c2 < kcp; c2 += 2) {
+                    const float av = wsa[c2 * BM];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const float bv = xsb[c2 * a.xrow + n * 32];
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    const int out_base = p.phase_out_base[ph];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int ql = q0 + (wn * NT + n) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const int ml = m_base + wm * 32 + row;
+            if (ml < a.Cout_g && ql < nq) {
+                const int co = g * a.Cout_g + ml;
+                const int pos = ql * a.out_stride + out_base;
+                float v = acc[n][r];
+                if (a.bias) v += a.bias[co];
+                v = svb_apply_act(v, a.out_act, a.out_slope);
+                const size_t oi = ((size_t)b * a.Cout + co) * a.Tout + pos;
+                if (a.out_gate) v *= svb_gate(a.out_gate[oi], a.out_gate_slope);
+                if (a.residual) v += a.residual[oi];
+                if (a.mask) v *= a.mask[(size_t)b * a.Tout + pos];
+                a.y[oi] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Weight gradient: part[split][a][b][j] = sum over this split's (batch, q-chunk)s of A[b,a,q] * Bt[b,b,q*sx+off_j]
+// A is the q-indexed tensor (dy for Conv1d, x for ConvTranspose1d), Bt the tap-strided one.
+// ------------------------------------------------------------------------------------------------------
+template <int TGW>
+__global__ __launch_bounds__(256) void svb_conv1d_wgrad_kernel(SvbWgradArgs a) {
+    constexpr int QCMAX = 64, AROW = QCMAX + 1;
+    __shared__ float As[64 * AROW];
+    __shared__ float Bs[SVB_WGRAD_BS_TOTAL];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int kk = lane >> 5, l31 = lane & 31;
+
+    int idx = blockIdx.x;
+    const int tgi = idx % a.n_tg; idx /= a.n_tg;
+    const int bt = idx % a.b_tiles; idx /= a.b_tiles;
+    const int at = idx % a.a_tiles;
+    const int g = idx / a.a_tiles;
+    const int a0 = at * 64, b0 = bt * 64;
+    const int j0 = tgi * TGW;
+    const int ntap = min(TGW, a.k - j0);
+    const int min_off = a.off0 + j0 * a.dil;
+    const int span = (a.qc - 1) * a.sx + (ntap - 1) * a.dil + 1;
+
+    f32x16 acc[TGW];
+#pragma unroll
+    for (int t = 0; t < TGW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int chunk = blockIdx.y; chunk < a.total_chunks; chunk += a.nsplit) {
+        const int bb = chunk / a.chunks_per_b;
+        const int q0 = (chunk - bb * a.chunks_per_b) * a.qc;
+        __syncthreads();
+        for (int r = wave; r < 64; r += 4) {
+            const bool rv = (a0 + r) < a.CA_g;
+            const size_t roff = ((size_t)bb * a.CA + (size_t)g * a.CA_g + a0 + r) * a.TA;
+            const float* ar = a.a + roff;
+            const float* gr = a.a_gate ? a.a_gate + roff : nullptr;
+            if (lane < a.qc) {
+                const int q = q0 + lane;
+                float v = 0.f;
+                if (rv && q < a.TA) {
+                    v = ar[q];
+                    if (gr) v *= svb_gate(gr[q], a.a_slope);
+                }
+                As[r * AROW + lane] = v;
+            }
+        }
+        const int lo = q0 * a.sx + min_off;
+        for (int r = wave; r < 64; r += 4) {
+            const bool rv = (b0 + r) < a.CB_g;
+            const size_t roff = ((size_t)bb * a.CB + (size_t)g * a.CB_g + b0 + r) * a.TB;
+            const float* br = a.b + roff;
+            const float* gr = a.b_gate ? a.b_gate + roff : nullptr;
+            float* bd = Bs + r * a.brow;
+            for (int i = lane; i < span; i += 64) {
+                const int pos = lo + i;
+                float v = 0.f;
+                if (rv && pos >= 0 && pos < a.TB) {
+                    v = br[pos];
+                    if (gr) v *= svb_gate(gr[pos], a.b_slope);
+                }
+                bd[i] = v;
+            }
+        }
+        __syncthreads();
+        const float* asa = As + (wm * 32 + l31) * AROW + kk;
+        const float* bsb = Bs + (wn * 32 + l31) * a.brow + kk * a.sx;
+        for (int qq = 0; qq < a.qc; qq += 2) {
+            const float av = asa[qq];
+#pragma unroll
+            for (int t = 0; t < TGW; ++t) {
+                if (t < ntap) {
+                    const float bv = bsb[qq * a.sx + t * a.dil];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    float* part = a.part + (size_t)blockIdx.y * a.CA * a.CB_g * a.k;
+#pragma unroll
+    for (int t = 0; t < TGW; ++t) {
+        if (t < ntap) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+                const int al = a0 + wm * 32 + row;
+                const int bl = b0 + wn * 32 + l31;
+                if (al < a.CA_g && bl < a.CB_g)
+                    part[((size_t)(g * a.CA_g + al) * a.CB_g + bl) * a.k + (j0 + t)] = acc[t][r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Second stage of the weight gradient: sum the split partials of one weight row; for weight-normalised
+// layers also apply d(g v/||v||): dg = <v,dW>/||v||, dv = g/||v|| dW - g <v,dW>/||v||^3 v
+// (torch.nn.utils.weight_norm, dim=0 -- reference fs2_vae.py:42,48,58 / hifigan.py:33-50).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void svb_wgrad_reduce_kernel(const float* part, int nsplit, size_t split_stride,
+                                                               const float* v, const float* gnorm, float* dv, float* dg,
+                                                               int rowlen, int weight_norm, int accumulate) {
+    __shared__ float red[8];
+    const int row = blockIdx.x;
+    const size_t base = (size_t)row * rowlen;
+    float dot = 0.f, vv = 0.f;
+    for (int e = threadIdx.x; e < rowlen; e += 256) {
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += part[(size_t)sp * split_stride + base + e];
+        if (weight_norm) {
+            const float ve = v[base + e];
+            dot += ve * s;
+            vv += ve * ve;
+            dv[base + e] = s;  // finalised below
+        } else {
+            dv[base + e] = accumulate ? dv[base + e] + s : s;
+        }
+    }
+    if (!weight_norm) return;
+    dot = svb_block_sum<256>(dot, red);
+    vv = svb_block_sum<256>(vv, red);
+    const float nrm = sqrtf(vv);
+    const float gg = gnorm[row];
+    const float sa = gg / nrm;
+    const float sb = gg * dot / (nrm * nrm * nrm);
+    if (threadIdx.x == 0) dg[row] = dot / nrm;
+    for (int e = threadIdx.x; e < rowlen; e += 256) dv[base + e] = sa * dv[base + e] - sb * v[base + e];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Weight pack (+ WeightNorm forward): source w/v is [d0][d1][k] (reference layout, norm over dim 0 rows);
+// pa[j][d1][d0] and pb[j][d0][d1] are the two operand layouts (see conv1d.h).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void svb_weight_pack_kernel(const float* v, const float* gnorm, float* pa, float* pb,
+                                                              int d0, int d1, int k, int weight_norm) {
+    __shared__ float red[8];
+    const int row = blockIdx.x;
+    const int rowlen = d1 * k;
+    const float* vr = v + (size_t)row * rowlen;
+    float scale = 1.f;
+    if (weight_norm) {
+        float vv = 0.f;
+        for (int e = threadIdx.x; e < rowlen; e += 256) vv += vr[e] * vr[e];
+        vv = svb_block_sum<256>(vv, red);
+        scale = gnorm[row] / sqrtf(vv);
+    }
+    for (int e = threadIdx.x; e < rowlen; e += 256) {
+        const int c1 = e / k, j = e - c1 * k;
+        const float w = vr[e] * scale;
+        if (pa) pa[((size_t)j * d1 + c1) * d0 + row] = w;
+        if (pb) pb[((size_t)j * d0 + row) * d1 + c1] = w;
+    }
+}
+
+// db[c] = sum_{b,t} dy[b,c,t] * gate'(gate[b,c,t])
+__global__ __launch_bounds__(256) void svb_bias_grad_kernel(const float* dy, const float* gate, float slope, float* db,
+                                                            int B, int C, int T) {
+    __shared__ float red[8];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const size_t off = ((size_t)b * C + c) * T;
+        for (int t = threadIdx.x; t < T; t += 256) {
+            float v = dy[off + t];
+            if (gate) v *= svb_gate(gate[off + t], slope);
+            s += v;
+        }
+    }
+    s = svb_block_sum<256>(s, red);
+    if (threadIdx.x == 0) db[c] = s;
+}
+
+// ======================================================================================================
+// Host side: plan construction + launch (C ABI, see include/svb_hip.h)
+// ======================================================================================================
+struct SvbTileCfg { int BM, BN; };
+static const SvbTileCfg kCfgs[5] = {{64, 128}, {128, 96}, {128, 128}, {64, 64}, {32, 128}};
+
+static int pick_cfg(int cout_g, int nq_max) {
+    long best_cost = -1;
+    int best = 0;
+    for (int i = 0; i < 5; ++i) {
+        const long mt = svb_cdiv(cout_g, kCfgs[i].BM), qt = svb_cdiv(nq_max, kCfgs[i].BN);
+        const long cost = mt * kCfgs[i].BM * qt * kCfgs[i].BN;
+        const long area = (long)kCfgs[i].BM * kCfgs[i].BN;
+        if (best_cost < 0 || cost < best_cost ||
+            (cost == best_cost && area > (long)kCfgs[best].BM * kCfgs[best].BN)) {
+            best_cost = cost;
+            best = i;
+        }
+    }
+    return best;
+}
+
+template <int WM, int WN, int NT, int XS, int WS>
+static int launch_cfg(SvbConvArgs& a, const SvbConvPlan& p, int nq_max, int span_off_max, hipStream_t stream) {
+    constexpr int BM = 32 * WM, BN = 32 * WN * NT;
+    const int span_max = (BN - 1) * a.sx + span_off_max + 1;
+    a.ph_len = svb_cdiv(span_max, a.sx);
+    a.xrow = a.ph_len * a.sx;
+    int kc = XS / a.xrow;
+    if (kc > 16) kc = 16;
+    kc &= ~1;
+    if (kc < 2) return SVB_ERR_UNSUPPORTED;
+    a.kc = kc;
+    dim3 grid(a.G * svb_cdiv(a.Cout_g, BM), svb_cdiv(nq_max, BN), a.B * p.n_phase);
+    hipLaunchKernelGGL((svb_conv1d_mfma_kernel<WM, WN, NT, XS, WS>), grid, dim3(256), 0, stream, a, p);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+static int launch_conv(SvbConvArgs& a, const SvbConvPlan& p, hipStream_t stream) {
+    int nq_max = 0, span_off_max = 0;
+    for (int ph = 0; ph < p.n_phase; ++ph) {
+        if (p.phase_nq[ph] > nq_max) nq_max = p.phase_nq[ph];
+        if (p.phase_span_off[ph] > span_off_max) span_off_max = p.phase_span_off[ph];
+    }
+    if (nq_max <= 0) return SVB_OK;
+    if ((long)a.B * p.n_phase > 65535) return SVB_ERR_UNSUPPORTED;
+    int cfg = pick_cfg(a.Cout_g, nq_max);
+    if (a.force_cfg >= 0 && a.force_cfg < 5) cfg = a.force_cfg;
+    switch (cfg) {
+        case 0: return launch_cfg<2, 2, 2, 8192, 5120>(a, p, nq_max, span_off_max, stream);
+        case 1: return launch_cfg<4, 1, 3, 8192, 10240>(a, p, nq_max, span_off_max, stream);
+        case 2: return launch_cfg<4, 1, 4, 8192, 10240>(a, p, nq_max, span_off_max, stream);
+        case 3: return launch_cfg<2, 2, 1, 8192, 5120>(a, p, nq_max, span_off_max, stream);
+        default: return launch_cfg<1, 4, 1, 8192, 2560>(a, p, nq_max, span_off_max, stream);
+    }
+}
+
+static void fill_epilogue(SvbConvArgs& a, const SvbConvEpilogue* e) {
+    a.bias = e ? e->bias : nullptr;
+    a.in_gate = e ? e->in_gate : nullptr;
+    a.in_slope = e ? e->in_slope : 0.f;
+    a.out_act = e ? e->out_act : 0;
+    a.out_slope = e ? e->out_slope : 0.f;
+    a.out_gate = e ? e->out_gate : nullptr;
+    a.out_gate_slope = e ? e->out_gate_slope : 0.f;
+    a.residual = e ? e->residual : nullptr;
+    a.mask = e ? e->mask : nullptr;
+    a.force_cfg = e ? e->force_cfg - 1 : -1;
+}
+
+extern "C" int svb_conv1d_forward(const float* x, const float* wp, float* y, int B, int Cin, int Cout, int groups,
+                                  int Tin, int Tout, int k, int stride, int pad, int dil,
+                                  const SvbConvEpilogue* epi, void* stream) {
+    if (!x || !wp || !y || B <= 0 || groups <= 0 || Cin % groups || Cout % groups || k <= 0 || k > SVB_MAX_TAPS ||
+        stride <= 0 || dil <= 0)
+        return SVB_ERR_ARG;
+    if (Tout != (Tin + 2 * pad - dil * (k - 1) - 1) / stride + 1 || Tout <= 0) return SVB_ERR_ARG;
+    SvbConvArgs a;
+    SvbConvPlan p;
+    memset(&p, 0, sizeof(p));
+    a.x = x; a.wp = wp; a.y = y;
+    fill_epilogue(a, epi);
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.G = groups; a.Cin_g = Cin / groups; a.Cout_g = Cout / groups;
+    a.Tin = Tin; a.Tout = Tout; a.sx = stride; a.out_stride = 1;
+    a.w_tap_stride = a.Cin_g * Cout; a.w_ld = Cout; a.w_goff_k = 0; a.w_goff_m = a.Cout_g;
+    p.n_phase = 1;
+    p.phase_start[0] = 0; p.phase_start[1] = k;
+    for (int j = 0; j < k; ++j) { p.tap_off[j] = j * dil - pad; p.tap_w[j] = j; }
+    p.phase_nq[0] = Tout; p.phase_out_base[0] = 0; p.phase_min_off[0] = -pad; p.phase_span_off[0] = (k - 1) * dil;
+    return launch_conv(a, p, (hipStream_t)stream);
+}
+
+// y[b,co,pos] = sum_{ci,j : pos = t*stride - pad + j*dil} wp[j][ci][co] x[b,ci,t]   (gather form, no zero insertion)
+extern "C" int svb_conv1d_transposed(const float* x, const float* wp, float* y, int B, int Cin, int Cout, int groups,
+                                     int Tin, int Tout, int k, int stride, int pad, int dil,
+                                     const SvbConvEpilogue* epi, void* stream) {
+    if (!x || !wp || !y || B <= 0 || groups <= 0 || Cin % groups || Cout % groups || k <= 0 || k > SVB_MAX_TAPS ||
+        stride <= 0 || stride > SVB_MAX_PHASE || dil <= 0 || Tout <= 0)
+        return SVB_ERR_ARG;
+    SvbConvArgs a;
+    SvbConvPlan p;
+    memset(&p, 0, sizeof(p));
+    a.x = x; a.wp = wp; a.y = y;
+    fill_epilogue(a, epi);
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.G = groups; a.Cin_g = Cin / groups; a.Cout_g = Cout / groups;
+    a.Tin = Tin; a.Tout = Tout; a.sx = 1; a.out_stride = stride;
+    // packed as [j][Cin (global)][Cout_g]
+    a.w_tap_stride = Cin * a.Cout_g; a.w_ld = a.Cout_g; a.w_goff_k = a.Cin_g; a.w_goff_m = 0;
+    p.n_phase = stride;
+    int nt = 0;
+    for (int r = 0; r < stride; ++r) {
+        p.phase_start[r] = nt;
+        // output positions pos = stride*u + r - pad >= 0  ->  u >= ceil((pad - r)/stride)
+        int umin = (pad - r) > 0 ? (pad - r + stride - 1) / stride : 0;
+        const int pos0 = stride * umin + r - pad;
+        p.phase_out_base[r] = pos0;
+        p.phase_nq[r] = pos0 < Tout ? (Tout - 1 - pos0) / stride + 1 : 0;
+        int mn = 0, mx = 0, first = 1;
+        for (int j = 0; j < k; ++j) {
+            if ((j * dil) % stride != r) continue;
+            const int off = umin + (r - j * dil) / stride;  // exact division
+            p.tap_off[nt] = off; p.tap_w[nt] = j;
+            if (first || off < mn) mn = off;
+            if (first || off > mx) mx = off;
+            first = 0;
+            ++nt;
+        }
+        p.phase_min_off[r] = mn; p.phase_span_off[r] = mx - mn;
+    }
+    p.phase_start[stride] = nt;
+    return launch_conv(a, p, (hipStream_t)stream);
+}
+
+extern "C" size_t svb_conv1d_wgrad_workspace_floats(int B, int CA, int CB, int groups, int TA, int k, int sx,
+                                                    int* nsplit_out) {
+    const int CA_g = CA / groups, CB_g = CB / groups;
+    int qc = 64 / sx; if (qc < 2) qc = 2; qc &= ~1;
+    const int tgw = k <= 5 ? k : (k % 5 == 0 ? 5 : (svb_cdiv(k, 4) <= svb_cdiv(k, 5) ? 4 : 5));
+    const int n_tg = svb_cdiv(k, tgw);
+    const long tiles = (long)groups * svb_cdiv(CA_g, 64) * svb_cdiv(CB_g, 64) * n_tg;
+    const long chunks = (long)B * svb_cdiv(TA, qc);
+    long ns = 1024 / tiles; if (ns < 1) ns = 1; if (ns > chunks) ns = chunks; if (ns > 256) ns = 256;
+    if (nsplit_out) *nsplit_out = (int)ns;
+    return (size_t)ns * CA * CB_g * k;
+}
+
+extern "C" int svb_conv1d_wgrad(const float* a_t, const float* b_t, float* part, int B, int CA, int CB, int groups,
+                                int TA, int TB, int k, int sx, int pad, int dil, const float* a_gate, float a_slope,
+                                const float* b_gate, float b_slope, int nsplit, void* stream) {
+    if (!a_t || !b_t || !part || B <= 0 || groups <= 0 || CA % groups || CB % groups || k <= 0 || k > SVB_MAX_TAPS ||
+        sx <= 0 || dil <= 0 || nsplit <= 0)
+        return SVB_ERR_ARG;
+    SvbWgradArgs a;
+    a.a = a_t; a.b = b_t; a.part = part; a.a_gate = a_gate; a.b_gate = b_gate; a.a_slope = a_slope; a.b_slope = b_slope;
+    a.B = B; a.CA = CA; a.CB = CB; a.G = groups; a.CA_g = CA / groups; a.CB_g = CB / groups; a.TA = TA; a.TB = TB;
+    a.k = k; a.sx = sx; a.off0 = -pad; a.dil = dil;
+    int qc = 64 / sx; if (qc < 2) qc = 2; qc &= ~1;
+    a.qc = qc;
+    const int tgw = k <= 5 ? k : (k % 5 == 0 ? 5 : (svb_cdiv(k, 4) <= svb_cdiv(k, 5) ? 4 : 5));
+    a.n_tg = svb_cdiv(k, tgw);
+    a.a_tiles = svb_cdiv(a.CA_g, 64); a.b_tiles = svb_cdiv(a.CB_g, 64);
+    a.chunks_per_b = svb_cdiv(TA, qc); a.total_chunks = B * a.chunks_per_b;
+    if (nsplit > a.total_chunks) return SVB_ERR_ARG;
+    a.nsplit = nsplit;
+    a.brow = ((qc - 1) * sx + (tgw - 1) * dil + 1) | 1;
+    if ((long)a.brow * 64 > SVB_WGRAD_BS_TOTAL) return SVB_ERR_UNSUPPORTED;
+    dim3 grid(groups * a.a_tiles * a.b_tiles * a.n_tg, nsplit);
+    hipStream_t st = (hipStream_t)stream;
+    switch (tgw) {
+        case 1: hipLaunchKernelGGL((svb_conv1d_wgrad_kernel<1>), grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((svb_conv1d_wgrad_kernel<2>), grid, dim3(256), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((svb_conv1d_wgrad_kernel<3>), grid, dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((svb_conv1d_wgrad_kernel<4>), grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((svb_conv1d_wgrad_kernel<5>), grid, dim3(256), 0, st, a); break;
+    }
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_wgrad_reduce(const float* part, int nsplit, const float* v, const float* g, float* dv, float* dg,
+                                int rows, int rowlen, int weight_norm, int accumulate, void* stream) {
+    if (!part || !dv || rows <= 0 || rowlen <= 0 || nsplit <= 0) return SVB_ERR_ARG;
+    if (weight_norm && (!v || !g || !dg)) return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_wgrad_reduce_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, part, nsplit,
+                       (size_t)rows * rowlen, v, g, dv, dg, rowlen, weight_norm, accumulate);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_weight_pack(const float* v, const float* g, float* pa, float* pb, int d0, int d1, int k,
+                               int weight_norm, void* stream) {
+    if (!v || (!pa && !pb) || d0 <= 0 || d1 <= 0 || k <= 0 || (weight_norm && !g)) return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_weight_pack_kernel, dim3(d0), dim3(256), 0, (hipStream_t)stream, v, g, pa, pb, d0, d1, k,
+                       weight_norm);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_bias_grad(const float* dy, const float* gate, float slope, float* db, int B, int C, int T,
+                             void* stream) {
+    if (!dy || !db || B <= 0 || C <= 0 || T <= 0) return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, gate, slope, db, B, C, T);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}

@@ -1,0 +1,60 @@
+// Shared device helpers for the svb HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#define SVB_OK 0
+#define SVB_ERR_ARG (-1)
+#define SVB_ERR_LAUNCH (-2)
+#define SVB_ERR_UNSUPPORTED (-3)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Output activation codes shared by host wrappers and kernels.
+enum { SVB_ACT_NONE = 0, SVB_ACT_RELU = 1, SVB_ACT_LRELU = 2, SVB_ACT_TANH = 3 };
+
+__device__ __forceinline__ float svb_gate(float g, float slope) { return g > 0.f ? 1.f : slope; }
+
+__device__ __forceinline__ float svb_apply_act(float v, int act, float slope) {
+    if (act == SVB_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == SVB_ACT_LRELU) return v > 0.f ? v : v * slope;
+    if (act == SVB_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+__device__ __forceinline__ float svb_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+// 64-lane wave reductions (wavefront = 64 on CDNA).
+__device__ __forceinline__ float svb_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float svb_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blocks of NT threads (NT multiple of 64, <= 1024). `red` is >= NT/64 floats of LDS.
+template <int NT>
+__device__ __forceinline__ float svb_block_sum(float v, float* red) {
+    v = svb_wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) t += red[w];
+    return t;
+}
+
+static inline int svb_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+#define SVB_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return SVB_ERR_LAUNCH; \
+    } while (0)

@@ -1,0 +1,257 @@
+"""Tensor-level wrappers over the C ABI (include/svb_hip.h).  No autograd here (see functional.py).
+
+Every function takes torch tensors that live on the MI355X, passes raw device pointers + the current
+HIP stream, and allocates outputs / workspaces with torch (plumbing only).  CPU tensors are rejected
+unless the CPU lane emulator was injected by tests/emu (test infrastructure).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _prep(*tensors):
+    """Validate device/dtype/contiguity; return (lib, stream)."""
+    lib = L.get_lib()
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_contiguous():
+            raise ValueError("svb kernels need contiguous tensors")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError(f"tensors on different devices: {dev} vs {t.device}")
+    if dev is None:
+        raise ValueError("no tensors")
+    if dev.type == "cuda":
+        if L.lib_is_emulator():
+            raise RuntimeError("CPU emulator library is loaded but tensors are on the GPU")
+        return lib, torch.cuda.current_stream(dev).cuda_stream
+    if not L.lib_is_emulator():
+        raise RuntimeError("neuralsvb_amd kernels run on the MI355X only (got CPU tensors); there is no CPU fallback")
+    return lib, None
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError(f"expected float32, got {t.dtype}")
+
+
+def make_epilogue(bias=None, in_gate=None, in_slope=0.0, out_act=ACT_NONE, out_slope=0.0, out_gate=None,
+                  out_gate_slope=0.0, residual=None, mask=None, force_cfg=0):
+    e = L.SvbConvEpilogue()
+    e.bias, e.in_gate, e.out_gate = _ptr(bias), _ptr(in_gate), _ptr(out_gate)
+    e.residual, e.mask = _ptr(residual), _ptr(mask)
+    e.in_slope, e.out_slope, e.out_gate_slope = float(in_slope), float(out_slope), float(out_gate_slope)
+    e.out_act, e.force_cfg = int(out_act), int(force_cfg)
+    return e
+
+
+def conv_out_len(Tin, k, stride, pad, dil):
+    return (Tin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def weight_pack(v, g=None, want_a=True, want_b=True):
+    """v: [d0, d1, k] (reference layout).  Returns (pa [k,d1,d0], pb [k,d0,d1]); w = g*v/||v|| if g given."""
+    _f32(v, g)
+    lib, st = _prep(v, g)
+    d0, d1, k = v.shape
+    pa = torch.empty((k, d1, d0), device=v.device, dtype=torch.float32) if want_a else None
+    pb = torch.empty((k, d0, d1), device=v.device, dtype=torch.float32) if want_b else None
+    L.check(lib.svb_weight_pack(_ptr(v), _ptr(g), _ptr(pa), _ptr(pb), d0, d1, k, int(g is not None), st),
+            "svb_weight_pack")
+    return pa, pb
+
+
+def conv1d_forward(x, pa, cout, k, stride=1, pad=0, dil=1, groups=1, out=None, **epi):
+    _f32(x, pa)
+    tensors = [x, pa, out] + [epi.get(n) for n in ("bias", "in_gate", "out_gate", "residual", "mask")]
+    lib, st = _prep(*tensors)
+    B, cin, tin = x.shape
+    tout = conv_out_len(tin, k, stride, pad, dil)
+    y = out if out is not None else torch.empty((B, cout, tout), device=x.device, dtype=torch.float32)
+    e = make_epilogue(**epi)
+    L.check(lib.svb_conv1d_forward(_ptr(x), _ptr(pa), _ptr(y), B, cin, cout, groups, tin, tout, k, stride, pad, dil,
+                                   C.byref(e), st), "svb_conv1d_forward")
+    return y
+
+
+def conv1d_transposed(x, pb, cout, tout, k, stride=1, pad=0, dil=1, groups=1, out=None, **epi):
+    _f32(x, pb)
+    tensors = [x, pb, out] + [epi.get(n) for n in ("bias", "in_gate", "out_gate", "residual", "mask")]
+    lib, st = _prep(*tensors)
+    B, cin, tin = x.shape
+    y = out if out is not None else torch.empty((B, cout, tout), device=x.device, dtype=torch.float32)
+    e = make_epilogue(**epi)
+    L.check(lib.svb_conv1d_transposed(_ptr(x), _ptr(pb), _ptr(y), B, cin, cout, groups, tin, tout, k, stride, pad, dil,
+                                      C.byref(e), st), "svb_conv1d_transposed")
+    return y
+
+
+def conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0, b_gate=None, b_slope=0.0,
+                 v=None, g=None, accumulate_into=None):
+    """dW[ca, cb/groups, k] = sum_{n,q} a[n,ca,q] * b[n,cb,q*sx + j*dil - pad].
+
+    With (v, g) given returns (dv, dg) of the weight-normalised parametrisation instead of dW."""
+    _f32(a, b, a_gate, b_gate, v, g)
+    lib, st = _prep(a, b, a_gate, b_gate, v, g, accumulate_into)
+    B, ca, ta = a.shape
+    _, cb, tb = b.shape
+    ns = C.c_int(0)
+    nfl = lib.svb_conv1d_wgrad_workspace_floats(B, ca, cb, groups, ta, k, sx, C.byref(ns))
+    part = torch.empty((nfl,), device=a.device, dtype=torch.float32)
+    L.check(lib.svb_conv1d_wgrad(_ptr(a), _ptr(b), _ptr(part), B, ca, cb, groups, ta, tb, k, sx, pad, dil,
+                                 _ptr(a_gate), float(a_slope), _ptr(b_gate), float(b_slope), ns.value, st),
+            "svb_conv1d_wgrad")
+    rows, rowlen = ca, (cb // groups) * k
+    wn = g is not None
+    if accumulate_into is not None and not wn:
+        dw = accumulate_into
+        acc = 1
+    else:
+        dw = torch.empty((ca, cb // groups, k), device=a.device, dtype=torch.float32)
+        acc = 0
+    dg = torch.empty_like(g) if wn else None
+    L.check(lib.svb_wgrad_reduce(_ptr(part), ns.value, _ptr(v), _ptr(g), _ptr(dw), _ptr(dg), rows, rowlen, int(wn),
+                                 acc, st), "svb_wgrad_reduce")
+    return (dw, dg) if wn else dw
+
+
+def bias_grad(dy, gate=None, slope=0.0):
+    _f32(dy, gate)
+    lib, st = _prep(dy, gate)
+    B, c, t = dy.shape
+    db = torch.empty((c,), device=dy.device, dtype=torch.float32)
+    L.check(lib.svb_bias_grad(_ptr(dy), _ptr(gate), float(slope), _ptr(db), B, c, t, st), "svb_bias_grad")
+    return db
+
+
+def wn_gate_fwd(xin, g=None, g_off=0):
+    _f32(xin, g)
+    lib, st = _prep(xin, g)
+    B, c2, t = xin.shape
+    c = c2 // 2
+    acts = torch.empty((B, c, t), device=xin.device, dtype=torch.float32)
+    gch = g.shape[1] if g is not None else 0
+    L.check(lib.svb_wn_gate_fwd(_ptr(xin), _ptr(g), _ptr(acts), B, c, t, gch, g_off, st), "svb_wn_gate_fwd")
+    return acts
+
+
+def wn_gate_bwd(xin, g, dacts, g_off=0, dg=None, want_dxin=True):
+    _f32(xin, g, dacts, dg)
+    lib, st = _prep(xin, g, dacts, dg)
+    B, c2, t = xin.shape
+    c = c2 // 2
+    dxin = torch.empty_like(xin) if want_dxin else None
+    gch = g.shape[1] if g is not None else (dg.shape[1] if dg is not None else 0)
+    L.check(lib.svb_wn_gate_bwd(_ptr(xin), _ptr(g), _ptr(dacts), _ptr(dxin), _ptr(dg), B, c, t, gch, g_off, st),
+            "svb_wn_gate_bwd")
+    return dxin
+
+
+def wn_res_skip(x, rs, mask, out, last):
+    """Returns (x_new, out_new); `out` may be None (first layer).  mask: [B, T] or None."""
+    _f32(x, rs, mask, out)
+    lib, st = _prep(x, rs, mask, out)
+    B, rc, t = rs.shape
+    c = rc if last else rc // 2
+    out_new = torch.empty((B, c, t), device=rs.device, dtype=torch.float32)
+    x_new = None if last else torch.empty((B, c, t), device=rs.device, dtype=torch.float32)
+    L.check(lib.svb_wn_res_skip(_ptr(x), _ptr(rs), _ptr(mask), _ptr(out), _ptr(x_new), _ptr(out_new), B, c, t,
+                                int(last), st), "svb_wn_res_skip")
+    return x_new, out_new
+
+
+def wn_res_skip_bwd(dx_new, dout, mask, want_dxm=True):
+    _f32(dx_new, dout, mask)
+    lib, st = _prep(dx_new, dout, mask)
+    B, c, t = dout.shape
+    drs = torch.empty((B, 2 * c, t), device=dout.device, dtype=torch.float32)
+    dxm = torch.empty_like(dout) if want_dxm else None
+    L.check(lib.svb_wn_res_skip_bwd(_ptr(dx_new), _ptr(dout), _ptr(mask), _ptr(drs), _ptr(dxm), B, c, t, st),
+            "svb_wn_res_skip_bwd")
+    return drs, dxm
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, save_stats=False):
+    _f32(x, gamma, beta)
+    lib, st = _prep(x, gamma, beta)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    y = torch.empty_like(x)
+    mean = torch.empty((rows,), device=x.device, dtype=torch.float32) if save_stats else None
+    rstd = torch.empty((rows,), device=x.device, dtype=torch.float32) if save_stats else None
+    L.check(lib.svb_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), rows, c,
+                                  float(eps), st), "svb_layernorm_fwd")
+    return (y, mean, rstd) if save_stats else y
+
+
+def layernorm_bwd(x, gamma, dy, mean, rstd, n_part=128):
+    _f32(x, gamma, dy, mean, rstd)
+    lib, st = _prep(x, gamma, dy, mean, rstd)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    n_part = max(1, min(n_part, (rows + 3) // 4))
+    dx = torch.empty_like(x)
+    dgp = torch.empty((n_part, c), device=x.device, dtype=torch.float32)
+    dbp = torch.empty((n_part, c), device=x.device, dtype=torch.float32)
+    L.check(lib.svb_layernorm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dgp),
+                                  _ptr(dbp), rows, c, n_part, st), "svb_layernorm_bwd")
+    return dx, dgp.sum(0), dbp.sum(0)
+
+
+def stft_mel(wav, window, mel_basis, n_fft, hop, mode, eps):
+    """wav [B, N] -> mode 0: [B, 1+N//hop, n_mels] log10 ; mode 1: [B, n_mels, N//hop] ln."""
+    _f32(wav, window, mel_basis)
+    lib, st = _prep(wav, window, mel_basis)
+    B, n = wav.shape
+    n_mels = mel_basis.shape[0]
+    if mode == 0:
+        nf = 1 + n // hop
+        out = torch.empty((B, nf, n_mels), device=wav.device, dtype=torch.float32)
+    else:
+        nf = n // hop
+        out = torch.empty((B, n_mels, nf), device=wav.device, dtype=torch.float32)
+    L.check(lib.svb_stft_mel(_ptr(wav), _ptr(window), _ptr(mel_basis), _ptr(out), B, n, n_fft, hop, n_mels, nf, mode,
+                             float(eps), st), "svb_stft_mel")
+    return out
+
+
+def nsf_source(f0, rand_ini, noise, lin_w, lin_b, upp, sample_rate, sine_amp=0.1, noise_std=0.003,
+               want_sine_waves=False, want_uv=False):
+    """f0 [B, frames]; rand_ini [B, H]; noise [B, frames*upp, H].  Returns (merged [B, L], sine_waves|None, uv|None)."""
+    _f32(f0, rand_ini, noise, lin_w, lin_b)
+    lib, st = _prep(f0, rand_ini, noise, lin_w, lin_b)
+    B, frames = f0.shape
+    H = rand_ini.shape[1]
+    Ls = frames * upp
+    merged = torch.empty((B, Ls), device=f0.device, dtype=torch.float32)
+    sw = torch.empty((B, Ls, H), device=f0.device, dtype=torch.float32) if want_sine_waves else None
+    uv = torch.empty((B, Ls), device=f0.device, dtype=torch.float32) if want_uv else None
+    L.check(lib.svb_nsf_source(_ptr(f0), _ptr(rand_ini), _ptr(noise), _ptr(lin_w), _ptr(lin_b), _ptr(sw), _ptr(merged),
+                               _ptr(uv), B, frames, upp, H, float(sample_rate), float(sine_amp), float(noise_std), st),
+            "svb_nsf_source")
+    return merged, sw, uv
+
+
+def f0_to_coarse(f0):
+    """float64 tensor -> numpy semantics (rint); float32 tensor -> torch semantics ((x+0.5).long())."""
+    lib, st = _prep(f0)
+    out = torch.empty(f0.shape, device=f0.device, dtype=torch.int64)
+    if f0.dtype == torch.float64:
+        L.check(lib.svb_f0_to_coarse_f64(_ptr(f0), _ptr(out), f0.numel(), st), "svb_f0_to_coarse_f64")
+    elif f0.dtype == torch.float32:
+        L.check(lib.svb_f0_to_coarse_f32(_ptr(f0), _ptr(out), f0.numel(), st), "svb_f0_to_coarse_f32")
+    else:
+        raise TypeError(f0.dtype)
+    return out

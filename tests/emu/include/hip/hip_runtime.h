@@ -1,0 +1,158 @@
+// TEST INFRASTRUCTURE ONLY -- a lane-level CPU emulator of the subset of HIP / gfx950 used by
+// neuralsvb_amd/csrc.  It is NOT a product path and is never loaded by neuralsvb_amd: the build
+// container has no GPU, so tests/emu compiles the *unmodified* kernel sources against this header
+// (it shadows <hip/hip_runtime.h> via -I) to check index math, LDS staging, MFMA fragment maps and
+// barriers before a kernel is sent to a real MI355X.  Every HIP thread is a ucontext fiber; a
+// workgroup's fibers are scheduled round-robin and blocks run one after another.
+//
+// Emulated semantics (must match the gfx950 ISA; layouts from cdna_hip_programming.md §3):
+//   __builtin_amdgcn_mfma_f32_32x32x2f32 : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
+//        D reg r of lane l -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31; k-ordered fmaf chain.
+//   __builtin_amdgcn_mfma_f32_16x16x4f32 : A[l&15][k=l>>4], B[k=l>>4][l&15],
+//        D reg r of lane l -> row (l>>4)*4+r, col l&15.
+//   __shfl / __shfl_xor / __shfl_down / __shfl_up over 64-lane waves.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define SVB_HIP_EMU 1
+
+struct emu_uint3 { unsigned x, y, z; };
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+extern emu_uint3 threadIdx, blockIdx;
+extern dim3 blockDim, gridDim;
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+typedef float float2 __attribute__((ext_vector_type(2)));
+typedef float float4 __attribute__((ext_vector_type(4)));
+typedef int int2 __attribute__((ext_vector_type(2)));
+typedef int int4 __attribute__((ext_vector_type(4)));
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+static inline float2 make_float2(float a, float b) { return float2{a, b}; }
+
+// ---- runtime hooks (emu_runtime.cpp) ----
+void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void emu_syncthreads();
+void emu_wave_exchange_begin(const void* src, size_t bytes);  // publish this lane's payload
+const unsigned char* emu_wave_slot(int lane);                 // read another lane's payload
+void emu_wave_exchange_end();
+int emu_lane_id();
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    emu_launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+
+static inline void __syncthreads() { emu_syncthreads(); }
+static inline void __builtin_amdgcn_s_barrier_emu() { emu_syncthreads(); }
+#define __builtin_amdgcn_s_barrier() emu_syncthreads()
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+
+typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+
+static inline emu_f32x16 emu_mfma_32x32x2f32(float a, float b, emu_f32x16 c, int, int, int) {
+    float ab[2] = {a, b};
+    emu_wave_exchange_begin(ab, sizeof(ab));
+    const int l = emu_lane_id();
+    const int col = l & 31;
+    emu_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            const float av = ((const float*)emu_wave_slot(row + 32 * k))[0];   // A[i=row][k]
+            const float bv = ((const float*)emu_wave_slot(col + 32 * k))[1];   // B[k][j=col]
+            acc = fmaf(av, bv, acc);
+        }
+        d[r] = acc;
+    }
+    emu_wave_exchange_end();
+    return d;
+}
+static inline emu_f32x4 emu_mfma_16x16x4f32(float a, float b, emu_f32x4 c, int, int, int) {
+    float ab[2] = {a, b};
+    emu_wave_exchange_begin(ab, sizeof(ab));
+    const int l = emu_lane_id();
+    const int col = l & 15;
+    emu_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = (l >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            const float av = ((const float*)emu_wave_slot(row + 16 * k))[0];
+            const float bv = ((const float*)emu_wave_slot(col + 16 * k))[1];
+            acc = fmaf(av, bv, acc);
+        }
+        d[r] = acc;
+    }
+    emu_wave_exchange_end();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_32x32x2f32
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_16x16x4f32
+
+template <typename T>
+static inline T emu_shfl_from(T v, int src_lane) {
+    emu_wave_exchange_begin(&v, sizeof(T));
+    T out;
+    memcpy(&out, emu_wave_slot(src_lane & 63), sizeof(T));
+    emu_wave_exchange_end();
+    return out;
+}
+template <typename T> static inline T __shfl(T v, int src, int width = 64) {
+    const int l = emu_lane_id();
+    return emu_shfl_from(v, (l & ~(width - 1)) | (src & (width - 1)));
+}
+template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+    const int l = emu_lane_id();
+    const int s = l ^ mask;
+    return emu_shfl_from(v, ((s & ~(width - 1)) == (l & ~(width - 1))) ? s : l);
+}
+template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+    const int l = emu_lane_id();
+    const int s = l + (int)d;
+    return emu_shfl_from(v, ((s & ~(width - 1)) == (l & ~(width - 1))) ? s : l);
+}
+template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
+    const int l = emu_lane_id();
+    const int s = l - (int)d;
+    return emu_shfl_from(v, (s >= 0 && (s & ~(width - 1)) == (l & ~(width - 1))) ? s : l);
+}
+static inline float __builtin_amdgcn_readfirstlane_f(float v) { return emu_shfl_from(v, 0); }
+static inline int __builtin_amdgcn_readfirstlane_emu(int v) { return emu_shfl_from(v, 0); }
+#define __builtin_amdgcn_readfirstlane(v) __builtin_amdgcn_readfirstlane_emu(v)
+
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __frcp_rn(float x) { return 1.0f / x; }
+static inline void sincosf_emu(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
+static inline float sinpif(float x) { return (float)sin(M_PI * (double)x); }
+static inline float cospif(float x) { return (float)cos(M_PI * (double)x); }
+static inline int __float2int_rn(float x) { return (int)nearbyintf(x); }
+static inline float __int2float_rn(int x) { return (float)x; }
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }

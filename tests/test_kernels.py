@@ -1,0 +1,294 @@
+"""Kernel-level parity: every C-ABI entry point vs the op-level CPU oracle (oracle/ops.py, oracle/frontend.py).
+
+Each test runs twice: `emu` (CPU lane emulator of the same kernel sources -- runs in the GPU-less build
+container) and `gpu` (the product: libsvb_hip.so on an MI355X, marked `gpu`).
+Tolerances: fp32 conv/GEMM results differ from the oracle only by summation order -> rtol 2e-5 of the
+output scale (stated per test); integer outputs are compared exactly.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from neuralsvb_amd import kernels as K
+from oracle import frontend as ofe
+from oracle import ops as oops
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+CONV_CASES = [
+    # B, Cin, Cout, G, T, k, s, pad, dil
+    (2, 8, 16, 1, 50, 5, 1, 2, 1),
+    (1, 20, 70, 1, 140, 5, 1, 2, 1),      # ragged channel / time tails
+    (2, 6, 10, 2, 37, 3, 2, 1, 1),        # grouped + strided
+    (1, 16, 24, 1, 64, 8, 4, 2, 1),       # pre-net shape family: k8 s4 p2 (fs2_vae.py:109-114)
+    (1, 12, 12, 1, 90, 7, 1, 9, 3),       # dilated resblock conv (hifigan.py:33-41)
+    (1, 32, 32, 4, 70, 41, 4, 20, 1),     # MSD grouped k41 s4 (hifigan.py:264-266)
+    (1, 1, 16, 1, 300, 15, 1, 7, 1),      # single input channel (hifigan.py:262)
+    (1, 24, 1, 1, 120, 7, 1, 3, 1),       # single output channel (conv_post, hifigan.py:140)
+    (2, 40, 40, 1, 33, 1, 1, 0, 1),       # 1x1 conv / Linear
+    (3, 5, 3, 1, 29, 3, 3, 1, 1),         # MPD-style stride 3
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv1d_forward_dgrad_wgrad(dev, case):
+    B, Cin, Cout, G, T, k, s, pad, dil = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin // G, k, generator=g) * 0.2
+    bias = torch.randn(Cout, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ref = oops.conv1d(xr, wr, br, s, pad, dil, G)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+
+    xd, wd, bd, dyd = x.to(dev), w.to(dev), bias.to(dev), dy.to(dev)
+    pa, pb = K.weight_pack(wd)
+    y = K.conv1d_forward(xd, pa, Cout, k, s, pad, dil, G, bias=bd)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < 2e-5
+    dx = K.conv1d_transposed(dyd, pb, Cin, T, k, s, pad, dil, G)
+    assert rel_err(dx, xr.grad) < 2e-5
+    dw = K.conv1d_wgrad(dyd, xd, k, s, pad, dil, G)
+    assert dw.shape == w.shape
+    assert rel_err(dw, wr.grad) < 2e-5
+    db = K.bias_grad(dyd)
+    assert rel_err(db, br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+def test_conv1d_all_tile_configs(dev, cfg):
+    g = torch.Generator().manual_seed(cfg)
+    B, Cin, Cout, T, k = 2, 18, 150, 200, 5
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) * 0.2
+    ref = oops.conv1d(x, w, None, 1, 2, 1, 1)
+    pa, pb = K.weight_pack(w.to(dev))
+    y = K.conv1d_forward(x.to(dev), pa, Cout, k, 1, 2, 1, 1, force_cfg=cfg)
+    assert rel_err(y, ref) < 2e-5
+    dy = torch.randn(ref.shape, generator=g)
+    dref = torch.autograd.grad(oops.conv1d(x.requires_grad_(True), w, None, 1, 2, 1, 1), x, dy)[0]
+    dx = K.conv1d_transposed(dy.to(dev), pb, Cin, T, k, 1, 2, 1, 1, force_cfg=cfg)
+    assert rel_err(dx, dref) < 2e-5
+
+
+def test_conv1d_fused_epilogue(dev):
+    """y = mask * (residual + out_gate' * act(conv(lrelu(x)) + bias))  -- the fusions used by the HifiGAN
+    resblocks (hifigan.py:54-61) and the masked pre-nets (fs2_vae.py:121-123)."""
+    g = torch.Generator().manual_seed(7)
+    B, Cin, Cout, T, k, d = 2, 24, 40, 77, 3, 3
+    pad = (k * d - d) // 2
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) * 0.2
+    bias = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, T, generator=g)
+    og = torch.randn(B, Cout, T, generator=g)
+    mask = (torch.rand(B, T, generator=g) > 0.3).float()
+    for act, fn in ((K.ACT_NONE, lambda v: v), (K.ACT_RELU, torch.relu), (K.ACT_LRELU, lambda v: F.leaky_relu(v, 0.1)),
+                    (K.ACT_TANH, torch.tanh)):
+        ref = fn(oops.conv1d(F.leaky_relu(x, 0.1), w, bias, 1, pad, d)) * oops.lrelu_gate(og, 0.2)
+        ref = (ref + res) * mask[:, None, :]
+        pa, _ = K.weight_pack(w.to(dev))
+        y = K.conv1d_forward(x.to(dev), pa, Cout, k, 1, pad, d, 1, bias=bias.to(dev), in_gate=x.to(dev), in_slope=0.1,
+                             out_act=act, out_slope=0.1, out_gate=og.to(dev), out_gate_slope=0.2,
+                             residual=res.to(dev), mask=mask.to(dev))
+        assert rel_err(y, ref) < 2e-5, act
+
+
+CONVT_CASES = [
+    # B, Cin, Cout, T, k, s, pad   (decoder pre_net k4 s4: vae_models.py:115-120; HifiGAN ups: hifigan.py:122-125)
+    (2, 16, 24, 21, 4, 4, 0),
+    (1, 32, 16, 17, 16, 8, 4),
+    (1, 16, 8, 30, 8, 4, 2),
+    (2, 8, 4, 25, 4, 2, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_conv_transpose1d(dev, case):
+    B, Cin, Cout, T, k, s, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cin, Cout, k, generator=g) * 0.2
+    bias = torch.randn(Cout, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = oops.conv_transpose1d(xr, wr, bias, s, pad)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    Tout = ref.shape[-1]
+    pa, pb = K.weight_pack(w.to(dev))
+    y = K.conv1d_transposed(x.to(dev), pb, Cout, Tout, k, s, pad, 1, 1, bias=bias.to(dev))
+    assert rel_err(y, ref) < 2e-5
+    # data gradient of a transposed conv is an ordinary strided conv with the `pa` pack
+    dx = K.conv1d_forward(dy.to(dev), pa, Cin, k, s, pad, 1, 1)
+    assert dx.shape == x.shape and rel_err(dx, xr.grad) < 2e-5
+    # weight gradient: A = x (q-indexed), B = dy (tap-strided)
+    dw = K.conv1d_wgrad(x.to(dev), dy.to(dev), k, s, pad, 1, 1)
+    assert rel_err(dw, wr.grad) < 2e-5
+
+
+def test_weight_norm_pack_and_backward(dev):
+    """w = g v/||v|| (fs2_vae.py:48) forward through the pack kernel, (dv, dg) through the reduce kernel."""
+    g_ = torch.Generator().manual_seed(11)
+    B, Cin, Cout, T, k = 2, 12, 20, 60, 5
+    x = torch.randn(B, Cin, T, generator=g_)
+    v = (torch.randn(Cout, Cin, k, generator=g_) * 0.3).requires_grad_(True)
+    gn = (torch.rand(Cout, 1, 1, generator=g_) + 0.5).requires_grad_(True)
+    ref = oops.conv1d(x, oops.weight_norm(v, gn), None, 1, 2)
+    dy = torch.randn(ref.shape, generator=g_)
+    ref.backward(dy)
+    vd, gd = v.detach().to(dev), gn.detach().to(dev)
+    pa, _ = K.weight_pack(vd, gd)
+    y = K.conv1d_forward(x.to(dev), pa, Cout, k, 1, 2)
+    assert rel_err(y, ref) < 2e-5
+    dv, dg = K.conv1d_wgrad(dy.to(dev), x.to(dev), k, 1, 2, 1, 1, v=vd, g=gd)
+    assert rel_err(dv, v.grad) < 5e-5
+    assert rel_err(dg, gn.grad) < 5e-5
+
+
+def test_wgrad_with_activation_gates(dev):
+    """dW of  y = relu(conv(lrelu(x)))  given dy: gates on both operands (a_gate = y, b_gate = x)."""
+    g_ = torch.Generator().manual_seed(5)
+    B, Cin, Cout, T, k = 2, 10, 14, 45, 3
+    x = torch.randn(B, Cin, T, generator=g_)
+    w = (torch.randn(Cout, Cin, k, generator=g_) * 0.3).requires_grad_(True)
+    b = torch.randn(Cout, generator=g_).requires_grad_(True)
+    y = torch.relu(oops.conv1d(F.leaky_relu(x, 0.1), w, b, 1, 1))
+    dy = torch.randn(y.shape, generator=g_)
+    y.backward(dy)
+    dw = K.conv1d_wgrad(dy.to(dev), x.to(dev), k, 1, 1, 1, 1, a_gate=y.detach().to(dev), a_slope=0.0,
+                        b_gate=x.to(dev), b_slope=0.1)
+    assert rel_err(dw, w.grad) < 2e-5
+    db = K.bias_grad(dy.to(dev), y.detach().to(dev), 0.0)
+    assert rel_err(db, b.grad) < 2e-5
+
+
+@pytest.mark.parametrize("T", [36, 37])
+def test_wn_gate_and_res_skip(dev, T):
+    g_ = torch.Generator().manual_seed(T)
+    B, C, L = 2, 6, 3
+    xin = torch.randn(B, 2 * C, T, generator=g_).requires_grad_(True)
+    gc = torch.randn(B, 2 * C * L, T, generator=g_).requires_grad_(True)
+    off = 2 * C
+    acts = oops.wn_gate(xin, gc[:, off:off + 2 * C])
+    da = torch.randn(acts.shape, generator=g_)
+    acts.backward(da)
+    a = K.wn_gate_fwd(xin.detach().to(dev), gc.detach().to(dev), off)
+    assert rel_err(a, acts) < 1e-5
+    dgc = torch.zeros_like(gc).to(dev)
+    dxin = K.wn_gate_bwd(xin.detach().to(dev), gc.detach().to(dev), da.to(dev), off, dg=dgc)
+    assert rel_err(dxin, xin.grad) < 1e-5
+    assert rel_err(dgc, gc.grad) < 1e-5
+    # res/skip (fs2_vae.py:83-89) and its backward
+    x = torch.randn(B, C, T, generator=g_)
+    rs = torch.randn(B, 2 * C, T, generator=g_)
+    out = torch.randn(B, C, T, generator=g_)
+    mask = (torch.rand(B, T, generator=g_) > 0.3).float()
+    xn, on = K.wn_res_skip(x.to(dev), rs.to(dev), mask.to(dev), out.to(dev), last=False)
+    assert torch.equal(xn.cpu(), (x + rs[:, :C]) * mask[:, None])
+    assert torch.equal(on.cpu(), out + rs[:, C:])
+    _, ol = K.wn_res_skip(None, rs[:, :C].contiguous().to(dev), None, None, last=True)
+    assert torch.equal(ol.cpu(), rs[:, :C])
+    drs, dxm = K.wn_res_skip_bwd(x.to(dev), out.to(dev), mask.to(dev))
+    assert torch.equal(drs.cpu(), torch.cat([x * mask[:, None], out], 1))
+    assert torch.equal(dxm.cpu(), x * mask[:, None])
+
+
+@pytest.mark.parametrize("C", [256, 80])
+def test_layernorm(dev, C):
+    g_ = torch.Generator().manual_seed(C)
+    x = (torch.randn(3, 17, C, generator=g_) * 2 + 0.5).requires_grad_(True)
+    gamma = torch.randn(C, generator=g_).requires_grad_(True)
+    beta = torch.randn(C, generator=g_).requires_grad_(True)
+    ref = oops.layernorm(x, gamma, beta)
+    dy = torch.randn(ref.shape, generator=g_)
+    ref.backward(dy)
+    y, mean, rstd = K.layernorm_fwd(x.detach().to(dev), gamma.detach().to(dev), beta.detach().to(dev), 1e-5, True)
+    assert (y.cpu() - ref.detach()).abs().max() < 2e-5
+    dx, dgm, dbt = K.layernorm_bwd(x.detach().to(dev), gamma.detach().to(dev), dy.to(dev), mean, rstd, n_part=5)
+    assert rel_err(dx, x.grad) < 2e-5
+    assert rel_err(dgm, gamma.grad) < 2e-5
+    assert rel_err(dbt, beta.grad) < 2e-5
+
+
+def _synth_wav(n, sr, seed):
+    rng = np.random.RandomState(seed)
+    t = np.arange(n) / sr
+    f0 = 220 * 2 ** ((3 * np.sin(2 * np.pi * 0.25 * t) + 0.3 * np.sin(2 * np.pi * 5.5 * t)) / 12)
+    ph = 2 * np.pi * np.cumsum(f0) / sr
+    w = sum(np.sin(h * ph) / h for h in range(1, 8))
+    w = 0.5 * w / np.abs(w).max() + 0.03 * rng.randn(n)
+    return w.astype(np.float32)
+
+
+@pytest.mark.parametrize("sr,fmax", [(24000, 12000), (22050, 11025)])
+def test_stft_mel_offline(dev, sr, fmax):
+    """D2: data_gen_utils.py:123-134.  Bit-exact frame count (1 + N//hop); log10-mel within 1e-4 abs
+    (north-star: mel-L1 <= 1e-4)."""
+    n = 128 * 37 + 51
+    wav = np.stack([_synth_wav(n, sr, 0), _synth_wav(n, sr, 1)])
+    basis = ofe.librosa_mel_filterbank(sr, 512, 80, 50, fmax)
+    win = ofe.hann_periodic(512).astype(np.float32)
+    ref = np.stack([ofe.wav2mel_offline(w, 512, 128, 512, 80, 50, fmax, sr)[1] for w in wav])
+    out = K.stft_mel(torch.from_numpy(wav).to(dev), torch.from_numpy(win).to(dev), torch.from_numpy(basis).to(dev),
+                     512, 128, 0, 1e-10)
+    assert out.shape == (2, 1 + n // 128, 80) == ref.shape
+    assert np.abs(out.cpu().numpy() - ref).mean() < 1e-5
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-3
+
+
+def test_stft_mel_ingraph(dev):
+    """D4: mel_utils.py:59-76 (reflect pad, center=False, ln, clamp 1e-5) -> [B, 80, N/hop]."""
+    sr, n = 24000, 8192
+    wav = np.stack([_synth_wav(n, sr, 2) * 1.9, _synth_wav(n, sr, 3)])  # first clip exercises the [-1,1] clamp
+    ref = ofe.mel_spectrogram_ingraph(torch.from_numpy(wav), 512, 128, 512, 80, 50, 12000, sr)
+    basis = ofe.librosa_mel_filterbank(sr, 512, 80, 50, 12000)
+    win = torch.hann_window(512, periodic=True)
+    out = K.stft_mel(torch.from_numpy(wav).to(dev), win.to(dev), torch.from_numpy(basis).to(dev), 512, 128, 1, 1e-5)
+    assert out.shape == (2, 80, 64) == tuple(ref.shape)
+    assert (out.cpu() - ref).abs().mean() < 1e-5
+    assert (out.cpu() - ref).abs().max() < 1e-3
+
+
+def test_nsf_source(dev):
+    """V2: source.py:44-137,385-398.  waveform within 2e-4 of the reference's fp32 arithmetic; the fp64-phase
+    restatement bounds how much of that is the reference's own cumsum rounding."""
+    g_ = torch.Generator().manual_seed(3)
+    B, frames, upp, H, sr = 3, 40, 128, 9, 24000.0
+    f0 = 100 + 300 * torch.rand(B, frames, generator=g_)
+    f0[:, 5:9] = 0.0
+    f0[1, 20:] = 0.0
+    rand_ini = torch.rand(B, H, generator=g_)
+    rand_ini[:, 0] = 0
+    noise = torch.randn(B, frames * upp, H, generator=g_)
+    lw = torch.randn(H, generator=g_) * 0.5
+    lb = torch.randn(1, generator=g_) * 0.1
+    m_ref, sw_ref, uv_ref = oops.sine_source(f0, rand_ini, noise, lw, lb, upp, sr)
+    m64, sw64, _ = oops.sine_source_f64(f0, rand_ini, noise, lw, lb, upp, sr)
+    m, sw, uv = K.nsf_source(f0.to(dev), rand_ini.to(dev), noise.to(dev), lw.to(dev), lb.to(dev), upp, sr,
+                             want_sine_waves=True, want_uv=True)
+    assert torch.equal(uv.cpu(), uv_ref)
+    assert (sw.cpu() - sw64).abs().max() < 2e-5          # vs exact-phase restatement
+    assert (sw.cpu() - sw_ref).abs().max() < 2e-4          # vs the reference's fp32 cumsum
+    assert (m.cpu() - m_ref).abs().max() < 2e-4
+
+
+def test_f0_to_coarse_bit_exact(dev):
+    """D3: pitch_utils.py:130-146; numpy (rint) and torch ((x+0.5).long()) branches, exact integers."""
+    rng = np.random.RandomState(0)
+    f0 = np.concatenate([np.zeros(50), rng.uniform(40, 1300, 5000), [50.0, 1100.0, 1e-3, 49.9]])
+    ref = ofe.f0_to_coarse(f0)
+    out = K.f0_to_coarse(torch.from_numpy(f0).to(dev))
+    assert out.dtype == torch.int64 and np.array_equal(out.cpu().numpy(), ref)
+    f32 = torch.from_numpy(f0.astype(np.float32))
+    ref32 = ofe.f0_to_coarse(f32)
+    out32 = K.f0_to_coarse(f32.to(dev))
+    assert (out32.cpu() != ref32).float().mean() < 1e-3  # fp32 log may differ by 1 ulp at a bin edge
+    assert (out32.cpu() - ref32).abs().max() <= 1
