@@ -1,0 +1,267 @@
+"""Differentiable ops of the hot path: torch.autograd.Function wrappers whose forward AND backward run on the
+hand-written HIP kernels (neuralsvb_amd/kernels.py -> libsvb_hip.so).  torch is used for autograd bookkeeping,
+memory and streams only.
+
+conv1d / conv_transpose1d carry the fusions the reference expresses as separate torch ops:
+    y = mask * (residual + act(conv(lrelu_in(x); w) + bias)),      w = g * v / ||v||  when weight-normalised
+(reference: modules/hifigan/hifigan.py:54-61 `c1(leaky_relu(x))`, `xt + x`; modules/fastspeech/fs2_vae.py:121-123
+`pre_net(x) * mask`; modules/fastspeech/pe.py:16-18 conv+ReLU; torch.nn.utils.weight_norm at fs2_vae.py:42,48,58).
+wn_stack is the whole gated conv stack `WN.forward` (fs2_vae.py:61-91) as ONE autograd node with a hand-scheduled
+backward, so no intermediate is kept that the backward does not need.
+"""
+import torch
+
+from . import kernels as K
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = K.ACT_NONE, K.ACT_RELU, K.ACT_LRELU, K.ACT_TANH
+
+
+def _c(t):
+    return None if t is None else t.contiguous()
+
+
+class _Conv1dFn(torch.autograd.Function):
+    """args: x, v (weight or weight_v), g (weight_g or None), bias, residual, mask ; cfg tuple."""
+
+    @staticmethod
+    def forward(ctx, x, v, g, bias, residual, mask, cfg):
+        stride, pad, dil, groups, in_slope, out_act, out_slope = cfg
+        if out_act == ACT_TANH:
+            raise ValueError("fuse tanh outside (its backward is not a sign gate)")
+        if out_act != ACT_NONE and (residual is not None or mask is not None):
+            raise ValueError("activation cannot be combined with residual/mask in one node")
+        x, v, g, bias, residual, mask = _c(x), _c(v), _c(g), _c(bias), _c(residual), _c(mask)
+        cout, _, k = v.shape
+        pa, pb = K.weight_pack(v, g, want_a=True, want_b=ctx.needs_input_grad[0])
+        y = K.conv1d_forward(x, pa, cout, k, stride, pad, dil, groups, bias=bias,
+                             in_gate=x if in_slope is not None else None,
+                             in_slope=in_slope if in_slope is not None else 0.0,
+                             out_act=out_act, out_slope=out_slope, residual=residual, mask=mask)
+        ctx.cfg = cfg
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, v, g, pb, mask, y if out_act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, pad, dil, groups, in_slope, out_act, out_slope = ctx.cfg
+        x, v, g, pb, mask, yact = ctx.saved_tensors
+        dy = dy.contiguous()
+        if mask is not None:
+            dy = dy * mask[:, None, :]
+        d_res = dy if ctx.has_res else None
+        cout, cin_g, k = v.shape
+        a_slope = 0.0 if out_act == ACT_RELU else out_slope
+        dx = dv = dg = db = None
+        if ctx.needs_input_grad[0]:
+            dx = K.conv1d_transposed(dy, pb, x.shape[1], x.shape[2], k, stride, pad, dil, groups,
+                                     in_gate=yact, in_slope=a_slope,
+                                     out_gate=x if in_slope is not None else None,
+                                     out_gate_slope=in_slope if in_slope is not None else 0.0)
+        if ctx.needs_input_grad[1]:
+            r = K.conv1d_wgrad(dy, x, k, stride, pad, dil, groups, a_gate=yact, a_slope=a_slope,
+                               b_gate=x if in_slope is not None else None,
+                               b_slope=in_slope if in_slope is not None else 0.0, v=v if g is not None else None, g=g)
+            if g is not None:
+                dv, dg = r
+            else:
+                dv = r
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = K.bias_grad(dy, yact, a_slope)
+        return dx, dv, dg, db, d_res, None, None
+
+
+def conv1d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, weight_g=None, in_slope=None,
+           out_act=ACT_NONE, out_slope=0.0, residual=None, mask=None):
+    """x [B,Cin,T]; weight [Cout,Cin/groups,k] (or weight_v with weight_g [Cout,1,1]); mask [B,Tout]."""
+    cfg = (int(stride), int(padding), int(dilation), int(groups), in_slope, int(out_act), float(out_slope))
+    return _Conv1dFn.apply(x, weight, weight_g, bias, residual, mask, cfg)
+
+
+class _ConvT1dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, v, g, bias, mask, cfg):
+        stride, pad, dil, out_pad, in_slope = cfg
+        x, v, g, bias, mask = _c(x), _c(v), _c(g), _c(bias), _c(mask)
+        cin, cout, k = v.shape
+        tout = (x.shape[2] - 1) * stride - 2 * pad + dil * (k - 1) + out_pad + 1
+        pa, pb = K.weight_pack(v, g, want_a=ctx.needs_input_grad[0], want_b=True)
+        y = K.conv1d_transposed(x, pb, cout, tout, k, stride, pad, dil, 1, bias=bias,
+                                in_gate=x if in_slope is not None else None,
+                                in_slope=in_slope if in_slope is not None else 0.0, mask=mask)
+        ctx.cfg = cfg
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, v, g, pa, mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, pad, dil, out_pad, in_slope = ctx.cfg
+        x, v, g, pa, mask = ctx.saved_tensors
+        dy = dy.contiguous()
+        if mask is not None:
+            dy = dy * mask[:, None, :]
+        cin, cout, k = v.shape
+        dx = dv = dg = db = None
+        if ctx.needs_input_grad[0]:
+            dx = K.conv1d_forward(dy, pa, cin, k, stride, pad, dil, 1,
+                                  out_gate=x if in_slope is not None else None,
+                                  out_gate_slope=in_slope if in_slope is not None else 0.0)
+            assert dx.shape == x.shape
+        if ctx.needs_input_grad[1]:
+            r = K.conv1d_wgrad(x, dy, k, stride, pad, dil, 1, a_gate=x if in_slope is not None else None,
+                               a_slope=in_slope if in_slope is not None else 0.0, v=v if g is not None else None, g=g)
+            if g is not None:
+                dv, dg = r
+            else:
+                dv = r
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = K.bias_grad(dy)
+        return dx, dv, dg, db, None, None
+
+
+def conv_transpose1d(x, weight, bias=None, stride=1, padding=0, dilation=1, output_padding=0, weight_g=None,
+                     in_slope=None, mask=None):
+    """x [B,Cin,T]; weight [Cin,Cout,k] (weight_g [Cin,1,1] for weight_norm dim 0)."""
+    cfg = (int(stride), int(padding), int(dilation), int(output_padding), in_slope)
+    return _ConvT1dFn.apply(x, weight, weight_g, bias, mask, cfg)
+
+
+def linear_nct(x, weight, bias=None):
+    """nn.Linear applied over the channel dim of an NCT tensor = 1x1 conv.  weight [out, in]."""
+    return conv1d(x, weight[:, :, None], bias)
+
+
+class _WNStackFn(torch.autograd.Function):
+    """WN.forward (reference modules/fastspeech/fs2_vae.py:61-91) with p_dropout = 0.
+
+    tensors = [x, mask, gcond, cond_v, cond_g, cond_b, (in_v, in_g, in_b, rs_v, rs_g, rs_b) * n_layers]
+    """
+
+    @staticmethod
+    def forward(ctx, n_layers, kernel_size, dilation_rate, *tensors):
+        x, mask, gcond = _c(tensors[0]), _c(tensors[1]), _c(tensors[2])
+        cond_v, cond_g, cond_b = tensors[3:6]
+        layers = [tensors[6 + 6 * i: 12 + 6 * i] for i in range(n_layers)]
+        B, C, T = x.shape
+        G = None
+        cond_pb = None
+        if gcond is not None:
+            pa, cond_pb = K.weight_pack(_c(cond_v), _c(cond_g), want_b=ctx.needs_input_grad[5])
+            G = K.conv1d_forward(gcond, pa, cond_v.shape[0], 1, bias=_c(cond_b))
+        saved_x, saved_xin, saved_acts, packs_b = [], [], [], []
+        out = None
+        for i, (in_v, in_g, in_b, rs_v, rs_g, rs_b) in enumerate(layers):
+            dil = dilation_rate ** i
+            pad = (kernel_size * dil - dil) // 2
+            pa_in, pb_in = K.weight_pack(_c(in_v), _c(in_g))
+            xin = K.conv1d_forward(x, pa_in, 2 * C, kernel_size, 1, pad, dil, 1, bias=_c(in_b))
+            acts = K.wn_gate_fwd(xin, G, i * 2 * C)
+            pa_rs, pb_rs = K.weight_pack(_c(rs_v), _c(rs_g))
+            last = i == n_layers - 1
+            rs = K.conv1d_forward(acts, pa_rs, rs_v.shape[0], 1, bias=_c(rs_b))
+            saved_x.append(x)
+            saved_xin.append(xin)
+            saved_acts.append(acts)
+            packs_b.append((pb_in, pb_rs))
+            x_new, out = K.wn_res_skip(x, rs, mask, out, last)
+            if not last:
+                x = x_new
+        if mask is not None:
+            out = out * mask[:, None, :]
+        ctx.meta = (n_layers, kernel_size, dilation_rate, C)
+        ctx.n_in = len(tensors)
+        flat = [mask, gcond, G, cond_pb, _c(cond_v), _c(cond_g)]
+        for i in range(n_layers):
+            flat += [saved_x[i], saved_xin[i], saved_acts[i], packs_b[i][0], packs_b[i][1]]
+            flat += [_c(t) for t in layers[i]]
+        ctx.save_for_backward(*flat)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n_layers, ks, dr, C = ctx.meta
+        sv = ctx.saved_tensors
+        mask, gcond, G, cond_pb, cond_v, cond_g = sv[:6]
+        dout = dout.contiguous()
+        if mask is not None:
+            dout = dout * mask[:, None, :]
+        grads = [None] * ctx.n_in
+        dG = torch.empty_like(G) if G is not None else None
+        dx_next = None  # gradient flowing into x_{i+1}
+        for i in reversed(range(n_layers)):
+            base = 6 + 11 * i
+            x_i, xin, acts, pb_in, pb_rs = sv[base:base + 5]
+            in_v, in_g, in_b, rs_v, rs_g, rs_b = sv[base + 5:base + 11]
+            dil = dr ** i
+            pad = (ks * dil - dil) // 2
+            last = i == n_layers - 1
+            if last:
+                drs, dxm = dout, None
+            else:
+                drs, dxm = K.wn_res_skip_bwd(dx_next, dout, mask, want_dxm=True)
+            # res/skip 1x1 conv
+            r = K.conv1d_wgrad(drs, acts, 1, v=rs_v if rs_g is not None else None, g=rs_g)
+            p = 6 + 6 * i
+            if rs_g is not None:
+                grads[p + 3], grads[p + 4] = r
+            else:
+                grads[p + 3] = r
+            grads[p + 5] = K.bias_grad(drs)
+            dacts = K.conv1d_transposed(drs, pb_rs, C, acts.shape[2], 1)
+            dxin = K.wn_gate_bwd(xin, G, dacts, i * 2 * C, dg=dG)
+            r = K.conv1d_wgrad(dxin, x_i, ks, 1, pad, dil, v=in_v if in_g is not None else None, g=in_g)
+            if in_g is not None:
+                grads[p + 0], grads[p + 1] = r
+            else:
+                grads[p + 0] = r
+            grads[p + 2] = K.bias_grad(dxin)
+            if i > 0 or ctx.needs_input_grad[3]:
+                dx_next = K.conv1d_transposed(dxin, pb_in, C, x_i.shape[2], ks, 1, pad, dil, residual=dxm)
+            else:
+                dx_next = None
+        grads[0] = dx_next
+        if G is not None:
+            r = K.conv1d_wgrad(dG, gcond, 1, v=cond_v if cond_g is not None else None, g=cond_g)
+            if cond_g is not None:
+                grads[3], grads[4] = r
+            else:
+                grads[3] = r
+            grads[5] = K.bias_grad(dG)
+            if ctx.needs_input_grad[5]:
+                grads[2] = K.conv1d_transposed(dG, cond_pb, gcond.shape[1], gcond.shape[2], 1)
+        return (None, None, None) + tuple(grads)
+
+
+def wn_stack(x, mask, gcond, cond_params, layer_params, kernel_size, dilation_rate=1):
+    """x [B,C,T]; mask [B,T] or None; gcond [B,gin,T] or None.
+    cond_params = (weight_v, weight_g, bias) or None; layer_params = [(in_v,in_g,in_b,rs_v,rs_g,rs_b), ...]."""
+    flat = [x, mask, gcond] + list(cond_params if cond_params is not None else (None, None, None))
+    for lp in layer_params:
+        flat += list(lp)
+    return _WNStackFn.apply(len(layer_params), int(kernel_size), int(dilation_rate), *flat)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        need = x.requires_grad or gamma.requires_grad
+        if need:
+            y, mean, rstd = K.layernorm_fwd(x, gamma, beta, eps, save_stats=True)
+            ctx.save_for_backward(x, gamma, mean, rstd)
+        else:
+            y = K.layernorm_fwd(x, gamma, beta, eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dx, dgm, dbt = K.layernorm_bwd(x, gamma, dy.contiguous(), mean, rstd)
+        return dx, dgm, dbt, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    """LayerNorm over the last dim (torch.nn.LayerNorm; reference conformer/layers.py:160-170)."""
+    return _LayerNormFn.apply(x, gamma, beta, float(eps))

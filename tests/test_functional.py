@@ -1,0 +1,167 @@
+"""Autograd-level parity: neuralsvb_amd.functional (HIP forward + HIP backward) vs torch autograd over the
+op-level oracle.  Runs on the emulator (CPU) and on the MI355X (gpu mark)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from neuralsvb_amd import functional as SF
+from oracle import ops as oops
+from tests.test_kernels import rel_err
+
+
+def _leaf(t, dev):
+    return t.detach().clone().to(dev).requires_grad_(True)
+
+
+@pytest.mark.parametrize("wn", [False, True])
+@pytest.mark.parametrize("variant", ["plain", "relu", "lrelu_in_res", "mask", "strided_grouped"])
+def test_conv1d_autograd(dev, wn, variant):
+    g_ = torch.Generator().manual_seed(17)
+    B, Cin, Cout, T, k = 2, 12, 16, 41, 5
+    stride, pad, dil, groups = 1, 2, 1, 1
+    kw = {}
+    if variant == "strided_grouped":
+        stride, pad, groups = 2, 1, 2
+        k = 3
+    x = torch.randn(B, Cin, T, generator=g_)
+    v = torch.randn(Cout, Cin // groups, k, generator=g_) * 0.3
+    gn = torch.rand(Cout, 1, 1, generator=g_) + 0.5
+    b = torch.randn(Cout, generator=g_)
+    Tout = (T + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    res = torch.randn(B, Cout, Tout, generator=g_)
+    mask = (torch.rand(B, Tout, generator=g_) > 0.3).float()
+
+    def ref_fn(x, v, gn, b, res):
+        w = oops.weight_norm(v, gn) if wn else v
+        if variant == "relu":
+            return torch.relu(oops.conv1d(x, w, b, stride, pad, dil, groups))
+        if variant == "lrelu_in_res":
+            return oops.conv1d(F.leaky_relu(x, 0.1), w, b, stride, pad, dil, groups) + res
+        if variant == "mask":
+            return oops.conv1d(x, w, b, stride, pad, dil, groups) * mask[:, None]
+        return oops.conv1d(x, w, b, stride, pad, dil, groups)
+
+    rl = [t.clone().requires_grad_(True) for t in (x, v, gn, b, res)]
+    yr = ref_fn(*rl)
+    dy = torch.randn(yr.shape, generator=g_)
+    yr.backward(dy)
+
+    xd, vd, gd, bd, rd = (_leaf(t, dev) for t in (x, v, gn, b, res))
+    if variant == "relu":
+        kw = dict(out_act=SF.ACT_RELU)
+    elif variant == "lrelu_in_res":
+        kw = dict(in_slope=0.1, residual=rd)
+    elif variant == "mask":
+        kw = dict(mask=mask.to(dev))
+    y = SF.conv1d(xd, vd, bd, stride, pad, dil, groups, weight_g=gd if wn else None, **kw)
+    assert rel_err(y, yr) < 2e-5
+    y.backward(dy.to(dev))
+    assert rel_err(xd.grad, rl[0].grad) < 3e-5
+    assert rel_err(vd.grad, rl[1].grad) < 5e-5
+    assert rel_err(bd.grad, rl[3].grad) < 3e-5
+    if wn:
+        assert rel_err(gd.grad, rl[2].grad) < 5e-5
+    if variant == "lrelu_in_res":
+        assert rel_err(rd.grad, rl[4].grad) < 1e-6
+
+
+@pytest.mark.parametrize("wn", [False, True])
+def test_conv_transpose1d_autograd(dev, wn):
+    g_ = torch.Generator().manual_seed(23)
+    B, Cin, Cout, T, k, s, pad = 2, 10, 6, 19, 8, 4, 2
+    x = torch.randn(B, Cin, T, generator=g_)
+    v = torch.randn(Cin, Cout, k, generator=g_) * 0.3
+    gn = torch.rand(Cin, 1, 1, generator=g_) + 0.5
+    b = torch.randn(Cout, generator=g_)
+    rl = [t.clone().requires_grad_(True) for t in (x, v, gn, b)]
+    w = oops.weight_norm(rl[1], rl[2]) if wn else rl[1]
+    yr = oops.conv_transpose1d(F.leaky_relu(rl[0], 0.1), w, rl[3], s, pad)
+    dy = torch.randn(yr.shape, generator=g_)
+    yr.backward(dy)
+    xd, vd, gd, bd = (_leaf(t, dev) for t in (x, v, gn, b))
+    y = SF.conv_transpose1d(xd, vd, bd, s, pad, weight_g=gd if wn else None, in_slope=0.1)
+    assert rel_err(y, yr) < 2e-5
+    y.backward(dy.to(dev))
+    assert rel_err(xd.grad, rl[0].grad) < 3e-5
+    assert rel_err(vd.grad, rl[1].grad) < 5e-5
+    assert rel_err(bd.grad, rl[3].grad) < 3e-5
+    if wn:
+        assert rel_err(gd.grad, rl[2].grad) < 5e-5
+
+
+def _wn_ref(x, mask, gcond, cond, layers, ks):
+    """WN.forward restated with stock torch ops (reference modules/fastspeech/fs2_vae.py:61-91)."""
+    C = x.shape[1]
+    m = mask[:, None, :] if mask is not None else 1
+    out = torch.zeros_like(x)
+    G = oops.conv1d(gcond, oops.weight_norm(cond[0], cond[1]), cond[2]) if gcond is not None else None
+    n = len(layers)
+    for i, (iv, ig, ib, rv, rg, rb) in enumerate(layers):
+        xin = oops.conv1d(x, oops.weight_norm(iv, ig), ib, 1, (ks - 1) // 2)
+        gl = G[:, i * 2 * C:(i + 1) * 2 * C] if G is not None else torch.zeros_like(xin)
+        acts = oops.wn_gate(xin, gl)
+        rs = oops.conv1d(acts, oops.weight_norm(rv, rg), rb)
+        if i < n - 1:
+            x = (x + rs[:, :C]) * m
+            out = out + rs[:, C:]
+        else:
+            out = out + rs
+    return out * m
+
+
+@pytest.mark.parametrize("with_cond,with_mask", [(True, True), (False, False)])
+def test_wn_stack_autograd(dev, with_cond, with_mask):
+    g_ = torch.Generator().manual_seed(31)
+    B, C, T, gin, n, ks = 2, 8, 45, 10, 3, 5
+    x = torch.randn(B, C, T, generator=g_)
+    gcond = torch.randn(B, gin, T, generator=g_) if with_cond else None
+    mask = (torch.rand(B, T, generator=g_) > 0.25).float() if with_mask else None
+    cond = [torch.randn(2 * C * n, gin, 1, generator=g_) * 0.3, torch.rand(2 * C * n, 1, 1, generator=g_) + 0.5,
+            torch.randn(2 * C * n, generator=g_) * 0.1]
+    layers = []
+    for i in range(n):
+        rc = 2 * C if i < n - 1 else C
+        layers.append([torch.randn(2 * C, C, ks, generator=g_) * 0.3, torch.rand(2 * C, 1, 1, generator=g_) + 0.5,
+                       torch.randn(2 * C, generator=g_) * 0.1,
+                       torch.randn(rc, C, 1, generator=g_) * 0.3, torch.rand(rc, 1, 1, generator=g_) + 0.5,
+                       torch.randn(rc, generator=g_) * 0.1])
+    # reference
+    xr = x.clone().requires_grad_(True)
+    gr = gcond.clone().requires_grad_(True) if with_cond else None
+    cr = [t.clone().requires_grad_(True) for t in cond]
+    lr = [[t.clone().requires_grad_(True) for t in lp] for lp in layers]
+    yr = _wn_ref(xr, mask, gr, cr, lr, ks)
+    dy = torch.randn(yr.shape, generator=g_)
+    yr.backward(dy)
+    # HIP
+    xd = _leaf(x, dev)
+    gd = _leaf(gcond, dev) if with_cond else None
+    cd = [_leaf(t, dev) for t in cond]
+    ld = [[_leaf(t, dev) for t in lp] for lp in layers]
+    y = SF.wn_stack(xd, mask.to(dev) if with_mask else None, gd, cd if with_cond else None, ld, ks)
+    assert rel_err(y, yr) < 3e-5
+    y.backward(dy.to(dev))
+    assert rel_err(xd.grad, xr.grad) < 5e-5
+    if with_cond:
+        assert rel_err(gd.grad, gr.grad) < 5e-5
+        for a, b in zip(cd, cr):
+            assert rel_err(a.grad, b.grad) < 1e-4
+    for la, lb in zip(ld, lr):
+        for a, b in zip(la, lb):
+            assert rel_err(a.grad, b.grad) < 1e-4
+
+
+def test_layer_norm_autograd(dev):
+    g_ = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 9, 64, generator=g_)
+    gm, bt = torch.randn(64, generator=g_), torch.randn(64, generator=g_)
+    rl = [t.clone().requires_grad_(True) for t in (x, gm, bt)]
+    yr = oops.layernorm(*rl)
+    dy = torch.randn(yr.shape, generator=g_)
+    yr.backward(dy)
+    dl = [_leaf(t, dev) for t in (x, gm, bt)]
+    y = SF.layer_norm(*dl)
+    y.backward(dy.to(dev))
+    assert (y.detach().cpu() - yr.detach()).abs().max() < 2e-5
+    for a, b in zip(dl, rl):
+        assert rel_err(a.grad, b.grad) < 3e-5
