@@ -54,6 +54,8 @@ def sine_source(f0_frames, rand_ini, noise, lin_w, lin_b, upp, sr, sine_amp=0.1,
     for idx in range(H - 1):
         f0_buf[:, :, idx + 1] = f0_buf[:, :, 0] * (idx + 2)                  # source.py:114-117
     rad = (f0_buf / sr) % 1                                                  # :50
+    rand_ini = rand_ini.clone()
+    rand_ini[:, 0] = 0                                                       # :55 (no phase noise on the fundamental)
     rad[:, 0, :] = rad[:, 0, :] + rand_ini                                   # :53-56
     tmp_over_one = torch.cumsum(rad, 1) % 1                                  # :66
     over_idx = (tmp_over_one[:, 1:, :] - tmp_over_one[:, :-1, :]) < 0        # :67-68
@@ -79,6 +81,8 @@ def sine_source_f64(f0_frames, rand_ini, noise, lin_w, lin_b, upp, sr, sine_amp=
     for idx in range(H - 1):
         f0_buf[:, :, idx + 1] = f0_buf[:, :, 0] * (idx + 2)
     rad = ((f0_buf / sr) % 1).double()
+    rand_ini = rand_ini.clone()
+    rand_ini[:, 0] = 0
     rad[:, 0, :] = rad[:, 0, :] + rand_ini.double()
     phase = torch.cumsum(rad, 1) % 1.0
     sines = torch.sin((phase.float()) * 2 * np.pi)

@@ -1,0 +1,191 @@
+"""Generate the committed golden vectors by running the UNMODIFIED reference (/root/reference) on CPU.
+
+Build-container only (the reference is not present on the GPU box).  Usage:  python tests/golden/make_golden.py
+Writes tests/golden/ref_state_keys.json (state_dict key/shape lists of the reference modules at the real
+hparams) and tests/golden/*.npz (inputs, injected randomness, reference outputs).  Weights are procedural
+(oracle/procedural.py), so no state_dict is stored.
+"""
+import contextlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import procedural, ref_shims  # noqa: E402
+
+HIFIGAN_CFG = {  # hop-128 NSF configuration (working assumption, configurable)
+    "resblock": "1", "upsample_rates": [8, 4, 2, 2], "upsample_kernel_sizes": [16, 8, 4, 4],
+    "upsample_initial_channel": 512, "resblock_kernel_sizes": [3, 7, 11],
+    "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]], "use_pitch_embed": True,
+    "audio_sample_rate": 24000, "hop_size": 128,
+}
+
+
+@contextlib.contextmanager
+def record_rng(store):
+    """Record every torch.randn_like / torch.rand / torch.randn draw the reference makes (injected later)."""
+    o_rl, o_r, o_rn = torch.randn_like, torch.rand, torch.randn
+
+    def rl(*a, **k):
+        t = o_rl(*a, **k); store.append(("randn_like", t.clone())); return t
+
+    def r(*a, **k):
+        t = o_r(*a, **k); store.append(("rand", t.clone())); return t
+
+    def rn(*a, **k):
+        t = o_rn(*a, **k); store.append(("randn", t.clone())); return t
+    torch.randn_like, torch.rand, torch.randn = rl, r, rn
+    try:
+        yield
+    finally:
+        torch.randn_like, torch.rand, torch.randn = o_rl, o_r, o_rn
+
+
+def keys_of(module):
+    return [[k, list(v.shape), str(v.dtype)] for k, v in module.state_dict().items()]
+
+
+def load_procedural(module, prefix):
+    ks = keys_of(module)
+    sd = procedural.state_dict_for(ks, prefix=prefix)
+    module.load_state_dict(sd, strict=True)
+    return ks
+
+
+def fmap_stats(t):
+    t = t.detach().double()
+    flat = t.flatten()
+    idx = torch.linspace(0, flat.numel() - 1, 16).long()
+    return np.concatenate([[t.mean().item(), t.abs().mean().item(), (t * t).mean().item()], flat[idx].numpy()])
+
+
+def make_vae_inputs(B=2, T=64, lens=(64, 52), seed=0):
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name in ("mels", "prof_mels"):
+        m = torch.randn(B, T, 80, generator=g) * 0.8 - 3.0
+        for b, L in enumerate(lens):
+            m[b, L:] = 0.0
+        out[name] = m
+    for name in ("pitch", "prof_pitch"):
+        p = torch.randint(1, 256, (B, T), generator=g)
+        for b, L in enumerate(lens):
+            p[b, L:] = 0
+        out[name] = p
+    spk = torch.randn(B, 256, generator=g)
+    out["spk"] = spk / spk.norm(dim=-1, keepdim=True)
+    al = torch.stack([torch.clamp((torch.arange(T) * 0.97 + 1.5 * torch.sin(torch.arange(T) / 7.0)).round().long(), 0, L - 1)
+                      for L in lens])
+    out["a2p_alignment"] = al
+    return out
+
+
+def main():
+    torch.manual_seed(1234)
+    torch.set_num_threads(8)
+    hp = ref_shims.set_reference_hparams()
+    keys = {}
+    resolved = {k: v for k, v in hp.items() if isinstance(v, (int, float, str, bool, list, dict)) or v is None}
+    with open(os.path.join(HERE, "ref_hparams_vae_global_mle_eng.json"), "w") as f:
+        json.dump(resolved, f, indent=0, sort_keys=True)
+
+    # ---------------- pitch bins (D3) ----------------
+    from utils.pitch_utils import f0_to_coarse
+    rng = np.random.RandomState(0)
+    f0 = np.concatenate([np.zeros(16), rng.uniform(30, 1400, 2000), [50.0, 1100.0, 700.0, 1e-3]])
+    np.savez_compressed(os.path.join(HERE, "f0_to_coarse.npz"), f0=f0, coarse_np=f0_to_coarse(f0.copy()),
+                        coarse_torch=f0_to_coarse(torch.from_numpy(f0.astype(np.float32))).numpy())
+
+    # ---------------- MleSVBVAE (M1-M8), real dims ----------------
+    from modules.voice_conversion.svb_vae import MleSVBVAE
+    model = MleSVBVAE(70)
+    keys["MleSVBVAE"] = load_procedural(model, "model.")
+    model.train()
+    model.vc_asr.eval()
+    inp = make_vae_inputs()
+    rec = []
+    with record_rng(rec):
+        out = model(amateur_mel=inp["mels"], prof_mel=inp["prof_mels"], amateur_pitch=inp["pitch"],
+                    prof_pitch=inp["prof_pitch"], amateur_spk_id=inp["spk"], prof_spk_id=inp["spk"],
+                    a2p_alignment=inp["a2p_alignment"], p2a_alignment=None, infer=False,
+                    concurrent_ways=["a2a", "p2p", "a2p"], disable_map=False)
+    conds = model.prepare_condition(inp["mels"], inp["pitch"], spk_ids=inp["spk"])
+    save = {k: v.numpy() for k, v in inp.items()}
+    assert [k for k, _ in rec] == ["randn_like", "randn_like"], [k for k, _ in rec]
+    save["eps_a2a"], save["eps_p2p"] = rec[0][1].numpy(), rec[1][1].numpy()
+    for way in ("a2a", "p2p", "a2p"):
+        for k, v in out[way].items():
+            if isinstance(v, torch.Tensor):
+                save[f"{way}.{k}"] = v.detach().numpy()
+    for k in ("h_pitch", "h_content", "h_style", "tgt_nonpadding"):
+        save[f"cond_a.{k}"] = conds[k].detach().numpy()
+    # mel losses (L1): tasks/tts/fs2.py:158-175 call modules.commons.ssim.ssim on [B,1,T,80]+6
+    from modules.commons.ssim import ssim
+    mo, tg = out["a2a"]["mel_out"].detach(), inp["mels"]
+    save["loss.ssim_map_a2a"] = ssim(mo[:, None] + 6.0, tg[:, None] + 6.0, size_average=False).numpy()
+    np.savez_compressed(os.path.join(HERE, "vae_mle.npz"), **save)
+
+    # ---------------- mel discriminator (G1), eval mode (Dropout2d off), fixed windows ----------------
+    from modules.fastspeech.multi_window_disc import Discriminator
+    disc = Discriminator(time_lengths=[32, 64, 128], freq_length=80, hidden_size=128, kernel=(3, 3), cond_size=0,
+                         norm_type="in", reduction="stack")
+    keys["Discriminator"] = load_procedural(disc, "mel_disc.")
+    disc.eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 140, 80, generator=g) * 0.8 - 3.0
+    x[1, 131:] = 0.0
+    starts = [[7, 7], [40, 40], [3, 3]]
+    o = disc(x, None, start_frames_wins=[list(s) for s in starts])
+    np.savez_compressed(os.path.join(HERE, "mel_disc.npz"), x=x.numpy(), starts=np.array(starts), y=o["y"].detach().numpy(),
+                        h_stats=np.stack([fmap_stats(h) for h in o["h"]]))
+
+    # ---------------- NSF-HifiGAN generator (V1, V2) ----------------
+    from modules.hifigan.hifigan import HifiGanGenerator, MultiPeriodDiscriminator, MultiScaleDiscriminator
+    gen = HifiGanGenerator(HIFIGAN_CFG)
+    keys["HifiGanGenerator"] = load_procedural(gen, "model_gen.")
+    gen.eval()
+    g = torch.Generator().manual_seed(9)
+    mel = torch.randn(2, 80, 12, generator=g) * 0.8 - 3.0
+    f0 = 120 + 300 * torch.rand(2, 12, generator=g)
+    f0[0, 3:5] = 0.0
+    f0[1, 9:] = 0.0
+    rec = []
+    with record_rng(rec), torch.no_grad():
+        wav = gen(mel, f0)
+    kinds = [k for k, _ in rec]
+    assert kinds == ["rand", "randn_like", "randn_like"], kinds
+    np.savez_compressed(os.path.join(HERE, "hifigan_gen.npz"), mel=mel.numpy(), f0=f0.numpy(), rand_ini=rec[0][1].numpy(),
+                        noise=rec[1][1].numpy(), wav=wav.numpy())
+
+    # ---------------- MPD / MSD (V3, V4), eval mode (no spectral-norm power iteration) ----------------
+    mpd, msd = MultiPeriodDiscriminator(), MultiScaleDiscriminator()
+    keys["MultiPeriodDiscriminator"] = load_procedural(mpd, "model_disc.mpd.")
+    keys["MultiScaleDiscriminator"] = load_procedural(msd, "model_disc.msd.")
+    mpd.eval(); msd.eval()
+    g = torch.Generator().manual_seed(13)
+    y = torch.tanh(torch.randn(2, 1, 2101, generator=g))
+    yh = torch.tanh(torch.randn(2, 1, 2101, generator=g))
+    save = dict(y=y.numpy(), y_hat=yh.numpy())
+    with torch.no_grad():
+        for name, d in (("mpd", mpd), ("msd", msd)):
+            y_d_rs, y_d_gs, fmap_rs, fmap_gs = d(y, yh)
+            for i, (a, b) in enumerate(zip(y_d_rs, y_d_gs)):
+                save[f"{name}.y_d_r.{i}"], save[f"{name}.y_d_g.{i}"] = a.numpy(), b.numpy()
+            save[f"{name}.fmap_r_stats"] = np.stack([fmap_stats(t) for fm in fmap_rs for t in fm])
+            save[f"{name}.fmap_g_stats"] = np.stack([fmap_stats(t) for fm in fmap_gs for t in fm])
+            save[f"{name}.fmap_shapes"] = np.array([list(t.shape) + [0] * (4 - t.dim()) for fm in fmap_rs for t in fm])
+    np.savez_compressed(os.path.join(HERE, "hifigan_disc.npz"), **save)
+
+    with open(os.path.join(HERE, "ref_state_keys.json"), "w") as f:
+        json.dump(keys, f)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
