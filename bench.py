@@ -1,0 +1,184 @@
+"""bench.py -- audio-seconds/sec of the vae_global_mle_eng training step on N MI355X (BASELINE.json metric).
+
+A "step" is one full `Trainer.run_training_batch` of SVBVAEMleTask in phase 2 (ways a2a,p2p; generator pass with the
+adversarial term + discriminator pass; backward, clipping, AdamW, schedulers) on one batch of synthetic paired clips
+(config #2: per-GPU batch 16 x 6 s @ 24 kHz, hop 128 -> T=1124, 80-bin mel from the HIP front-end).  The batch is
+resident in HBM before the timed region.  One sample (amateur+professional pair) counts its clip length once.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the fp32-MFMA implicit-GEMM conv) and `cpu_baseline`
+(the oracle's CPU port of the same step, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def build_task(args, rank, world, device, tmp):
+    from neuralsvb_amd.utils.hparams import set_hparams, hparams
+    from neuralsvb_amd.utils import synth
+    cfg = os.path.join(ROOT, "egs/datasets/audio/PopBuTFy/vae_global_mle_eng.yaml")
+    data_dir, asr_dir = os.path.join(tmp, f"binary_r{rank}"), os.path.join(tmp, f"asr_r{rank}")
+    set_hparams(config=cfg, exp_name="", print_hparams=False,
+                hparams_str=f"audio_sample_rate={args.sample_rate},fmax={args.sample_rate // 2},max_sentences={args.batch},"
+                            f"max_tokens=100000,ds_workers=0,num_sanity_val_steps=0,endless_ds=False")
+    hparams["binary_data_dir"], hparams["pretrain_asr_ckpt"], hparams["work_dir"] = data_dir, asr_dir, ""
+    hparams["amp"] = bool(args.bf16)
+    torch.manual_seed(1234 + rank)
+    np.random.seed(1234)
+    synth.write_binary_dataset(data_dir, hparams, synth.mel_fn_hip(hparams, device), n_train=args.batch, n_valid=1,
+                               seconds=args.seconds)
+    synth.write_fake_asr_ckpt(asr_dir, 60 + 10, hparams)
+    from neuralsvb_amd.tasks.svb_vae_task import SVBVAEMleTask
+    from neuralsvb_amd.utils.trainer import Trainer, move_to_device
+    trainer = Trainer(work_dir="", max_updates=10 ** 9, num_sanity_val_steps=0, amp=hparams["amp"])
+    torch.manual_seed(1234)          # identical replicas on every rank
+    task = trainer.setup(SVBVAEMleTask())
+    task.train()
+    loader = task.build_dataloader(task.dataset_cls("train", False), False, hparams["max_tokens"], args.batch)
+    batch = move_to_device(next(iter(loader)), device)
+    return task, trainer, batch, hparams
+
+
+def run_steps(trainer, task, batch, n, start_step):
+    for i in range(n):
+        task.global_step = trainer.global_step = start_step + i      # phase 2, disc active (global_step >= 1)
+        trainer.run_training_batch(i, batch)
+
+
+def conv_roofline(trainer, task, batch, steps, start_step):
+    """Profiled pass (not part of `value`): HIP events around every launch of the implicit-GEMM conv kernel."""
+    from neuralsvb_amd import kernels as K
+    K.PROFILE = []
+    run_steps(trainer, task, batch, steps, start_step)
+    torch.cuda.synchronize()
+    rec, K.PROFILE = K.PROFILE, None
+    by_cfg = {}
+    for name, flops, e0, e1 in rec:
+        d = by_cfg.setdefault(name, [0.0, 0.0, 0])
+        d[0] += flops
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += 1
+    if not by_cfg:
+        return None
+    name, (fl, sec, cnt) = max(by_cfg.items(), key=lambda kv: kv[1][1])
+    tot_fl = sum(v[0] for v in by_cfg.values())
+    tot_s = sum(v[1] for v in by_cfg.values())
+    return {"bound": "mfma", "kernel": name, "achieved": fl / sec / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+            "frac": fl / sec / PEAK_F32_MFMA, "traffic": None, "launches_per_step": cnt / steps,
+            "avg_launch_us": sec / cnt * 1e6, "gflop_per_launch": fl / cnt / 1e9,
+            "all_conv_kernels": {"achieved": tot_fl / tot_s / 1e12, "frac": tot_fl / tot_s / PEAK_F32_MFMA,
+                                 "ms_per_step": tot_s / steps * 1e3, "launches_per_step": sum(v[2] for v in by_cfg.values()) / steps}}
+
+
+def cpu_baseline(task, batch, hp, args):
+    """Oracle CPU port of the same step on a bounded sample (B = cpu_batch clips), all host cores."""
+    from oracle.train_step_ref import CpuStep
+    nb = min(args.cpu_batch, batch["mels"].shape[0])
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    msd = {k: v.detach().cpu() for k, v in task.model.state_dict().items()}
+    dsd = {k: v.detach().cpu() for k, v in task.mel_disc.state_dict().items()}
+    sample = {k: (v[:nb].cpu() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    step = CpuStep(msd, dsd, hp)
+    L = hp["latent_size"]
+    g = torch.Generator().manual_seed(0)
+    starts = {w: [[5, 5], [9, 9], [3, 3]] for w in ("a2a", "p2p")}
+    sd = {w: {"real": [[5, 5], [9, 9], [3, 3]], "fake": [[7, 7], [2, 2], [11, 11]]} for w in ("a2a", "p2p")}
+    times = []
+    for i in range(1 + args.cpu_steps):
+        eps = [torch.randn(nb, L, 1, generator=g) for _ in range(2)]
+        t0 = time.perf_counter()
+        step.step(sample, 1, eps[0], eps[1], starts, sd, global_step=1 + i)
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:])) if len(times) > 1 else times[0]
+    return {"value": nb * args.seconds / t, "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle CPU port of the phase-2 step (gen+disc passes, AdamW), B={nb} x {args.seconds:g} s clips, "
+                      f"median of {args.cpu_steps} steps after 1 warm-up, torch fp32 on {cores} host threads",
+            "s_per_step": t}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--seconds", type=float, default=6.0)
+    ap.add_argument("--sample-rate", type=int, default=24000)
+    ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: an MI355X is required"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    with tempfile.TemporaryDirectory() as tmp:
+        task, trainer, batch, hp = build_task(args, rank, world, device, tmp)
+        T = batch["mels"].shape[1]
+        run_steps(trainer, task, batch, args.warmup, 1)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(trainer, task, batch, args.steps, 1 + args.warmup)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = tt.item()
+        ms = dt / args.steps * 1e3
+        value = args.batch * args.seconds * world / (dt / args.steps)
+        roof = cpu = None
+        if rank == 0 and not args.no_roofline:
+            roof = conv_roofline(trainer, task, batch, 3, 1 + args.warmup + args.steps) if world == 1 else None
+        if world > 1:
+            dist.barrier()
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(task, batch, hp, args)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "audio-seconds/sec per train step (vae_global_mle_eng)", "value": value,
+                "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
+                "config": {"workload": "vae_global_mle_eng phase-2 train step (gen+disc passes), configs[1]: per-GPU "
+                                       f"batch {args.batch} x {args.seconds:g} s synthetic clips @ {args.sample_rate} Hz, "
+                                       f"hop 128, T={T}, 80-bin mel", "global_batch": args.batch * world,
+                           "parallelism": f"dp{world}", "random_init_weights": True},
+                "roofline": roof, "cpu_baseline": cpu}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,11 @@ int svb_weight_pack(const float* v, const float* g, float* pa, float* pb, int d0
 int svb_conv1d_forward(const float* x, const float* wp, float* y, int B, int Cin, int Cout, int groups, int Tin,
                        int Tout, int k, int stride, int pad, int dil, const SvbConvEpilogue* epi, void* stream);
 
+/* Tile configuration (0..4) the conv launcher picks for Cout/groups output channels and nq_max output positions
+ * per phase: {64x128, 128x96, 128x128, 64x64, 32x128} = svb_conv1d_mfma_kernel<2,2,2>, <4,1,3>, <4,1,4>, <2,2,1>, <1,4,1>.
+ * (profiling aid: lets a caller name the kernel instantiation a launch used)                                   */
+int svb_conv1d_pick_cfg(int cout_g, int nq_max);
+
 /* Transposed conv (gather form): y[b,co,p] = sum_{ci,j : p = t*stride - pad + j*dil} w[ci,co,j] x[b,ci,t].
  * Replaces F.conv_transpose1d (reference vae_models.py:115-120,126; hifigan.py:122-125,156) and the data
  * gradient of F.conv1d.  wp: [k][Cin][Cout/groups] (= pb of a ConvTranspose1d weight, = pb of a Conv1d weight
@@ -94,6 +99,10 @@ int svb_wn_res_skip_bwd(const float* dx_new, const float* dout, const float* mas
  * conformer.py:30; torch.nn.LayerNorm eps 1e-5).                                                             */
 int svb_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                       int rows, int C, float eps, void* stream);
+/* Same normalisation over the channel dim of an NCT tensor [B, C, T] (forward only: the PPG encoder is frozen,
+ * reference tasks/singing/svb_vae_task.py:558-561).                                                          */
+int svb_layernorm_nct_fwd(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T, float eps,
+                          void* stream);
 int svb_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* mean, const float* rstd,
                       float* dx, float* dgamma_part, float* dbeta_part, int rows, int C, int n_part, void* stream);
 

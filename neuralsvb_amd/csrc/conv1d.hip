@@ -371,6 +371,8 @@ static int launch_conv(SvbConvArgs& a, const SvbConvPlan& p, hipStream_t stream)
     }
 }
 
+extern "C" int svb_conv1d_pick_cfg(int cout_g, int nq_max) { return pick_cfg(cout_g, nq_max); }
+
 static void fill_epilogue(SvbConvArgs& a, const SvbConvEpilogue* e) {
     a.bias = e ? e->bias : nullptr;
     a.in_gate = e ? e->in_gate : nullptr;

@@ -187,6 +187,36 @@ __global__ __launch_bounds__(256) void svb_layernorm_bwd_kernel(const float* x, 
     }
 }
 
+
+// LayerNorm over the channel dim of an NCT tensor: one thread per (b,t) column, lanes along t (coalesced rows).
+// Shifted single-pass moments (shift = first channel) + one normalise pass: 2 reads + 1 write of x.
+__global__ __launch_bounds__(256) void svb_layernorm_nct_fwd_kernel(const float* x, const float* gamma, const float* beta,
+                                                                    float* y, int B, int C, int T, float eps) {
+    const long total = (long)B * T;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / T), t = (int)(i - (long)b * T);
+        const float* xc = x + (size_t)b * C * T + t;
+        float* yc = y + (size_t)b * C * T + t;
+        const float x0 = xc[0];
+        float s = 0.f, ss = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float d = xc[(size_t)c * T] - x0;
+            s += d;
+            ss = fmaf(d, d, ss);
+        }
+        const float md = s / (float)C;
+        const float var = fmaxf(ss / (float)C - md * md, 0.f);
+        const float mu = x0 + md;
+        const float rs = 1.f / sqrtf(var + eps);
+        for (int c = 0; c < C; ++c) {
+            float o = (xc[(size_t)c * T] - mu) * rs;
+            if (gamma) o *= gamma[c];
+            if (beta) o += beta[c];
+            yc[(size_t)c * T] = o;
+        }
+    }
+}
+
 static inline int ew_grid(long total) {
     long g = (total + 255) / 256;
     if (g > 8192) g = 8192;
@@ -255,6 +285,15 @@ extern "C" int svb_layernorm_bwd(const float* x, const float* gamma, const float
     if (!x || !dy || !mean || !rstd || rows <= 0 || C <= 0 || C > 1024 || n_part <= 0) return SVB_ERR_ARG;
     hipLaunchKernelGGL(svb_layernorm_bwd_kernel, dim3(n_part), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, mean, rstd,
                        dx, dgamma_part, dbeta_part, rows, C);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_layernorm_nct_fwd(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
+                                     float eps, void* stream) {
+    if (!x || !y || B <= 0 || C <= 0 || T <= 0) return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_layernorm_nct_fwd_kernel, dim3(ew_grid((long)B * T)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                       beta, y, B, C, T, eps);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }

@@ -265,3 +265,10 @@ class _LayerNormFn(torch.autograd.Function):
 def layer_norm(x, gamma, beta, eps=1e-5):
     """LayerNorm over the last dim (torch.nn.LayerNorm; reference conformer/layers.py:160-170)."""
     return _LayerNormFn.apply(x, gamma, beta, float(eps))
+
+
+def layer_norm_nct(x, gamma, beta, eps=1e-5):
+    """LayerNorm over the channel dim of [B, C, T]; forward only (used inside the frozen PPG encoder)."""
+    if torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad):
+        raise RuntimeError("layer_norm_nct is forward-only (frozen encoder); use layer_norm for trainable paths")
+    return K.layernorm_nct_fwd(x.contiguous(), gamma, beta, eps)

@@ -12,6 +12,27 @@ from . import _lib as L
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 
+# bench.py sets PROFILE = [] to collect (kernel instantiation, algorithmic FLOPs, start event, end event) per conv launch
+PROFILE = None
+_CFG_NAMES = ["svb_conv1d_mfma_kernel<2,2,2,8192,5120>", "svb_conv1d_mfma_kernel<4,1,3,8192,10240>",
+              "svb_conv1d_mfma_kernel<4,1,4,8192,10240>", "svb_conv1d_mfma_kernel<2,2,1,8192,5120>",
+              "svb_conv1d_mfma_kernel<1,4,1,8192,2560>"]
+
+
+class _ConvProbe:
+    def __init__(self, lib, x, cout_g, nq_max, flops):
+        self.on = PROFILE is not None and x.is_cuda
+        if self.on:
+            self.name = _CFG_NAMES[lib.svb_conv1d_pick_cfg(int(cout_g), int(nq_max))]
+            self.flops = flops
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def done(self):
+        if self.on:
+            self.e1.record()
+            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+
 
 def _ptr(t):
     return None if t is None else t.data_ptr()
@@ -81,8 +102,10 @@ def conv1d_forward(x, pa, cout, k, stride=1, pad=0, dil=1, groups=1, out=None, *
     tout = conv_out_len(tin, k, stride, pad, dil)
     y = out if out is not None else torch.empty((B, cout, tout), device=x.device, dtype=torch.float32)
     e = make_epilogue(**epi)
+    probe = _ConvProbe(lib, x, cout // groups, tout, 2.0 * B * cout * tout * (cin // groups) * k)
     L.check(lib.svb_conv1d_forward(_ptr(x), _ptr(pa), _ptr(y), B, cin, cout, groups, tin, tout, k, stride, pad, dil,
                                    C.byref(e), st), "svb_conv1d_forward")
+    probe.done()
     return y
 
 
@@ -93,8 +116,10 @@ def conv1d_transposed(x, pb, cout, tout, k, stride=1, pad=0, dil=1, groups=1, ou
     B, cin, tin = x.shape
     y = out if out is not None else torch.empty((B, cout, tout), device=x.device, dtype=torch.float32)
     e = make_epilogue(**epi)
+    probe = _ConvProbe(lib, x, cout // groups, -(-tout // stride), 2.0 * B * cin * tin * (cout // groups) * k)
     L.check(lib.svb_conv1d_transposed(_ptr(x), _ptr(pb), _ptr(y), B, cin, cout, groups, tin, tout, k, stride, pad, dil,
                                       C.byref(e), st), "svb_conv1d_transposed")
+    probe.done()
     return y
 
 
@@ -194,6 +219,17 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, save_stats=False):
     L.check(lib.svb_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), rows, c,
                                   float(eps), st), "svb_layernorm_fwd")
     return (y, mean, rstd) if save_stats else y
+
+
+def layernorm_nct_fwd(x, gamma, beta, eps=1e-5):
+    """LayerNorm over dim 1 of [B, C, T]."""
+    _f32(x, gamma, beta)
+    lib, st = _prep(x, gamma, beta)
+    B, c, t = x.shape
+    y = torch.empty_like(x)
+    L.check(lib.svb_layernorm_nct_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), B, c, t, float(eps), st),
+            "svb_layernorm_nct_fwd")
+    return y
 
 
 def layernorm_bwd(x, gamma, dy, mean, rstd, n_part=128):

@@ -1,0 +1,72 @@
+"""Multi-window mel-spectrogram critic (the GAN discriminator of the vae_global_mle_eng step).
+
+Drop-in for reference modules/fastspeech/multi_window_disc.py:154-199 `Discriminator` as built by
+tasks/tts/fs2_adv.py:22-35 (uncond, norm 'in', reduction 'stack'): identical state_dict keys
+(`discriminator.conv_layers.<w>.model.<b>.{0,3}.*`, `...adv_layer.*`), call signature and result dict.
+Semantics kept: one np.random window start per window length shared by the whole batch (:144-148), x_len from
+non-zero frames (:190), Dropout2d(0.25) on whole channels in train mode (:23), `y=None` when a clip is shorter
+than a window (:140-142).
+
+Round-1 status: the 3x3 stride-2 Conv2d blocks (0.42 GFLOP/sample/call, ~2 % of the step FLOPs) still run on
+torch-ROCm ops; they are the next convs to move onto the HIP implicit-GEMM kernel ("next").
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+def _critic_tower(time_length, freq_length, kernel, c_in, hidden, norm_type, reduction):
+    """One window's conv tower as bare containers named like the reference's Discriminator2DFactory (:6-44)."""
+    tower = nn.Module()
+    blocks = []
+    for b in range(3):
+        mods = [nn.Conv2d(c_in if b == 0 else hidden, hidden, kernel, (2, 2), (kernel[0] // 2, kernel[1] // 2)),
+                nn.LeakyReLU(0.2), nn.Dropout2d(0.25)]
+        if b > 0 and norm_type == "in":
+            mods.append(nn.InstanceNorm2d(hidden, affine=True))
+        elif b > 0 and norm_type == "bn":
+            mods.append(nn.BatchNorm2d(hidden, 0.8))
+        blocks.append(nn.Sequential(*mods))
+    tower.model = nn.ModuleList(blocks)
+    t8, f8 = time_length // 8, (freq_length + 7) // 8
+    tower.adv_layer = nn.Linear(hidden * f8 * (t8 if reduction != "none" else 1), 1)
+    return tower
+
+
+class Discriminator(nn.Module):
+    def __init__(self, time_lengths=(32, 64, 128), freq_length=80, cond_size=0, kernel=(3, 3), c_in=1, hidden_size=128,
+                 norm_type="bn", reduction="sum", uncond_disc=True):
+        super().__init__()
+        if cond_size > 0 or not uncond_disc:
+            raise NotImplementedError("vae_global_mle_eng uses the unconditional critic only (use_cond_disc: false)")
+        if reduction not in ("sum", "stack"):
+            raise NotImplementedError(reduction)
+        self.time_lengths, self.reduction = list(time_lengths), reduction
+        self.discriminator = nn.Module()
+        self.discriminator.conv_layers = nn.ModuleList(
+            [_critic_tower(tl, freq_length, kernel, c_in, hidden_size, norm_type, reduction) for tl in self.time_lengths])
+
+    def forward(self, x, cond=None, start_frames_wins=None):
+        """x [B,T,n_mels] (or [B,1,T,n_mels]).  Returns {'y': [B,1,W] or None, 'y_c': None, 'h': fmaps,
+        'start_frames_wins': [[s]*B per window]}."""
+        if x.dim() == 3:
+            x = x[:, None]
+        longest = int(x.sum([1, -1]).ne(0).int().sum(-1).max().item())
+        starts = list(start_frames_wins) if start_frames_wins is not None else [None] * len(self.time_lengths)
+        scores, fmaps = [], []
+        for w, (tower, wl) in enumerate(zip(self.discriminator.conv_layers, self.time_lengths)):
+            if longest - wl < 0:
+                continue
+            if starts[w] is None:
+                starts[w] = [int(np.random.randint(low=0, high=longest - wl + 1))] * x.size(0)
+            s = starts[w][0]
+            h = x[:, :, s:s + wl]
+            for blk in tower.model:
+                h = blk(h)
+                fmaps.append(h)
+            scores.append(tower.adv_layer(h.flatten(1)))
+        y = None
+        if len(scores) == len(self.time_lengths):
+            y = torch.stack(scores, -1) if self.reduction == "stack" else sum(scores)
+        return {"y": y, "y_c": None, "h": fmaps, "start_frames_wins": starts}

@@ -1,0 +1,199 @@
+"""Frozen PPG / content encoder (VCASR, encoder side only) in NCT layout.
+
+Host-side mirror of reference modules/voice_conversion/vc_modules.py:56-80 (VCASR), modules/fastspeech/pe.py:7-41
+(Prenet), modules/fastspeech/conformer/conformer.py:9-53 (ConformerLayers), conformer/layers.py (EncoderLayer,
+ConvolutionModule, MultiLayeredConv1d), modules/commons/espnet_transformer_attn.py:106-186 and
+espnet_positional_embedding.py:89-112.  Same state_dict keys (incl. the never-executed asr_decoder / token_embed,
+kept as opaque frozen parameters so reference checkpoints load strictly).
+
+Forward-only (the task freezes it, svb_vae_task.py:558-561) and eval-mode (BatchNorm running stats, no dropout).
+All dense projections / FFN / k5 convs and the five LayerNorms per block run on the HIP kernels; the rel-pos
+attention products, softmax, GLU, the depthwise k31 conv and Swish stay on torch-ROCm ops this round.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import functional as SF
+from .layers import Conv1d, LinearNCT, LayerNormNCT, attach_opaque
+
+
+class Prenet(nn.Module):
+    def __init__(self, in_dim=80, out_dim=256, kernel=5, n_layers=3, strides=None):
+        super().__init__()
+        self.strides = strides if strides is not None else [1] * n_layers
+        layers = []
+        for l in range(n_layers):
+            layers.append(nn.Sequential(Conv1d(in_dim, out_dim, kernel, stride=self.strides[l], padding=kernel // 2),
+                                        nn.ReLU(), nn.BatchNorm1d(out_dim)))
+            in_dim = out_dim
+        self.layers = nn.ModuleList(layers)
+        self.out_proj = LinearNCT(out_dim, out_dim, xavier=False)
+
+    def forward(self, mel_nct, nonpad):
+        """mel_nct [B,80,T]; nonpad [B,T] float.  Returns ([B,H,T'], nonpad' [B,T'])  (pe.py:23-41)."""
+        x = mel_nct
+        for i, l in enumerate(self.layers):
+            nonpad = nonpad[:, ::self.strides[i]]
+            x = l[0](x, out_act=SF.ACT_RELU)
+            x = l[2](x) * nonpad[:, None, :]
+        nonpad = nonpad.contiguous()
+        return self.out_proj(x, mask=nonpad), nonpad
+
+
+class RelPositionMultiHeadedAttention(nn.Module):
+    def __init__(self, n_head, n_feat):
+        super().__init__()
+        self.d_k, self.h = n_feat // n_head, n_head
+        self.linear_q, self.linear_k = LinearNCT(n_feat, n_feat, xavier=False), LinearNCT(n_feat, n_feat, xavier=False)
+        self.linear_v, self.linear_out = LinearNCT(n_feat, n_feat, xavier=False), LinearNCT(n_feat, n_feat, xavier=False)
+        self.linear_pos = LinearNCT(n_feat, n_feat, bias=False, xavier=False)
+        self.pos_bias_u = nn.Parameter(torch.empty(self.h, self.d_k))
+        self.pos_bias_v = nn.Parameter(torch.empty(self.h, self.d_k))
+        nn.init.xavier_uniform_(self.pos_bias_u)
+        nn.init.xavier_uniform_(self.pos_bias_v)
+
+    def forward(self, x, pos_emb, mask):
+        """x [B,D,T]; pos_emb [1,D,T]; mask [B,T] bool (True = keep)  (espnet_transformer_attn.py:150-186)."""
+        B, D, T = x.shape
+        h, dk = self.h, self.d_k
+        q = self.linear_q(x).view(B, h, dk, T)
+        k = self.linear_k(x).view(B, h, dk, T)
+        v = self.linear_v(x).view(B, h, dk, T)
+        p = self.linear_pos(pos_emb).view(1, h, dk, T)
+        q_u = (q + self.pos_bias_u[None, :, :, None]).transpose(-1, -2)
+        q_v = (q + self.pos_bias_v[None, :, :, None]).transpose(-1, -2)
+        ac = torch.matmul(q_u, k)                                   # [B,h,T,T]
+        bd = torch.matmul(q_v, p)
+        bd = F.pad(bd, (1, 0)).view(B, h, T + 1, T)[:, :, 1:].reshape(B, h, T, T)   # rel_shift :125-148
+        scores = (ac + bd) / math.sqrt(dk)
+        drop = ~mask[:, None, None, :]
+        scores = scores.masked_fill(drop, torch.finfo(torch.float32).min)
+        attn = torch.softmax(scores, dim=-1).masked_fill(drop, 0.0)
+        o = torch.matmul(v, attn.transpose(-1, -2)).reshape(B, D, T)
+        return self.linear_out(o)
+
+
+class MultiLayeredConv1d(nn.Module):
+    def __init__(self, in_chans, hidden_chans, kernel_size):
+        super().__init__()
+        self.w_1 = Conv1d(in_chans, hidden_chans, kernel_size, padding=(kernel_size - 1) // 2)
+        self.w_2 = Conv1d(hidden_chans, in_chans, kernel_size, padding=(kernel_size - 1) // 2)
+
+    def forward(self, x):
+        return self.w_2(self.w_1(x, out_act=SF.ACT_RELU))
+
+
+class ConvolutionModule(nn.Module):
+    def __init__(self, channels, kernel_size):
+        super().__init__()
+        self.pointwise_conv1 = Conv1d(channels, 2 * channels, 1)
+        self.depthwise_conv = nn.Conv1d(channels, channels, kernel_size, padding=(kernel_size - 1) // 2, groups=channels)
+        self.norm = nn.BatchNorm1d(channels)
+        self.pointwise_conv2 = Conv1d(channels, channels, 1)
+
+    def forward(self, x):
+        x = F.glu(self.pointwise_conv1(x), dim=1)
+        x = self.norm(self.depthwise_conv(x))
+        x = x * torch.sigmoid(x)
+        return self.pointwise_conv2(x)
+
+
+class EncoderLayer(nn.Module):
+    """Macaron conformer block, normalize_before, eval mode (conformer/layers.py:182-258)."""
+
+    def __init__(self, size, num_heads, kernel_size):
+        super().__init__()
+        self.self_attn = RelPositionMultiHeadedAttention(num_heads, size)
+        self.feed_forward = MultiLayeredConv1d(size, size * 4, 1)
+        self.feed_forward_macaron = MultiLayeredConv1d(size, size * 4, 1)
+        self.conv_module = ConvolutionModule(size, kernel_size)
+        self.norm_ff, self.norm_mha = LayerNormNCT(size), LayerNormNCT(size)
+        self.norm_ff_macaron = LayerNormNCT(size)
+        self.norm_conv, self.norm_final = LayerNormNCT(size), LayerNormNCT(size)
+
+    def forward(self, x, pos_emb, mask):
+        x = x + 0.5 * self.feed_forward_macaron(self.norm_ff_macaron(x))
+        x = x + self.self_attn(self.norm_mha(x), pos_emb, mask)
+        x = x + self.conv_module(self.norm_conv(x))
+        x = x + 0.5 * self.feed_forward(self.norm_ff(x))
+        return self.norm_final(x)
+
+
+class ConformerLayers(nn.Module):
+    def __init__(self, hidden_size, num_layers, kernel_size=31, num_heads=4, use_last_norm=True):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.encoder_layers = nn.ModuleList([EncoderLayer(hidden_size, num_heads, kernel_size) for _ in range(num_layers)])
+        self.layer_norm = LayerNormNCT(hidden_size) if use_last_norm else LinearNCT(hidden_size, hidden_size, xavier=False)
+        self._pe = None
+
+    def _pos_emb(self, T, device):
+        """First T rows of the reversed 5000-long table (espnet_positional_embedding.py:23-46,107-112), as [1,D,T]."""
+        if self._pe is None or self._pe.device != device:
+            D, max_len = self.hidden_size, 5000
+            pos = torch.arange(max_len - 1, -1, -1.0, dtype=torch.float32).unsqueeze(1)
+            div = torch.exp(torch.arange(0, D, 2, dtype=torch.float32) * -(math.log(10000.0) / D))
+            pe = torch.zeros(max_len, D)
+            pe[:, 0::2] = torch.sin(pos * div)
+            pe[:, 1::2] = torch.cos(pos * div)
+            self._pe = pe.t().contiguous().to(device)              # [D, 5000]
+        return self._pe[None, :, :T].contiguous()
+
+    def forward(self, x):
+        """x [B,D,T] -> [B,D,T]  (conformer.py:37-53)."""
+        nonpadding = x.abs().sum(1) > 0                             # [B,T]
+        pos_emb = self._pos_emb(x.shape[-1], x.device)
+        x = x * math.sqrt(self.hidden_size)
+        for l in self.encoder_layers:
+            x = l(x, pos_emb, nonpadding)
+        return self.layer_norm(x) * nonpadding[:, None, :].float()
+
+
+def _asr_decoder_spec(hidden, n_layers, dict_size, ffn_kernel=9):
+    """state_dict keys of TransformerASRDecoder (modules/asr/seq2seq.py:11-33) -- stored, never executed on the path."""
+    spec = [("asr_decoder.embed_positions._float_tensor", (1,), True)]
+    for i in range(n_layers):
+        p = f"asr_decoder.layers.{i}.op."
+        spec += [(p + "layer_norm1.weight", (hidden,), False), (p + "layer_norm1.bias", (hidden,), False),
+                 (p + "self_attn.in_proj_weight", (3 * hidden, hidden), False),
+                 (p + "self_attn.out_proj.weight", (hidden, hidden), False),
+                 (p + "layer_norm2.weight", (hidden,), False), (p + "layer_norm2.bias", (hidden,), False),
+                 (p + "encoder_attn.in_proj_weight", (3 * hidden, hidden), False),
+                 (p + "encoder_attn.out_proj.weight", (hidden, hidden), False),
+                 (p + "layer_norm3.weight", (hidden,), False), (p + "layer_norm3.bias", (hidden,), False),
+                 (p + "ffn.ffn_1.1.weight", (4 * hidden, hidden, ffn_kernel), False),
+                 (p + "ffn.ffn_1.1.bias", (4 * hidden,), False),
+                 (p + "ffn.ffn_2.weight", (hidden, 4 * hidden), False), (p + "ffn.ffn_2.bias", (hidden,), False)]
+    spec += [("asr_decoder.layer_norm.weight", (hidden,), False), ("asr_decoder.layer_norm.bias", (hidden,), False),
+             ("asr_decoder.project_out_dim.weight", (dict_size, hidden), False)]
+    return spec
+
+
+class VCASR(nn.Module):
+    def __init__(self, dict_size, n_mel_bins, hparams):
+        super().__init__()
+        self.hidden_size = hparams["hidden_size"]
+        if hparams["asr_enc_type"] != "conformer":
+            raise NotImplementedError("vae_global_mle_eng uses asr_enc_type=conformer (vc_ppg.yaml)")
+        self.mel_prenet = Prenet(n_mel_bins, self.hidden_size, strides=hparams["mel_strides"])
+        self.content_encoder = ConformerLayers(self.hidden_size, hparams["asr_enc_layers"], 31,
+                                               use_last_norm=hparams["asr_last_norm"])
+        self.token_embed = nn.Embedding(dict_size, self.hidden_size, padding_idx=0)
+        for key, shape, is_buf in _asr_decoder_spec(self.hidden_size, hparams["asr_dec_layers"], dict_size,
+                                                    hparams.get("dec_ffn_kernel_size", 9)):
+            attach_opaque(self, key, shape, buffer=is_buf)
+
+    def train(self, mode=True):
+        return super().train(False)          # always eval: frozen pretrained extractor (svb_vae_task.py:559)
+
+    @torch.no_grad()
+    def forward(self, mel_input, prev_tokens=None):
+        """mel_input [B,T,80] -> {'h_content': [B, H, T/2] (NCT)}  (vc_modules.py:75-80, encoder only)."""
+        if prev_tokens is not None:
+            raise NotImplementedError("the ASR decoder is not on the hot path")
+        nonpad = (mel_input.abs().sum(-1) != 0).float()
+        x, _ = self.mel_prenet(mel_input.transpose(1, 2).contiguous(), nonpad)
+        return {"h_content": self.content_encoder(x)}

@@ -1,0 +1,270 @@
+"""SVBVAEMleTask -- the vae_global_mle_eng training / validation / inference task.
+
+Drop-in for `tasks.singing.svb_vae_task.SVBVAEMleTask` (reference tasks/singing/svb_vae_task.py:543-726) with its
+inherited pieces flattened into one class: three optimizers (generator / mel-discriminator / latent map,
+:84-118), three phases (:585-595), `run_model` (:120-165), LS-GAN helper steps (tasks/singing/svb_para.py:118-170),
+mel losses (tasks/tts/fs2.py:143-175, SSIM of modules/commons/ssim.py:320-351), gradient clipping and scheduler
+stepping hooks (:390-404).  The Trainer-facing hook API (tasks/base_task.py:131-355) is unchanged.
+
+Differences that do not change results: loss terms stay on the GPU (no `.item()` per term per step -- they are
+converted when something logs them), and the NaN/Inf guards of :665-672 are expressed with torch.where so the
+step never synchronises the host.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..modules.mel_disc import Discriminator
+from ..modules.svb_vae import MleSVBVAE
+from ..utils import ckpt_utils
+from ..utils.hparams import hparams
+from ..utils.schedulers import NoneSchedule, RSQRTSchedule
+from .base_task import BaseTask, data_loader
+
+
+def _gauss_window(size=11, sigma=1.5):
+    g = torch.tensor([math.exp(-(x - size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(size)])
+    g = (g / g.sum()).unsqueeze(1)
+    return g.mm(g.t()).float()[None, None]
+
+
+def ssim_map(img1, img2, window):
+    """Per-pixel SSIM of [B,1,T,80] images, 11x11 gaussian (modules/commons/ssim.py:331-351), mean over channel."""
+    p = window.shape[-1] // 2
+    mu1, mu2 = F.conv2d(img1, window, padding=p), F.conv2d(img2, window, padding=p)
+    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s1 = F.conv2d(img1 * img1, window, padding=p) - mu1_sq
+    s2 = F.conv2d(img2 * img2, window, padding=p) - mu2_sq
+    s12 = F.conv2d(img1 * img2, window, padding=p) - mu12
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu12 + c1) * (2 * s12 + c2)) / ((mu1_sq + mu2_sq + c1) * (s1 + s2 + c2))).mean(1)
+
+
+class SVBVAEMleTask(BaseTask):
+    def __init__(self):
+        super().__init__()
+        from .dataset import MultiSpkEmbDataset
+        self.dataset_cls = MultiSpkEmbDataset
+        self.mse_loss_fn = nn.MSELoss()
+        self.loss_and_lambda = {}
+        for part in hparams["mel_loss"].split("|"):
+            name, _, lbd = part.partition(":")
+            self.loss_and_lambda[name] = float(lbd) if lbd else 1.0
+        self.register_buffer("_ssim_window", _gauss_window(), persistent=False)
+        self.vocoder = None
+        self.model_out = self.model_out_gt = None
+
+    # ------------------------------------------------------------------ model / optimizers
+    def build_tts_model(self):
+        phone_list = json.load(open(os.path.join(hparams["binary_data_dir"], "phone_set.json")))
+        self.model = MleSVBVAE(len(phone_list) + 10, hparams)
+
+    def build_disc_model(self):
+        self.disc_params = []
+        if hparams["mel_gan"]:
+            self.mel_disc = Discriminator(time_lengths=[32, 64, 128][:hparams["disc_win_num"]], freq_length=80,
+                                          hidden_size=hparams["mel_disc_hidden_size"], kernel=(3, 3),
+                                          cond_size=hparams["hidden_size"] if hparams["use_cond_disc"] else 0,
+                                          norm_type=hparams["disc_norm"], reduction=hparams["disc_reduction"])
+            self.disc_params = list(self.mel_disc.parameters())
+
+    def build_model(self):
+        self.build_tts_model()
+        if hparams.get("pretrain_asr_ckpt"):
+            ckpt_utils.load_ckpt(self.model.vc_asr, hparams["pretrain_asr_ckpt"], model_name="model",
+                                 force=hparams.get("pretrain_asr_required", True))
+        self.model.vc_asr.eval()
+        for p in self.model.vc_asr.parameters():
+            p.requires_grad = False
+        if hparams.get("load_ckpt", "") != "":
+            self.load_ckpt(hparams["load_ckpt"], strict=False)
+        self.build_disc_model()
+        self.gen_params = [p for n, p in self.model.named_parameters()
+                           if "vc_asr" not in n and "z_mapping_function" not in n]
+        self.mapping_params = list(self.model.z_mapping_function.parameters())
+        return self.model
+
+    def configure_optimizers(self):
+        betas = (hparams["optimizer_adam_beta1"], hparams["optimizer_adam_beta2"])
+        fused = all(p.is_cuda for p in self.gen_params)
+        opt_gen = torch.optim.AdamW(self.gen_params, lr=hparams["lr"], betas=betas, weight_decay=hparams["weight_decay"],
+                                    fused=fused)
+        opt_disc = torch.optim.AdamW(self.disc_params, lr=hparams["disc_lr"], betas=betas, fused=fused,
+                                     **hparams["discriminator_optimizer_params"]) if len(self.disc_params) > 0 else None
+        opt_map = torch.optim.AdamW(self.mapping_params, lr=hparams["map_lr"], betas=betas,
+                                    weight_decay=hparams["weight_decay"], fused=fused)
+        gen_sched = RSQRTSchedule(opt_gen, hparams) if hparams["scheduler"] == "rsqrt" else NoneSchedule(opt_gen, hparams)
+        self.scheduler = {
+            "gen": gen_sched,
+            "disc": torch.optim.lr_scheduler.StepLR(optimizer=opt_disc, **hparams["discriminator_scheduler_params"])
+            if opt_disc is not None else None,
+            "map": torch.optim.lr_scheduler.StepLR(optimizer=opt_map, **hparams["map_scheduler_params"]),
+        }
+        return [opt_gen, opt_disc, opt_map]
+
+    # ------------------------------------------------------------------ losses (tasks/tts/fs2.py:143-175)
+    @staticmethod
+    def weights_nonzero_speech(target):
+        return target.abs().sum(-1, keepdim=True).ne(0).float().expand(-1, -1, target.size(-1))
+
+    def l1_loss(self, out, target):
+        w = self.weights_nonzero_speech(target)
+        return ((out - target).abs() * w).sum() / w.sum()
+
+    def ssim_loss(self, out, target, bias=6.0):
+        w = self.weights_nonzero_speech(target)
+        s = 1 - ssim_map(out[:, None] + bias, target[:, None] + bias, self._ssim_window)
+        return (s * w).sum() / w.sum()
+
+    def add_mel_loss(self, mel_out, target, losses, postfix=""):
+        for name, lbd in self.loss_and_lambda.items():
+            if name == "l1":
+                l = self.l1_loss(mel_out, target)
+            elif name == "ssim":
+                l = self.ssim_loss(mel_out, target)
+            else:
+                raise NotImplementedError(name)
+            losses[f"{name}{postfix}"] = l * lbd
+
+    @staticmethod
+    def get_corresponding_gtmel(way, sample):
+        return sample["mels"] if way in ("a2a", "p2a") else sample["prof_mels"]
+
+    # ------------------------------------------------------------------ model run (svb_vae_task.py:120-165)
+    def run_model(self, model, sample, concurrent_ways, return_output=False, infer=False, disable_map=False, **inject):
+        model.vc_asr.eval()
+        idx = 0 if infer else np.random.randint(1, sample["multi_spk_emb"].shape[1])
+        spk = sample["multi_spk_emb"][:, idx, :]
+        output = model(amateur_mel=sample["mels"], prof_mel=sample["prof_mels"], amateur_pitch=sample["pitch"],
+                       prof_pitch=sample["prof_pitch"], amateur_spk_id=spk, prof_spk_id=spk,
+                       a2p_alignment=sample["a2p_f0_alignment"], p2a_alignment=None, infer=False,
+                       concurrent_ways=concurrent_ways, disable_map=disable_map, **inject)
+        losses = {}
+        for way in concurrent_ways:
+            if "kl" in output[way]:
+                losses[f"{way}_kl"] = output[way]["kl"] * hparams["lambda_kl"]
+            if way not in ("a2a", "p2p") and hparams["cross_way_no_recon_loss"]:
+                continue
+            self.add_mel_loss(output[way]["mel_out"], self.get_corresponding_gtmel(way, sample), losses, postfix=way)
+        return (losses, output) if return_output else losses
+
+    # ------------------------------------------------------------------ GAN helpers (svb_para.py:118-170)
+    def gen_cheat_disc(self, way, model_out, log_outputs, loss_weights):
+        p_ = self.mel_disc(model_out[way]["mel_out"], None)["y"]
+        if p_ is not None:
+            log_outputs[f"{way}_a"] = self.mse_loss_fn(p_, torch.ones_like(p_))
+            loss_weights[f"{way}_a"] = hparams["lambda_mel_adv"]
+
+    def disc_judge_gen(self, way, sample, log_outputs):
+        p = self.mel_disc(self.get_corresponding_gtmel(way, sample), None)["y"]
+        p_ = self.mel_disc(self.model_out_gt[way]["mel_out"], None)["y"]
+        if p_ is not None:
+            log_outputs[f"{way}_r"] = self.mse_loss_fn(p, torch.ones_like(p))
+            log_outputs[f"{way}_f"] = self.mse_loss_fn(p_, torch.zeros_like(p_))
+
+    def phase_of(self, step):
+        if step <= hparams["phase_1_steps"]:
+            return 1, hparams["phase_1_concurrent_ways"].split(",")
+        if step <= hparams["phase_2_steps"]:
+            return 2, hparams["phase_2_concurrent_ways"].split(",")
+        return 3, hparams["phase_3_concurrent_ways"].split(",")
+
+    # ------------------------------------------------------------------ the step (svb_vae_task.py:579-676)
+    def _training_step(self, sample, batch_idx, optimizer_idx):
+        log_outputs, loss_weights = {}, {}
+        disc_start = hparams["mel_gan"] and self.global_step > hparams["disc_start_steps"] and hparams["lambda_mel_adv"] > 0
+        phase, ways = self.phase_of(self.global_step)
+        if optimizer_idx == 0:
+            if phase in (1, 2):
+                self.model.z_mapping_function.eval()
+                log_outputs, model_out = self.run_model(self.model, sample, ways, return_output=True)
+                self.model_out = {w: {k: v.detach() for k, v in o.items() if isinstance(v, torch.Tensor)}
+                                  for w, o in model_out.items()}
+                self.model_out_gt = self.model_out
+                if disc_start:
+                    for way in ways:
+                        self.gen_cheat_disc(way, model_out, log_outputs, loss_weights)
+        elif optimizer_idx == 1:
+            if phase in (1, 2):
+                self.model.z_mapping_function.eval()
+                if disc_start and self.global_step % hparams["disc_interval"] == 0:
+                    for way in ways:
+                        self.disc_judge_gen(way, sample, log_outputs)
+        elif optimizer_idx == 2:
+            if phase == 3:
+                self.model.eval()
+                self.model.z_mapping_function.train()
+                log_outputs, model_out = self.run_model(self.model, sample, ["a2a", "p2p"] + ways, return_output=True)
+                for way in ways:
+                    cross = model_out[way]
+                    log_outputs[f"{way}_mle"] = cross["mle"]
+                    loss_weights[f"{way}_mle"] = hparams["lambda_mle"]
+                    if not hparams["cross_way_no_disc_loss"]:
+                        p_ = self.mel_disc(cross["mel_out"], None)["y"]
+                        if p_ is not None:
+                            log_outputs[f"{way}_a"] = self.mse_loss_fn(p_, torch.ones_like(p_))
+                            loss_weights[f"{way}_a"] = hparams["lambda_mel_adv"]
+        if len(log_outputs) == 0:
+            return None
+        for way in ("a2a", "p2p", "a2p"):           # non-finite KL / MLE terms contribute no gradient (:665-672)
+            for suffix in ("kl", "mle"):
+                k = f"{way}_{suffix}"
+                if k in log_outputs:
+                    v = log_outputs[k]
+                    log_outputs[k] = torch.where(torch.isfinite(v), v, v.detach())
+        total = sum(loss_weights.get(k, 1) * v for k, v in log_outputs.items())
+        log_outputs["bs"] = sample["mels"].shape[0]
+        return total, log_outputs
+
+    def on_before_optimization(self, opt_idx):
+        params, norm = ((self.gen_params, hparams["generator_grad_norm"]),
+                        (self.disc_params, hparams["discriminator_grad_norm"]),
+                        (self.mapping_params, hparams["generator_grad_norm"]))[opt_idx]
+        torch.nn.utils.clip_grad_norm_(params, norm, foreach=True)
+
+    def on_after_optimization(self, epoch, batch_idx, optimizer, optimizer_idx):
+        if optimizer_idx == 0:
+            self.scheduler["gen"].step(self.global_step)
+        elif optimizer_idx == 1:
+            self.scheduler["disc"].step(max(self.global_step - hparams["disc_start_steps"], 1))
+        elif optimizer_idx == 2:
+            self.scheduler["map"].step(self.global_step)
+
+    # ------------------------------------------------------------------ validation / test
+    def validation_step(self, sample, batch_idx):
+        phase, _ = self.phase_of(self.global_step)
+        ways = {1: ["p2p"], 2: ["a2a", "p2p"], 3: ["a2a", "p2p", "a2p"]}[phase]
+        losses, model_out = self.run_model(self.model, sample, ways, return_output=True, infer=True,
+                                           disable_map=hparams["disable_map"])
+        for way in ways:
+            if "mle" in model_out[way]:
+                losses[f"{way}_mle"] = model_out[way]["mle"]
+        out = {"losses": losses, "total_loss": sum(losses.values()), "nsamples": sample["nsamples"]}
+        return {k: ({kk: float(vv) for kk, vv in v.items()} if isinstance(v, dict) else float(v)) for k, v in out.items()}
+
+    def test_step(self, sample, batch_idx):
+        from .infer import infer_and_save
+        return infer_and_save(self, sample, batch_idx)
+
+    # ------------------------------------------------------------------ data (tasks/tts/tts.py:57-101)
+    @data_loader
+    def train_dataloader(self):
+        ds = self.dataset_cls(hparams["train_set_name"], True)
+        return self.build_dataloader(ds, True, hparams["max_tokens"], hparams["max_sentences"],
+                                     endless=hparams["endless_ds"])
+
+    @data_loader
+    def val_dataloader(self):
+        ds = self.dataset_cls(hparams["valid_set_name"], False)
+        return self.build_dataloader(ds, False, hparams["max_valid_tokens"], hparams["max_valid_sentences"])
+
+    @data_loader
+    def test_dataloader(self):
+        ds = self.dataset_cls(hparams["test_set_name"], False)
+        return self.build_dataloader(ds, False, hparams["max_valid_tokens"], hparams["max_valid_sentences"],
+                                     batch_by_size=False)

@@ -1,0 +1,102 @@
+"""Module-level parity of the HIP MleSVBVAE against (a) the reference's state_dict layout, (b) golden vectors
+produced by the unmodified reference and (c) the CPU oracle's gradients.  emu (CPU) + gpu."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import modules_ref as R
+from oracle import procedural
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+KEYS = json.load(open(os.path.join(G, "ref_state_keys.json")))
+HP = json.load(open(os.path.join(G, "ref_hparams_vae_global_mle_eng.json")))
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def build_model(dev):
+    from neuralsvb_amd.modules.svb_vae import MleSVBVAE
+    model = MleSVBVAE(70, HP)
+    sd = procedural.state_dict_for(KEYS["MleSVBVAE"], prefix="model.")
+    ref_keys = [(k, tuple(s)) for k, s, _ in KEYS["MleSVBVAE"]]
+    mine = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert sorted(mine) == sorted(ref_keys), (set(mine) ^ set(ref_keys))
+    model.load_state_dict(sd, strict=True)
+    return model.to(dev), sd
+
+
+def test_state_dict_layout_matches_reference():
+    build_model(torch.device("cpu"))
+
+
+def _skip_slow_emu(dev):
+    if dev.type == "cpu" and not os.environ.get("SVB_SLOW_EMU"):
+        pytest.skip("full-size model through the lane emulator takes minutes; set SVB_SLOW_EMU=1 (runs on the GPU by default)")
+
+
+def test_mle_svb_vae_forward_matches_reference_golden(dev):
+    _skip_slow_emu(dev)
+    d = np.load(os.path.join(G, "vae_mle.npz"))
+    model, _ = build_model(dev)
+    model.train()
+    with torch.no_grad():
+        out = model(amateur_mel=t(d["mels"]).to(dev), prof_mel=t(d["prof_mels"]).to(dev),
+                    amateur_pitch=t(d["pitch"]).to(dev), prof_pitch=t(d["prof_pitch"]).to(dev),
+                    amateur_spk_id=t(d["spk"]).to(dev), prof_spk_id=t(d["spk"]).to(dev),
+                    a2p_alignment=t(d["a2p_alignment"]).to(dev), infer=False, concurrent_ways=["a2a", "p2p", "a2p"],
+                    eps_a2a=t(d["eps_a2a"]).to(dev), eps_p2p=t(d["eps_p2p"]).to(dev))
+    ca, _ = model._last_conds
+    for k in ("h_pitch", "h_content"):
+        err = (ca[k].transpose(1, 2).cpu() - t(d[f"cond_a.{k}"])).abs().max().item()
+        assert err < 2e-4, (k, err)
+    for way in ("a2a", "p2p"):
+        for k in ("mel_out", "kl", "m_q", "logs_q", "z_q", "x_mask_sqz"):
+            ref = t(d[f"{way}.{k}"])
+            err = (out[way][k].cpu() - ref).abs().max().item()
+            assert out[way][k].shape == ref.shape
+            # latent statistics go through exp() and train-mode BatchNorm over very few positions: relative bound
+            tol = 2e-4 * max(1.0, ref.abs().max().item()) if k in ("z_q", "m_q", "logs_q") else 1e-4
+            assert err < tol, (way, k, err)
+    # north-star gate: mel-L1 vs reference <= 1e-4
+    for way in ("a2a", "p2p", "a2p"):
+        l1 = (out[way]["mel_out"].cpu() - t(d[f"{way}.mel_out"])).abs().mean().item()
+        assert l1 <= 1e-4, (way, l1)
+    assert abs(out["a2p"]["mle"].item() - float(d["a2p.mle"])) < 2e-4
+
+
+@pytest.mark.slow
+def test_mle_svb_vae_gradients_match_oracle(dev):
+    """d(loss)/d(params) of the a2a+p2p generator objective (KL + L1) vs torch autograd over the CPU oracle."""
+    _skip_slow_emu(dev)
+    d = np.load(os.path.join(G, "vae_mle.npz"))
+    model, sd = build_model(dev)
+    model.train()
+    args = [t(d[k]) for k in ("mels", "prof_mels", "pitch", "prof_pitch", "spk", "a2p_alignment")]
+    sdr = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.startswith("vc_asr") else v)
+           for k, v in sd.items()}
+    ret, _, _ = R.mle_svb_vae(sdr, *args, ["a2a", "p2p"], t(d["eps_a2a"]), t(d["eps_p2p"]), HP, training=True)
+    loss_r = sum(ret[w]["kl"] * 0.001 + R.l1_loss(ret[w]["mel_out"], tg) for w, tg in (("a2a", args[0]), ("p2p", args[1])))
+    loss_r.backward()
+    out = model(amateur_mel=args[0].to(dev), prof_mel=args[1].to(dev), amateur_pitch=args[2].to(dev),
+                prof_pitch=args[3].to(dev), amateur_spk_id=args[4].to(dev), prof_spk_id=args[4].to(dev),
+                a2p_alignment=args[5].to(dev), infer=False, concurrent_ways=["a2a", "p2p"],
+                eps_a2a=t(d["eps_a2a"]).to(dev), eps_p2p=t(d["eps_p2p"]).to(dev))
+    loss = sum(out[w]["kl"] * 0.001 + R.l1_loss(out[w]["mel_out"], tg.to(dev))
+               for w, tg in (("a2a", args[0]), ("p2p", args[1])))
+    assert abs(loss.item() - loss_r.item()) < 1e-4
+    loss.backward()
+    worst = 0.0
+    for k, p in model.named_parameters():
+        if k.startswith("vc_asr") or k.startswith("z_mapping_function"):
+            continue
+        gr = sdr[k].grad
+        assert gr is not None and p.grad is not None, k
+        rel = ((p.grad.cpu() - gr).abs().max() / gr.abs().max().clamp_min(1e-8)).item()
+        worst = max(worst, rel)
+        assert rel < 2e-3, (k, rel)
+    print("worst relative grad error", worst)
