@@ -89,7 +89,11 @@ def cpu_baseline(task, batch, hp, args):
     """Oracle CPU port of the same step on a bounded sample (B = cpu_batch clips), all host cores."""
     from oracle.train_step_ref import CpuStep
     nb = min(args.cpu_batch, batch["mels"].shape[0])
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, args.cpu_threads)) if args.cpu_threads > 0 else cores
     torch.set_num_threads(cores)
     msd = {k: v.detach().cpu() for k, v in task.model.state_dict().items()}
     dsd = {k: v.detach().cpu() for k, v in task.mel_disc.state_dict().items()}
@@ -112,7 +116,13 @@ def cpu_baseline(task, batch, hp, args):
             "s_per_step": t}
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(600, exit=False, file=sys.stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -123,6 +133,7 @@ def main():
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all cores in this process's affinity mask")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -139,9 +150,13 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     with tempfile.TemporaryDirectory() as tmp:
+        log("building synthetic dataset + task")
         task, trainer, batch, hp = build_task(args, rank, world, device, tmp)
         T = batch["mels"].shape[1]
+        log(f"task ready, batch mels {tuple(batch['mels'].shape)}; warmup")
         run_steps(trainer, task, batch, args.warmup, 1)
+        torch.cuda.synchronize()
+        log("timed region")
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -157,6 +172,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = tt.item()
         ms = dt / args.steps * 1e3
+        log(f"{ms:.2f} ms/step")
         value = args.batch * args.seconds * world / (dt / args.steps)
         roof = cpu = None
         if rank == 0 and not args.no_roofline:
@@ -164,7 +180,9 @@ def main():
         if world > 1:
             dist.barrier()
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline (oracle port)")
             cpu = cpu_baseline(task, batch, hp, args)
+            log(f"cpu baseline done: {cpu['s_per_step']:.2f} s/step on {cpu['cores']} threads")
         if rank == 0:
             print(json.dumps({
                 "metric": "audio-seconds/sec per train step (vae_global_mle_eng)", "value": value,

@@ -106,6 +106,15 @@ int svb_layernorm_nct_fwd(const float* x, const float* gamma, const float* beta,
 int svb_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* mean, const float* rstd,
                       float* dx, float* dgamma_part, float* dbeta_part, int rows, int C, int n_part, void* stream);
 
+/* ---- SSIM map of two [B, T, F] mel images (+bias), 11x11 gaussian sigma 1.5, zero padding, C1=1e-4, C2=9e-4
+ * (reference modules/commons/ssim.py:331-351 via tasks/tts/fs2.py:166-175).  Inputs are addressed with element
+ * strides (batch, time, bin) so the decoder's [B,F,T] output is read in place.  out_map/dmap/dpred: contiguous
+ * [B,T,F].  Only `pred` receives a gradient.  workspace: 3*B*T*F floats.                                      */
+int svb_ssim_fwd(const float* pred, long psb, long pst, long psf, const float* tgt, long tsb, long tst, long tsf,
+                 float* out_map, int B, int T, int F, float bias, void* stream);
+int svb_ssim_bwd(const float* pred, long psb, long pst, long psf, const float* tgt, long tsb, long tst, long tsf,
+                 const float* dmap, float* dpred, float* workspace, int B, int T, int F, float bias, void* stream);
+
 /* ---- STFT magnitude + mel filterbank + log, one kernel (reference data_gen/tts/data_gen_utils.py:123-134 and
  * modules/hifigan/mel_utils.py:45-79).  wav: [B, N].  mode 0 = offline front-end: zero-pad n_fft/2 both sides
  * ("center", pad_mode constant), frames = 1 + N/hop, |X|, log10(max(eps, mel)), out [B, frames, n_mels];

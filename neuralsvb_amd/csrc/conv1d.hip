@@ -18,14 +18,17 @@
 #include "svb_common.h"
 #include "conv1d.h"
 
-template <int WM, int WN, int NT, int XS_TOTAL, int WS_TOTAL>
+template <int WM, int WN, int NT, int XS_TOTAL, int WS_ROWS>
 __global__ __launch_bounds__(256) void svb_conv1d_mfma_kernel(SvbConvArgs a, SvbConvPlan p) {
-    constexpr int BM = 32 * WM, BN = 32 * WN * NT, KCMAX = 16;
-    constexpr int TG = WS_TOTAL / (KCMAX * BM);
+    constexpr int BM = 32 * WM, BN = 32 * WN * NT;
+    constexpr int RPW = 16;                              // x rows staged per wave per chunk (kc <= 64)
+    constexpr int NJ = 3;                                // 64-lane column groups per x row on the fast path (span <= 192)
+    constexpr int BM4 = BM / 4;
+    constexpr int WUNITS = WS_ROWS * BM4;                // float4 units in the W tile
+    constexpr int WU = (WUNITS + 255) / 256;
     static_assert(WM * WN == 4, "256 threads = 4 waves");
-    static_assert(TG >= 1, "weight stage too small");
-    __shared__ float xs[XS_TOTAL];
-    __shared__ float ws[WS_TOTAL];
+    __shared__ __attribute__((aligned(16))) float xs[XS_TOTAL];
+    __shared__ __attribute__((aligned(16))) float ws[WS_ROWS * BM];
     __shared__ int tap_lds[SVB_MAX_TAPS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -63,53 +66,151 @@ __global__ __launch_bounds__(256) void svb_conv1d_mfma_kernel(SvbConvArgs a, Svb
 
     const int m_base = mtile * BM;
     const int m_valid = min(BM, a.Cout_g - m_base);
+    const float* xb = a.x + ((size_t)b * a.Cin + (size_t)g * a.Cin_g) * a.Tin;
+    const float* gb = a.in_gate ? a.in_gate + ((size_t)b * a.Cin + (size_t)g * a.Cin_g) * a.Tin : nullptr;
+    const float* wbase = a.wp + (size_t)g * a.w_goff_k * a.w_ld + (size_t)g * a.w_goff_m + m_base;
 
-    for (int c0 = 0; c0 < a.Cin_g; c0 += a.kc) {
+    // ---- register staging (all global loads of a stage are issued before any LDS store) ----------------------
+    float xr[RPW][NJ];
+    float4 wr[WU];
+
+    auto load_x = [&](int c0) {
         const int kc = min(a.kc, a.Cin_g - c0);
         const int kcp = (kc + 1) & ~1;
-        for (int tg = 0; tg < ntap; tg += TG) {
-            const int nt_here = min(TG, ntap - tg);
-            __syncthreads();
-            if (tg == 0) {
-                for (int r = wave; r < kcp; r += 4) {
-                    const bool rv = r < kc;
-                    const size_t roff = ((size_t)b * a.Cin + (size_t)g * a.Cin_g + c0 + r) * a.Tin;
-                    const float* xr = a.x + roff;
-                    const float* gr = a.in_gate ? a.in_gate + roff : nullptr;
-                    float* xd = xs + r * a.xrow;
-                    for (int i = lane; i < span; i += 64) {
-                        const int pos = lo + i;
-                        float v = 0.f;
-                        if (rv && pos >= 0 && pos < a.Tin) {
-                            v = xr[pos];
-                            if (gr) v *= svb_gate(gr[pos], a.in_slope);
-                        }
-                        const int di = (a.sx == 1) ? i : (i % a.sx) * a.ph_len + i / a.sx;
-                        xd[di] = v;
-                    }
-                }
-            }
-            for (int r = wave; r < nt_here * kcp; r += 4) {
-                const int t = r / kcp, c = r - t * kcp;
-                const int wt = p.tap_w[t0 + tg + t];
-                const float* wr = a.wp + (size_t)wt * a.w_tap_stride +
-                                  (size_t)(g * a.w_goff_k + c0 + c) * a.w_ld + (size_t)g * a.w_goff_m + m_base;
-                float* wd = ws + (t * KCMAX + c) * BM;
-                for (int m = lane; m < BM; m += 64) wd[m] = (c < kc && m < m_valid) ? wr[m] : 0.f;
-            }
-            __syncthreads();
-            for (int t = 0; t < nt_here; ++t) {
-                const float* wsa = ws + (t * KCMAX + kk) * BM + wm * 32 + l31;
-                const float* xsb = xs + kk * a.xrow + tap_lds[tg + t] + (wn * NT) * 32 + l31;
-                for (int c2 = 0; c2 < kcp; c2 += 2) {
-                    const float av = wsa[c2 * BM];
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        const float bv = xsb[c2 * a.xrow + n * 32];
-                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[n], 0, 0, 0);
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave + 4 * rr;
+            if (r < kcp) {
+                const float* xrow_p = xb + (size_t)(c0 + r) * a.Tin;
+                const float* grow_p = gb ? gb + (size_t)(c0 + r) * a.Tin : nullptr;
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    const int i = lane + 64 * jj;
+                    const int pos = lo + i;
+                    float v = 0.f;
+                    if (r < kc && i < span && pos >= 0 && pos < a.Tin) {
+                        v = xrow_p[pos];
+                        if (grow_p) v *= svb_gate(grow_p[pos], a.in_slope);
+                    }
+                    xr[rr][jj] = v;
+                }
+            }
+        }
+    };
+    auto store_x = [&](int c0) {
+        const int kc = min(a.kc, a.Cin_g - c0);
+        const int kcp = (kc + 1) & ~1;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave + 4 * rr;
+            if (r < kcp) {
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) {
+                    const int i = lane + 64 * jj;
+                    if (i < span) {
+                        const int di = (a.sx == 1) ? i : (i % a.sx) * a.ph_len + i / a.sx;
+                        xs[r * a.xrow + di] = xr[rr][jj];
                     }
                 }
             }
+        }
+    };
+    // generic (slow) x staging for wide spans / many rows: direct global -> LDS
+    auto stage_x_slow = [&](int c0) {
+        const int kc = min(a.kc, a.Cin_g - c0);
+        const int kcp = (kc + 1) & ~1;
+        for (int r = wave; r < kcp; r += 4) {
+            const float* xrow_p = xb + (size_t)(c0 + r) * a.Tin;
+            const float* grow_p = gb ? gb + (size_t)(c0 + r) * a.Tin : nullptr;
+            for (int i = lane; i < span; i += 64) {
+                const int pos = lo + i;
+                float v = 0.f;
+                if (r < kc && pos >= 0 && pos < a.Tin) {
+                    v = xrow_p[pos];
+                    if (grow_p) v *= svb_gate(grow_p[pos], a.in_slope);
+                }
+                const int di = (a.sx == 1) ? i : (i % a.sx) * a.ph_len + i / a.sx;
+                xs[r * a.xrow + di] = v;
+            }
+        }
+    };
+    auto load_w = [&](int c0, int tg) {
+        const int kc = min(a.kc, a.Cin_g - c0);
+        const int nt_here = min(a.tg, ntap - tg);
+        const int rows_here = nt_here * a.kc;
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            const int unit = u * 256 + tid;
+            const int row = unit / BM4, col = (unit - row * BM4) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (unit < WUNITS && row < rows_here) {
+                const int t = row / a.kc, c = row - t * a.kc;
+                if (c < kc && col < m_valid) {
+                    const float* src = wbase + (size_t)p.tap_w[t0 + tg + t] * a.w_tap_stride + (size_t)(c0 + c) * a.w_ld + col;
+                    if (a.w_vec && col + 3 < m_valid) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        v.x = src[0];
+                        if (col + 1 < m_valid) v.y = src[1];
+                        if (col + 2 < m_valid) v.z = src[2];
+                        if (col + 3 < m_valid) v.w = src[3];
+                    }
+                }
+            }
+            wr[u] = v;
+        }
+    };
+    auto store_w = [&](int tg) {
+        const int nt_here = min(a.tg, ntap - tg);
+        const int rows_here = nt_here * a.kc;
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            const int unit = u * 256 + tid;
+            const int row = unit / BM4;
+            if (unit < WUNITS && row < rows_here) *reinterpret_cast<float4*>(ws + unit * 4) = wr[u];
+        }
+    };
+    auto compute = [&](int c0, int tg) {
+        const int kc = min(a.kc, a.Cin_g - c0);
+        const int kcp = (kc + 1) & ~1;
+        const int nt_here = min(a.tg, ntap - tg);
+        for (int t = 0; t < nt_here; ++t) {
+            const float* wsa = ws + (t * a.kc + kk) * BM + wm * 32 + l31;
+            const float* xsb = xs + kk * a.xrow + tap_lds[tg + t] + (wn * NT) * 32 + l31;
+            for (int c2 = 0; c2 < kcp; c2 += 2) {
+                const float av = wsa[c2 * BM];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float bv = xsb[c2 * a.xrow + n * 32];
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[n], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- software pipeline: global loads of step s+1 are in flight while step s runs on the matrix cores --------
+    int c0 = 0, tg = 0;
+    if (ntap > 0) {
+        __syncthreads();                                   // tap_lds visible
+        if (a.fast_x) { load_x(0); store_x(0); } else { stage_x_slow(0); }
+        load_w(0, 0);
+        store_w(0);
+        __syncthreads();
+        while (true) {
+            int ntg = tg + a.tg, nc0 = c0;
+            if (ntg >= ntap) { ntg = 0; nc0 = c0 + a.kc; }
+            const bool has_next = nc0 < a.Cin_g;
+            if (has_next) {
+                if (ntg == 0 && a.fast_x) load_x(nc0);
+                load_w(nc0, ntg);
+            }
+            compute(c0, tg);
+            if (!has_next) break;
+            __syncthreads();
+            if (ntg == 0) { if (a.fast_x) store_x(nc0); else stage_x_slow(nc0); }
+            store_w(ntg);
+            __syncthreads();
+            c0 = nc0; tg = ntg;
         }
     }
 
@@ -168,54 +269,106 @@ __global__ __launch_bounds__(256) void svb_conv1d_wgrad_kernel(SvbWgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    for (int chunk = blockIdx.y; chunk < a.total_chunks; chunk += a.nsplit) {
+    constexpr int NJB = 2;                                  // 64-lane column groups of the tap-strided tile (span <= 128)
+    const bool fast = span <= 64 * NJB;
+    float ar[16];
+    float br[16][NJB];
+    const float* a_base = a.a + (size_t)g * a.CA_g * a.TA;
+    const float* ag_base = a.a_gate ? a.a_gate + (size_t)g * a.CA_g * a.TA : nullptr;
+    const float* b_base = a.b + (size_t)g * a.CB_g * a.TB;
+    const float* bg_base = a.b_gate ? a.b_gate + (size_t)g * a.CB_g * a.TB : nullptr;
+
+    auto load_tiles = [&](int chunk) {
         const int bb = chunk / a.chunks_per_b;
         const int q0 = (chunk - bb * a.chunks_per_b) * a.qc;
-        __syncthreads();
-        for (int r = wave; r < 64; r += 4) {
-            const bool rv = (a0 + r) < a.CA_g;
-            const size_t roff = ((size_t)bb * a.CA + (size_t)g * a.CA_g + a0 + r) * a.TA;
-            const float* ar = a.a + roff;
-            const float* gr = a.a_gate ? a.a_gate + roff : nullptr;
-            if (lane < a.qc) {
+        const int lo = q0 * a.sx + min_off;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int r = wave + 4 * rr;
+            {
+                const size_t roff = ((size_t)bb * a.CA + a0 + r) * a.TA;
                 const int q = q0 + lane;
                 float v = 0.f;
-                if (rv && q < a.TA) {
-                    v = ar[q];
-                    if (gr) v *= svb_gate(gr[q], a.a_slope);
+                if ((a0 + r) < a.CA_g && lane < a.qc && q < a.TA) {
+                    v = a_base[roff + q];
+                    if (ag_base) v *= svb_gate(ag_base[roff + q], a.a_slope);
                 }
-                As[r * AROW + lane] = v;
+                ar[rr] = v;
             }
-        }
-        const int lo = q0 * a.sx + min_off;
-        for (int r = wave; r < 64; r += 4) {
-            const bool rv = (b0 + r) < a.CB_g;
-            const size_t roff = ((size_t)bb * a.CB + (size_t)g * a.CB_g + b0 + r) * a.TB;
-            const float* br = a.b + roff;
-            const float* gr = a.b_gate ? a.b_gate + roff : nullptr;
-            float* bd = Bs + r * a.brow;
-            for (int i = lane; i < span; i += 64) {
-                const int pos = lo + i;
-                float v = 0.f;
-                if (rv && pos >= 0 && pos < a.TB) {
-                    v = br[pos];
-                    if (gr) v *= svb_gate(gr[pos], a.b_slope);
-                }
-                bd[i] = v;
-            }
-        }
-        __syncthreads();
-        const float* asa = As + (wm * 32 + l31) * AROW + kk;
-        const float* bsb = Bs + (wn * 32 + l31) * a.brow + kk * a.sx;
-        for (int qq = 0; qq < a.qc; qq += 2) {
-            const float av = asa[qq];
+            if (fast) {
+                const size_t roff = ((size_t)bb * a.CB + b0 + r) * a.TB;
 #pragma unroll
-            for (int t = 0; t < TGW; ++t) {
-                if (t < ntap) {
-                    const float bv = bsb[qq * a.sx + t * a.dil];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                for (int jj = 0; jj < NJB; ++jj) {
+                    const int i = lane + 64 * jj;
+                    const int pos = lo + i;
+                    float v = 0.f;
+                    if ((b0 + r) < a.CB_g && i < span && pos >= 0 && pos < a.TB) {
+                        v = b_base[roff + pos];
+                        if (bg_base) v *= svb_gate(bg_base[roff + pos], a.b_slope);
+                    }
+                    br[rr][jj] = v;
                 }
             }
+        }
+    };
+    auto store_tiles = [&](int chunk) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int r = wave + 4 * rr;
+            if (lane < a.qc) As[r * AROW + lane] = ar[rr];
+            if (fast) {
+#pragma unroll
+                for (int jj = 0; jj < NJB; ++jj) {
+                    const int i = lane + 64 * jj;
+                    if (i < span) Bs[r * a.brow + i] = br[rr][jj];
+                }
+            }
+        }
+        if (!fast) {   // wide (strided) spans: direct global -> LDS
+            const int bb = chunk / a.chunks_per_b;
+            const int q0 = (chunk - bb * a.chunks_per_b) * a.qc;
+            const int lo = q0 * a.sx + min_off;
+            for (int r = wave; r < 64; r += 4) {
+                const size_t roff = ((size_t)bb * a.CB + b0 + r) * a.TB;
+                for (int i = lane; i < span; i += 64) {
+                    const int pos = lo + i;
+                    float v = 0.f;
+                    if ((b0 + r) < a.CB_g && pos >= 0 && pos < a.TB) {
+                        v = b_base[roff + pos];
+                        if (bg_base) v *= svb_gate(bg_base[roff + pos], a.b_slope);
+                    }
+                    Bs[r * a.brow + i] = v;
+                }
+            }
+        }
+    };
+
+    int chunk = blockIdx.y;
+    if (chunk < a.total_chunks) {
+        load_tiles(chunk);
+        store_tiles(chunk);
+        __syncthreads();
+        while (true) {
+            const int next = chunk + a.nsplit;
+            const bool has_next = next < a.total_chunks;
+            if (has_next) load_tiles(next);
+            const float* asa = As + (wm * 32 + l31) * AROW + kk;
+            const float* bsb = Bs + (wn * 32 + l31) * a.brow + kk * a.sx;
+            for (int qq = 0; qq < a.qc; qq += 2) {
+                const float av = asa[qq];
+#pragma unroll
+                for (int t = 0; t < TGW; ++t) {
+                    if (t < ntap) {
+                        const float bv = bsb[qq * a.sx + t * a.dil];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            if (!has_next) break;
+            __syncthreads();
+            store_tiles(next);
+            __syncthreads();
+            chunk = next;
         }
     }
 
@@ -335,39 +488,47 @@ static int pick_cfg(int cout_g, int nq_max) {
     return best;
 }
 
-template <int WM, int WN, int NT, int XS, int WS>
-static int launch_cfg(SvbConvArgs& a, const SvbConvPlan& p, int nq_max, int span_off_max, hipStream_t stream) {
+template <int WM, int WN, int NT, int XS, int WS_ROWS>
+static int launch_cfg(SvbConvArgs& a, const SvbConvPlan& p, int nq_max, int span_off_max, int ntap_max, hipStream_t stream) {
     constexpr int BM = 32 * WM, BN = 32 * WN * NT;
     const int span_max = (BN - 1) * a.sx + span_off_max + 1;
     a.ph_len = svb_cdiv(span_max, a.sx);
     a.xrow = a.ph_len * a.sx;
-    int kc = XS / a.xrow;
-    if (kc > 16) kc = 16;
+    a.tg = ntap_max < 5 ? (ntap_max > 0 ? ntap_max : 1) : 5;       // taps per weight stage
+    int kc = XS / a.xrow;                                            // channels per K-chunk
+    if (kc > WS_ROWS / a.tg) kc = WS_ROWS / a.tg;
+    if (kc > 64) kc = 64;
+    if (kc > ((a.Cin_g + 1) & ~1)) kc = (a.Cin_g + 1) & ~1;
     kc &= ~1;
     if (kc < 2) return SVB_ERR_UNSUPPORTED;
     a.kc = kc;
+    a.fast_x = span_max <= 192 ? 1 : 0;
+    a.w_vec = (a.w_ld % 4 == 0 && a.w_tap_stride % 4 == 0 && a.w_goff_m % 4 == 0 &&
+               ((size_t)a.w_goff_k * a.w_ld) % 4 == 0 && ((uintptr_t)a.wp % 16) == 0) ? 1 : 0;
     dim3 grid(a.G * svb_cdiv(a.Cout_g, BM), svb_cdiv(nq_max, BN), a.B * p.n_phase);
-    hipLaunchKernelGGL((svb_conv1d_mfma_kernel<WM, WN, NT, XS, WS>), grid, dim3(256), 0, stream, a, p);
+    hipLaunchKernelGGL((svb_conv1d_mfma_kernel<WM, WN, NT, XS, WS_ROWS>), grid, dim3(256), 0, stream, a, p);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
 
 static int launch_conv(SvbConvArgs& a, const SvbConvPlan& p, hipStream_t stream) {
-    int nq_max = 0, span_off_max = 0;
+    int nq_max = 0, span_off_max = 0, ntap_max = 0;
     for (int ph = 0; ph < p.n_phase; ++ph) {
         if (p.phase_nq[ph] > nq_max) nq_max = p.phase_nq[ph];
         if (p.phase_span_off[ph] > span_off_max) span_off_max = p.phase_span_off[ph];
+        const int nt = p.phase_start[ph + 1] - p.phase_start[ph];
+        if (nt > ntap_max) ntap_max = nt;
     }
     if (nq_max <= 0) return SVB_OK;
     if ((long)a.B * p.n_phase > 65535) return SVB_ERR_UNSUPPORTED;
     int cfg = pick_cfg(a.Cout_g, nq_max);
     if (a.force_cfg >= 0 && a.force_cfg < 5) cfg = a.force_cfg;
     switch (cfg) {
-        case 0: return launch_cfg<2, 2, 2, 8192, 5120>(a, p, nq_max, span_off_max, stream);
-        case 1: return launch_cfg<4, 1, 3, 8192, 10240>(a, p, nq_max, span_off_max, stream);
-        case 2: return launch_cfg<4, 1, 4, 8192, 10240>(a, p, nq_max, span_off_max, stream);
-        case 3: return launch_cfg<2, 2, 1, 8192, 5120>(a, p, nq_max, span_off_max, stream);
-        default: return launch_cfg<1, 4, 1, 8192, 2560>(a, p, nq_max, span_off_max, stream);
+        case 0: return launch_cfg<2, 2, 2, 8192, 80>(a, p, nq_max, span_off_max, ntap_max, stream);
+        case 1: return launch_cfg<4, 1, 3, 8192, 80>(a, p, nq_max, span_off_max, ntap_max, stream);
+        case 2: return launch_cfg<4, 1, 4, 8192, 80>(a, p, nq_max, span_off_max, ntap_max, stream);
+        case 3: return launch_cfg<2, 2, 1, 8192, 80>(a, p, nq_max, span_off_max, ntap_max, stream);
+        default: return launch_cfg<1, 4, 1, 8192, 80>(a, p, nq_max, span_off_max, ntap_max, stream);
     }
 }
 

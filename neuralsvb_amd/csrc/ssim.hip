@@ -1,0 +1,181 @@
+// ssim.hip -- SSIM map of two mel "images" [B, T, F] with an 11x11 gaussian window, forward and backward, as
+// streaming stencil kernels (gfx950).  Replaces the five depthwise F.conv2d calls + ~15 elementwise passes of the
+// reference's mel loss (modules/commons/ssim.py:331-351, called by tasks/tts/fs2.py:166-175 on [B,1,T,80]+6).
+//
+// One workgroup owns a tile of TT frames x all F bins; x=pred+bias and y=target+bias are staged once into LDS with the
+// 5-wide zero halo that F.conv2d(padding=5) implies, and every thread evaluates full 11x11 windows from LDS
+// (121 taps x 5 moments per pixel: ~1.7 GFLOP at B=16 -- VALU work that hides under the HBM stream).
+// Algorithmic bytes: forward reads 2 and writes 1 value per pixel (12 B/pixel); backward reads 3, writes 1 (+3 maps
+// of workspace written and re-read).  Strided inputs are accepted so the [B,80,T] decoder output is read in place.
+#include "svb_common.h"
+#include "../../include/svb_hip.h"
+
+#define SSIM_W 11
+#define SSIM_R 5
+#define SSIM_TT 16
+#define SSIM_FMAX 128
+
+struct SsimWin { float g[SSIM_W]; };
+
+struct SsimStats { float mu1, mu2, e11, e22, e12; };
+
+__device__ __forceinline__ SsimStats ssim_window(const float* xs, const float* ys, int row, int col, int ld, const SsimWin& w) {
+    SsimStats s = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < SSIM_W; ++i) {
+        const float gi = w.g[i];
+        const float* xr = xs + (row + i) * ld + col;
+        const float* yr = ys + (row + i) * ld + col;
+#pragma unroll
+        for (int j = 0; j < SSIM_W; ++j) {
+            const float wij = gi * w.g[j];
+            const float x = xr[j], y = yr[j];
+            s.mu1 = fmaf(wij, x, s.mu1);
+            s.mu2 = fmaf(wij, y, s.mu2);
+            s.e11 = fmaf(wij, x * x, s.e11);
+            s.e22 = fmaf(wij, y * y, s.e22);
+            s.e12 = fmaf(wij, x * y, s.e12);
+        }
+    }
+    return s;
+}
+
+// stage x,y rows [t0-halo, t0+TT+halo) x cols [-5, F+5) into LDS (zero outside the image)
+__device__ __forceinline__ void ssim_stage(const float* p, long sb, long st, long sf, int b, int T, int F, int t_first, int rows,
+                                           float bias, float* dst, int ld) {
+    const int n = rows * ld;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int r = i / ld, c = i - r * ld;
+        const int t = t_first + r, f = c - SSIM_R;
+        float v = 0.f;
+        if (t >= 0 && t < T && f >= 0 && f < F) v = p[(long)b * sb + (long)t * st + (long)f * sf] + bias;
+        dst[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void svb_ssim_fwd_kernel(const float* pred, long psb, long pst, long psf, const float* tgt,
+                                                           long tsb, long tst, long tsf, float* out, int B, int T, int F,
+                                                           float bias, SsimWin w) {
+    __shared__ float xs[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    __shared__ float ys[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    const int b = blockIdx.y, t0 = blockIdx.x * SSIM_TT;
+    const int ld = F + 2 * SSIM_R, rows = SSIM_TT + 2 * SSIM_R;
+    ssim_stage(pred, psb, pst, psf, b, T, F, t0 - SSIM_R, rows, bias, xs, ld);
+    ssim_stage(tgt, tsb, tst, tsf, b, T, F, t0 - SSIM_R, rows, bias, ys, ld);
+    __syncthreads();
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
+        const int r = i / F, c = i - r * F;
+        const int t = t0 + r;
+        if (t >= T) continue;
+        const SsimStats s = ssim_window(xs, ys, r, c, ld, w);
+        const float mu1_sq = s.mu1 * s.mu1, mu2_sq = s.mu2 * s.mu2, mu12 = s.mu1 * s.mu2;
+        const float s1 = s.e11 - mu1_sq, s2 = s.e22 - mu2_sq, s12 = s.e12 - mu12;
+        out[((long)b * T + t) * F + c] = ((2.f * mu12 + C1) * (2.f * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2));
+    }
+}
+
+// backward stage 1: per-pixel cotangents of (mu1, E[xx], E[xy]) given d(map)
+__global__ __launch_bounds__(256) void svb_ssim_bwd1_kernel(const float* pred, long psb, long pst, long psf, const float* tgt,
+                                                            long tsb, long tst, long tsf, const float* dmap, float* gws, int B,
+                                                            int T, int F, float bias, SsimWin w) {
+    __shared__ float xs[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    __shared__ float ys[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    const int b = blockIdx.y, t0 = blockIdx.x * SSIM_TT;
+    const int ld = F + 2 * SSIM_R, rows = SSIM_TT + 2 * SSIM_R;
+    ssim_stage(pred, psb, pst, psf, b, T, F, t0 - SSIM_R, rows, bias, xs, ld);
+    ssim_stage(tgt, tsb, tst, tsf, b, T, F, t0 - SSIM_R, rows, bias, ys, ld);
+    __syncthreads();
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const long plane = (long)B * T * F;
+    for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
+        const int r = i / F, c = i - r * F;
+        const int t = t0 + r;
+        if (t >= T) continue;
+        const SsimStats s = ssim_window(xs, ys, r, c, ld, w);
+        const float mu1_sq = s.mu1 * s.mu1, mu2_sq = s.mu2 * s.mu2, mu12 = s.mu1 * s.mu2;
+        const float s1 = s.e11 - mu1_sq, s2 = s.e22 - mu2_sq, s12 = s.e12 - mu12;
+        const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s1 + s2 + C2;
+        const float inv = 1.f / (B1 * B2);
+        const float m = A1 * A2 * inv;
+        const long o = ((long)b * T + t) * F + c;
+        const float dm = dmap[o];
+        const float dA1 = A2 * inv, dA2 = A1 * inv, dB1 = -m / B1, dB2 = -m / B2;
+        gws[o] = dm * (2.f * s.mu2 * dA1 - 2.f * s.mu2 * dA2 + 2.f * s.mu1 * dB1 - 2.f * s.mu1 * dB2);   // d/d mu1
+        gws[plane + o] = dm * dB2;                                                                        // d/d E[xx]
+        gws[2 * plane + o] = dm * 2.f * dA2;                                                              // d/d E[xy]
+    }
+}
+
+// backward stage 2: dpred = G*g_mu1 + 2 x (G*g_e11) + y (G*g_e12)   (G symmetric 11x11, zero padded)
+__global__ __launch_bounds__(256) void svb_ssim_bwd2_kernel(const float* pred, long psb, long pst, long psf, const float* tgt,
+                                                            long tsb, long tst, long tsf, const float* gws, float* dpred, int B,
+                                                            int T, int F, float bias, SsimWin w) {
+    __shared__ float ga[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    __shared__ float gb[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    __shared__ float gc[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    const int b = blockIdx.y, t0 = blockIdx.x * SSIM_TT;
+    const int ld = F + 2 * SSIM_R, rows = SSIM_TT + 2 * SSIM_R;
+    const long plane = (long)B * T * F;
+    const long sb = (long)T * F;
+    ssim_stage(gws, sb, F, 1, b, T, F, t0 - SSIM_R, rows, 0.f, ga, ld);
+    ssim_stage(gws + plane, sb, F, 1, b, T, F, t0 - SSIM_R, rows, 0.f, gb, ld);
+    ssim_stage(gws + 2 * plane, sb, F, 1, b, T, F, t0 - SSIM_R, rows, 0.f, gc, ld);
+    __syncthreads();
+    for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
+        const int r = i / F, c = i - r * F;
+        const int t = t0 + r;
+        if (t >= T) continue;
+        float fa = 0.f, fb = 0.f, fc = 0.f;
+#pragma unroll
+        for (int ii = 0; ii < SSIM_W; ++ii) {
+            const float gi = w.g[ii];
+            const int base = (r + ii) * ld + c;
+#pragma unroll
+            for (int j = 0; j < SSIM_W; ++j) {
+                const float wij = gi * w.g[j];
+                fa = fmaf(wij, ga[base + j], fa);
+                fb = fmaf(wij, gb[base + j], fb);
+                fc = fmaf(wij, gc[base + j], fc);
+            }
+        }
+        const float x = pred[(long)b * psb + (long)t * pst + (long)c * psf] + bias;
+        const float y = tgt[(long)b * tsb + (long)t * tst + (long)c * tsf] + bias;
+        dpred[((long)b * T + t) * F + c] = fa + 2.f * x * fb + y * fc;
+    }
+}
+
+static SsimWin make_window() {
+    SsimWin w;
+    float sum = 0.f;
+    for (int i = 0; i < SSIM_W; ++i) {
+        w.g[i] = (float)exp(-(double)((i - SSIM_R) * (i - SSIM_R)) / (2.0 * 1.5 * 1.5));
+        sum += w.g[i];
+    }
+    for (int i = 0; i < SSIM_W; ++i) w.g[i] /= sum;
+    return w;
+}
+
+extern "C" int svb_ssim_fwd(const float* pred, long psb, long pst, long psf, const float* tgt, long tsb, long tst, long tsf,
+                            float* out_map, int B, int T, int F, float bias, void* stream) {
+    if (!pred || !tgt || !out_map || B <= 0 || T <= 0 || F <= 0 || F > SSIM_FMAX || B > 65535) return SVB_ERR_ARG;
+    dim3 grid(svb_cdiv(T, SSIM_TT), B);
+    hipLaunchKernelGGL(svb_ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, pred, psb, pst, psf, tgt, tsb, tst, tsf,
+                       out_map, B, T, F, bias, make_window());
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_ssim_bwd(const float* pred, long psb, long pst, long psf, const float* tgt, long tsb, long tst, long tsf,
+                            const float* dmap, float* dpred, float* workspace, int B, int T, int F, float bias, void* stream) {
+    if (!pred || !tgt || !dmap || !dpred || !workspace || B <= 0 || T <= 0 || F <= 0 || F > SSIM_FMAX || B > 65535)
+        return SVB_ERR_ARG;
+    dim3 grid(svb_cdiv(T, SSIM_TT), B);
+    const SsimWin w = make_window();
+    hipLaunchKernelGGL(svb_ssim_bwd1_kernel, grid, dim3(256), 0, (hipStream_t)stream, pred, psb, pst, psf, tgt, tsb, tst, tsf,
+                       dmap, workspace, B, T, F, bias, w);
+    hipLaunchKernelGGL(svb_ssim_bwd2_kernel, grid, dim3(256), 0, (hipStream_t)stream, pred, psb, pst, psf, tgt, tsb, tst, tsf,
+                       workspace, dpred, B, T, F, bias, w);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}

@@ -188,27 +188,39 @@ __global__ __launch_bounds__(256) void svb_layernorm_bwd_kernel(const float* x, 
 }
 
 
-// LayerNorm over the channel dim of an NCT tensor: one thread per (b,t) column, lanes along t (coalesced rows).
-// Shifted single-pass moments (shift = first channel) + one normalise pass: 2 reads + 1 write of x.
+// LayerNorm over the channel dim of an NCT tensor.  Block = 64 time columns x 4 channel groups: lanes run along t
+// (coalesced 256-byte row segments), the 4 waves split the channels and combine their moments through LDS.
+// Shifted single-pass moments (shift = channel 0) + one normalise pass: 2 reads + 1 write of x.
 __global__ __launch_bounds__(256) void svb_layernorm_nct_fwd_kernel(const float* x, const float* gamma, const float* beta,
                                                                     float* y, int B, int C, int T, float eps) {
-    const long total = (long)B * T;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int b = (int)(i / T), t = (int)(i - (long)b * T);
-        const float* xc = x + (size_t)b * C * T + t;
-        float* yc = y + (size_t)b * C * T + t;
-        const float x0 = xc[0];
-        float s = 0.f, ss = 0.f;
-        for (int c = 0; c < C; ++c) {
+    __shared__ float s_sum[4][64];
+    __shared__ float s_sq[4][64];
+    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int tiles = (T + 63) / 64;
+    const int b = blockIdx.x / tiles, t = (blockIdx.x % tiles) * 64 + tl;
+    const bool ok = t < T;
+    const float* xc = x + (size_t)b * C * T + (ok ? t : 0);
+    float* yc = y + (size_t)b * C * T + (ok ? t : 0);
+    const float x0 = ok ? xc[0] : 0.f;
+    float s = 0.f, ss = 0.f;
+    if (ok) {
+        for (int c = cg; c < C; c += 4) {
             const float d = xc[(size_t)c * T] - x0;
             s += d;
             ss = fmaf(d, d, ss);
         }
-        const float md = s / (float)C;
-        const float var = fmaxf(ss / (float)C - md * md, 0.f);
-        const float mu = x0 + md;
-        const float rs = 1.f / sqrtf(var + eps);
-        for (int c = 0; c < C; ++c) {
+    }
+    s_sum[cg][tl] = s;
+    s_sq[cg][tl] = ss;
+    __syncthreads();
+    s = s_sum[0][tl] + s_sum[1][tl] + s_sum[2][tl] + s_sum[3][tl];
+    ss = s_sq[0][tl] + s_sq[1][tl] + s_sq[2][tl] + s_sq[3][tl];
+    const float md = s / (float)C;
+    const float var = fmaxf(ss / (float)C - md * md, 0.f);
+    const float mu = x0 + md;
+    const float rs = 1.f / sqrtf(var + eps);
+    if (ok) {
+        for (int c = cg; c < C; c += 4) {
             float o = (xc[(size_t)c * T] - mu) * rs;
             if (gamma) o *= gamma[c];
             if (beta) o += beta[c];
@@ -292,7 +304,7 @@ extern "C" int svb_layernorm_bwd(const float* x, const float* gamma, const float
 extern "C" int svb_layernorm_nct_fwd(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
                                      float eps, void* stream) {
     if (!x || !y || B <= 0 || C <= 0 || T <= 0) return SVB_ERR_ARG;
-    hipLaunchKernelGGL(svb_layernorm_nct_fwd_kernel, dim3(ew_grid((long)B * T)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+    hipLaunchKernelGGL(svb_layernorm_nct_fwd_kernel, dim3(B * ((T + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, gamma,
                        beta, y, B, C, T, eps);
     SVB_CHECK_LAUNCH();
     return SVB_OK;

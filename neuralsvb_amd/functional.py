@@ -272,3 +272,22 @@ def layer_norm_nct(x, gamma, beta, eps=1e-5):
     if torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad):
         raise RuntimeError("layer_norm_nct is forward-only (frozen encoder); use layer_norm for trainable paths")
     return K.layernorm_nct_fwd(x.contiguous(), gamma, beta, eps)
+
+
+class _SsimMapFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, bias):
+        ctx.bias = bias
+        ctx.save_for_backward(pred, target)
+        return K.ssim_fwd(pred, target, bias)
+
+    @staticmethod
+    def backward(ctx, dmap):
+        pred, target = ctx.saved_tensors
+        return K.ssim_bwd(pred, target, dmap, ctx.bias), None, None
+
+
+def ssim_map(pred, target, bias=6.0):
+    """Per-pixel SSIM of (pred+bias, target+bias), [B,T,F] -> [B,T,F]; gradient flows to `pred` only
+    (reference modules/commons/ssim.py:331-351 with size_average=False, as called by tasks/tts/fs2.py:166-175)."""
+    return _SsimMapFn.apply(pred, target.detach(), float(bias))

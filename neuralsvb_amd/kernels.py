@@ -14,9 +14,9 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 
 # bench.py sets PROFILE = [] to collect (kernel instantiation, algorithmic FLOPs, start event, end event) per conv launch
 PROFILE = None
-_CFG_NAMES = ["svb_conv1d_mfma_kernel<2,2,2,8192,5120>", "svb_conv1d_mfma_kernel<4,1,3,8192,10240>",
-              "svb_conv1d_mfma_kernel<4,1,4,8192,10240>", "svb_conv1d_mfma_kernel<2,2,1,8192,5120>",
-              "svb_conv1d_mfma_kernel<1,4,1,8192,2560>"]
+_CFG_NAMES = ["svb_conv1d_mfma_kernel<2,2,2,8192,80>", "svb_conv1d_mfma_kernel<4,1,3,8192,80>",
+              "svb_conv1d_mfma_kernel<4,1,4,8192,80>", "svb_conv1d_mfma_kernel<2,2,1,8192,80>",
+              "svb_conv1d_mfma_kernel<1,4,1,8192,80>"]
 
 
 class _ConvProbe:
@@ -244,6 +244,40 @@ def layernorm_bwd(x, gamma, dy, mean, rstd, n_part=128):
     L.check(lib.svb_layernorm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dgp),
                                   _ptr(dbp), rows, c, n_part, st), "svb_layernorm_bwd")
     return dx, dgp.sum(0), dbp.sum(0)
+
+
+def _prep_strided(*tensors):
+    """like _prep but allows non-contiguous tensors (kernels that take element strides)."""
+    lib = L.get_lib()
+    dev = next(t.device for t in tensors if t is not None)
+    if dev.type == "cuda":
+        return lib, torch.cuda.current_stream(dev).cuda_stream
+    if not L.lib_is_emulator():
+        raise RuntimeError("neuralsvb_amd kernels run on the MI355X only (got CPU tensors); there is no CPU fallback")
+    return lib, None
+
+
+def ssim_fwd(pred, target, bias=6.0):
+    """pred/target [B,T,F] (any strides) -> SSIM map [B,T,F] contiguous."""
+    _f32(pred, target)
+    lib, st = _prep_strided(pred, target)
+    B, T, Fb = pred.shape
+    out = torch.empty((B, T, Fb), device=pred.device, dtype=torch.float32)
+    L.check(lib.svb_ssim_fwd(_ptr(pred), *pred.stride(), _ptr(target), *target.stride(), _ptr(out), B, T, Fb, float(bias), st),
+            "svb_ssim_fwd")
+    return out
+
+
+def ssim_bwd(pred, target, dmap, bias=6.0):
+    _f32(pred, target, dmap)
+    lib, st = _prep_strided(pred, target, dmap)
+    B, T, Fb = pred.shape
+    dmap = dmap.contiguous()
+    dpred = torch.empty((B, T, Fb), device=pred.device, dtype=torch.float32)
+    ws = torch.empty((3 * B * T * Fb,), device=pred.device, dtype=torch.float32)
+    L.check(lib.svb_ssim_bwd(_ptr(pred), *pred.stride(), _ptr(target), *target.stride(), _ptr(dmap), _ptr(dpred), _ptr(ws),
+                             B, T, Fb, float(bias), st), "svb_ssim_bwd")
+    return dpred
 
 
 def stft_mel(wav, window, mel_basis, n_fft, hop, mode, eps):

@@ -19,6 +19,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import functional as SF
 from ..modules.mel_disc import Discriminator
 from ..modules.svb_vae import MleSVBVAE
 from ..utils import ckpt_utils
@@ -118,7 +119,7 @@ class SVBVAEMleTask(BaseTask):
 
     def ssim_loss(self, out, target, bias=6.0):
         w = self.weights_nonzero_speech(target)
-        s = 1 - ssim_map(out[:, None] + bias, target[:, None] + bias, self._ssim_window)
+        s = 1 - SF.ssim_map(out, target, bias)
         return (s * w).sum() / w.sum()
 
     def add_mel_loss(self, mel_out, target, losses, postfix=""):

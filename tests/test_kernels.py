@@ -292,3 +292,30 @@ def test_f0_to_coarse_bit_exact(dev):
     out32 = K.f0_to_coarse(f32.to(dev))
     assert (out32.cpu() != ref32).float().mean() < 1e-3  # fp32 log may differ by 1 ulp at a bin edge
     assert (out32.cpu() - ref32).abs().max() <= 1
+
+
+def test_ssim_map_forward_backward(dev):
+    """L1: modules/commons/ssim.py:331-351 on [B,1,T,80]+6; pred is read through its [B,80,T] (transposed) strides."""
+    from oracle import modules_ref as R
+    g_ = torch.Generator().manual_seed(4)
+    B, T, Fb = 2, 37, 80
+    pred_nct = (torch.randn(B, Fb, T, generator=g_) * 0.8 - 3).requires_grad_(True)
+    tgt = torch.randn(B, T, Fb, generator=g_) * 0.8 - 3
+    tgt[1, 30:] = 0.0
+    ref = R.ssim_map(pred_nct.transpose(1, 2)[:, None] + 6.0, tgt[:, None] + 6.0)
+    dm = torch.randn(ref.shape, generator=g_)
+    ref.backward(dm)
+    p = pred_nct.detach().to(dev).transpose(1, 2)            # non-contiguous view, as in the model
+    out = K.ssim_fwd(p, tgt.to(dev), 6.0)
+    assert (out.cpu() - ref.detach()).abs().max() < 2e-5
+    dp = K.ssim_bwd(p, tgt.to(dev), dm.to(dev), 6.0)
+    assert rel_err(dp, pred_nct.grad.transpose(1, 2)) < 1e-4
+
+
+def test_layernorm_nct(dev):
+    g_ = torch.Generator().manual_seed(8)
+    x = torch.randn(3, 96, 70, generator=g_) * 2 + 0.3
+    gm, bt = torch.randn(96, generator=g_), torch.randn(96, generator=g_)
+    ref = oops.layernorm(x.transpose(1, 2), gm, bt).transpose(1, 2)
+    y = K.layernorm_nct_fwd(x.to(dev), gm.to(dev), bt.to(dev))
+    assert (y.cpu() - ref).abs().max() < 3e-5
