@@ -36,6 +36,7 @@ struct SvbConvArgs {
     int sx, out_stride;
     int w_tap_stride, w_ld, w_goff_k, w_goff_m;
     int xrow, kc, ph_len;
+    int ws_floats, xs_floats;   // dynamic LDS carve (weight tile, x tile)
     int tg, fast_x, w_vec;   // taps per weight stage; register-staged x path; 16-byte weight loads allowed
     int force_cfg;
 };

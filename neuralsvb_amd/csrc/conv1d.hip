@@ -18,18 +18,20 @@
 #include "svb_common.h"
 #include "conv1d.h"
 
-template <int WM, int WN, int NT, int XS_TOTAL, int WS_ROWS>
-__global__ __launch_bounds__(256) void svb_conv1d_mfma_kernel(SvbConvArgs a, SvbConvPlan p) {
+template <int WM, int WN, int NT, int RPW, int WS_ROWS>
+__global__ __launch_bounds__(256, 2) void svb_conv1d_mfma_kernel(SvbConvArgs a, SvbConvPlan p) {
     constexpr int BM = 32 * WM, BN = 32 * WN * NT;
-    constexpr int RPW = 16;                              // x rows staged per wave per chunk (kc <= 64)
+    // RPW: x rows staged per wave per chunk (kc <= 4*RPW)
     constexpr int NJ = 3;                                // 64-lane column groups per x row on the fast path (span <= 192)
     constexpr int BM4 = BM / 4;
     constexpr int WUNITS = WS_ROWS * BM4;                // float4 units in the W tile
     constexpr int WU = (WUNITS + 255) / 256;
     static_assert(WM * WN == 4, "256 threads = 4 waves");
-    __shared__ __attribute__((aligned(16))) float xs[XS_TOTAL];
-    __shared__ __attribute__((aligned(16))) float ws[WS_ROWS * BM];
-    __shared__ int tap_lds[SVB_MAX_TAPS];
+    // dynamic LDS, sized per launch: [ws: tg*kc*BM floats | xs: kc*xrow floats | tap table]
+    HIP_DYNAMIC_SHARED(float, dyn_smem)
+    float* ws = dyn_smem;
+    float* xs = dyn_smem + a.ws_floats;
+    int* tap_lds = reinterpret_cast<int*>(xs + a.xs_floats);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
@@ -71,26 +73,50 @@ __global__ __launch_bounds__(256) void svb_conv1d_mfma_kernel(SvbConvArgs a, Svb
     const float* wbase = a.wp + (size_t)g * a.w_goff_k * a.w_ld + (size_t)g * a.w_goff_m + m_base;
 
     // ---- register staging (all global loads of a stage are issued before any LDS store) ----------------------
+    // Everything that does not depend on the K-chunk is hoisted: per-lane column validity / LDS destinations of the
+    // x tile, and per-unit (tap,row,col) decode + element offsets of the weight tile.
     float xr[RPW][NJ];
     float4 wr[WU];
+    bool xok[NJ];
+    int xsrc[NJ], xdst[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int i = lane + 64 * jj;
+        const int pos = lo + i;
+        xok[jj] = i < span && pos >= 0 && pos < a.Tin;
+        xsrc[jj] = pos;
+        xdst[jj] = (a.sx == 1) ? i : (i % a.sx) * a.ph_len + i / a.sx;
+    }
+    const int tap_step = ntap > 1 ? (p.tap_w[t0 + 1] - p.tap_w[t0]) : 0;   // tap slabs form an arithmetic progression
+    int woff[WU], wch[WU], wtap[WU];
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+        const int unit = u * 256 + tid;
+        const int row = unit / BM4, col = (unit - row * BM4) * 4;
+        const int t = row / a.kc, c = row - t * a.kc;
+        const bool ok = unit < WUNITS && t < a.tg && col < m_valid;
+        wtap[u] = ok ? t : 1 << 20;                       // invalid units never pass `t < nt_here`
+        wch[u] = c;
+        woff[u] = ok ? (p.tap_w[t0 + min(t, max(ntap - 1, 0))] * a.w_tap_stride + c * a.w_ld + col) : 0;
+    }
 
     auto load_x = [&](int c0) {
         const int kc = min(a.kc, a.Cin_g - c0);
         const int kcp = (kc + 1) & ~1;
+        const float* xchunk = xb + (size_t)(c0 + wave) * a.Tin;
+        const float* gchunk = gb ? gb + (size_t)(c0 + wave) * a.Tin : nullptr;
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             const int r = wave + 4 * rr;
             if (r < kcp) {
-                const float* xrow_p = xb + (size_t)(c0 + r) * a.Tin;
-                const float* grow_p = gb ? gb + (size_t)(c0 + r) * a.Tin : nullptr;
+                const bool rv = r < kc;
+                const float* xrow_p = xchunk + (size_t)(4 * rr) * a.Tin;
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) {
-                    const int i = lane + 64 * jj;
-                    const int pos = lo + i;
                     float v = 0.f;
-                    if (r < kc && i < span && pos >= 0 && pos < a.Tin) {
-                        v = xrow_p[pos];
-                        if (grow_p) v *= svb_gate(grow_p[pos], a.in_slope);
+                    if (rv && xok[jj]) {
+                        v = xrow_p[xsrc[jj]];
+                        if (gchunk) v *= svb_gate(gchunk[(size_t)(4 * rr) * a.Tin + xsrc[jj]], a.in_slope);
                     }
                     xr[rr][jj] = v;
                 }
@@ -104,14 +130,10 @@ __global__ __launch_bounds__(256) void svb_conv1d_mfma_kernel(SvbConvArgs a, Svb
         for (int rr = 0; rr < RPW; ++rr) {
             const int r = wave + 4 * rr;
             if (r < kcp) {
+                float* xd = xs + r * a.xrow;
 #pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) {
-                    const int i = lane + 64 * jj;
-                    if (i < span) {
-                        const int di = (a.sx == 1) ? i : (i % a.sx) * a.ph_len + i / a.sx;
-                        xs[r * a.xrow + di] = xr[rr][jj];
-                    }
-                }
+                for (int jj = 0; jj < NJ; ++jj)
+                    if (lane + 64 * jj < span) xd[xdst[jj]] = xr[rr][jj];
             }
         }
     };
@@ -137,38 +159,35 @@ __global__ __launch_bounds__(256) void svb_conv1d_mfma_kernel(SvbConvArgs a, Svb
     auto load_w = [&](int c0, int tg) {
         const int kc = min(a.kc, a.Cin_g - c0);
         const int nt_here = min(a.tg, ntap - tg);
-        const int rows_here = nt_here * a.kc;
+        const float* wchunk = wbase + (size_t)c0 * a.w_ld + (size_t)tg * tap_step * a.w_tap_stride;
+        if (a.w_vec) {
 #pragma unroll
-        for (int u = 0; u < WU; ++u) {
-            const int unit = u * 256 + tid;
-            const int row = unit / BM4, col = (unit - row * BM4) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (unit < WUNITS && row < rows_here) {
-                const int t = row / a.kc, c = row - t * a.kc;
-                if (c < kc && col < m_valid) {
-                    const float* src = wbase + (size_t)p.tap_w[t0 + tg + t] * a.w_tap_stride + (size_t)(c0 + c) * a.w_ld + col;
-                    if (a.w_vec && col + 3 < m_valid) {
-                        v = *reinterpret_cast<const float4*>(src);
-                    } else {
-                        v.x = src[0];
-                        if (col + 1 < m_valid) v.y = src[1];
-                        if (col + 2 < m_valid) v.z = src[2];
-                        if (col + 3 < m_valid) v.w = src[3];
-                    }
-                }
+            for (int u = 0; u < WU; ++u) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (wtap[u] < nt_here && wch[u] < kc) v = *reinterpret_cast<const float4*>(wchunk + woff[u]);
+                wr[u] = v;
             }
-            wr[u] = v;
+        } else {
+#pragma unroll
+            for (int u = 0; u < WU; ++u) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (wtap[u] < nt_here && wch[u] < kc) {
+                    const int col = ((u * 256 + tid) % BM4) * 4;
+                    const float* src = wchunk + woff[u];
+                    v.x = src[0];
+                    if (col + 1 < m_valid) v.y = src[1];
+                    if (col + 2 < m_valid) v.z = src[2];
+                    if (col + 3 < m_valid) v.w = src[3];
+                }
+                wr[u] = v;
+            }
         }
     };
     auto store_w = [&](int tg) {
         const int nt_here = min(a.tg, ntap - tg);
-        const int rows_here = nt_here * a.kc;
 #pragma unroll
-        for (int u = 0; u < WU; ++u) {
-            const int unit = u * 256 + tid;
-            const int row = unit / BM4;
-            if (unit < WUNITS && row < rows_here) *reinterpret_cast<float4*>(ws + unit * 4) = wr[u];
-        }
+        for (int u = 0; u < WU; ++u)
+            if (wtap[u] < nt_here) *reinterpret_cast<float4*>(ws + (u * 256 + tid) * 4) = wr[u];
     };
     auto compute = [&](int c0, int tg) {
         const int kc = min(a.kc, a.Cin_g - c0);
@@ -177,13 +196,22 @@ __global__ __launch_bounds__(256) void svb_conv1d_mfma_kernel(SvbConvArgs a, Svb
         for (int t = 0; t < nt_here; ++t) {
             const float* wsa = ws + (t * a.kc + kk) * BM + wm * 32 + l31;
             const float* xsb = xs + kk * a.xrow + tap_lds[tg + t] + (wn * NT) * 32 + l31;
-            for (int c2 = 0; c2 < kcp; c2 += 2) {
-                const float av = wsa[c2 * BM];
+            // operands of step c2+2 are read from LDS while the MFMAs of step c2 run.  The read past the last step lands
+            // in the two padding rows each tile carries (value unused), so the loop body is branch-free.
+            float av = wsa[0];
+            float bv[NT];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const float bv = xsb[c2 * a.xrow + n * 32];
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[n], 0, 0, 0);
-                }
+            for (int n = 0; n < NT; ++n) bv[n] = xsb[n * 32];
+            for (int c2 = 0; c2 < kcp; c2 += 2) {
+                const float an = wsa[(c2 + 2) * BM];
+                float bn[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bn[n] = xsb[(c2 + 2) * a.xrow + n * 32];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[n], acc[n], 0, 0, 0);
+                av = an;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bv[n] = bn[n];
             }
         }
     };
@@ -488,16 +516,30 @@ static int pick_cfg(int cout_g, int nq_max) {
     return best;
 }
 
-template <int WM, int WN, int NT, int XS, int WS_ROWS>
+template <int WM, int WN, int NT, int RPW, int WS_ROWS>
+static int launch_one(SvbConvArgs& a, const SvbConvPlan& p, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+    static bool attr_set = false;   // allow > 64 KiB of dynamic LDS (wide strided tiles); set once per instantiation
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_mfma_kernel<WM, WN, NT, RPW, WS_ROWS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((svb_conv1d_mfma_kernel<WM, WN, NT, RPW, WS_ROWS>), grid, dim3(256), lds_bytes, stream, a, p);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+template <int WM, int WN, int NT>
 static int launch_cfg(SvbConvArgs& a, const SvbConvPlan& p, int nq_max, int span_off_max, int ntap_max, hipStream_t stream) {
-    constexpr int BM = 32 * WM, BN = 32 * WN * NT;
+    constexpr int BM = 32 * WM, BN = 32 * WN * NT, WS_ROWS = 80, XS_MAX = 8192;
     const int span_max = (BN - 1) * a.sx + span_off_max + 1;
     a.ph_len = svb_cdiv(span_max, a.sx);
     a.xrow = a.ph_len * a.sx;
     a.tg = ntap_max < 5 ? (ntap_max > 0 ? ntap_max : 1) : 5;       // taps per weight stage
-    int kc = XS / a.xrow;                                            // channels per K-chunk
+    int kc = XS_MAX / a.xrow;                                        // channels per K-chunk
     if (kc > WS_ROWS / a.tg) kc = WS_ROWS / a.tg;
-    if (kc > 64) kc = 64;
+    constexpr int RPW_BIG = (BM >= 128) ? 8 : 16;                   // register budget: 128-row tiles stage fewer x rows
+    if (kc > 4 * RPW_BIG) kc = 4 * RPW_BIG;
     if (kc > ((a.Cin_g + 1) & ~1)) kc = (a.Cin_g + 1) & ~1;
     kc &= ~1;
     if (kc < 2) return SVB_ERR_UNSUPPORTED;
@@ -505,10 +547,12 @@ static int launch_cfg(SvbConvArgs& a, const SvbConvPlan& p, int nq_max, int span
     a.fast_x = span_max <= 192 ? 1 : 0;
     a.w_vec = (a.w_ld % 4 == 0 && a.w_tap_stride % 4 == 0 && a.w_goff_m % 4 == 0 &&
                ((size_t)a.w_goff_k * a.w_ld) % 4 == 0 && ((uintptr_t)a.wp % 16) == 0) ? 1 : 0;
+    a.ws_floats = (a.tg * a.kc + 2) * BM;                            // +2 padding rows (operand prefetch over-read)
+    a.xs_floats = ((a.kc + 2) * a.xrow + BN + 3) & ~3;               // multiple of 4 floats keeps the carve 16-byte aligned
+    const size_t lds_bytes = (size_t)(a.ws_floats + a.xs_floats + SVB_MAX_TAPS) * 4;
     dim3 grid(a.G * svb_cdiv(a.Cout_g, BM), svb_cdiv(nq_max, BN), a.B * p.n_phase);
-    hipLaunchKernelGGL((svb_conv1d_mfma_kernel<WM, WN, NT, XS, WS_ROWS>), grid, dim3(256), 0, stream, a, p);
-    SVB_CHECK_LAUNCH();
-    return SVB_OK;
+    if (kc <= 16) return launch_one<WM, WN, NT, 4, WS_ROWS>(a, p, grid, lds_bytes, stream);
+    return launch_one<WM, WN, NT, RPW_BIG, WS_ROWS>(a, p, grid, lds_bytes, stream);
 }
 
 static int launch_conv(SvbConvArgs& a, const SvbConvPlan& p, hipStream_t stream) {
@@ -524,11 +568,11 @@ static int launch_conv(SvbConvArgs& a, const SvbConvPlan& p, hipStream_t stream)
     int cfg = pick_cfg(a.Cout_g, nq_max);
     if (a.force_cfg >= 0 && a.force_cfg < 5) cfg = a.force_cfg;
     switch (cfg) {
-        case 0: return launch_cfg<2, 2, 2, 8192, 80>(a, p, nq_max, span_off_max, ntap_max, stream);
-        case 1: return launch_cfg<4, 1, 3, 8192, 80>(a, p, nq_max, span_off_max, ntap_max, stream);
-        case 2: return launch_cfg<4, 1, 4, 8192, 80>(a, p, nq_max, span_off_max, ntap_max, stream);
-        case 3: return launch_cfg<2, 2, 1, 8192, 80>(a, p, nq_max, span_off_max, ntap_max, stream);
-        default: return launch_cfg<1, 4, 1, 8192, 80>(a, p, nq_max, span_off_max, ntap_max, stream);
+        case 0: return launch_cfg<2, 2, 2>(a, p, nq_max, span_off_max, ntap_max, stream);
+        case 1: return launch_cfg<4, 1, 3>(a, p, nq_max, span_off_max, ntap_max, stream);
+        case 2: return launch_cfg<4, 1, 4>(a, p, nq_max, span_off_max, ntap_max, stream);
+        case 3: return launch_cfg<2, 2, 1>(a, p, nq_max, span_off_max, ntap_max, stream);
+        default: return launch_cfg<1, 4, 1>(a, p, nq_max, span_off_max, ntap_max, stream);
     }
 }
 

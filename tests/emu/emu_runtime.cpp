@@ -8,6 +8,16 @@
 
 emu_uint3 threadIdx, blockIdx;
 dim3 blockDim, gridDim;
+unsigned char* emu_dyn_smem = nullptr;
+static size_t emu_dyn_cap = 0;
+void emu_set_dyn_smem(size_t bytes) {
+    if (bytes > 160 * 1024) { fprintf(stderr, "emu: dynamic LDS request %zu > 160 KiB\n", bytes); abort(); }
+    if (bytes > emu_dyn_cap) {
+        free(emu_dyn_smem);
+        emu_dyn_cap = bytes + 4096;
+        emu_dyn_smem = (unsigned char*)aligned_alloc(64, (emu_dyn_cap + 63) & ~(size_t)63);
+    }
+}
 
 namespace {
 constexpr size_t kStack = 192 * 1024;

@@ -58,8 +58,13 @@ const unsigned char* emu_wave_slot(int lane);                 // read another la
 void emu_wave_exchange_end();
 int emu_lane_id();
 
+#define hipFuncAttributeMaxDynamicSharedMemorySize 0
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+extern unsigned char* emu_dyn_smem;
+void emu_set_dyn_smem(size_t bytes);
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(emu_dyn_smem);
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    emu_launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+    (emu_set_dyn_smem(shmem), emu_launch((grid), (block), [=]() { kernel(__VA_ARGS__); }))
 
 static inline void __syncthreads() { emu_syncthreads(); }
 static inline void __builtin_amdgcn_s_barrier_emu() { emu_syncthreads(); }

@@ -66,7 +66,8 @@ def test_mle_svb_vae_forward_matches_reference_golden(dev):
     for way in ("a2a", "p2p", "a2p"):
         l1 = (out[way]["mel_out"].cpu() - t(d[f"{way}.mel_out"])).abs().mean().item()
         assert l1 <= 1e-4, (way, l1)
-    assert abs(out["a2p"]["mle"].item() - float(d["a2p.mle"])) < 2e-4
+    mle_ref = float(d["a2p.mle"])      # sum of ((z' - m_p)/sigma_p)^2 terms: relative bound
+    assert abs(out["a2p"]["mle"].item() - mle_ref) < 5e-4 * max(1.0, abs(mle_ref)), (out["a2p"]["mle"].item(), mle_ref)
 
 
 @pytest.mark.slow
