@@ -106,6 +106,14 @@ int svb_layernorm_nct_fwd(const float* x, const float* gamma, const float* beta,
 int svb_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* mean, const float* rstd,
                       float* dx, float* dgamma_part, float* dbeta_part, int rows, int C, int n_part, void* stream);
 
+/* ---- im2col / col2im for small strided Conv2d layers (reference modules/fastspeech/multi_window_disc.py:14-31).
+ * cols: [B, C*KH*KW, Ho*Wo]; the GEMM runs as svb_conv1d_forward(k=1) over cols (=> y is [B, Cout, Ho, Wo]),
+ * its data gradient as svb_conv1d_transposed(k=1) followed by svb_col2im, its weight gradient as svb_conv1d_wgrad. */
+int svb_im2col(const float* x, float* cols, int B, int C, int H, int W, int KH, int KW, int SH, int SW, int PH, int PW,
+               int Ho, int Wo, void* stream);
+int svb_col2im(const float* dcols, float* dx, int B, int C, int H, int W, int KH, int KW, int SH, int SW, int PH, int PW,
+               int Ho, int Wo, void* stream);
+
 /* ---- SSIM map of two [B, T, F] mel images (+bias), 11x11 gaussian sigma 1.5, zero padding, C1=1e-4, C2=9e-4
  * (reference modules/commons/ssim.py:331-351 via tasks/tts/fs2.py:166-175).  Inputs are addressed with element
  * strides (batch, time, bin) so the decoder's [B,F,T] output is read in place.  out_map/dmap/dpred: contiguous

@@ -1,0 +1,84 @@
+// conv2d.hip -- im2col / col2im for the small strided 2-D convolutions of the multi-window mel critic
+// (reference modules/fastspeech/multi_window_disc.py:14-31: Conv2d(c, 128, 3x3, stride 2, pad 1) on [B,c,T,80] windows).
+//
+// The GEMM itself runs on the implicit-GEMM conv kernel of conv1d.hip as a 1x1 conv over the column matrix:
+//   cols[b, (ci,jh,jw), (ho,wo)] = x[b, ci, ho*sh + jh - ph, wo*sw + jw - pw]      (zero outside)
+//   y[b, co, (ho,wo)]            = sum_k w[co, k] * cols[b, k, (ho,wo)]              -> exactly [B, Cout, Ho, Wo]
+// Both kernels are pure streaming (HBM-bound): lanes run along the contiguous (ho,wo) axis.
+#include "svb_common.h"
+#include "../../include/svb_hip.h"
+
+__global__ __launch_bounds__(256) void svb_im2col_kernel(const float* x, float* cols, int B, int C, int H, int W, int KH,
+                                                         int KW, int SH, int SW, int PH, int PW, int Ho, int Wo) {
+    const long n_pos = (long)Ho * Wo;
+    const long total = (long)B * C * KH * KW * n_pos;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long pos = i % n_pos;
+        long r = i / n_pos;
+        const int jw = (int)(r % KW); r /= KW;
+        const int jh = (int)(r % KH); r /= KH;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        const int ho = (int)(pos / Wo), wo = (int)(pos - (long)ho * Wo);
+        const int h = ho * SH + jh - PH, w = wo * SW + jw - PW;
+        float v = 0.f;
+        if (h >= 0 && h < H && w >= 0 && w < W) v = x[(((long)b * C + c) * H + h) * W + w];
+        cols[i] = v;
+    }
+}
+
+// dx[b,c,h,w] = sum over (jh,jw) with (h+PH-jh) % SH == 0 and (w+PW-jw) % SW == 0 of dcols[b,(c,jh,jw),(ho,wo)]  (gather form)
+__global__ __launch_bounds__(256) void svb_col2im_kernel(const float* dcols, float* dx, int B, int C, int H, int W, int KH,
+                                                         int KW, int SH, int SW, int PH, int PW, int Ho, int Wo) {
+    const long total = (long)B * C * H * W;
+    const long n_pos = (long)Ho * Wo;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int w = (int)(i % W);
+        long r = i / W;
+        const int h = (int)(r % H); r /= H;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        float s = 0.f;
+        for (int jh = 0; jh < KH; ++jh) {
+            const int th = h + PH - jh;
+            if (th < 0 || th % SH) continue;
+            const int ho = th / SH;
+            if (ho >= Ho) continue;
+            for (int jw = 0; jw < KW; ++jw) {
+                const int tw = w + PW - jw;
+                if (tw < 0 || tw % SW) continue;
+                const int wo = tw / SW;
+                if (wo >= Wo) continue;
+                s += dcols[((((long)b * C + c) * KH + jh) * KW + jw) * n_pos + (long)ho * Wo + wo];
+            }
+        }
+        dx[i] = s;
+    }
+}
+
+static inline int g1d(long total) {
+    long g = (total + 255) / 256;
+    if (g > 16384) g = 16384;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int svb_im2col(const float* x, float* cols, int B, int C, int H, int W, int KH, int KW, int SH, int SW, int PH,
+                          int PW, int Ho, int Wo, void* stream) {
+    if (!x || !cols || B <= 0 || C <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || SH <= 0 || SW <= 0 || Ho <= 0 || Wo <= 0)
+        return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_im2col_kernel, dim3(g1d((long)B * C * KH * KW * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, cols,
+                       B, C, H, W, KH, KW, SH, SW, PH, PW, Ho, Wo);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_col2im(const float* dcols, float* dx, int B, int C, int H, int W, int KH, int KW, int SH, int SW, int PH,
+                          int PW, int Ho, int Wo, void* stream) {
+    if (!dcols || !dx || B <= 0 || C <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || SH <= 0 || SW <= 0 || Ho <= 0 || Wo <= 0)
+        return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_col2im_kernel, dim3(g1d((long)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, dcols, dx, B, C, H,
+                       W, KH, KW, SH, SW, PH, PW, Ho, Wo);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}

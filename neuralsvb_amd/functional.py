@@ -291,3 +291,47 @@ def ssim_map(pred, target, bias=6.0):
     """Per-pixel SSIM of (pred+bias, target+bias), [B,T,F] -> [B,T,F]; gradient flows to `pred` only
     (reference modules/commons/ssim.py:331-351 with size_average=False, as called by tasks/tts/fs2.py:166-175)."""
     return _SsimMapFn.apply(pred, target.detach(), float(bias))
+
+
+class _Conv2dFn(torch.autograd.Function):
+    """Small strided Conv2d = im2col + the implicit-GEMM 1x1 conv kernel (+ fused LeakyReLU epilogue).
+    reference: modules/fastspeech/multi_window_disc.py:14-31 (Conv2d 3x3 stride 2 pad 1 + LeakyReLU(0.2))."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cfg):
+        stride, pad, slope = cfg
+        x, weight = x.contiguous(), weight.contiguous()
+        B, C, H, W = x.shape
+        cout, _, KH, KW = weight.shape
+        cols, Ho, Wo = K.im2col(x, KH, KW, stride, stride, pad, pad)
+        w3 = weight.view(cout, C * KH * KW, 1)
+        pa, pb = K.weight_pack(w3, None, want_a=True, want_b=ctx.needs_input_grad[0])
+        y = K.conv1d_forward(cols, pa, cout, 1, bias=bias, out_act=ACT_LRELU if slope is not None else ACT_NONE,
+                             out_slope=slope if slope is not None else 0.0)
+        ctx.cfg, ctx.shape = cfg, (B, C, H, W, KH, KW, Ho, Wo)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(cols if ctx.needs_input_grad[1] else None, pb, y if slope is not None else None)
+        return y.view(B, cout, Ho, Wo)
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, pad, slope = ctx.cfg
+        B, C, H, W, KH, KW, Ho, Wo = ctx.shape
+        cols, pb, yact = ctx.saved_tensors
+        cout = dy.shape[1]
+        dy = dy.contiguous().view(B, cout, Ho * Wo)
+        a_slope = slope if slope is not None else 0.0
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dcols = K.conv1d_transposed(dy, pb, C * KH * KW, Ho * Wo, 1, in_gate=yact, in_slope=a_slope)
+            dx = K.col2im(dcols, B, C, H, W, KH, KW, stride, stride, pad, pad)
+        if ctx.needs_input_grad[1]:
+            dw = K.conv1d_wgrad(dy, cols, 1, a_gate=yact, a_slope=a_slope).view(cout, C, KH, KW)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = K.bias_grad(dy, yact, a_slope)
+        return dx, dw, db, None
+
+
+def conv2d_lrelu(x, weight, bias, stride, padding, lrelu_slope=None):
+    """x [B,C,H,W]; weight [Cout,C,KH,KW]; returns leaky_relu(conv2d(x)) (or conv2d(x) when lrelu_slope is None)."""
+    return _Conv2dFn.apply(x, weight, bias, (int(stride), int(padding), lrelu_slope))

@@ -246,6 +246,30 @@ def layernorm_bwd(x, gamma, dy, mean, rstd, n_part=128):
     return dx, dgp.sum(0), dbp.sum(0)
 
 
+def conv2d_out_hw(H, W, KH, KW, SH, SW, PH, PW):
+    return (H + 2 * PH - KH) // SH + 1, (W + 2 * PW - KW) // SW + 1
+
+
+def im2col(x, KH, KW, SH, SW, PH, PW):
+    """x [B,C,H,W] -> cols [B, C*KH*KW, Ho*Wo]."""
+    _f32(x)
+    lib, st = _prep(x)
+    B, Cc, H, W = x.shape
+    Ho, Wo = conv2d_out_hw(H, W, KH, KW, SH, SW, PH, PW)
+    cols = torch.empty((B, Cc * KH * KW, Ho * Wo), device=x.device, dtype=torch.float32)
+    L.check(lib.svb_im2col(_ptr(x), _ptr(cols), B, Cc, H, W, KH, KW, SH, SW, PH, PW, Ho, Wo, st), "svb_im2col")
+    return cols, Ho, Wo
+
+
+def col2im(dcols, B, Cc, H, W, KH, KW, SH, SW, PH, PW):
+    _f32(dcols)
+    lib, st = _prep(dcols)
+    Ho, Wo = conv2d_out_hw(H, W, KH, KW, SH, SW, PH, PW)
+    dx = torch.empty((B, Cc, H, W), device=dcols.device, dtype=torch.float32)
+    L.check(lib.svb_col2im(_ptr(dcols), _ptr(dx), B, Cc, H, W, KH, KW, SH, SW, PH, PW, Ho, Wo, st), "svb_col2im")
+    return dx
+
+
 def _prep_strided(*tensors):
     """like _prep but allows non-contiguous tensors (kernels that take element strides)."""
     lib = L.get_lib()

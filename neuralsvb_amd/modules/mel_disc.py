@@ -7,13 +7,16 @@ Semantics kept: one np.random window start per window length shared by the whole
 non-zero frames (:190), Dropout2d(0.25) on whole channels in train mode (:23), `y=None` when a clip is shorter
 than a window (:140-142).
 
-Round-1 status: the 3x3 stride-2 Conv2d blocks (0.42 GFLOP/sample/call, ~2 % of the step FLOPs) still run on
-torch-ROCm ops; they are the next convs to move onto the HIP implicit-GEMM kernel ("next").
+The 3x3 stride-2 Conv2d + LeakyReLU blocks run on the HIP kernels (im2col -> implicit-GEMM conv kernel with the
+LeakyReLU fused in its epilogue, col2im / split-K wgrad for the backward); Dropout2d and InstanceNorm2d are
+elementwise/statistics passes left on torch-ROCm ops.
 """
 import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
+
+from .. import functional as SF
 
 
 def _critic_tower(time_length, freq_length, kernel, c_in, hidden, norm_type, reduction):
@@ -63,7 +66,10 @@ class Discriminator(nn.Module):
             s = starts[w][0]
             h = x[:, :, s:s + wl]
             for blk in tower.model:
-                h = blk(h)
+                conv = blk[0]     # Conv2d 3x3 s2 p1 + LeakyReLU(0.2): im2col + HIP implicit-GEMM kernel, fused epilogue
+                h = SF.conv2d_lrelu(h, conv.weight, conv.bias, conv.stride[0], conv.padding[0], 0.2)
+                for m in list(blk)[2:]:                      # Dropout2d(0.25) [, InstanceNorm2d]
+                    h = m(h)
                 fmaps.append(h)
             scores.append(tower.adv_layer(h.flatten(1)))
         y = None

@@ -165,3 +165,22 @@ def test_layer_norm_autograd(dev):
     assert (y.detach().cpu() - yr.detach()).abs().max() < 2e-5
     for a, b in zip(dl, rl):
         assert rel_err(a.grad, b.grad) < 3e-5
+
+
+def test_conv2d_lrelu_autograd(dev):
+    """mel-critic block: Conv2d(c,128,3x3,s2,p1)+LeakyReLU(0.2) (multi_window_disc.py:14-22) via im2col + GEMM kernel."""
+    g_ = torch.Generator().manual_seed(41)
+    for cin, H, W in ((1, 32, 80), (6, 16, 40), (6, 5, 10)):
+        x = torch.randn(2, cin, H, W, generator=g_)
+        w = torch.randn(10, cin, 3, 3, generator=g_) * 0.3
+        b = torch.randn(10, generator=g_)
+        rl = [t.clone().requires_grad_(True) for t in (x, w, b)]
+        yr = F.leaky_relu(F.conv2d(rl[0], rl[1], rl[2], 2, 1), 0.2)
+        dy = torch.randn(yr.shape, generator=g_)
+        yr.backward(dy)
+        dl = [_leaf(t, dev) for t in (x, w, b)]
+        y = SF.conv2d_lrelu(dl[0], dl[1], dl[2], 2, 1, 0.2)
+        assert y.shape == yr.shape and rel_err(y, yr) < 2e-5
+        y.backward(dy.to(dev))
+        for a, r in zip(dl, rl):
+            assert rel_err(a.grad, r.grad) < 3e-5
