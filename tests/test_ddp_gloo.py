@@ -1,0 +1,91 @@
+"""Data-parallel path on CPU: world_size 2, gloo backend (the MI355X run uses the same code with backend "nccl" = RCCL).
+
+Checks (a) the reference's batch sharding rule (tasks/tts/tts.py:93-96: rank r takes batch[r::world], indivisible
+batches dropped, max_sentences scaled by world), (b) FlatGradSync: one flat all-reduce per optimizer makes every rank
+hold the full-batch gradient, through the HIP autograd functions (emulator build on CPU), and (c) rank 0 -> all
+broadcast of parameters/buffers at start-up.
+"""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, emu_lib, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, ROOT)
+    from neuralsvb_amd import _lib
+    _lib._LIB, _lib._LIB_IS_EMU = _lib.bind(emu_lib), True     # test harness: CPU lane emulator
+    from neuralsvb_amd import functional as SF
+    from neuralsvb_amd.utils.trainer import FlatGradSync, Trainer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                                 # different init per rank on purpose
+    conv_v = torch.nn.Parameter(torch.randn(6, 4, 3) * 0.3)
+    conv_g = torch.nn.Parameter(torch.rand(6, 1, 1) + 0.5)
+    bias = torch.nn.Parameter(torch.randn(6) * 0.1)
+    params = [conv_v, conv_g, bias]
+    # (c) start-up broadcast as Trainer._broadcast_module_state does
+    for p in params:
+        dist.broadcast(p.data, 0)
+    sync = FlatGradSync(params, world)
+    g = torch.Generator().manual_seed(7)
+    x_full = torch.randn(4, 4, 20, generator=g)                   # global batch of 4 clips
+    dy_full = torch.randn(4, 6, 20, generator=g)
+    xs, dys = x_full[rank::world], dy_full[rank::world]          # (a) rank r takes batch[r::world]
+    y = SF.conv1d(xs, conv_v, bias, 1, 1, weight_g=conv_g)
+    loss = (y * dys).sum() / xs.shape[0]                          # per-rank mean over its clips
+    loss.backward()
+    sync.all_reduce()
+    res = {"grad": sync.flat.clone().numpy(), "w": torch.cat([p.detach().flatten() for p in params]).numpy()}
+    if rank == 0:
+        # single-process reference on the whole batch with stock torch ops
+        v, gn, b = (p.detach().clone().requires_grad_(True) for p in params)
+        w = v * (gn / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+        yr = torch.nn.functional.conv1d(x_full, w, b, 1, 1)
+        ((yr * dy_full).sum() / 4).backward()
+        res["ref"] = torch.cat([t.grad.flatten() for t in (v, gn, b)]).numpy()
+    np.save(os.path.join(out, f"r{rank}.npy"), res, allow_pickle=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_two_ranks_gloo(tmp_path, _emu_lib):
+    from tests.conftest import EMU_LIB
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, EMU_LIB, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "r0.npy", allow_pickle=True).item()
+    r1 = np.load(tmp_path / "r1.npy", allow_pickle=True).item()
+    assert np.array_equal(r0["w"], r1["w"])                       # identical replicas after broadcast
+    assert np.array_equal(r0["grad"], r1["grad"])                 # identical averaged gradients on every rank
+    assert np.abs(r0["grad"] - r0["ref"]).max() < 2e-5 * max(1.0, np.abs(r0["ref"]).max())
+
+
+def test_batch_sharding_rule():
+    """build_dataloader: global batches of max_sentences*world clips, rank r takes every world-th item."""
+    from neuralsvb_amd.utils.batching import batch_by_size
+    sizes = [100, 90, 120, 80, 110, 95, 70, 130, 60]
+    world, max_sentences = 2, 2
+    batches = batch_by_size(list(range(len(sizes))), lambda i: sizes[i], max_tokens=10 ** 6,
+                            max_sentences=max_sentences * world, required_batch_size_multiple=world)
+    assert all(len(b) <= max_sentences * world for b in batches) and batches[0] == [0, 1, 2, 3]
+    kept = [b for b in batches if len(b) % world == 0]
+    shards = [[b[r::world] for b in kept] for r in range(world)]
+    assert shards[0][0] == [0, 2] and shards[1][0] == [1, 3]
+    assert all(len(a) == len(b) for a, b in zip(*shards))
+    flat = sorted(i for r in range(world) for b in shards[r] for i in b)
+    assert flat == sorted(i for b in kept for i in b)             # disjoint cover of the kept batches
