@@ -1,0 +1,105 @@
+"""NSF-HifiGAN generator / MPD / MSD on the HIP kernels vs golden vectors produced by the unmodified reference
+(tests/golden/make_golden.py), with the reference's state_dict layout loaded strictly."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import procedural
+from tests.test_oracle_golden import HIFIGAN_CFG
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+KEYS = json.load(open(os.path.join(G, "ref_state_keys.json")))
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _load(module, name, prefix):
+    ref = sorted((k, tuple(s)) for k, s, _ in KEYS[name])
+    mine = sorted((k, tuple(v.shape)) for k, v in module.state_dict().items())
+    assert mine == ref, set(mine) ^ set(ref)
+    module.load_state_dict(procedural.state_dict_for(KEYS[name], prefix=prefix), strict=True)
+    return module
+
+
+def test_state_dict_layouts_match_reference():
+    from neuralsvb_amd.modules.hifigan import HifiGanGenerator, MultiPeriodDiscriminator, MultiScaleDiscriminator
+    _load(HifiGanGenerator(HIFIGAN_CFG), "HifiGanGenerator", "model_gen.")
+    _load(MultiPeriodDiscriminator(), "MultiPeriodDiscriminator", "model_disc.mpd.")
+    _load(MultiScaleDiscriminator(), "MultiScaleDiscriminator", "model_disc.msd.")
+
+
+def _slow(dev):
+    if dev.type == "cpu" and not os.environ.get("SVB_SLOW_EMU"):
+        pytest.skip("full-size vocoder through the lane emulator takes minutes; set SVB_SLOW_EMU=1 (runs on the GPU by default)")
+
+
+def test_generator_matches_reference_golden(dev):
+    _slow(dev)
+    from neuralsvb_amd.modules.hifigan import HifiGanGenerator
+    d = np.load(os.path.join(G, "hifigan_gen.npz"))
+    gen = _load(HifiGanGenerator(HIFIGAN_CFG), "HifiGanGenerator", "model_gen.").to(dev).eval()
+    with torch.no_grad():
+        wav = gen(t(d["mel"]).to(dev), t(d["f0"]).to(dev), rand_ini=t(d["rand_ini"]).to(dev), noise=t(d["noise"]).to(dev))
+    assert wav.shape == d["wav"].shape
+    # waveform tolerance: 2e-4 abs (|wav| <= 1); the NSF phase differs from the reference's fp32 cumsum by its own rounding
+    assert np.abs(wav.cpu().numpy() - d["wav"]).max() < 2e-4
+    # weight-norm folding (vocoders/hifigan.py:29) must not change the output
+    gen.remove_weight_norm()
+    with torch.no_grad():
+        wav2 = gen(t(d["mel"]).to(dev), t(d["f0"]).to(dev), rand_ini=t(d["rand_ini"]).to(dev), noise=t(d["noise"]).to(dev))
+    assert (wav2 - wav).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("name", ["mpd", "msd"])
+def test_discriminators_match_reference_golden(dev, name):
+    _slow(dev)
+    from neuralsvb_amd.modules.hifigan import MultiPeriodDiscriminator, MultiScaleDiscriminator
+    from tests.golden.make_golden import fmap_stats
+    d = np.load(os.path.join(G, "hifigan_disc.npz"))
+    if name == "mpd":
+        m = _load(MultiPeriodDiscriminator(), "MultiPeriodDiscriminator", "model_disc.mpd.")
+    else:
+        m = _load(MultiScaleDiscriminator(), "MultiScaleDiscriminator", "model_disc.msd.")
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        rs, gs, fr, fg = m(t(d["y"]).to(dev), t(d["y_hat"]).to(dev))
+    for i, (a, b) in enumerate(zip(rs, gs)):
+        assert a.shape == d[f"{name}.y_d_r.{i}"].shape
+        assert np.abs(a.cpu().numpy() - d[f"{name}.y_d_r.{i}"]).max() < 5e-5, (name, i)
+        assert np.abs(b.cpu().numpy() - d[f"{name}.y_d_g.{i}"]).max() < 5e-5, (name, i)
+    shapes = [list(x.shape) + [0] * (4 - x.dim()) for fm in fr for x in fm]
+    assert np.array_equal(np.array(shapes), d[f"{name}.fmap_shapes"])
+    st = np.stack([fmap_stats(x.cpu()) for fm in fr for x in fm])
+    np.testing.assert_allclose(st, d[f"{name}.fmap_r_stats"], atol=5e-5, rtol=3e-4)
+
+
+def test_small_generator_and_discriminators_autograd(dev):
+    """Small-width G / MPD / MSD step (G loss = adversarial + feature matching) vs torch autograd over the CPU oracle."""
+    from neuralsvb_amd.modules import hifigan as H
+    from oracle import modules_ref as R
+    cfg = dict(HIFIGAN_CFG, upsample_initial_channel=32)
+    torch.manual_seed(0)
+    gen = H.HifiGanGenerator(cfg)
+    sd = {k: v.clone() for k, v in gen.state_dict().items()}
+    g_ = torch.Generator().manual_seed(1)
+    mel = torch.randn(1, 80, 6, generator=g_) - 3
+    f0 = 150 + 200 * torch.rand(1, 6, generator=g_)
+    ri = torch.rand(1, 9, generator=g_)
+    nz = torch.randn(1, 6 * 128, 9, generator=g_)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    wr = R.hifigan_generator(sdr, mel, f0, ri, nz, cfg)
+    tgt = torch.randn(wr.shape, generator=g_) * 0.1
+    ((wr - tgt) ** 2).mean().backward()
+    gen = gen.to(dev).train()
+    w = gen(mel.to(dev), f0.to(dev), rand_ini=ri.to(dev), noise=nz.to(dev))
+    assert (w.detach().cpu() - wr.detach()).abs().max() < 2e-4
+    ((w - tgt.to(dev)) ** 2).mean().backward()
+    for k, p in gen.named_parameters():
+        gr = sdr[k].grad
+        rel = ((p.grad.cpu() - gr).abs().max() / gr.abs().max().clamp_min(1e-10)).item()
+        assert rel < 5e-3, (k, rel)
