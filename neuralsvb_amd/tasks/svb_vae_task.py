@@ -28,24 +28,6 @@ from ..utils.schedulers import NoneSchedule, RSQRTSchedule
 from .base_task import BaseTask, data_loader
 
 
-def _gauss_window(size=11, sigma=1.5):
-    g = torch.tensor([math.exp(-(x - size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(size)])
-    g = (g / g.sum()).unsqueeze(1)
-    return g.mm(g.t()).float()[None, None]
-
-
-def ssim_map(img1, img2, window):
-    """Per-pixel SSIM of [B,1,T,80] images, 11x11 gaussian (modules/commons/ssim.py:331-351), mean over channel."""
-    p = window.shape[-1] // 2
-    mu1, mu2 = F.conv2d(img1, window, padding=p), F.conv2d(img2, window, padding=p)
-    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
-    s1 = F.conv2d(img1 * img1, window, padding=p) - mu1_sq
-    s2 = F.conv2d(img2 * img2, window, padding=p) - mu2_sq
-    s12 = F.conv2d(img1 * img2, window, padding=p) - mu12
-    c1, c2 = 0.01 ** 2, 0.03 ** 2
-    return (((2 * mu12 + c1) * (2 * s12 + c2)) / ((mu1_sq + mu2_sq + c1) * (s1 + s2 + c2))).mean(1)
-
-
 class SVBVAEMleTask(BaseTask):
     def __init__(self):
         super().__init__()
@@ -56,7 +38,6 @@ class SVBVAEMleTask(BaseTask):
         for part in hparams["mel_loss"].split("|"):
             name, _, lbd = part.partition(":")
             self.loss_and_lambda[name] = float(lbd) if lbd else 1.0
-        self.register_buffer("_ssim_window", _gauss_window(), persistent=False)
         self.vocoder = None
         self.model_out = self.model_out_gt = None
 
@@ -251,6 +232,9 @@ class SVBVAEMleTask(BaseTask):
     def test_step(self, sample, batch_idx):
         from .infer import infer_and_save
         return infer_and_save(self, sample, batch_idx)
+
+    def test_end(self, outputs):
+        return {}
 
     # ------------------------------------------------------------------ data (tasks/tts/tts.py:57-101)
     @data_loader
