@@ -11,7 +11,7 @@ import torch
 import yaml
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ("hidden_size=64,fvae_enc_dec_hidden=64,latent_size=16,fvae_enc_n_layers=2,fvae_dec_n_layers=2,"
+SMALL = ("hidden_size=256,fvae_enc_dec_hidden=64,latent_size=16,fvae_enc_n_layers=2,fvae_dec_n_layers=2,"
          "mel_disc_hidden_size=32,max_sentences=2,ds_workers=0,num_sanity_val_steps=1,endless_ds=False,"
          "audio_sample_rate=24000,fmax=12000,max_updates=3,val_check_interval=2,phase_2_steps=2,tb_log_interval=1,"
          "max_valid_sentences=1")
