@@ -55,7 +55,7 @@ int svb_conv1d_forward(const float* x, const float* wp, float* y, int B, int Cin
 /* Tile configuration (0..4) the conv launcher picks for Cout/groups output channels and nq_max output positions
  * per phase: {64x128, 128x96, 128x128, 64x64, 32x128} = svb_conv1d_mfma_kernel<2,2,2>, <4,1,3>, <4,1,4>, <2,2,1>, <1,4,1>.
  * (profiling aid: lets a caller name the kernel instantiation a launch used)                                   */
-int svb_conv1d_pick_cfg(int cout_g, int nq_max);
+int svb_conv1d_pick_cfg(int cout_g, int nq_max, int nz /* batch * phases * groups */);
 
 /* Transposed conv (gather form): y[b,co,p] = sum_{ci,j : p = t*stride - pad + j*dil} w[ci,co,j] x[b,ci,t].
  * Replaces F.conv_transpose1d (reference vae_models.py:115-120,126; hifigan.py:122-125,156) and the data

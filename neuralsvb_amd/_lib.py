@@ -29,7 +29,7 @@ SIGNATURES = {
     "svb_weight_pack": (I, [P, P, P, P, I, I, I, I, P]),
     "svb_conv1d_forward": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),
     "svb_conv1d_transposed": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),
-    "svb_conv1d_pick_cfg": (I, [I, I]),
+    "svb_conv1d_pick_cfg": (I, [I, I, I]),
     "svb_conv1d_wgrad_workspace_floats": (SZ, [I, I, I, I, I, I, I, C.POINTER(I)]),
     "svb_conv1d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, P, F, P, F, I, P]),
     "svb_wgrad_reduce": (I, [P, I, P, P, P, P, I, I, I, I, P]),

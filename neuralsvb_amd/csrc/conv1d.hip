@@ -500,13 +500,17 @@ __global__ __launch_bounds__(256) void svb_bias_grad_kernel(const float* dy, con
 struct SvbTileCfg { int BM, BN; };
 static const SvbTileCfg kCfgs[5] = {{64, 128}, {128, 96}, {128, 128}, {64, 64}, {32, 128}};
 
-static int pick_cfg(int cout_g, int nq_max) {
+// Tile choice = smallest estimated makespan: blocks are dealt round-robin to the 256 CUs, so the kernel takes
+// ceil(blocks / 256) "rounds" of one tile's work each (padding waste and CU under-fill both show up here);
+// ties go to the larger tile (fewer weight re-reads).  `nz` = batch * phases (grid.z), `groups` multiplies grid.x.
+static int pick_cfg(int cout_g, int nq_max, long nz) {
     long best_cost = -1;
     int best = 0;
     for (int i = 0; i < 5; ++i) {
         const long mt = svb_cdiv(cout_g, kCfgs[i].BM), qt = svb_cdiv(nq_max, kCfgs[i].BN);
-        const long cost = mt * kCfgs[i].BM * qt * kCfgs[i].BN;
         const long area = (long)kCfgs[i].BM * kCfgs[i].BN;
+        const long rounds = (mt * qt * nz + 255) / 256;
+        const long cost = rounds * area;
         if (best_cost < 0 || cost < best_cost ||
             (cost == best_cost && area > (long)kCfgs[best].BM * kCfgs[best].BN)) {
             best_cost = cost;
@@ -565,7 +569,7 @@ static int launch_conv(SvbConvArgs& a, const SvbConvPlan& p, hipStream_t stream)
     }
     if (nq_max <= 0) return SVB_OK;
     if ((long)a.B * p.n_phase > 65535) return SVB_ERR_UNSUPPORTED;
-    int cfg = pick_cfg(a.Cout_g, nq_max);
+    int cfg = pick_cfg(a.Cout_g, nq_max, (long)a.B * p.n_phase * a.G);
     if (a.force_cfg >= 0 && a.force_cfg < 5) cfg = a.force_cfg;
     switch (cfg) {
         case 0: return launch_cfg<2, 2, 2>(a, p, nq_max, span_off_max, ntap_max, stream);
@@ -576,7 +580,7 @@ static int launch_conv(SvbConvArgs& a, const SvbConvPlan& p, hipStream_t stream)
     }
 }
 
-extern "C" int svb_conv1d_pick_cfg(int cout_g, int nq_max) { return pick_cfg(cout_g, nq_max); }
+extern "C" int svb_conv1d_pick_cfg(int cout_g, int nq_max, int nz) { return pick_cfg(cout_g, nq_max, nz); }
 
 static void fill_epilogue(SvbConvArgs& a, const SvbConvEpilogue* e) {
     a.bias = e ? e->bias : nullptr;
@@ -662,7 +666,7 @@ extern "C" size_t svb_conv1d_wgrad_workspace_floats(int B, int CA, int CB, int g
     const int n_tg = svb_cdiv(k, tgw);
     const long tiles = (long)groups * svb_cdiv(CA_g, 64) * svb_cdiv(CB_g, 64) * n_tg;
     const long chunks = (long)B * svb_cdiv(TA, qc);
-    long ns = 1024 / tiles; if (ns < 1) ns = 1; if (ns > chunks) ns = chunks; if (ns > 256) ns = 256;
+    long ns = 768 / tiles; if (ns < 1) ns = 1; if (ns > chunks) ns = chunks; if (ns > 24) ns = 24;
     if (nsplit_out) *nsplit_out = (int)ns;
     return (size_t)ns * CA * CB_g * k;
 }

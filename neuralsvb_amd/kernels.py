@@ -5,6 +5,7 @@ HIP stream, and allocates outputs / workspaces with torch (plumbing only).  CPU 
 unless the CPU lane emulator was injected by tests/emu (test infrastructure).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -14,16 +15,43 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 
 # bench.py sets PROFILE = [] to collect (kernel instantiation, algorithmic FLOPs, start event, end event) per conv launch
 PROFILE = None
-_CFG_NAMES = ["svb_conv1d_mfma_kernel<2,2,2,8192,80>", "svb_conv1d_mfma_kernel<4,1,3,8192,80>",
-              "svb_conv1d_mfma_kernel<4,1,4,8192,80>", "svb_conv1d_mfma_kernel<2,2,1,8192,80>",
-              "svb_conv1d_mfma_kernel<1,4,1,8192,80>"]
+_CFG_NAMES = ["svb_conv1d_mfma_kernel<2,2,2,*,80> (64x128)", "svb_conv1d_mfma_kernel<4,1,3,*,80> (128x96)",
+              "svb_conv1d_mfma_kernel<4,1,4,*,80> (128x128)", "svb_conv1d_mfma_kernel<2,2,1,*,80> (64x64)",
+              "svb_conv1d_mfma_kernel<1,4,1,*,80> (32x128)"]
+
+
+# ---- per-shape tile autotuning ("measure, don't guess"): the first time a conv signature is seen on the GPU all five
+# tile configurations are timed with HIP events and the fastest is cached for the life of the process.
+AUTOTUNE = os.environ.get("SVB_AUTOTUNE", "1") != "0"
+_TUNED = {}
+
+
+def _tuned_cfg(sig, launch):
+    """launch(force_cfg) enqueues the kernel once.  Returns the cached/measured best force_cfg (1..5) or 0 (heuristic)."""
+    if not AUTOTUNE or PROFILE is not None:
+        return _TUNED.get(sig, 0)
+    best = _TUNED.get(sig)
+    if best is None:
+        times = []
+        for cfg in range(1, 6):
+            launch(cfg)                                   # warm (also validates the configuration)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                launch(cfg)
+            e1.record()
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1))
+        best = 1 + min(range(5), key=lambda i: times[i])
+        _TUNED[sig] = best
+    return best
 
 
 class _ConvProbe:
-    def __init__(self, lib, x, cout_g, nq_max, flops):
+    def __init__(self, lib, x, cout_g, nq_max, flops, nz=1, forced=0):
         self.on = PROFILE is not None and x.is_cuda
         if self.on:
-            self.name = _CFG_NAMES[lib.svb_conv1d_pick_cfg(int(cout_g), int(nq_max))]
+            self.name = _CFG_NAMES[forced - 1 if forced else lib.svb_conv1d_pick_cfg(int(cout_g), int(nq_max), int(nz))]
             self.flops = flops
             self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self.e0.record()
@@ -102,7 +130,13 @@ def conv1d_forward(x, pa, cout, k, stride=1, pad=0, dil=1, groups=1, out=None, *
     tout = conv_out_len(tin, k, stride, pad, dil)
     y = out if out is not None else torch.empty((B, cout, tout), device=x.device, dtype=torch.float32)
     e = make_epilogue(**epi)
-    probe = _ConvProbe(lib, x, cout // groups, tout, 2.0 * B * cout * tout * (cin // groups) * k)
+    if x.is_cuda and not epi.get("force_cfg"):
+        def launch(cfg):
+            e.force_cfg = cfg
+            L.check(lib.svb_conv1d_forward(_ptr(x), _ptr(pa), _ptr(y), B, cin, cout, groups, tin, tout, k, stride, pad,
+                                           dil, C.byref(e), st), "svb_conv1d_forward")
+        e.force_cfg = _tuned_cfg(("f", B, cin, cout, groups, tin, k, stride, pad, dil), launch)
+    probe = _ConvProbe(lib, x, cout // groups, tout, 2.0 * B * cout * tout * (cin // groups) * k, B * groups, e.force_cfg)
     L.check(lib.svb_conv1d_forward(_ptr(x), _ptr(pa), _ptr(y), B, cin, cout, groups, tin, tout, k, stride, pad, dil,
                                    C.byref(e), st), "svb_conv1d_forward")
     probe.done()
@@ -116,7 +150,14 @@ def conv1d_transposed(x, pb, cout, tout, k, stride=1, pad=0, dil=1, groups=1, ou
     B, cin, tin = x.shape
     y = out if out is not None else torch.empty((B, cout, tout), device=x.device, dtype=torch.float32)
     e = make_epilogue(**epi)
-    probe = _ConvProbe(lib, x, cout // groups, -(-tout // stride), 2.0 * B * cin * tin * (cout // groups) * k)
+    if x.is_cuda and not epi.get("force_cfg"):
+        def launch(cfg):
+            e.force_cfg = cfg
+            L.check(lib.svb_conv1d_transposed(_ptr(x), _ptr(pb), _ptr(y), B, cin, cout, groups, tin, tout, k, stride,
+                                              pad, dil, C.byref(e), st), "svb_conv1d_transposed")
+        e.force_cfg = _tuned_cfg(("t", B, cin, cout, groups, tin, tout, k, stride, pad, dil), launch)
+    probe = _ConvProbe(lib, x, cout // groups, -(-tout // stride), 2.0 * B * cin * tin * (cout // groups) * k,
+                       B * groups * stride, e.force_cfg)
     L.check(lib.svb_conv1d_transposed(_ptr(x), _ptr(pb), _ptr(y), B, cin, cout, groups, tin, tout, k, stride, pad, dil,
                                       C.byref(e), st), "svb_conv1d_transposed")
     probe.done()
