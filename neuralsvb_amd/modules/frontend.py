@@ -74,6 +74,26 @@ class MelFrontend:
         return (wav[0], mel[0]) if squeeze else (wav, mel)
 
     def mel_spectrogram(self, y):
-        """In-graph variant (D4): y [B, N] -> [B, n_mels, N // hop] natural-log mel (forward only this round)."""
-        return K.stft_mel(y.to(self.device, torch.float32).contiguous(), self.window, self.basis, self.n_fft, self.hop, 1,
-                          1e-5)
+        """In-graph variant (D4): y [B, N] -> [B, n_mels, N // hop] natural-log mel.
+
+        Without grad: the fused STFT+mel+log kernel.  With grad (vocoder mel loss): the same arithmetic as two GEMMs on the
+        implicit-GEMM conv kernel -- frames [B, n_fft, F] x windowed DFT basis [2*(n_fft/2+1), n_fft], then the mel basis
+        -- so the backward also runs on the HIP kernels (reference modules/hifigan/mel_utils.py:59-76)."""
+        y = y.to(self.device, torch.float32)
+        if not (torch.is_grad_enabled() and y.requires_grad):
+            return K.stft_mel(y.contiguous(), self.window, self.basis, self.n_fft, self.hop, 1, 1e-5)
+        from .. import functional as SF
+        if not hasattr(self, "_dft"):
+            n = torch.arange(self.n_fft, dtype=torch.float64)
+            k = torch.arange(self.n_fft // 2 + 1, dtype=torch.float64)[:, None]
+            ang = 2.0 * np.pi * k * n[None, :] / self.n_fft
+            w = self.window.double().cpu()[None, :]
+            self._dft = torch.cat([torch.cos(ang) * w, -torch.sin(ang) * w], 0).float().to(self.device)[:, :, None].contiguous()
+        p = (self.n_fft - self.hop) // 2
+        yp = torch.nn.functional.pad(y.clamp(min=-1.0, max=1.0)[:, None], (p, p), mode="reflect")[:, 0]
+        frames = yp.unfold(-1, self.n_fft, self.hop).transpose(1, 2).contiguous()       # [B, n_fft, F]
+        spec = SF.conv1d(frames, self._dft)                                              # [B, 2*(n_fft/2+1), F]
+        nb = self.n_fft // 2 + 1
+        mag = torch.sqrt(spec[:, :nb] ** 2 + spec[:, nb:] ** 2 + 1e-9)
+        mel = SF.conv1d(mag.contiguous(), self.basis[:, :, None].contiguous())
+        return torch.log(torch.clamp(mel, min=1e-5))

@@ -1,0 +1,80 @@
+"""HifiGanTask -- NSF-HifiGAN vocoder training (generator + MPD + MSD), BASELINE config #3.
+
+The reference names `tasks.vocoder.hifigan.HifiGanTask` in egs/egs_bases/tts/vocoder/hifigan.yaml:2 but ships no
+`tasks/vocoder/`: this task is *composed* from the reference's modules and loss functions
+(modules/hifigan/hifigan.py:328-365, mel_utils.py:45-79) and that YAML's hyper-parameters with the upstream-standard
+two-optimizer GAN step, and is therefore parity-unpinned at task level (its pieces are pinned individually).
+
+  opt 0 (generator):      y_ = G(mel, f0);  lambda_mel * L1(mel(y), mel(y_)) + lambda_adv * [gen_loss(MPD) + gen_loss(MSD)]
+                          (+ feature matching when use_fm_loss) -- active adversarial terms after disc_start_steps
+  opt 1 (discriminators): disc_loss(MPD(y, y_.detach())) + disc_loss(MSD(y, y_.detach()))
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..modules.frontend import MelFrontend
+from ..modules.hifigan import (HifiGanGenerator, MultiPeriodDiscriminator, MultiScaleDiscriminator, discriminator_loss,
+                               feature_loss, generator_loss)
+from ..utils.hparams import hparams
+from .base_task import BaseTask
+
+
+class HifiGanTask(BaseTask):
+    def __init__(self):
+        super().__init__()
+        self._fe = None
+
+    def build_model(self):
+        self.model_gen = HifiGanGenerator(hparams)
+        self.model_disc = nn.ModuleDict()
+        self.model_disc["mpd"] = MultiPeriodDiscriminator()
+        self.model_disc["msd"] = MultiScaleDiscriminator()
+        self.gen_params = list(self.model_gen.parameters())
+        self.disc_params = list(self.model_disc.parameters())
+        return self.model_gen
+
+    def configure_optimizers(self):
+        betas = (hparams["adam_b1"], hparams["adam_b2"])
+        fused = all(p.is_cuda for p in self.gen_params)
+        og = torch.optim.AdamW(self.gen_params, betas=betas, fused=fused, **hparams["generator_optimizer_params"])
+        od = torch.optim.AdamW(self.disc_params, betas=betas, fused=fused, **hparams["discriminator_optimizer_params"])
+        self.scheduler = {"gen": torch.optim.lr_scheduler.StepLR(og, **hparams["generator_scheduler_params"]),
+                          "disc": torch.optim.lr_scheduler.StepLR(od, **hparams["discriminator_scheduler_params"])}
+        return [og, od]
+
+    def mel(self, y):
+        if self._fe is None or self._fe.device != y.device:
+            self._fe = MelFrontend(hparams, y.device)
+        return self._fe.mel_spectrogram(y)
+
+    def _training_step(self, sample, batch_idx, optimizer_idx):
+        mel, y, f0 = sample["mels"], sample["wavs"], sample.get("f0")
+        logs = {}
+        adv = self.global_step >= hparams["disc_start_steps"]
+        if optimizer_idx == 0:
+            y_ = self.model_gen(mel, f0)
+            logs["mel"] = F.l1_loss(self.mel(y_[:, 0]), self.mel(y[:, 0]).detach()) * hparams["lambda_mel"]
+            self.y_ = y_.detach()
+            if adv:
+                for name in ("mpd", "msd"):
+                    _, y_g, fr, fg = self.model_disc[name](y, y_)
+                    logs[f"a_{name}"] = generator_loss(y_g) * hparams["lambda_adv"]
+                    if hparams["use_fm_loss"]:
+                        logs[f"fm_{name}"] = feature_loss(fr, fg)
+        else:
+            if not adv:
+                return None
+            for name in ("mpd", "msd"):
+                y_r, y_g, _, _ = self.model_disc[name](y, self.y_)
+                r, g = discriminator_loss(y_r, y_g)
+                logs[f"r_{name}"], logs[f"f_{name}"] = r, g
+        return sum(logs.values()), logs
+
+    def on_before_optimization(self, opt_idx):
+        params, norm = ((self.gen_params, hparams["generator_grad_norm"]),
+                        (self.disc_params, hparams["discriminator_grad_norm"]))[opt_idx]
+        torch.nn.utils.clip_grad_norm_(params, norm, foreach=True)
+
+    def on_after_optimization(self, epoch, batch_idx, optimizer, optimizer_idx):
+        self.scheduler["gen" if optimizer_idx == 0 else "disc"].step()

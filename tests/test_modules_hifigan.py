@@ -105,3 +105,25 @@ def test_small_generator_and_discriminators_autograd(dev):
         gr = sdr[k].grad
         rel = ((p.grad.cpu() - gr).abs().max() / gr.abs().max().clamp_min(1e-10)).item()
         assert rel < 5e-3, (k, rel)
+
+
+def test_ingraph_mel_with_grad_matches_fused_kernel_and_oracle(dev):
+    """D4 with a gradient: the two-GEMM differentiable mel equals the fused STFT kernel and the oracle
+    (mel_utils.py:59-76), and d(mel)/d(wav) equals torch autograd through the oracle."""
+    from neuralsvb_amd.modules.frontend import MelFrontend
+    from oracle import frontend as ofe
+    hp = dict(fft_size=512, hop_size=128, win_size=512, audio_num_mel_bins=80, fmin=50, fmax=12000, audio_sample_rate=24000)
+    g_ = torch.Generator().manual_seed(3)
+    y = (torch.randn(2, 1024, generator=g_) * 0.3).requires_grad_(True)
+    ref = ofe.mel_spectrogram_ingraph(y, 512, 128, 512, 80, 50, 12000, 24000)
+    dm = torch.randn(ref.shape, generator=g_)
+    ref.backward(dm)
+    fe = MelFrontend(hp, dev)
+    yd = y.detach().to(dev).requires_grad_(True)
+    m = fe.mel_spectrogram(yd)
+    assert (m.detach().cpu() - ref.detach()).abs().max() < 2e-4
+    with torch.no_grad():
+        fused = fe.mel_spectrogram(yd.detach())
+    assert (fused.cpu() - ref.detach()).abs().max() < 2e-4
+    m.backward(dm.to(dev))
+    assert ((yd.grad.cpu() - y.grad).abs().max() / y.grad.abs().max()).item() < 2e-3
