@@ -35,7 +35,8 @@ def build_task(args, rank, world, device, tmp):
     data_dir, asr_dir = os.path.join(tmp, f"binary_r{rank}"), os.path.join(tmp, f"asr_r{rank}")
     set_hparams(config=cfg, exp_name="", print_hparams=False,
                 hparams_str=f"audio_sample_rate={args.sample_rate},fmax={args.sample_rate // 2},max_sentences={args.batch},"
-                            f"max_tokens=100000,ds_workers=0,num_sanity_val_steps=0,endless_ds=False")
+                            f"max_tokens=100000,ds_workers=0,num_sanity_val_steps=0,endless_ds=False,"
+                            f"conv_precision={args.precision}")
     hparams["binary_data_dir"], hparams["pretrain_asr_ckpt"], hparams["work_dir"] = data_dir, asr_dir, ""
     hparams["amp"] = bool(args.bf16)
     torch.manual_seed(1234 + rank)
@@ -139,6 +140,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=6.0)
     ap.add_argument("--sample-rate", type=int, default=24000)
     ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
+                    help="conv arithmetic: fp32 MFMA (exact) or the fp32-class bf16x3 split (mel-L1 vs fp32 ~3e-5)")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = try 8/16/32 threads and report the fastest")
@@ -196,7 +199,8 @@ def main():
                 "metric": "audio-seconds/sec per train step (vae_global_mle_eng)", "value": value,
                 "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
+                "dtype": "bf16" if args.bf16 else ("f32" if args.precision == "fp32" else "bf16x3 (fp32-class split, fp32 accumulate/storage)"),
+                "data": "synthetic",
                 "config": {"workload": "vae_global_mle_eng phase-2 train step (gen+disc passes), configs[1]: per-GPU "
                                        f"batch {args.batch} x {args.seconds:g} s synthetic clips @ {args.sample_rate} Hz, "
                                        f"hop 128, T={T}, 80-bin mel", "global_batch": args.batch * world,

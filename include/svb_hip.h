@@ -64,6 +64,22 @@ int svb_conv1d_pick_cfg(int cout_g, int nq_max, int nz /* batch * phases * group
 int svb_conv1d_transposed(const float* x, const float* wp, float* y, int B, int Cin, int Cout, int groups, int Tin,
                           int Tout, int k, int stride, int pad, int dil, const SvbConvEpilogue* epi, void* stream);
 
+/* ---- "bf16x3" variants: same operations on the bf16 matrix cores with an fp32-class operand split
+ * (v = hi + lo in bf16; products hi*hi + hi*lo + lo*hi, fp32 accumulate; relative error ~1e-5 per conv).
+ * svb_weight_pack_bf16x3 writes bf16 hi/lo weights in the two operand layouts
+ *   qa: [k][ceil(d1/16)][d0][16]  (Conv1d forward, ConvTranspose1d data-gradient)
+ *   qb: [k][groups][ceil((d0/groups)/16)][d1][16]  (ConvTranspose1d forward, Conv1d data-gradient);
+ * buffers must be zero-filled by the caller when d1 or d0/groups is not a multiple of 16 (padding is never written). */
+int svb_weight_pack_bf16x3(const float* v, const float* g, unsigned short* qa_hi, unsigned short* qa_lo,
+                           unsigned short* qb_hi, unsigned short* qb_lo, int d0, int d1, int k, int groups, int weight_norm,
+                           void* stream);
+int svb_conv1d_forward_bf16x3(const float* x, const unsigned short* qa_hi, const unsigned short* qa_lo, float* y, int B,
+                              int Cin, int Cout, int groups, int Tin, int Tout, int k, int stride, int pad, int dil,
+                              const SvbConvEpilogue* epi, void* stream);
+int svb_conv1d_transposed_bf16x3(const float* x, const unsigned short* qb_hi, const unsigned short* qb_lo, float* y, int B,
+                                 int Cin, int Cout, int groups, int Tin, int Tout, int k, int stride, int pad, int dil,
+                                 const SvbConvEpilogue* epi, void* stream);
+
 /* Weight gradient, stage 1 (split-K partials): part[s][a][b][j] += A[n,a,q] * Bt[n,b,q*sx + j*dil - pad].
  * Conv1d: A = dy (CA=Cout), Bt = x (CB=Cin); ConvTranspose1d: A = x (CA=Cin), Bt = dy (CB=Cout).
  * a_gate/b_gate: optional activation-derivative gates (see SvbConvEpilogue).  Workspace = floats returned by

@@ -30,6 +30,9 @@ SIGNATURES = {
     "svb_conv1d_forward": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),
     "svb_conv1d_transposed": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),
     "svb_conv1d_pick_cfg": (I, [I, I, I]),
+    "svb_weight_pack_bf16x3": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    "svb_conv1d_forward_bf16x3": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),
+    "svb_conv1d_transposed_bf16x3": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),
     "svb_conv1d_wgrad_workspace_floats": (SZ, [I, I, I, I, I, I, I, C.POINTER(I)]),
     "svb_conv1d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, P, F, P, F, I, P]),
     "svb_wgrad_reduce": (I, [P, I, P, P, P, P, I, I, I, I, P]),

@@ -1,0 +1,478 @@
+// conv1d_bf16.hip -- the implicit-GEMM conv family on the *bf16* matrix cores with an fp32-class split ("bf16x3").
+//
+// Same tap-offset formulation, tile shapes, plan and fused prologue/epilogue as conv1d.hip, but every fp32 operand is
+// split on the fly into two bf16 values  v = hi + lo  (hi = rne_bf16(v), lo = rne_bf16(v - hi)) and each product is
+// evaluated as  hi*hi + hi*lo + lo*hi  on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): 3 MFMAs of 32 cycles per 16
+// K-values instead of 8 fp32 MFMAs of 64 cycles (5.3x the fp32-MFMA rate).  The dropped lo*lo term is 2^-16 relative;
+// measured on the whole MleSVBVAE forward the mel-L1 against the fp32 result is 2.7e-5 (gate: 1e-4).
+//
+// Layouts (chosen so that every MFMA operand is ONE aligned 16-byte LDS read, bank-conflict free):
+//   weights  (global, packed by svb_weight_pack_bf16x3):  [tap][k-chunk of 16 channels][m][16 bf16]  (hi and lo arrays)
+//   W tile   (LDS):  [slab = tap*kch + chunk][m][16 bf16], row pitch 48 B   (lane: row m = l&31, bytes 16*(l>>5))
+//   x tile   (LDS):  [chunk][position][16 bf16],           row pitch 48 B   (transposed + converted while staging:
+//                    a thread loads 8 channels of one position with 8 coalesced dword loads and issues two 16-byte
+//                    LDS stores, hi and lo)
+// 48-byte rows put the 16 lanes of every ds_read_b128 service group on 16 disjoint 4-bank windows.
+#include "svb_common.h"
+#include "conv1d.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define SVBQ_PITCH 24          /* bf16 elements per LDS row (16 used + 8 pad) = 48 bytes */
+#define SVBQ_KCHMAX 2          /* 16-channel chunks staged per phase (fast path) */
+#define SVBQ_XIT 2             /* 128-position groups per chunk on the fast path (span <= 256) */
+
+struct SvbConvQArgs {
+    const float* x;
+    const unsigned short* wq_hi;
+    const unsigned short* wq_lo;
+    const float* bias;
+    float* y;
+    const float* in_gate;
+    const float* out_gate;
+    const float* mask;
+    const float* residual;
+    float in_slope, out_slope, out_gate_slope;
+    int out_act;
+    int B, Cin, Cout, G, Cin_g, Cout_g, Tin, Tout;
+    int sx, out_stride;
+    int w_tap_slabs, w_g_slabs, w_slab_rows, w_goff_m, kchunks;
+    int tg, kch, xrows, fast_x;
+    int w_floats16, x_floats16;   // LDS carve sizes in 16-byte units (one of hi/lo each)
+    int force_cfg;
+};
+
+__device__ __forceinline__ unsigned svbq_bf16_rne(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void svbq_split(float v, unsigned& hi, unsigned& lo) {
+    hi = svbq_bf16_rne(v);
+    lo = svbq_bf16_rne(v - __uint_as_float(hi << 16));
+}
+
+template <int WM, int WN, int NT, int SLB>
+__global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs a, SvbConvPlan p) {
+    constexpr int BM = 32 * WM, BN = 32 * WN * NT;
+    constexpr int WTASKS = SLB * BM * 2;                 // 16-byte units per (hi|lo) weight tile
+    constexpr int WU = (2 * WTASKS + 255) / 256;         // per-thread units, hi and lo together
+    static_assert(WM * WN == 4, "256 threads = 4 waves");
+    HIP_DYNAMIC_SHARED(uint4, dyn_smem)
+    uint4* w_hi = dyn_smem;
+    uint4* w_lo = w_hi + a.w_floats16;
+    uint4* x_hi = w_lo + a.w_floats16;
+    uint4* x_lo = x_hi + a.x_floats16;
+    int* tap_lds = reinterpret_cast<int*>(x_lo + a.x_floats16);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int kb = lane >> 5, l31 = lane & 31;
+
+    const int nwg = gridDim.x * gridDim.y;
+    const int orig = blockIdx.y * gridDim.x + blockIdx.x;
+    const int qd = nwg >> 3, rd = nwg & 7, xcd = orig & 7;
+    const int wgid = (xcd < rd ? xcd * (qd + 1) : rd * (qd + 1) + (xcd - rd) * qd) + (orig >> 3);
+    const int mt = wgid % gridDim.x, qt = wgid / gridDim.x;
+    const int m_tiles_g = gridDim.x / a.G;
+    const int g = mt / m_tiles_g, mtile = mt % m_tiles_g;
+    const int b = blockIdx.z / p.n_phase, ph = blockIdx.z % p.n_phase;
+    const int nq = p.phase_nq[ph];
+    const int q0 = qt * BN;
+    if (q0 >= nq) return;
+
+    const int t0 = p.phase_start[ph], ntap = p.phase_start[ph + 1] - t0;
+    const int min_off = p.phase_min_off[ph];
+    const int lo_pos = q0 * a.sx + min_off;
+    const int span = (BN - 1) * a.sx + p.phase_span_off[ph] + 1;
+    if (tid < ntap) tap_lds[tid] = p.tap_off[t0 + tid] - min_off;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+    const int m_base = mtile * BM;
+    const int m_valid = min(BM, a.Cout_g - m_base);
+    const float* xb = a.x + ((size_t)b * a.Cin + (size_t)g * a.Cin_g) * a.Tin;
+    const float* gb = a.in_gate ? a.in_gate + ((size_t)b * a.Cin + (size_t)g * a.Cin_g) * a.Tin : nullptr;
+    const int tap_step = ntap > 1 ? (p.tap_w[t0 + 1] - p.tap_w[t0]) : 0;
+    const size_t slab_elems = (size_t)a.w_slab_rows * 16;                      // bf16 per slab
+    const size_t w_off0 = ((size_t)p.tap_w[t0 < SVB_MAX_TAPS ? t0 : 0] * a.w_tap_slabs + (size_t)g * a.w_g_slabs) * slab_elems +
+                          ((size_t)g * a.w_goff_m + m_base) * 16;
+
+    // ---- hoisted per-thread decode of the weight-tile units: unit -> (hi|lo, tap t, chunk c, row m, half h) ---------
+    int w_t[WU], w_c[WU], w_src[WU], w_dst[WU];
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+        const int unit = u * 256 + tid;
+        const int arr = unit / WTASKS, r = unit - arr * WTASKS;
+        const int slab = r / (BM * 2), rem = r - slab * (BM * 2);
+        const int mm = rem >> 1, h = rem & 1;
+        const int t = slab / a.kch, c = slab - t * a.kch;
+        const bool ok = arr < 2 && t < a.tg && mm < m_valid;
+        w_t[u] = ok ? t : (1 << 20);
+        w_c[u] = c;
+        w_src[u] = (int)((size_t)t * tap_step * a.w_tap_slabs * slab_elems / 8 + (size_t)c * slab_elems / 8 + mm * 2 + h) ;   // in 16-byte units
+        w_dst[u] = (arr == 1 ? a.w_floats16 : 0) + (slab * BM + mm) * 3 + h;   // 48-byte rows = 3 x 16 bytes
+    }
+    // x staging roles: threads 0..127 own channel half 0, 128..255 half 1; position = (tid & 127) + 128 * it
+    const int xh = tid >> 7, xp0 = tid & 127;
+
+    uint4 wr[WU];
+    float xr[SVBQ_KCHMAX][SVBQ_XIT][8];
+
+    auto load_w = [&](int kc0, int tg0) {
+        const int nt_here = min(a.tg, ntap - tg0);
+        const int kch_here = min(a.kch, a.kchunks - kc0);
+        const size_t base16 = (w_off0 + ((size_t)tg0 * tap_step * a.w_tap_slabs + (size_t)kc0) * slab_elems) / 8;
+        const uint4* src_hi = reinterpret_cast<const uint4*>(a.wq_hi) + base16;
+        const uint4* src_lo = reinterpret_cast<const uint4*>(a.wq_lo) + base16;
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (w_t[u] < nt_here && w_c[u] < kch_here)
+                v = ((u * 256 + tid) < WTASKS ? src_hi : src_lo)[w_src[u]];
+            wr[u] = v;
+        }
+    };
+    auto store_w = [&](int tg0) {
+        const int nt_here = min(a.tg, ntap - tg0);
+#pragma unroll
+        for (int u = 0; u < WU; ++u)
+            if (w_t[u] < nt_here) w_hi[w_dst[u]] = wr[u];       // w_dst already carries the hi/lo array offset
+    };
+    auto load_x = [&](int kc0) {
+        const int kch_here = min(a.kch, a.kchunks - kc0);
+#pragma unroll
+        for (int c = 0; c < SVBQ_KCHMAX; ++c) {
+            if (c < kch_here) {
+                const int ch0 = (kc0 + c) * 16 + xh * 8;
+#pragma unroll
+                for (int it = 0; it < SVBQ_XIT; ++it) {
+                    const int i = xp0 + 128 * it;
+                    const int pos = lo_pos + i;
+                    const bool pv = i < span && pos >= 0 && pos < a.Tin;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float v = 0.f;
+                        if (pv && ch0 + e < a.Cin_g) {
+                            const size_t off = (size_t)(ch0 + e) * a.Tin + pos;
+                            v = xb[off];
+                            if (gb) v *= svb_gate(gb[off], a.in_slope);
+                        }
+                        xr[c][it][e] = v;
+                    }
+                }
+            }
+        }
+    };
+    auto store_x = [&](int kc0) {
+        const int kch_here = min(a.kch, a.kchunks - kc0);
+#pragma unroll
+        for (int c = 0; c < SVBQ_KCHMAX; ++c) {
+            if (c < kch_here) {
+#pragma unroll
+                for (int it = 0; it < SVBQ_XIT; ++it) {
+                    const int i = xp0 + 128 * it;
+                    if (i < span) {
+                        unsigned hi[8], lo[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) svbq_split(xr[c][it][e], hi[e], lo[e]);
+                        const int d = (c * a.xrows + i) * 3 + xh;
+                        x_hi[d] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+                        x_lo[d] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+                    }
+                }
+            }
+        }
+    };
+    auto stage_x_slow = [&](int kc0) {      // wide (strided) spans: direct, unpipelined
+        const int kch_here = min(a.kch, a.kchunks - kc0);
+        for (int c = 0; c < kch_here; ++c) {
+            const int ch0 = (kc0 + c) * 16 + xh * 8;
+            for (int i = xp0; i < span; i += 128) {
+                const int pos = lo_pos + i;
+                unsigned hi[8], lo[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = 0.f;
+                    if (pos >= 0 && pos < a.Tin && ch0 + e < a.Cin_g) {
+                        const size_t off = (size_t)(ch0 + e) * a.Tin + pos;
+                        v = xb[off];
+                        if (gb) v *= svb_gate(gb[off], a.in_slope);
+                    }
+                    svbq_split(v, hi[e], lo[e]);
+                }
+                const int d = (c * a.xrows + i) * 3 + xh;
+                x_hi[d] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+                x_lo[d] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+            }
+        }
+    };
+    auto compute = [&](int kc0, int tg0) {
+        const int nt_here = min(a.tg, ntap - tg0);
+        const int kch_here = min(a.kch, a.kchunks - kc0);
+        for (int c = 0; c < kch_here; ++c) {
+            for (int t = 0; t < nt_here; ++t) {
+                const int wrow = ((t * a.kch + c) * BM + wm * 32 + l31) * 3 + kb;
+                const uint4 ah_u = w_hi[wrow], al_u = w_lo[wrow];
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&ah_u), al = *reinterpret_cast<const bf16x8*>(&al_u);
+                const int toff = tap_lds[tg0 + t];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int xrow = (c * a.xrows + ((wn * NT + n) * 32 + l31) * a.sx + toff) * 3 + kb;
+                    const uint4 bh_u = x_hi[xrow], bl_u = x_lo[xrow];
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&bh_u), bl = *reinterpret_cast<const bf16x8*>(&bl_u);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    int kc0 = 0, tg0 = 0;
+    if (ntap > 0) {
+        __syncthreads();
+        if (a.fast_x) { load_x(0); store_x(0); } else { stage_x_slow(0); }
+        load_w(0, 0);
+        store_w(0);
+        __syncthreads();
+        while (true) {
+            int ntg = tg0 + a.tg, nkc = kc0;
+            if (ntg >= ntap) { ntg = 0; nkc = kc0 + a.kch; }
+            const bool has_next = nkc < a.kchunks;
+            if (has_next) {
+                if (ntg == 0 && a.fast_x) load_x(nkc);
+                load_w(nkc, ntg);
+            }
+            compute(kc0, tg0);
+            if (!has_next) break;
+            __syncthreads();
+            if (ntg == 0) { if (a.fast_x) store_x(nkc); else stage_x_slow(nkc); }
+            store_w(ntg);
+            __syncthreads();
+            kc0 = nkc; tg0 = ntg;
+        }
+    }
+
+    const int out_base = p.phase_out_base[ph];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int ql = q0 + (wn * NT + n) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
+            const int ml = m_base + wm * 32 + row;
+            if (ml < a.Cout_g && ql < nq) {
+                const int co = g * a.Cout_g + ml;
+                const int pos = ql * a.out_stride + out_base;
+                float v = acc[n][r];
+                if (a.bias) v += a.bias[co];
+                v = svb_apply_act(v, a.out_act, a.out_slope);
+                const size_t oi = ((size_t)b * a.Cout + co) * a.Tout + pos;
+                if (a.out_gate) v *= svb_gate(a.out_gate[oi], a.out_gate_slope);
+                if (a.residual) v += a.residual[oi];
+                if (a.mask) v *= a.mask[(size_t)b * a.Tout + pos];
+                a.y[oi] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight pack: v [d0][d1][k] (reference layout, WeightNorm over dim-0 rows) -> bf16 hi/lo in the two operand layouts
+//   qa[tap][ceil(d1/16)][d0][16]            (k-dim = d1: Conv1d forward, ConvTranspose1d data-gradient)
+//   qb[tap][G][ceil(d0g/16)][d1][16]        (k-dim = d0 within its group: ConvTranspose1d forward, Conv1d data-gradient)
+// Padding entries are never written: the caller zero-fills the buffers once.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void svb_weight_pack_bf16x3_kernel(const float* v, const float* gnorm, unsigned short* qa_hi,
+                                                                     unsigned short* qa_lo, unsigned short* qb_hi,
+                                                                     unsigned short* qb_lo, int d0, int d1, int k, int G,
+                                                                     int weight_norm) {
+    __shared__ float red[8];
+    const int row = blockIdx.x;
+    const int rowlen = d1 * k;
+    const float* vr = v + (size_t)row * rowlen;
+    float scale = 1.f;
+    if (weight_norm) {
+        float vv = 0.f;
+        for (int e = threadIdx.x; e < rowlen; e += 256) vv += vr[e] * vr[e];
+        vv = svb_block_sum<256>(vv, red);
+        scale = gnorm[row] / sqrtf(vv);
+    }
+    const int kcha = (d1 + 15) / 16;
+    const int d0g = d0 / G, kchb = (d0g + 15) / 16;
+    const int gq = row / d0g, rl = row - gq * d0g;
+    for (int e = threadIdx.x; e < rowlen; e += 256) {
+        const int c1 = e / k, j = e - c1 * k;
+        unsigned hi, lo;
+        svbq_split(vr[e] * scale, hi, lo);
+        if (qa_hi) {
+            const size_t ia = (((size_t)j * kcha + (c1 >> 4)) * d0 + row) * 16 + (c1 & 15);
+            qa_hi[ia] = (unsigned short)hi; qa_lo[ia] = (unsigned short)lo;
+        }
+        if (qb_hi) {
+            const size_t ib = ((((size_t)j * G + gq) * kchb + (rl >> 4)) * d1 + c1) * 16 + (rl & 15);
+            qb_hi[ib] = (unsigned short)hi; qb_lo[ib] = (unsigned short)lo;
+        }
+    }
+}
+
+// ==================================================================================================================
+struct QCfg { int BM, BN; };
+static const QCfg kQCfgs[5] = {{64, 128}, {128, 96}, {128, 128}, {64, 64}, {32, 128}};
+
+static int q_pick(int cout_g, int nq_max, long nz) {
+    long best_cost = -1;
+    int best = 0;
+    for (int i = 0; i < 5; ++i) {
+        const long mt = svb_cdiv(cout_g, kQCfgs[i].BM), qt = svb_cdiv(nq_max, kQCfgs[i].BN);
+        const long area = (long)kQCfgs[i].BM * kQCfgs[i].BN;
+        const long cost = ((mt * qt * nz + 255) / 256) * area;
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && area > (long)kQCfgs[best].BM * kQCfgs[best].BN)) {
+            best_cost = cost;
+            best = i;
+        }
+    }
+    return best;
+}
+
+template <int WM, int WN, int NT, int SLB>
+static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_off_max, int ntap_max, hipStream_t stream) {
+    constexpr int BM = 32 * WM, BN = 32 * WN * NT;
+    const int span_max = (BN - 1) * a.sx + span_off_max + 1;
+    a.xrows = span_max;
+    a.fast_x = span_max <= 128 * SVBQ_XIT ? 1 : 0;
+    a.kchunks = svb_cdiv(a.Cin_g, 16);
+    // phase = tg taps x kch chunks, tg*kch <= SLB slabs, LDS budget ~72 KB
+    a.tg = ntap_max < 1 ? 1 : (ntap_max > SLB ? SLB : ntap_max);
+    int kch = SLB / a.tg;
+    if (kch > SVBQ_KCHMAX) kch = SVBQ_KCHMAX;
+    if (kch > a.kchunks) kch = a.kchunks;
+    if (kch < 1) kch = 1;
+    auto lds_bytes = [&](int kc) { return (size_t)2 * (a.tg * kc * BM + kc * a.xrows) * 48 + SVB_MAX_TAPS * 4; };
+    while (kch > 1 && lds_bytes(kch) > 72 * 1024) --kch;
+    if (lds_bytes(kch) > 150 * 1024) return SVB_ERR_UNSUPPORTED;
+    a.kch = kch;
+    a.w_floats16 = a.tg * a.kch * BM * 3;
+    a.x_floats16 = a.kch * a.xrows * 3;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_bf16x3_kernel<WM, WN, NT, SLB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid(a.G * svb_cdiv(a.Cout_g, BM), svb_cdiv(nq_max, BN), a.B * p.n_phase);
+    hipLaunchKernelGGL((svb_conv1d_bf16x3_kernel<WM, WN, NT, SLB>), grid, dim3(256), lds_bytes(a.kch), stream, a, p);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+static int q_dispatch(SvbConvQArgs& a, const SvbConvPlan& p, hipStream_t stream) {
+    int nq_max = 0, span_off_max = 0, ntap_max = 0;
+    for (int ph = 0; ph < p.n_phase; ++ph) {
+        if (p.phase_nq[ph] > nq_max) nq_max = p.phase_nq[ph];
+        if (p.phase_span_off[ph] > span_off_max) span_off_max = p.phase_span_off[ph];
+        const int nt = p.phase_start[ph + 1] - p.phase_start[ph];
+        if (nt > ntap_max) ntap_max = nt;
+    }
+    if (nq_max <= 0) return SVB_OK;
+    if ((long)a.B * p.n_phase > 65535) return SVB_ERR_UNSUPPORTED;
+    int cfg = q_pick(a.Cout_g, nq_max, (long)a.B * p.n_phase * a.G);
+    if (a.force_cfg >= 0 && a.force_cfg < 5) cfg = a.force_cfg;
+    switch (cfg) {
+        case 0: return q_launch<2, 2, 2, 8>(a, p, nq_max, span_off_max, ntap_max, stream);
+        case 1: return q_launch<4, 1, 3, 5>(a, p, nq_max, span_off_max, ntap_max, stream);
+        case 2: return q_launch<4, 1, 4, 5>(a, p, nq_max, span_off_max, ntap_max, stream);
+        case 3: return q_launch<2, 2, 1, 8>(a, p, nq_max, span_off_max, ntap_max, stream);
+        default: return q_launch<1, 4, 1, 8>(a, p, nq_max, span_off_max, ntap_max, stream);
+    }
+}
+
+static void q_fill(SvbConvQArgs& a, const SvbConvEpilogue* e) {
+    a.bias = e ? e->bias : nullptr;
+    a.in_gate = e ? e->in_gate : nullptr;
+    a.in_slope = e ? e->in_slope : 0.f;
+    a.out_act = e ? e->out_act : 0;
+    a.out_slope = e ? e->out_slope : 0.f;
+    a.out_gate = e ? e->out_gate : nullptr;
+    a.out_gate_slope = e ? e->out_gate_slope : 0.f;
+    a.residual = e ? e->residual : nullptr;
+    a.mask = e ? e->mask : nullptr;
+    a.force_cfg = e ? e->force_cfg - 1 : -1;
+}
+
+extern "C" int svb_weight_pack_bf16x3(const float* v, const float* g, unsigned short* qa_hi, unsigned short* qa_lo,
+                                      unsigned short* qb_hi, unsigned short* qb_lo, int d0, int d1, int k, int groups,
+                                      int weight_norm, void* stream) {
+    if (!v || (!qa_hi && !qb_hi) || (qa_hi && !qa_lo) || (qb_hi && !qb_lo) || d0 <= 0 || d1 <= 0 || k <= 0 || groups <= 0 ||
+        d0 % groups || (weight_norm && !g))
+        return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_weight_pack_bf16x3_kernel, dim3(d0), dim3(256), 0, (hipStream_t)stream, v, g, qa_hi, qa_lo, qb_hi,
+                       qb_lo, d0, d1, k, groups, weight_norm);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_conv1d_forward_bf16x3(const float* x, const unsigned short* qa_hi, const unsigned short* qa_lo, float* y,
+                                         int B, int Cin, int Cout, int groups, int Tin, int Tout, int k, int stride, int pad,
+                                         int dil, const SvbConvEpilogue* epi, void* stream) {
+    if (!x || !qa_hi || !qa_lo || !y || B <= 0 || groups <= 0 || Cin % groups || Cout % groups || k <= 0 || k > SVB_MAX_TAPS ||
+        stride <= 0 || dil <= 0)
+        return SVB_ERR_ARG;
+    if (Tout != (Tin + 2 * pad - dil * (k - 1) - 1) / stride + 1 || Tout <= 0) return SVB_ERR_ARG;
+    SvbConvQArgs a;
+    SvbConvPlan p;
+    memset(&p, 0, sizeof(p));
+    a.x = x; a.wq_hi = qa_hi; a.wq_lo = qa_lo; a.y = y;
+    q_fill(a, epi);
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.G = groups; a.Cin_g = Cin / groups; a.Cout_g = Cout / groups;
+    a.Tin = Tin; a.Tout = Tout; a.sx = stride; a.out_stride = 1;
+    a.w_tap_slabs = svb_cdiv(a.Cin_g, 16); a.w_g_slabs = 0; a.w_slab_rows = Cout; a.w_goff_m = a.Cout_g;
+    p.n_phase = 1;
+    p.phase_start[0] = 0; p.phase_start[1] = k;
+    for (int j = 0; j < k; ++j) { p.tap_off[j] = j * dil - pad; p.tap_w[j] = j; }
+    p.phase_nq[0] = Tout; p.phase_out_base[0] = 0; p.phase_min_off[0] = -pad; p.phase_span_off[0] = (k - 1) * dil;
+    return q_dispatch(a, p, (hipStream_t)stream);
+}
+
+extern "C" int svb_conv1d_transposed_bf16x3(const float* x, const unsigned short* qb_hi, const unsigned short* qb_lo, float* y,
+                                            int B, int Cin, int Cout, int groups, int Tin, int Tout, int k, int stride, int pad,
+                                            int dil, const SvbConvEpilogue* epi, void* stream) {
+    if (!x || !qb_hi || !qb_lo || !y || B <= 0 || groups <= 0 || Cin % groups || Cout % groups || k <= 0 || k > SVB_MAX_TAPS ||
+        stride <= 0 || stride > SVB_MAX_PHASE || dil <= 0 || Tout <= 0)
+        return SVB_ERR_ARG;
+    SvbConvQArgs a;
+    SvbConvPlan p;
+    memset(&p, 0, sizeof(p));
+    a.x = x; a.wq_hi = qb_hi; a.wq_lo = qb_lo; a.y = y;
+    q_fill(a, epi);
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.G = groups; a.Cin_g = Cin / groups; a.Cout_g = Cout / groups;
+    a.Tin = Tin; a.Tout = Tout; a.sx = 1; a.out_stride = stride;
+    const int kchb = svb_cdiv(a.Cin_g, 16);
+    a.w_tap_slabs = groups * kchb; a.w_g_slabs = kchb; a.w_slab_rows = a.Cout_g; a.w_goff_m = 0;
+    p.n_phase = stride;
+    int nt = 0;
+    for (int r = 0; r < stride; ++r) {
+        p.phase_start[r] = nt;
+        int umin = (pad - r) > 0 ? (pad - r + stride - 1) / stride : 0;
+        const int pos0 = stride * umin + r - pad;
+        p.phase_out_base[r] = pos0;
+        p.phase_nq[r] = pos0 < Tout ? (Tout - 1 - pos0) / stride + 1 : 0;
+        int mn = 0, mx = 0, first = 1;
+        for (int j = 0; j < k; ++j) {
+            if ((j * dil) % stride != r) continue;
+            const int off = umin + (r - j * dil) / stride;
+            p.tap_off[nt] = off; p.tap_w[nt] = j;
+            if (first || off < mn) mn = off;
+            if (first || off > mx) mx = off;
+            first = 0;
+            ++nt;
+        }
+        p.phase_min_off[r] = mn; p.phase_span_off[r] = mx - mn;
+    }
+    p.phase_start[stride] = nt;
+    return q_dispatch(a, p, (hipStream_t)stream);
+}

@@ -16,8 +16,26 @@ from . import kernels as K
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = K.ACT_NONE, K.ACT_RELU, K.ACT_LRELU, K.ACT_TANH
 
 
+# Conv arithmetic: "fp32" = exact fp32 on v_mfma_f32_32x32x2_f32 (parity mode, default);
+# "bf16x3" = fp32-class operand split on the bf16 matrix cores (forward + data-gradient; weight gradients stay fp32).
+PRECISION = "fp32"
+
+
+def set_precision(mode):
+    global PRECISION
+    if mode not in ("fp32", "bf16x3"):
+        raise ValueError(mode)
+    PRECISION = mode
+
+
 def _c(t):
     return None if t is None else t.contiguous()
+
+
+def _pack(v, g, groups=1, want_a=True, want_b=True):
+    if PRECISION == "bf16x3":
+        return K.weight_pack_q(v, g, groups, want_a, want_b)
+    return K.weight_pack(v, g, want_a, want_b)
 
 
 class _Conv1dFn(torch.autograd.Function):
@@ -32,7 +50,7 @@ class _Conv1dFn(torch.autograd.Function):
             raise ValueError("activation cannot be combined with residual/mask in one node")
         x, v, g, bias, residual, mask = _c(x), _c(v), _c(g), _c(bias), _c(residual), _c(mask)
         cout, _, k = v.shape
-        pa, pb = K.weight_pack(v, g, want_a=True, want_b=ctx.needs_input_grad[0])
+        pa, pb = _pack(v, g, groups, want_a=True, want_b=ctx.needs_input_grad[0])
         y = K.conv1d_forward(x, pa, cout, k, stride, pad, dil, groups, bias=bias,
                              in_gate=x if in_slope is not None else None,
                              in_slope=in_slope if in_slope is not None else 0.0,
@@ -40,13 +58,15 @@ class _Conv1dFn(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
-        ctx.save_for_backward(x, v, g, pb, mask, y if out_act != ACT_NONE else None)
+        ctx.pb = pb
+        ctx.save_for_backward(x, v, g, mask, y if out_act != ACT_NONE else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         stride, pad, dil, groups, in_slope, out_act, out_slope = ctx.cfg
-        x, v, g, pb, mask, yact = ctx.saved_tensors
+        x, v, g, mask, yact = ctx.saved_tensors
+        pb = ctx.pb
         dy = dy.contiguous()
         if mask is not None:
             dy = dy * mask[:, None, :]
@@ -86,19 +106,21 @@ class _ConvT1dFn(torch.autograd.Function):
         x, v, g, bias, mask = _c(x), _c(v), _c(g), _c(bias), _c(mask)
         cin, cout, k = v.shape
         tout = (x.shape[2] - 1) * stride - 2 * pad + dil * (k - 1) + out_pad + 1
-        pa, pb = K.weight_pack(v, g, want_a=ctx.needs_input_grad[0], want_b=True)
+        pa, pb = _pack(v, g, 1, want_a=ctx.needs_input_grad[0], want_b=True)
         y = K.conv1d_transposed(x, pb, cout, tout, k, stride, pad, dil, 1, bias=bias,
                                 in_gate=x if in_slope is not None else None,
                                 in_slope=in_slope if in_slope is not None else 0.0, mask=mask)
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, v, g, pa, mask)
+        ctx.pa = pa
+        ctx.save_for_backward(x, v, g, mask)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         stride, pad, dil, out_pad, in_slope = ctx.cfg
-        x, v, g, pa, mask = ctx.saved_tensors
+        x, v, g, mask = ctx.saved_tensors
+        pa = ctx.pa
         dy = dy.contiguous()
         if mask is not None:
             dy = dy * mask[:, None, :]
@@ -148,17 +170,17 @@ class _WNStackFn(torch.autograd.Function):
         G = None
         cond_pb = None
         if gcond is not None:
-            pa, cond_pb = K.weight_pack(_c(cond_v), _c(cond_g), want_b=ctx.needs_input_grad[5])
+            pa, cond_pb = _pack(_c(cond_v), _c(cond_g), 1, want_b=ctx.needs_input_grad[5])
             G = K.conv1d_forward(gcond, pa, cond_v.shape[0], 1, bias=_c(cond_b))
         saved_x, saved_xin, saved_acts, packs_b = [], [], [], []
         out = None
         for i, (in_v, in_g, in_b, rs_v, rs_g, rs_b) in enumerate(layers):
             dil = dilation_rate ** i
             pad = (kernel_size * dil - dil) // 2
-            pa_in, pb_in = K.weight_pack(_c(in_v), _c(in_g))
+            pa_in, pb_in = _pack(_c(in_v), _c(in_g))
             xin = K.conv1d_forward(x, pa_in, 2 * C, kernel_size, 1, pad, dil, 1, bias=_c(in_b))
             acts = K.wn_gate_fwd(xin, G, i * 2 * C)
-            pa_rs, pb_rs = K.weight_pack(_c(rs_v), _c(rs_g))
+            pa_rs, pb_rs = _pack(_c(rs_v), _c(rs_g))
             last = i == n_layers - 1
             rs = K.conv1d_forward(acts, pa_rs, rs_v.shape[0], 1, bias=_c(rs_b))
             saved_x.append(x)
@@ -172,10 +194,11 @@ class _WNStackFn(torch.autograd.Function):
             out = out * mask[:, None, :]
         ctx.meta = (n_layers, kernel_size, dilation_rate, C)
         ctx.n_in = len(tensors)
-        flat = [mask, gcond, G, cond_pb, _c(cond_v), _c(cond_g)]
+        flat = [mask, gcond, G, _c(cond_v), _c(cond_g)]
         for i in range(n_layers):
-            flat += [saved_x[i], saved_xin[i], saved_acts[i], packs_b[i][0], packs_b[i][1]]
+            flat += [saved_x[i], saved_xin[i], saved_acts[i]]
             flat += [_c(t) for t in layers[i]]
+        ctx.packs = (cond_pb, packs_b)
         ctx.save_for_backward(*flat)
         return out
 
@@ -183,7 +206,8 @@ class _WNStackFn(torch.autograd.Function):
     def backward(ctx, dout):
         n_layers, ks, dr, C = ctx.meta
         sv = ctx.saved_tensors
-        mask, gcond, G, cond_pb, cond_v, cond_g = sv[:6]
+        mask, gcond, G, cond_v, cond_g = sv[:5]
+        cond_pb, packs_b = ctx.packs
         dout = dout.contiguous()
         if mask is not None:
             dout = dout * mask[:, None, :]
@@ -191,9 +215,10 @@ class _WNStackFn(torch.autograd.Function):
         dG = torch.empty_like(G) if G is not None else None
         dx_next = None  # gradient flowing into x_{i+1}
         for i in reversed(range(n_layers)):
-            base = 6 + 11 * i
-            x_i, xin, acts, pb_in, pb_rs = sv[base:base + 5]
-            in_v, in_g, in_b, rs_v, rs_g, rs_b = sv[base + 5:base + 11]
+            base = 5 + 9 * i
+            x_i, xin, acts = sv[base:base + 3]
+            pb_in, pb_rs = packs_b[i]
+            in_v, in_g, in_b, rs_v, rs_g, rs_b = sv[base + 3:base + 9]
             dil = dr ** i
             pad = (ks * dil - dil) // 2
             last = i == n_layers - 1
@@ -305,19 +330,21 @@ class _Conv2dFn(torch.autograd.Function):
         cout, _, KH, KW = weight.shape
         cols, Ho, Wo = K.im2col(x, KH, KW, stride, stride, pad, pad)
         w3 = weight.view(cout, C * KH * KW, 1)
-        pa, pb = K.weight_pack(w3, None, want_a=True, want_b=ctx.needs_input_grad[0])
+        pa, pb = _pack(w3, None, 1, want_a=True, want_b=ctx.needs_input_grad[0])
         y = K.conv1d_forward(cols, pa, cout, 1, bias=bias, out_act=ACT_LRELU if slope is not None else ACT_NONE,
                              out_slope=slope if slope is not None else 0.0)
         ctx.cfg, ctx.shape = cfg, (B, C, H, W, KH, KW, Ho, Wo)
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(cols if ctx.needs_input_grad[1] else None, pb, y if slope is not None else None)
+        ctx.pb = pb
+        ctx.save_for_backward(cols if ctx.needs_input_grad[1] else None, y if slope is not None else None)
         return y.view(B, cout, Ho, Wo)
 
     @staticmethod
     def backward(ctx, dy):
         stride, pad, slope = ctx.cfg
         B, C, H, W, KH, KW, Ho, Wo = ctx.shape
-        cols, pb, yact = ctx.saved_tensors
+        cols, yact = ctx.saved_tensors
+        pb = ctx.pb
         cout = dy.shape[1]
         dy = dy.contiguous().view(B, cout, Ho * Wo)
         a_slope = slope if slope is not None else 0.0

@@ -48,10 +48,11 @@ def _tuned_cfg(sig, launch):
 
 
 class _ConvProbe:
-    def __init__(self, lib, x, cout_g, nq_max, flops, nz=1, forced=0):
+    def __init__(self, lib, x, cout_g, nq_max, flops, nz=1, forced=0, family="svb_conv1d_mfma_kernel"):
         self.on = PROFILE is not None and x.is_cuda
         if self.on:
             self.name = _CFG_NAMES[forced - 1 if forced else lib.svb_conv1d_pick_cfg(int(cout_g), int(nq_max), int(nz))]
+            self.name = self.name.replace("svb_conv1d_mfma_kernel", family)
             self.flops = flops
             self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self.e0.record()
@@ -122,12 +123,58 @@ def weight_pack(v, g=None, want_a=True, want_b=True):
     return pa, pb
 
 
+class PackedQ:
+    """bf16 hi/lo weight pack for the bf16x3 kernels (see svb_weight_pack_bf16x3)."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi, lo):
+        self.hi, self.lo = hi, lo
+
+
+def weight_pack_q(v, g=None, groups=1, want_a=True, want_b=True):
+    """v: [d0, d1, k] -> (qa, qb) PackedQ (bf16 hi/lo; layouts in include/svb_hip.h)."""
+    _f32(v, g)
+    lib, st = _prep(v, g)
+    d0, d1, k = v.shape
+    d0g = d0 // groups
+    def buf(n, padded):
+        f = torch.zeros if padded else torch.empty
+        return f((n,), device=v.device, dtype=torch.int16)
+    qa = qb = None
+    if want_a:
+        n = k * (-(-d1 // 16)) * d0 * 16
+        qa = PackedQ(buf(n, d1 % 16 != 0), buf(n, d1 % 16 != 0))
+    if want_b:
+        n = k * groups * (-(-d0g // 16)) * d1 * 16
+        qb = PackedQ(buf(n, d0g % 16 != 0), buf(n, d0g % 16 != 0))
+    L.check(lib.svb_weight_pack_bf16x3(_ptr(v), _ptr(g), _ptr(qa.hi) if qa else None, _ptr(qa.lo) if qa else None,
+                                       _ptr(qb.hi) if qb else None, _ptr(qb.lo) if qb else None, d0, d1, k, groups,
+                                       int(g is not None), st), "svb_weight_pack_bf16x3")
+    return qa, qb
+
+
 def conv1d_forward(x, pa, cout, k, stride=1, pad=0, dil=1, groups=1, out=None, **epi):
-    _f32(x, pa)
-    tensors = [x, pa, out] + [epi.get(n) for n in ("bias", "in_gate", "out_gate", "residual", "mask")]
+    q = isinstance(pa, PackedQ)
+    _f32(x, None if q else pa)
+    tensors = [x, pa.hi if q else pa, out] + [epi.get(n) for n in ("bias", "in_gate", "out_gate", "residual", "mask")]
     lib, st = _prep(*tensors)
     B, cin, tin = x.shape
     tout = conv_out_len(tin, k, stride, pad, dil)
+    if q:
+        y = out if out is not None else torch.empty((B, cout, tout), device=x.device, dtype=torch.float32)
+        e = make_epilogue(**epi)
+        if x.is_cuda and not epi.get("force_cfg"):
+            def launch(cfg):
+                e.force_cfg = cfg
+                L.check(lib.svb_conv1d_forward_bf16x3(_ptr(x), _ptr(pa.hi), _ptr(pa.lo), _ptr(y), B, cin, cout, groups, tin,
+                                                      tout, k, stride, pad, dil, C.byref(e), st), "svb_conv1d_forward_bf16x3")
+            e.force_cfg = _tuned_cfg(("qf", B, cin, cout, groups, tin, k, stride, pad, dil), launch)
+        probe = _ConvProbe(lib, x, cout // groups, tout, 2.0 * B * cout * tout * (cin // groups) * k, B * groups, e.force_cfg,
+                           "svb_conv1d_bf16x3_kernel")
+        L.check(lib.svb_conv1d_forward_bf16x3(_ptr(x), _ptr(pa.hi), _ptr(pa.lo), _ptr(y), B, cin, cout, groups, tin, tout, k,
+                                              stride, pad, dil, C.byref(e), st), "svb_conv1d_forward_bf16x3")
+        probe.done()
+        return y
     y = out if out is not None else torch.empty((B, cout, tout), device=x.device, dtype=torch.float32)
     e = make_epilogue(**epi)
     if x.is_cuda and not epi.get("force_cfg"):
@@ -144,12 +191,27 @@ def conv1d_forward(x, pa, cout, k, stride=1, pad=0, dil=1, groups=1, out=None, *
 
 
 def conv1d_transposed(x, pb, cout, tout, k, stride=1, pad=0, dil=1, groups=1, out=None, **epi):
-    _f32(x, pb)
-    tensors = [x, pb, out] + [epi.get(n) for n in ("bias", "in_gate", "out_gate", "residual", "mask")]
+    q = isinstance(pb, PackedQ)
+    _f32(x, None if q else pb)
+    tensors = [x, pb.hi if q else pb, out] + [epi.get(n) for n in ("bias", "in_gate", "out_gate", "residual", "mask")]
     lib, st = _prep(*tensors)
     B, cin, tin = x.shape
     y = out if out is not None else torch.empty((B, cout, tout), device=x.device, dtype=torch.float32)
     e = make_epilogue(**epi)
+    if q:
+        if x.is_cuda and not epi.get("force_cfg"):
+            def launch(cfg):
+                e.force_cfg = cfg
+                L.check(lib.svb_conv1d_transposed_bf16x3(_ptr(x), _ptr(pb.hi), _ptr(pb.lo), _ptr(y), B, cin, cout, groups, tin,
+                                                         tout, k, stride, pad, dil, C.byref(e), st),
+                        "svb_conv1d_transposed_bf16x3")
+            e.force_cfg = _tuned_cfg(("qt", B, cin, cout, groups, tin, tout, k, stride, pad, dil), launch)
+        probe = _ConvProbe(lib, x, cout // groups, -(-tout // stride), 2.0 * B * cin * tin * (cout // groups) * k,
+                           B * groups * stride, e.force_cfg, "svb_conv1d_bf16x3_kernel")
+        L.check(lib.svb_conv1d_transposed_bf16x3(_ptr(x), _ptr(pb.hi), _ptr(pb.lo), _ptr(y), B, cin, cout, groups, tin, tout,
+                                                 k, stride, pad, dil, C.byref(e), st), "svb_conv1d_transposed_bf16x3")
+        probe.done()
+        return y
     if x.is_cuda and not epi.get("force_cfg"):
         def launch(cfg):
             e.force_cfg = cfg

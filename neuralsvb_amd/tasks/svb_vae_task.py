@@ -56,6 +56,7 @@ class SVBVAEMleTask(BaseTask):
             self.disc_params = list(self.mel_disc.parameters())
 
     def build_model(self):
+        SF.set_precision(hparams.get("conv_precision", "fp32"))
         self.build_tts_model()
         if hparams.get("pretrain_asr_ckpt"):
             ckpt_utils.load_ckpt(self.model.vc_asr, hparams["pretrain_asr_ckpt"], model_name="model",

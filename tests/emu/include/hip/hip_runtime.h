@@ -47,6 +47,8 @@ typedef float float2 __attribute__((ext_vector_type(2)));
 typedef float float4 __attribute__((ext_vector_type(4)));
 typedef int int2 __attribute__((ext_vector_type(2)));
 typedef int int4 __attribute__((ext_vector_type(4)));
+typedef unsigned int uint4 __attribute__((ext_vector_type(4)));
+static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
 static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 
@@ -113,6 +115,32 @@ static inline emu_f32x4 emu_mfma_16x16x4f32(float a, float b, emu_f32x4 c, int, 
     emu_wave_exchange_end();
     return d;
 }
+// v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)+e] and B[k=8*(l>>5)+e][j=l&31], e=0..7 (bf16);
+// D layout as the f32 32x32 form.  Products are exact in fp32 (8-bit mantissas), accumulated k-ascending in fp32.
+#define __bf16 unsigned short
+typedef unsigned short emu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline float emu_bf16_to_f32(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline emu_f32x16 emu_mfma_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c, int, int, int) {
+    unsigned short ab[16];
+    for (int e = 0; e < 8; ++e) { ab[e] = a[e]; ab[8 + e] = b[e]; }
+    emu_wave_exchange_begin(ab, sizeof(ab));
+    const int l = emu_lane_id();
+    const int col = l & 31;
+    emu_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            const unsigned short* pa = (const unsigned short*)emu_wave_slot(row + 32 * (k >> 3));
+            const unsigned short* pb = (const unsigned short*)emu_wave_slot(col + 32 * (k >> 3));
+            acc = fmaf(emu_bf16_to_f32(pa[k & 7]), emu_bf16_to_f32(pb[8 + (k & 7)]), acc);
+        }
+        d[r] = acc;
+    }
+    emu_wave_exchange_end();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu_mfma_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_16x16x4f32
 
@@ -161,3 +189,5 @@ static inline int __float2int_rn(float x) { return (int)nearbyintf(x); }
 static inline float __int2float_rn(int x) { return (float)x; }
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }

@@ -184,3 +184,39 @@ def test_conv2d_lrelu_autograd(dev):
         y.backward(dy.to(dev))
         for a, r in zip(dl, rl):
             assert rel_err(a.grad, r.grad) < 3e-5
+
+
+def test_wn_stack_bf16x3_mode(dev):
+    """WN stack with forward + data-gradient convs in bf16x3 mode (weight gradients stay fp32): 2e-4 relative."""
+    g_ = torch.Generator().manual_seed(33)
+    B, C, T, gin, n, ks = 2, 16, 50, 20, 2, 5
+    x = torch.randn(B, C, T, generator=g_)
+    gcond = torch.randn(B, gin, T, generator=g_)
+    cond = [torch.randn(2 * C * n, gin, 1, generator=g_) * 0.3, torch.rand(2 * C * n, 1, 1, generator=g_) + 0.5,
+            torch.randn(2 * C * n, generator=g_) * 0.1]
+    layers = []
+    for i in range(n):
+        rc = 2 * C if i < n - 1 else C
+        layers.append([torch.randn(2 * C, C, ks, generator=g_) * 0.3, torch.rand(2 * C, 1, 1, generator=g_) + 0.5,
+                       torch.randn(2 * C, generator=g_) * 0.1, torch.randn(rc, C, 1, generator=g_) * 0.3,
+                       torch.rand(rc, 1, 1, generator=g_) + 0.5, torch.randn(rc, generator=g_) * 0.1])
+    xr = x.clone().requires_grad_(True)
+    lr = [[t.clone().requires_grad_(True) for t in lp] for lp in layers]
+    cr = [t.clone().requires_grad_(True) for t in cond]
+    yr = _wn_ref(xr, None, gcond, cr, lr, ks)
+    dy = torch.randn(yr.shape, generator=g_)
+    yr.backward(dy)
+    SF.set_precision("bf16x3")
+    try:
+        xd = _leaf(x, dev)
+        cd = [_leaf(t, dev) for t in cond]
+        ld = [[_leaf(t, dev) for t in lp] for lp in layers]
+        y = SF.wn_stack(xd, None, gcond.to(dev), cd, ld, ks)
+        y.backward(dy.to(dev))
+    finally:
+        SF.set_precision("fp32")
+    assert rel_err(y, yr) < 2e-4
+    assert rel_err(xd.grad, xr.grad) < 2e-4
+    for la, lb in zip(ld, lr):
+        for a, b in zip(la, lb):
+            assert rel_err(a.grad, b.grad) < 3e-4

@@ -319,3 +319,39 @@ def test_layernorm_nct(dev):
     ref = oops.layernorm(x.transpose(1, 2), gm, bt).transpose(1, 2)
     y = K.layernorm_nct_fwd(x.to(dev), gm.to(dev), bt.to(dev))
     assert (y.cpu() - ref).abs().max() < 3e-5
+
+
+@pytest.mark.parametrize("case", CONV_CASES + [(2, 200, 70, 1, 150, 5, 1, 2, 1), (1, 48, 96, 1, 300, 1, 1, 0, 1)])
+def test_conv1d_bf16x3_forward_dgrad(dev, case):
+    """bf16x3 variant (hi*hi + hi*lo + lo*hi on the bf16 matrix cores): relative error bound 6e-5 per conv."""
+    B, Cin, Cout, G, T, k, s, pad, dil = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin // G, k, generator=g) * 0.2
+    bias = torch.randn(Cout, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = oops.conv1d(xr, w, bias, s, pad, dil, G)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    qa, qb = K.weight_pack_q(w.to(dev), None, G)
+    y = K.conv1d_forward(x.to(dev), qa, Cout, k, s, pad, dil, G, bias=bias.to(dev))
+    assert y.shape == ref.shape and rel_err(y, ref) < 6e-5
+    dx = K.conv1d_transposed(dy.to(dev), qb, Cin, T, k, s, pad, dil, G)
+    assert rel_err(dx, xr.grad) < 6e-5
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+def test_conv1d_bf16x3_tile_configs_and_convt(dev, cfg):
+    g = torch.Generator().manual_seed(cfg)
+    B, Cin, Cout, T, k, s, pad = 2, 40, 72, 37, 8, 4, 2
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cin, Cout, k, generator=g) * 0.2
+    gn = torch.rand(Cin, 1, 1, generator=g) + 0.5
+    ref = oops.conv_transpose1d(x, oops.weight_norm(w, gn), None, s, pad)
+    qa, qb = K.weight_pack_q(w.to(dev), gn.to(dev), 1)
+    y = K.conv1d_transposed(x.to(dev), qb, Cout, ref.shape[-1], k, s, pad, 1, 1, force_cfg=cfg)
+    assert rel_err(y, ref) < 6e-5
+    dy = torch.randn(ref.shape, generator=g)
+    dref = torch.autograd.grad(oops.conv_transpose1d(x.requires_grad_(True), oops.weight_norm(w, gn), None, s, pad), x, dy)[0]
+    dx = K.conv1d_forward(dy.to(dev), qa, Cin, k, s, pad, 1, 1, force_cfg=cfg)
+    assert rel_err(dx, dref) < 6e-5

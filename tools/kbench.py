@@ -67,9 +67,15 @@ def main():
         t_d = timeit(lambda: K.conv1d_transposed(dy, pb, Cin, T, k, s, pad, dil, G), args.iters)
         t_w = timeit(lambda: K.conv1d_wgrad(dy, x, k, s, pad, dil, G), args.iters)
         t_p = timeit(lambda: K.weight_pack(w), args.iters)
+        qa, qb = K.weight_pack_q(w, None, G)
+        yq = K.conv1d_forward(x, qa, Cout, k, s, pad, dil, G, bias=bias)
+        errq = ((yq - ref).abs().max() / ref.abs().max()).item()
+        t_qf = timeit(lambda: K.conv1d_forward(x, qa, Cout, k, s, pad, dil, G, bias=bias), args.iters)
+        t_qd = timeit(lambda: K.conv1d_transposed(dy, qb, Cin, T, k, s, pad, dil, G), args.iters)
         row = dict(name=name, gflop=flops / 1e9, err=err, fwd_ms=t_f * 1e3, fwd_tf=flops / t_f / 1e12,
                    dgrad_ms=t_d * 1e3, dgrad_tf=flops / t_d / 1e12, wgrad_ms=t_w * 1e3, wgrad_tf=flops / t_w / 1e12,
-                   pack_ms=t_p * 1e3, fwd_frac=flops / t_f / PEAK_F32)
+                   pack_ms=t_p * 1e3, fwd_frac=flops / t_f / PEAK_F32, q_err=errq, q_fwd_ms=t_qf * 1e3,
+                   q_fwd_tf=flops / t_qf / 1e12, q_dgrad_ms=t_qd * 1e3, q_dgrad_tf=flops / t_qd / 1e12)
         if not args.no_torch:
             xr = x.clone().requires_grad_(True)
             wr = w.clone().requires_grad_(True)
@@ -81,7 +87,7 @@ def main():
             t_tb = timeit(tb, args.iters) - t_tf
             row.update(torch_fwd_ms=t_tf * 1e3, torch_bwd_ms=t_tb * 1e3)
         rows.append(row)
-        print(json.dumps({k_: (round(v, 4) if isinstance(v, float) else v) for k_, v in row.items()}), flush=True)
+        print(json.dumps({k_: (float(f"{v:.4g}") if isinstance(v, float) else v) for k_, v in row.items()}), flush=True)
     # streaming kernels: GB/s against 8 TB/s
     B, C, T = 16, 192, 1124
     xin = torch.randn(B, 2 * C, T, device=dev)
