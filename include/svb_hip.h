@@ -88,6 +88,13 @@ size_t svb_conv1d_wgrad_workspace_floats(int B, int CA, int CB, int groups, int 
 int svb_conv1d_wgrad(const float* a, const float* b, float* part, int B, int CA, int CB, int groups, int TA, int TB,
                      int k, int sx, int pad, int dil, const float* a_gate, float a_slope, const float* b_gate,
                      float b_slope, int nsplit, void* stream);
+/* The same stage 1 for stride-1 convs on the bf16 matrix cores (bf16x3 split, see above).  The workspace query returns 0
+ * floats (and nsplit 0) for shapes outside its envelope ((taps per pass - 1)*dil > 23): use svb_conv1d_wgrad then.
+ * Partials have the same layout, so svb_wgrad_reduce finishes either.                                           */
+size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB, int groups, int TA, int k, int dil, int* nsplit_out);
+int svb_conv1d_wgrad_bf16x3(const float* a, const float* b, float* part, int B, int CA, int CB, int groups, int TA, int TB,
+                            int k, int pad, int dil, const float* a_gate, float a_slope, const float* b_gate,
+                            float b_slope, int nsplit, void* stream);
 /* Stage 2: reduce partials (+ WeightNorm backward: dv, dg from dW).  rows = d0, rowlen = d1*k.              */
 int svb_wgrad_reduce(const float* part, int nsplit, const float* v, const float* g, float* dv, float* dg, int rows,
                      int rowlen, int weight_norm, int accumulate, void* stream);

@@ -42,13 +42,30 @@ struct SvbConvQArgs {
     int force_cfg;
 };
 
-__device__ __forceinline__ unsigned svbq_bf16_rne(float f) {
-    const unsigned u = __float_as_uint(f);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+typedef __bf16 svbq_bf2 __attribute__((ext_vector_type(2)));
+typedef float svbq_f2 __attribute__((ext_vector_type(2)));
+
+// two fp32 values -> packed bf16 pairs  hi = rne(v), lo = rne(v - hi)   (v_cvt_pk_bf16_f32 x2 + 3 VALU ops on gfx950)
+__device__ __forceinline__ void svbq_split2(float v0, float v1, unsigned& hi, unsigned& lo) {
+    const svbq_f2 v = {v0, v1};
+    const svbq_bf2 h = __builtin_convertvector(v, svbq_bf2);
+    const svbq_f2 hf = __builtin_convertvector(h, svbq_f2);
+    const svbq_bf2 l = __builtin_convertvector(v - hf, svbq_bf2);
+    __builtin_memcpy(&hi, &h, 4);
+    __builtin_memcpy(&lo, &l, 4);
 }
 __device__ __forceinline__ void svbq_split(float v, unsigned& hi, unsigned& lo) {
-    hi = svbq_bf16_rne(v);
-    lo = svbq_bf16_rne(v - __uint_as_float(hi << 16));
+    unsigned h2, l2;
+    svbq_split2(v, 0.f, h2, l2);
+    hi = h2 & 0xFFFFu;
+    lo = l2 & 0xFFFFu;
+}
+__device__ __forceinline__ void svbq_split8(const float* v, uint4& hi, uint4& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) svbq_split2(v[2 * e], v[2 * e + 1], h[e], l[e]);
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
 template <int WM, int WN, int NT, int SLB>
@@ -176,12 +193,11 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
                 for (int it = 0; it < SVBQ_XIT; ++it) {
                     const int i = xp0 + 128 * it;
                     if (i < span) {
-                        unsigned hi[8], lo[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) svbq_split(xr[c][it][e], hi[e], lo[e]);
+                        uint4 hi, lo;
+                        svbq_split8(xr[c][it], hi, lo);
                         const int d = (c * a.xrows + i) * 3 + xh;
-                        x_hi[d] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
-                        x_lo[d] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+                        x_hi[d] = hi;
+                        x_lo[d] = lo;
                     }
                 }
             }
@@ -193,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
             const int ch0 = (kc0 + c) * 16 + xh * 8;
             for (int i = xp0; i < span; i += 128) {
                 const int pos = lo_pos + i;
-                unsigned hi[8], lo[8];
+                float vv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float v = 0.f;
@@ -202,11 +218,13 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
                         v = xb[off];
                         if (gb) v *= svb_gate(gb[off], a.in_slope);
                     }
-                    svbq_split(v, hi[e], lo[e]);
+                    vv[e] = v;
                 }
+                uint4 hi, lo;
+                svbq_split8(vv, hi, lo);
                 const int d = (c * a.xrows + i) * 3 + xh;
-                x_hi[d] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
-                x_lo[d] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+                x_hi[d] = hi;
+                x_lo[d] = lo;
             }
         }
     };
@@ -475,4 +493,316 @@ extern "C" int svb_conv1d_transposed_bf16x3(const float* x, const unsigned short
     }
     p.phase_start[stride] = nt;
     return q_dispatch(a, p, (hipStream_t)stream);
+}
+
+// ==================================================================================================================
+// Weight gradient on the bf16 matrix cores (stride-1 convs):
+//   part[split][ca][cb][j] = sum over this split's (batch, 64-position chunk)s of  A[n,ca,q] * Bt[n,cb,q + j*dil - pad]
+// The reduction runs over positions, so both MFMA operands are position-major in LDS: tiles [64 channels][positions]
+// of packed bf16 pairs (one dword = positions 2m, 2m+1), hi and lo.  Tap j needs the Bt operand shifted by j*dil
+// positions, which is not 16-byte aligned -- so operands are read dword-wise and the shifted fragment is assembled in
+// registers with v_alignbit (shift 0 or 16 bits).  For dil == 1 the taps share one window of 4+TGW/2 dwords per step.
+// K order inside an MFMA is free as long as A and B agree: lane group kb takes positions 32*kb + 8*s + e.  Row pitches
+// are 2*odd dwords: the 8-byte-aligned ds_read_b64 of the dil == 1 path and the dword reads of the general path are
+// both bank-conflict free (each is serviced per 32-lane half, i.e. per kb).
+// ==================================================================================================================
+struct SvbWgradQArgs {
+    const float* a;
+    const float* b;
+    float* part;
+    const float* a_gate;
+    const float* b_gate;
+    float a_slope, b_slope;
+    int B, CA, CB, G, CA_g, CB_g, TA, TB;
+    int k, off0, dil;
+    int n_tg, a_tiles, b_tiles, chunks_per_b, total_chunks, nsplit;
+    int pa, pb;   // LDS row pitches in dwords (2 * odd)
+};
+
+#define SVBQ_WG_QC 64
+#define SVBQ_WG_NXIT 3
+
+__device__ __forceinline__ void svbq_load2(const float* base, const float* gate, float slope, int pos, int T, bool rv,
+                                           float& v0, float& v1) {
+    v0 = 0.f; v1 = 0.f;
+    if (!rv) return;
+    if (pos >= 0 && pos + 1 < T) {
+        float2 t;
+        __builtin_memcpy(&t, base + pos, 8);
+        v0 = t.x; v1 = t.y;
+        if (gate) {
+            float2 gt;
+            __builtin_memcpy(&gt, gate + pos, 8);
+            v0 *= svb_gate(gt.x, slope); v1 *= svb_gate(gt.y, slope);
+        }
+    } else {
+        if (pos >= 0 && pos < T) { v0 = base[pos]; if (gate) v0 *= svb_gate(gate[pos], slope); }
+        if (pos + 1 >= 0 && pos + 1 < T) { v1 = base[pos + 1]; if (gate) v1 *= svb_gate(gate[pos + 1], slope); }
+    }
+}
+
+__device__ __forceinline__ unsigned svbq_funnel(unsigned hi, unsigned lo, unsigned sh) {
+    return (unsigned)((((unsigned long long)hi << 32) | lo) >> sh);
+}
+
+template <int TGW, int DIL>
+__global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgradQArgs a) {
+    HIP_DYNAMIC_SHARED(unsigned, wg_smem)
+    unsigned* A_hi = wg_smem;
+    unsigned* A_lo = A_hi + 64 * a.pa;
+    unsigned* B_hi = A_lo + 64 * a.pa;
+    unsigned* B_lo = B_hi + 64 * a.pb;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int kb = lane >> 5, l31 = lane & 31;
+
+    int idx = blockIdx.x;
+    const int tgi = idx % a.n_tg; idx /= a.n_tg;
+    const int bt = idx % a.b_tiles; idx /= a.b_tiles;
+    const int at = idx % a.a_tiles;
+    const int g = idx / a.a_tiles;
+    const int a0 = at * 64, b0 = bt * 64;
+    const int j0 = tgi * TGW;
+    const int ntap = min(TGW, a.k - j0);
+    const int min_off = a.off0 + j0 * a.dil;
+    const int span = SVBQ_WG_QC + (ntap - 1) * a.dil;
+    const int nxp = (span + 1) / 2 - 32;                    // Bt pairs beyond the first 32 of a row
+
+    f32x16 acc[TGW];
+#pragma unroll
+    for (int t = 0; t < TGW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float ar[8][2], br[8][2], bx[SVBQ_WG_NXIT][2];
+    const int srow = tid >> 5, spair = tid & 31;            // staging role: row srow + 8*it, pair spair
+    const float* a_base = a.a + (size_t)g * a.CA_g * a.TA;
+    const float* ag_base = a.a_gate ? a.a_gate + (size_t)g * a.CA_g * a.TA : nullptr;
+    const float* b_base = a.b + (size_t)g * a.CB_g * a.TB;
+    const float* bg_base = a.b_gate ? a.b_gate + (size_t)g * a.CB_g * a.TB : nullptr;
+
+    auto load_tiles = [&](int chunk) {
+        const int bb = chunk / a.chunks_per_b;
+        const int q0 = (chunk - bb * a.chunks_per_b) * SVBQ_WG_QC;
+        const int lo = q0 + min_off;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = srow + 8 * rr;
+            {
+                const size_t roff = ((size_t)bb * a.CA + a0 + r) * a.TA;
+                svbq_load2(a_base + roff, ag_base ? ag_base + roff : nullptr, a.a_slope, q0 + 2 * spair, a.TA,
+                           (a0 + r) < a.CA_g, ar[rr][0], ar[rr][1]);
+            }
+            {
+                const size_t roff = ((size_t)bb * a.CB + b0 + r) * a.TB;
+                svbq_load2(b_base + roff, bg_base ? bg_base + roff : nullptr, a.b_slope, lo + 2 * spair, a.TB,
+                           (b0 + r) < a.CB_g, br[rr][0], br[rr][1]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < SVBQ_WG_NXIT; ++e) {
+            const int task = tid + 256 * e;
+            bx[e][0] = 0.f; bx[e][1] = 0.f;
+            if (task < 64 * nxp) {
+                const int r = task / nxp, pr = 32 + task - r * nxp;
+                const size_t roff = ((size_t)bb * a.CB + b0 + r) * a.TB;
+                svbq_load2(b_base + roff, bg_base ? bg_base + roff : nullptr, a.b_slope, lo + 2 * pr, a.TB,
+                           (b0 + r) < a.CB_g, bx[e][0], bx[e][1]);
+            }
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = srow + 8 * rr;
+            unsigned hi, lo;
+            svbq_split2(ar[rr][0], ar[rr][1], hi, lo);
+            A_hi[r * a.pa + spair] = hi; A_lo[r * a.pa + spair] = lo;
+            svbq_split2(br[rr][0], br[rr][1], hi, lo);
+            B_hi[r * a.pb + spair] = hi; B_lo[r * a.pb + spair] = lo;
+        }
+#pragma unroll
+        for (int e = 0; e < SVBQ_WG_NXIT; ++e) {
+            const int task = tid + 256 * e;
+            if (task < 64 * nxp) {
+                const int r = task / nxp, pr = 32 + task - r * nxp;
+                unsigned hi, lo;
+                svbq_split2(bx[e][0], bx[e][1], hi, lo);
+                B_hi[r * a.pb + pr] = hi; B_lo[r * a.pb + pr] = lo;
+            }
+        }
+    };
+    auto mma3 = [&](const uint4& ah_u, const uint4& al_u, const uint4& bh_u, const uint4& bl_u, f32x16& c) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&ah_u), al = *reinterpret_cast<const bf16x8*>(&al_u);
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&bh_u), bl = *reinterpret_cast<const bf16x8*>(&bl_u);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+    };
+    auto compute = [&]() {
+        const unsigned* ahp = A_hi + (wm * 32 + l31) * a.pa + 16 * kb;
+        const unsigned* alp = A_lo + (wm * 32 + l31) * a.pa + 16 * kb;
+        const unsigned* bhp = B_hi + (wn * 32 + l31) * a.pb + 16 * kb;
+        const unsigned* blp = B_lo + (wn * 32 + l31) * a.pb + 16 * kb;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint2 ah0 = *reinterpret_cast<const uint2*>(ahp + 4 * s), ah1 = *reinterpret_cast<const uint2*>(ahp + 4 * s + 2);
+            const uint2 al0 = *reinterpret_cast<const uint2*>(alp + 4 * s), al1 = *reinterpret_cast<const uint2*>(alp + 4 * s + 2);
+            const uint4 ah = make_uint4(ah0.x, ah0.y, ah1.x, ah1.y);
+            const uint4 al = make_uint4(al0.x, al0.y, al1.x, al1.y);
+            if (DIL == 1) {
+                constexpr int NU2 = (4 + TGW / 2 + 1) / 2, NU = 2 * NU2;
+                unsigned uh[NU], ul[NU];
+#pragma unroll
+                for (int d = 0; d < NU2; ++d) {
+                    const uint2 th = *reinterpret_cast<const uint2*>(bhp + 4 * s + 2 * d);
+                    const uint2 tl = *reinterpret_cast<const uint2*>(blp + 4 * s + 2 * d);
+                    uh[2 * d] = th.x; uh[2 * d + 1] = th.y;
+                    ul[2 * d] = tl.x; ul[2 * d + 1] = tl.y;
+                }
+#pragma unroll
+                for (int t = 0; t < TGW; ++t) {
+                    if (t < ntap) {
+                        uint4 bh, bl;
+                        if (t & 1) {
+                            constexpr unsigned S16 = 16;
+                            const int o = t >> 1;
+                            bh = make_uint4(svbq_funnel(uh[o + 1], uh[o], S16), svbq_funnel(uh[o + 2], uh[o + 1], S16),
+                                            svbq_funnel(uh[o + 3], uh[o + 2], S16), svbq_funnel(uh[o + 4], uh[o + 3], S16));
+                            bl = make_uint4(svbq_funnel(ul[o + 1], ul[o], S16), svbq_funnel(ul[o + 2], ul[o + 1], S16),
+                                            svbq_funnel(ul[o + 3], ul[o + 2], S16), svbq_funnel(ul[o + 4], ul[o + 3], S16));
+                        } else {
+                            const int o = t >> 1;
+                            bh = make_uint4(uh[o], uh[o + 1], uh[o + 2], uh[o + 3]);
+                            bl = make_uint4(ul[o], ul[o + 1], ul[o + 2], ul[o + 3]);
+                        }
+                        mma3(ah, al, bh, bl, acc[t]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < TGW; ++t) {
+                    if (t < ntap) {
+                        const int bp = 8 * s + t * a.dil;
+                        const int dw = bp >> 1;
+                        const unsigned sh = (unsigned)(bp & 1) * 16u;
+                        unsigned uh[5], ul[5];
+#pragma unroll
+                        for (int d = 0; d < 5; ++d) { uh[d] = bhp[dw + d]; ul[d] = blp[dw + d]; }
+                        const uint4 bh = make_uint4(svbq_funnel(uh[1], uh[0], sh), svbq_funnel(uh[2], uh[1], sh),
+                                                    svbq_funnel(uh[3], uh[2], sh), svbq_funnel(uh[4], uh[3], sh));
+                        const uint4 bl = make_uint4(svbq_funnel(ul[1], ul[0], sh), svbq_funnel(ul[2], ul[1], sh),
+                                                    svbq_funnel(ul[3], ul[2], sh), svbq_funnel(ul[4], ul[3], sh));
+                        mma3(ah, al, bh, bl, acc[t]);
+                    }
+                }
+            }
+        }
+    };
+
+    int chunk = blockIdx.y;
+    if (chunk < a.total_chunks) {
+        load_tiles(chunk);
+        store_tiles();
+        __syncthreads();
+        while (true) {
+            const int next = chunk + a.nsplit;
+            const bool has_next = next < a.total_chunks;
+            if (has_next) load_tiles(next);
+            compute();
+            if (!has_next) break;
+            __syncthreads();
+            store_tiles();
+            __syncthreads();
+            chunk = next;
+        }
+    }
+
+    float* part = a.part + (size_t)blockIdx.y * a.CA * a.CB_g * a.k;
+#pragma unroll
+    for (int t = 0; t < TGW; ++t) {
+        if (t < ntap) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
+                const int al = a0 + wm * 32 + row;
+                const int bl = b0 + wn * 32 + l31;
+                if (al < a.CA_g && bl < a.CB_g)
+                    part[((size_t)(g * a.CA_g + al) * a.CB_g + bl) * a.k + (j0 + t)] = acc[t][r];
+            }
+        }
+    }
+}
+
+static int wgq_tgw(int k) { return k <= 5 ? k : (k % 5 == 0 ? 5 : (svb_cdiv(k, 4) <= svb_cdiv(k, 5) ? 4 : 5)); }
+
+// 0 floats (and *nsplit = 0) when the shape is outside this kernel's envelope: the caller uses svb_conv1d_wgrad.
+extern "C" size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB, int groups, int TA, int k, int dil,
+                                                           int* nsplit_out) {
+    if (nsplit_out) *nsplit_out = 0;
+    if (B <= 0 || groups <= 0 || CA % groups || CB % groups || k <= 0 || k > SVB_MAX_TAPS || dil <= 0 || TA <= 0) return 0;
+    const int tgw = wgq_tgw(k);
+    if (((tgw - 1) * dil + 1) / 2 > 4 * SVBQ_WG_NXIT) return 0;
+    const int CA_g = CA / groups, CB_g = CB / groups;
+    const long tiles = (long)groups * svb_cdiv(CA_g, 64) * svb_cdiv(CB_g, 64) * svb_cdiv(k, tgw);
+    const long chunks = (long)B * svb_cdiv(TA, SVBQ_WG_QC);
+    const long slab = (long)CA * CB_g * k;
+    long ns_cap = 512 / tiles;                                   // one resident wave of blocks at 2 per CU
+    if (ns_cap < 1) ns_cap = 1;
+    if (ns_cap > chunks) ns_cap = chunks;
+    while (ns_cap > 1 && ns_cap * slab > (16L << 20)) --ns_cap;  // <= 64 MB of partials
+    const long per = svb_cdiv(chunks, ns_cap);
+    const long ns = svb_cdiv(chunks, per);
+    if (nsplit_out) *nsplit_out = (int)ns;
+    return (size_t)ns * slab;
+}
+
+template <int TGW>
+static void wgq_launch(const SvbWgradQArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_wgrad_bf16x3_kernel<TGW, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_wgrad_bf16x3_kernel<TGW, 0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (a.dil == 1) hipLaunchKernelGGL((svb_conv1d_wgrad_bf16x3_kernel<TGW, 1>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((svb_conv1d_wgrad_bf16x3_kernel<TGW, 0>), grid, dim3(256), lds, st, a);
+}
+
+extern "C" int svb_conv1d_wgrad_bf16x3(const float* a_t, const float* b_t, float* part, int B, int CA, int CB, int groups,
+                                       int TA, int TB, int k, int pad, int dil, const float* a_gate, float a_slope,
+                                       const float* b_gate, float b_slope, int nsplit, void* stream) {
+    if (!a_t || !b_t || !part || B <= 0 || groups <= 0 || CA % groups || CB % groups || k <= 0 || k > SVB_MAX_TAPS ||
+        dil <= 0 || nsplit <= 0)
+        return SVB_ERR_ARG;
+    SvbWgradQArgs a;
+    a.a = a_t; a.b = b_t; a.part = part; a.a_gate = a_gate; a.b_gate = b_gate; a.a_slope = a_slope; a.b_slope = b_slope;
+    a.B = B; a.CA = CA; a.CB = CB; a.G = groups; a.CA_g = CA / groups; a.CB_g = CB / groups; a.TA = TA; a.TB = TB;
+    a.k = k; a.off0 = -pad; a.dil = dil;
+    const int tgw = wgq_tgw(k);
+    if (((tgw - 1) * dil + 1) / 2 > 4 * SVBQ_WG_NXIT) return SVB_ERR_UNSUPPORTED;
+    a.n_tg = svb_cdiv(k, tgw);
+    a.a_tiles = svb_cdiv(a.CA_g, 64); a.b_tiles = svb_cdiv(a.CB_g, 64);
+    a.chunks_per_b = svb_cdiv(TA, SVBQ_WG_QC); a.total_chunks = B * a.chunks_per_b;
+    if (nsplit > a.total_chunks) return SVB_ERR_ARG;
+    a.nsplit = nsplit;
+    a.pa = 34;
+    a.pb = 32 + ((tgw - 1) * dil + 1) / 2 + 6;
+    a.pb += a.pb & 1;
+    if (!((a.pb >> 1) & 1)) a.pb += 2;                       // 2 * odd
+    const size_t lds = (size_t)64 * (a.pa + a.pb) * 2 * sizeof(unsigned);
+    dim3 grid(groups * a.a_tiles * a.b_tiles * a.n_tg, nsplit);
+    hipStream_t st = (hipStream_t)stream;
+    switch (tgw) {
+        case 1: wgq_launch<1>(a, grid, lds, st); break;
+        case 2: wgq_launch<2>(a, grid, lds, st); break;
+        case 3: wgq_launch<3>(a, grid, lds, st); break;
+        case 4: wgq_launch<4>(a, grid, lds, st); break;
+        default: wgq_launch<5>(a, grid, lds, st); break;
+    }
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
 }

@@ -26,6 +26,7 @@ def set_precision(mode):
     if mode not in ("fp32", "bf16x3"):
         raise ValueError(mode)
     PRECISION = mode
+    K.WGRAD_BF16X3 = mode == "bf16x3"
 
 
 def _c(t):

@@ -226,8 +226,11 @@ def conv1d_transposed(x, pb, cout, tout, k, stride=1, pad=0, dil=1, groups=1, ou
     return y
 
 
+WGRAD_BF16X3 = False      # set by functional.set_precision: stride-1 weight gradients on the bf16x3 kernel
+
+
 def conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0, b_gate=None, b_slope=0.0,
-                 v=None, g=None, accumulate_into=None):
+                 v=None, g=None, accumulate_into=None, bf16x3=None):
     """dW[ca, cb/groups, k] = sum_{n,q} a[n,ca,q] * b[n,cb,q*sx + j*dil - pad].
 
     With (v, g) given returns (dv, dg) of the weight-normalised parametrisation instead of dW."""
@@ -236,11 +239,20 @@ def conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0
     B, ca, ta = a.shape
     _, cb, tb = b.shape
     ns = C.c_int(0)
-    nfl = lib.svb_conv1d_wgrad_workspace_floats(B, ca, cb, groups, ta, k, sx, C.byref(ns))
-    part = torch.empty((nfl,), device=a.device, dtype=torch.float32)
-    L.check(lib.svb_conv1d_wgrad(_ptr(a), _ptr(b), _ptr(part), B, ca, cb, groups, ta, tb, k, sx, pad, dil,
-                                 _ptr(a_gate), float(a_slope), _ptr(b_gate), float(b_slope), ns.value, st),
-            "svb_conv1d_wgrad")
+    nfl = 0
+    if (WGRAD_BF16X3 if bf16x3 is None else bf16x3) and sx == 1:
+        nfl = lib.svb_conv1d_wgrad_bf16x3_workspace_floats(B, ca, cb, groups, ta, k, dil, C.byref(ns))
+    if nfl:
+        part = torch.empty((nfl,), device=a.device, dtype=torch.float32)
+        L.check(lib.svb_conv1d_wgrad_bf16x3(_ptr(a), _ptr(b), _ptr(part), B, ca, cb, groups, ta, tb, k, pad, dil,
+                                            _ptr(a_gate), float(a_slope), _ptr(b_gate), float(b_slope), ns.value, st),
+                "svb_conv1d_wgrad_bf16x3")
+    else:
+        nfl = lib.svb_conv1d_wgrad_workspace_floats(B, ca, cb, groups, ta, k, sx, C.byref(ns))
+        part = torch.empty((nfl,), device=a.device, dtype=torch.float32)
+        L.check(lib.svb_conv1d_wgrad(_ptr(a), _ptr(b), _ptr(part), B, ca, cb, groups, ta, tb, k, sx, pad, dil,
+                                     _ptr(a_gate), float(a_slope), _ptr(b_gate), float(b_slope), ns.value, st),
+                "svb_conv1d_wgrad")
     rows, rowlen = ca, (cb // groups) * k
     wn = g is not None
     if accumulate_into is not None and not wn:

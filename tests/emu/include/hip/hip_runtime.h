@@ -48,6 +48,8 @@ typedef float float4 __attribute__((ext_vector_type(4)));
 typedef int int2 __attribute__((ext_vector_type(2)));
 typedef int int4 __attribute__((ext_vector_type(4)));
 typedef unsigned int uint4 __attribute__((ext_vector_type(4)));
+typedef unsigned int uint2 __attribute__((ext_vector_type(2)));
+static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
 static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
 static inline float2 make_float2(float a, float b) { return float2{a, b}; }
@@ -117,12 +119,13 @@ static inline emu_f32x4 emu_mfma_16x16x4f32(float a, float b, emu_f32x4 c, int, 
 }
 // v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)+e] and B[k=8*(l>>5)+e][j=l&31], e=0..7 (bf16);
 // D layout as the f32 32x32 form.  Products are exact in fp32 (8-bit mantissas), accumulated k-ascending in fp32.
-#define __bf16 unsigned short
-typedef unsigned short emu_bf16x8 __attribute__((ext_vector_type(8)));
+// (host clang has a native __bf16 with round-to-nearest-even conversions, the same as v_cvt_pk_bf16_f32)
+typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
 static inline float emu_bf16_to_f32(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
 static inline emu_f32x16 emu_mfma_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c, int, int, int) {
     unsigned short ab[16];
-    for (int e = 0; e < 8; ++e) { ab[e] = a[e]; ab[8 + e] = b[e]; }
+    memcpy(ab, &a, 16);
+    memcpy(ab + 8, &b, 16);
     emu_wave_exchange_begin(ab, sizeof(ab));
     const int l = emu_lane_id();
     const int col = l & 31;

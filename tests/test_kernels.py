@@ -355,3 +355,47 @@ def test_conv1d_bf16x3_tile_configs_and_convt(dev, cfg):
     dref = torch.autograd.grad(oops.conv_transpose1d(x.requires_grad_(True), oops.weight_norm(w, gn), None, s, pad), x, dy)[0]
     dx = K.conv1d_forward(dy.to(dev), qa, Cin, k, s, pad, 1, 1, force_cfg=cfg)
     assert rel_err(dx, dref) < 6e-5
+
+
+WGQ_CASES = [
+    # B, Cin, Cout, G, T, k, pad, dil
+    (2, 8, 16, 1, 50, 5, 2, 1),
+    (1, 70, 100, 1, 150, 5, 2, 1),       # ragged channel tiles, 3 chunks with a ragged tail
+    (2, 40, 40, 1, 33, 1, 0, 1),         # 1x1
+    (2, 12, 20, 1, 90, 3, 1, 1),
+    (1, 12, 12, 1, 200, 7, 9, 3),        # dilated, two tap groups (general shifted-operand path)
+    (1, 10, 6, 1, 130, 11, 25, 5),       # k11 d5 (hifigan.py:33-41)
+    (2, 8, 12, 2, 77, 4, 2, 1),          # grouped, even taps
+    (1, 6, 6, 1, 64, 2, 0, 1),
+]
+
+
+@pytest.mark.parametrize("case", WGQ_CASES)
+def test_conv1d_wgrad_bf16x3(dev, case):
+    """Weight gradient on the bf16x3 kernel (shifted operand assembled in registers) against torch autograd."""
+    B, Cin, Cout, G, T, k, pad, dil = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, Cin, T, generator=g)
+    w = (torch.randn(Cout, Cin // G, k, generator=g) * 0.2).requires_grad_(True)
+    y = oops.conv1d(x, w, None, 1, pad, dil, G)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dw = K.conv1d_wgrad(dy.to(dev), x.to(dev), k, 1, pad, dil, G, bf16x3=True)
+    assert dw.shape == w.shape
+    assert rel_err(dw, w.grad) < 6e-5
+
+
+def test_conv1d_wgrad_bf16x3_gates_and_weight_norm(dev):
+    g_ = torch.Generator().manual_seed(11)
+    B, Cin, Cout, T, k = 2, 10, 14, 145, 3
+    x = torch.randn(B, Cin, T, generator=g_)
+    v = (torch.randn(Cout, Cin, k, generator=g_) * 0.3).requires_grad_(True)
+    gn = (torch.rand(Cout, 1, 1, generator=g_) + 0.5).requires_grad_(True)
+    w = gn * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)
+    y = torch.relu(oops.conv1d(F.leaky_relu(x, 0.1), w, None, 1, 1))
+    dy = torch.randn(y.shape, generator=g_)
+    y.backward(dy)
+    dv, dg = K.conv1d_wgrad(dy.to(dev), x.to(dev), k, 1, 1, 1, 1, a_gate=y.detach().to(dev), a_slope=0.0,
+                            b_gate=x.to(dev), b_slope=0.1, v=v.detach().to(dev), g=gn.detach().to(dev), bf16x3=True)
+    assert rel_err(dv, v.grad) < 1e-4
+    assert rel_err(dg, gn.grad) < 1e-4
