@@ -46,12 +46,16 @@ def build_task(args, rank, world, device, tmp):
     synth.write_fake_asr_ckpt(asr_dir, 60 + 10, hparams)
     from neuralsvb_amd.tasks.svb_vae_task import SVBVAEMleTask
     from neuralsvb_amd.utils.trainer import Trainer, move_to_device
-    trainer = Trainer(work_dir="", max_updates=10 ** 9, num_sanity_val_steps=0, amp=hparams["amp"])
+    trainer = Trainer(work_dir="", max_updates=10 ** 9, num_sanity_val_steps=0, amp=hparams["amp"],
+                      hip_graph=not args.no_graph)
     torch.manual_seed(1234)          # identical replicas on every rank
     task = trainer.setup(SVBVAEMleTask())
     task.train()
     loader = task.build_dataloader(task.dataset_cls("train", False), False, hparams["max_tokens"], args.batch)
-    batch = move_to_device(next(iter(loader)), device)
+    host = next(iter(loader))
+    batch = move_to_device(host, device)                       # inputs resident in HBM before the timed region
+    for k in ("mel_lengths", "prof_mel_lengths"):              # clip lengths stay host-side too (no sync to read them)
+        batch[k] = host[k]
     return task, trainer, batch, hparams
 
 
@@ -65,15 +69,27 @@ def conv_roofline(trainer, task, batch, steps, start_step):
     """Profiled pass (not part of `value`): HIP events around every launch of the implicit-GEMM conv kernel."""
     from neuralsvb_amd import kernels as K
     K.PROFILE = []
+    graph_mode, trainer.hip_graph = trainer.hip_graph, False     # HIP events around single launches: issue them eagerly
     run_steps(trainer, task, batch, steps, start_step)
     torch.cuda.synchronize()
+    trainer.hip_graph = graph_mode
     rec, K.PROFILE = K.PROFILE, None
-    by_cfg = {}
-    for name, flops, e0, e1 in rec:
-        d = by_cfg.setdefault(name, [0.0, 0.0, 0])
+    by_cfg, by_shape = {}, {}
+    for name, flops, e0, e1, tag in rec:
+        sec = e0.elapsed_time(e1) * 1e-3
+        if not name.startswith("svb_conv1d_wgrad"):      # the roofline object is about the forward/data-gradient kernel
+            d = by_cfg.setdefault(name, [0.0, 0.0, 0])
+            d[0] += flops
+            d[1] += sec
+            d[2] += 1
+        d = by_shape.setdefault(tag, [0.0, 0.0, 0])
         d[0] += flops
-        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[1] += sec
         d[2] += 1
+    if os.environ.get("SVB_BENCH_SHAPES"):
+        log("per-shape conv time (op, B, C_a, C_b, groups, T, k, stride, dil): calls/step, ms/step, TFLOP/s")
+        for tag, (fl, sec, cnt) in sorted(by_shape.items(), key=lambda kv: -kv[1][1]):
+            log(f"  {str(tag):56s} {cnt / steps:6.1f} {sec / steps * 1e3:8.3f} {fl / sec / 1e12:8.1f}")
     if not by_cfg:
         return None
     name, (fl, sec, cnt) = max(by_cfg.items(), key=lambda kv: kv[1][1])
@@ -147,6 +163,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = try 8/16/32 threads and report the fastest")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying hipGraphs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -203,6 +220,7 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": "vae_global_mle_eng phase-2 train step (gen+disc passes), configs[1]: per-GPU "
                                        f"batch {args.batch} x {args.seconds:g} s synthetic clips @ {args.sample_rate} Hz, "
+                                       f"{'hipGraph replay' if not args.no_graph else 'eager launches'}, "
                                        f"hop 128, T={T}, 80-bin mel", "global_batch": args.batch * world,
                            "parallelism": f"dp{world}", "random_init_weights": True},
                 "roofline": roof, "cpu_baseline": cpu}))

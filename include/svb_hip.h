@@ -130,12 +130,15 @@ int svb_layernorm_bwd(const float* x, const float* gamma, const float* dy, const
                       float* dx, float* dgamma_part, float* dbeta_part, int rows, int C, int n_part, void* stream);
 
 /* ---- im2col / col2im for small strided Conv2d layers (reference modules/fastspeech/multi_window_disc.py:14-31).
- * cols: [B, C*KH*KW, Ho*Wo]; the GEMM runs as svb_conv1d_forward(k=1) over cols (=> y is [B, Cout, Ho, Wo]),
- * its data gradient as svb_conv1d_transposed(k=1) followed by svb_col2im, its weight gradient as svb_conv1d_wgrad. */
+ * The column matrix is addressed as cols[b*cols_sb + row*cols_sk + pos] (row = (c,jh,jw), pos = ho*Wo+wo): per clip
+ * ([B][K][L]: cols_sb = K*L, cols_sk = L) or with the batch folded into the position axis ([K][B*L]: cols_sb = L,
+ * cols_sk = B*L), x as x[b*x_sb + c*x_sc + h*W + w].  The GEMM runs as svb_conv1d_forward(k=1) over cols, its data
+ * gradient as svb_conv1d_transposed(k=1) followed by svb_col2im (dx: contiguous [B,C,H,W]), its weight gradient as
+ * svb_conv1d_wgrad.                                                                                              */
 int svb_im2col(const float* x, float* cols, int B, int C, int H, int W, int KH, int KW, int SH, int SW, int PH, int PW,
-               int Ho, int Wo, void* stream);
+               int Ho, int Wo, long x_sb, long x_sc, long cols_sb, long cols_sk, void* stream);
 int svb_col2im(const float* dcols, float* dx, int B, int C, int H, int W, int KH, int KW, int SH, int SW, int PH, int PW,
-               int Ho, int Wo, void* stream);
+               int Ho, int Wo, long cols_sb, long cols_sk, void* stream);
 
 /* ---- SSIM map of two [B, T, F] mel images (+bias), 11x11 gaussian sigma 1.5, zero padding, C1=1e-4, C2=9e-4
  * (reference modules/commons/ssim.py:331-351 via tasks/tts/fs2.py:166-175).  Inputs are addressed with element

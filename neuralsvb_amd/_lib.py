@@ -46,8 +46,8 @@ SIGNATURES = {
     "svb_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
     "svb_layernorm_nct_fwd": (I, [P, P, P, P, I, I, I, F, P]),
     "svb_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
-    "svb_im2col": (I, [P, P] + [I] * 12 + [P]),
-    "svb_col2im": (I, [P, P] + [I] * 12 + [P]),
+    "svb_im2col": (I, [P, P] + [I] * 12 + [C.c_long] * 4 + [P]),
+    "svb_col2im": (I, [P, P] + [I] * 12 + [C.c_long] * 2 + [P]),
     "svb_ssim_fwd": (I, [P, C.c_long, C.c_long, C.c_long, P, C.c_long, C.c_long, C.c_long, P, I, I, I, F, P]),
     "svb_ssim_bwd": (I, [P, C.c_long, C.c_long, C.c_long, P, C.c_long, C.c_long, C.c_long, P, P, P, I, I, I, F, P]),
     "svb_stft_mel": (I, [P, P, P, P, I, I, I, I, I, I, I, F, P]),

@@ -19,8 +19,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define SVBQ_PITCH 24          /* bf16 elements per LDS row (16 used + 8 pad) = 48 bytes */
-#define SVBQ_KCHMAX 2          /* 16-channel chunks staged per phase (fast path) */
-#define SVBQ_XIT 2             /* 128-position groups per chunk on the fast path (span <= 256) */
+#define SVBQ_XUNITS 4          /* register-staged x units per thread: (16-channel chunks per phase) x (128-position groups) */
 
 struct SvbConvQArgs {
     const float* x;
@@ -37,7 +36,7 @@ struct SvbConvQArgs {
     int B, Cin, Cout, G, Cin_g, Cout_g, Tin, Tout;
     int sx, out_stride;
     int w_tap_slabs, w_g_slabs, w_slab_rows, w_goff_m, kchunks;
-    int tg, kch, xrows, fast_x;
+    int tg, kch, xrows, fast_x, xit;   // xit: 128-position groups per chunk on the register-staged path (1 or 2)
     int w_floats16, x_floats16;   // LDS carve sizes in 16-byte units (one of hi/lo each)
     int force_cfg;
 };
@@ -137,7 +136,8 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     const int xh = tid >> 7, xp0 = tid & 127;
 
     uint4 wr[WU];
-    float xr[SVBQ_KCHMAX][SVBQ_XIT][8];
+    float xr[SVBQ_XUNITS][8];
+    const int xsh = a.xit - 1;                             // unit u -> chunk u >> xsh, position group u & xsh
 
     auto load_w = [&](int kc0, int tg0) {
         const int nt_here = min(a.tg, ntap - tg0);
@@ -162,24 +162,22 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     auto load_x = [&](int kc0) {
         const int kch_here = min(a.kch, a.kchunks - kc0);
 #pragma unroll
-        for (int c = 0; c < SVBQ_KCHMAX; ++c) {
+        for (int u = 0; u < SVBQ_XUNITS; ++u) {
+            const int c = u >> xsh, it = u & xsh;
             if (c < kch_here) {
                 const int ch0 = (kc0 + c) * 16 + xh * 8;
+                const int i = xp0 + 128 * it;
+                const int pos = lo_pos + i;
+                const bool pv = i < span && pos >= 0 && pos < a.Tin;
 #pragma unroll
-                for (int it = 0; it < SVBQ_XIT; ++it) {
-                    const int i = xp0 + 128 * it;
-                    const int pos = lo_pos + i;
-                    const bool pv = i < span && pos >= 0 && pos < a.Tin;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float v = 0.f;
-                        if (pv && ch0 + e < a.Cin_g) {
-                            const size_t off = (size_t)(ch0 + e) * a.Tin + pos;
-                            v = xb[off];
-                            if (gb) v *= svb_gate(gb[off], a.in_slope);
-                        }
-                        xr[c][it][e] = v;
+                for (int e = 0; e < 8; ++e) {
+                    float v = 0.f;
+                    if (pv && ch0 + e < a.Cin_g) {
+                        const size_t off = (size_t)(ch0 + e) * a.Tin + pos;
+                        v = xb[off];
+                        if (gb) v *= svb_gate(gb[off], a.in_slope);
                     }
+                    xr[u][e] = v;
                 }
             }
         }
@@ -187,19 +185,15 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     auto store_x = [&](int kc0) {
         const int kch_here = min(a.kch, a.kchunks - kc0);
 #pragma unroll
-        for (int c = 0; c < SVBQ_KCHMAX; ++c) {
-            if (c < kch_here) {
-#pragma unroll
-                for (int it = 0; it < SVBQ_XIT; ++it) {
-                    const int i = xp0 + 128 * it;
-                    if (i < span) {
-                        uint4 hi, lo;
-                        svbq_split8(xr[c][it], hi, lo);
-                        const int d = (c * a.xrows + i) * 3 + xh;
-                        x_hi[d] = hi;
-                        x_lo[d] = lo;
-                    }
-                }
+        for (int u = 0; u < SVBQ_XUNITS; ++u) {
+            const int c = u >> xsh, it = u & xsh;
+            const int i = xp0 + 128 * it;
+            if (c < kch_here && i < span) {
+                uint4 hi, lo;
+                svbq_split8(xr[u], hi, lo);
+                const int d = (c * a.xrows + i) * 3 + xh;
+                x_hi[d] = hi;
+                x_lo[d] = lo;
             }
         }
     };
@@ -362,16 +356,18 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     constexpr int BM = 32 * WM, BN = 32 * WN * NT;
     const int span_max = (BN - 1) * a.sx + span_off_max + 1;
     a.xrows = span_max;
-    a.fast_x = span_max <= 128 * SVBQ_XIT ? 1 : 0;
+    a.fast_x = span_max <= 256 ? 1 : 0;
+    a.xit = span_max > 128 && a.fast_x ? 2 : 1;
     a.kchunks = svb_cdiv(a.Cin_g, 16);
-    // phase = tg taps x kch chunks, tg*kch <= SLB slabs, LDS budget ~72 KB
+    // phase = tg taps x kch chunks, tg*kch <= SLB slabs, kch*xit <= SVBQ_XUNITS, LDS budget ~78 KB (2 blocks per CU)
     a.tg = ntap_max < 1 ? 1 : (ntap_max > SLB ? SLB : ntap_max);
     int kch = SLB / a.tg;
-    if (kch > SVBQ_KCHMAX) kch = SVBQ_KCHMAX;
+    const int kch_cap = a.fast_x ? SVBQ_XUNITS / a.xit : 2;
+    if (kch > kch_cap) kch = kch_cap;
     if (kch > a.kchunks) kch = a.kchunks;
     if (kch < 1) kch = 1;
     auto lds_bytes = [&](int kc) { return (size_t)2 * (a.tg * kc * BM + kc * a.xrows) * 48 + SVB_MAX_TAPS * 4; };
-    while (kch > 1 && lds_bytes(kch) > 72 * 1024) --kch;
+    while (kch > 1 && lds_bytes(kch) > 78 * 1024) --kch;
     if (lds_bytes(kch) > 150 * 1024) return SVB_ERR_UNSUPPORTED;
     a.kch = kch;
     a.w_floats16 = a.tg * a.kch * BM * 3;

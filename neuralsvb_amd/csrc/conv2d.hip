@@ -3,13 +3,17 @@
 //
 // The GEMM itself runs on the implicit-GEMM conv kernel of conv1d.hip as a 1x1 conv over the column matrix:
 //   cols[b, (ci,jh,jw), (ho,wo)] = x[b, ci, ho*sh + jh - ph, wo*sw + jw - pw]      (zero outside)
-//   y[b, co, (ho,wo)]            = sum_k w[co, k] * cols[b, k, (ho,wo)]              -> exactly [B, Cout, Ho, Wo]
+//   y[b, co, (ho,wo)]            = sum_k w[co, k] * cols[b, k, (ho,wo)]
+// x and cols carry explicit batch / channel(row) element strides, so the column matrix can be laid out either per
+// clip ([B][K][L]) or with the batch folded into the position axis ([K][B*L]) -- the latter turns the late critic
+// layers (L = 40..160 positions per clip) into one wide GEMM instead of B skinny ones.
 // Both kernels are pure streaming (HBM-bound): lanes run along the contiguous (ho,wo) axis.
 #include "svb_common.h"
 #include "../../include/svb_hip.h"
 
 __global__ __launch_bounds__(256) void svb_im2col_kernel(const float* x, float* cols, int B, int C, int H, int W, int KH,
-                                                         int KW, int SH, int SW, int PH, int PW, int Ho, int Wo) {
+                                                         int KW, int SH, int SW, int PH, int PW, int Ho, int Wo, long x_sb, long x_sc,
+                                                         long c_sb, long c_sk) {
     const long n_pos = (long)Ho * Wo;
     const long total = (long)B * C * KH * KW * n_pos;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -22,16 +26,15 @@ __global__ __launch_bounds__(256) void svb_im2col_kernel(const float* x, float* 
         const int ho = (int)(pos / Wo), wo = (int)(pos - (long)ho * Wo);
         const int h = ho * SH + jh - PH, w = wo * SW + jw - PW;
         float v = 0.f;
-        if (h >= 0 && h < H && w >= 0 && w < W) v = x[(((long)b * C + c) * H + h) * W + w];
-        cols[i] = v;
+        if (h >= 0 && h < H && w >= 0 && w < W) v = x[(long)b * x_sb + (long)c * x_sc + (long)h * W + w];
+        cols[(long)b * c_sb + (((long)c * KH + jh) * KW + jw) * c_sk + pos] = v;
     }
 }
 
 // dx[b,c,h,w] = sum over (jh,jw) with (h+PH-jh) % SH == 0 and (w+PW-jw) % SW == 0 of dcols[b,(c,jh,jw),(ho,wo)]  (gather form)
 __global__ __launch_bounds__(256) void svb_col2im_kernel(const float* dcols, float* dx, int B, int C, int H, int W, int KH,
-                                                         int KW, int SH, int SW, int PH, int PW, int Ho, int Wo) {
+                                                         int KW, int SH, int SW, int PH, int PW, int Ho, int Wo, long c_sb, long c_sk) {
     const long total = (long)B * C * H * W;
-    const long n_pos = (long)Ho * Wo;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int w = (int)(i % W);
         long r = i / W;
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(256) void svb_col2im_kernel(const float* dcols, flo
                 if (tw < 0 || tw % SW) continue;
                 const int wo = tw / SW;
                 if (wo >= Wo) continue;
-                s += dcols[((((long)b * C + c) * KH + jh) * KW + jw) * n_pos + (long)ho * Wo + wo];
+                s += dcols[(long)b * c_sb + (((long)c * KH + jh) * KW + jw) * c_sk + (long)ho * Wo + wo];
             }
         }
         dx[i] = s;
@@ -64,21 +67,21 @@ static inline int g1d(long total) {
 }
 
 extern "C" int svb_im2col(const float* x, float* cols, int B, int C, int H, int W, int KH, int KW, int SH, int SW, int PH,
-                          int PW, int Ho, int Wo, void* stream) {
+                          int PW, int Ho, int Wo, long x_sb, long x_sc, long cols_sb, long cols_sk, void* stream) {
     if (!x || !cols || B <= 0 || C <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || SH <= 0 || SW <= 0 || Ho <= 0 || Wo <= 0)
         return SVB_ERR_ARG;
     hipLaunchKernelGGL(svb_im2col_kernel, dim3(g1d((long)B * C * KH * KW * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, cols,
-                       B, C, H, W, KH, KW, SH, SW, PH, PW, Ho, Wo);
+                       B, C, H, W, KH, KW, SH, SW, PH, PW, Ho, Wo, x_sb, x_sc, cols_sb, cols_sk);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
 
 extern "C" int svb_col2im(const float* dcols, float* dx, int B, int C, int H, int W, int KH, int KW, int SH, int SW, int PH,
-                          int PW, int Ho, int Wo, void* stream) {
+                          int PW, int Ho, int Wo, long cols_sb, long cols_sk, void* stream) {
     if (!dcols || !dx || B <= 0 || C <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || SH <= 0 || SW <= 0 || Ho <= 0 || Wo <= 0)
         return SVB_ERR_ARG;
     hipLaunchKernelGGL(svb_col2im_kernel, dim3(g1d((long)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, dcols, dx, B, C, H,
-                       W, KH, KW, SH, SW, PH, PW, Ho, Wo);
+                       W, KH, KW, SH, SW, PH, PW, Ho, Wo, cols_sb, cols_sk);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }

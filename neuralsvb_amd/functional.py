@@ -321,24 +321,28 @@ def ssim_map(pred, target, bias=6.0):
 
 class _Conv2dFn(torch.autograd.Function):
     """Small strided Conv2d = im2col + the implicit-GEMM 1x1 conv kernel (+ fused LeakyReLU epilogue).
-    reference: modules/fastspeech/multi_window_disc.py:14-31 (Conv2d 3x3 stride 2 pad 1 + LeakyReLU(0.2))."""
+    reference: modules/fastspeech/multi_window_disc.py:14-31 (Conv2d 3x3 stride 2 pad 1 + LeakyReLU(0.2)).
+
+    The column matrix and the GEMM output keep the batch folded into the position axis ([K][B*L], [Cout][B*L]): one
+    wide GEMM per layer.  The result is returned as a [B,Cout,Ho,Wo] *view* of that buffer (channel-major memory); the
+    next block's im2col reads such a view in place."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, cfg):
         stride, pad, slope = cfg
-        x, weight = x.contiguous(), weight.contiguous()
+        weight = weight.contiguous()
         B, C, H, W = x.shape
         cout, _, KH, KW = weight.shape
-        cols, Ho, Wo = K.im2col(x, KH, KW, stride, stride, pad, pad)
+        cols, Ho, Wo = K.im2col(x, KH, KW, stride, stride, pad, pad, fold_batch=True)
         w3 = weight.view(cout, C * KH * KW, 1)
         pa, pb = _pack(w3, None, 1, want_a=True, want_b=ctx.needs_input_grad[0])
         y = K.conv1d_forward(cols, pa, cout, 1, bias=bias, out_act=ACT_LRELU if slope is not None else ACT_NONE,
-                             out_slope=slope if slope is not None else 0.0)
+                             out_slope=slope if slope is not None else 0.0)          # [1, cout, B*Ho*Wo]
         ctx.cfg, ctx.shape = cfg, (B, C, H, W, KH, KW, Ho, Wo)
         ctx.has_bias = bias is not None
         ctx.pb = pb
         ctx.save_for_backward(cols if ctx.needs_input_grad[1] else None, y if slope is not None else None)
-        return y.view(B, cout, Ho, Wo)
+        return y.view(cout, B, Ho, Wo).permute(1, 0, 2, 3)
 
     @staticmethod
     def backward(ctx, dy):
@@ -347,12 +351,12 @@ class _Conv2dFn(torch.autograd.Function):
         cols, yact = ctx.saved_tensors
         pb = ctx.pb
         cout = dy.shape[1]
-        dy = dy.contiguous().view(B, cout, Ho * Wo)
+        dy = dy.permute(1, 0, 2, 3).contiguous().view(1, cout, B * Ho * Wo)
         a_slope = slope if slope is not None else 0.0
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dcols = K.conv1d_transposed(dy, pb, C * KH * KW, Ho * Wo, 1, in_gate=yact, in_slope=a_slope)
-            dx = K.col2im(dcols, B, C, H, W, KH, KW, stride, stride, pad, pad)
+            dcols = K.conv1d_transposed(dy, pb, C * KH * KW, B * Ho * Wo, 1, in_gate=yact, in_slope=a_slope)
+            dx = K.col2im(dcols, B, C, H, W, KH, KW, stride, stride, pad, pad, fold_batch=True)
         if ctx.needs_input_grad[1]:
             dw = K.conv1d_wgrad(dy, cols, 1, a_gate=yact, a_slope=a_slope).view(cout, C, KH, KW)
         if ctx.has_bias and ctx.needs_input_grad[2]:

@@ -48,19 +48,23 @@ def _tuned_cfg(sig, launch):
 
 
 class _ConvProbe:
-    def __init__(self, lib, x, cout_g, nq_max, flops, nz=1, forced=0, family="svb_conv1d_mfma_kernel"):
+    def __init__(self, lib, x, cout_g, nq_max, flops, nz=1, forced=0, family="svb_conv1d_mfma_kernel", tag=None):
         self.on = PROFILE is not None and x.is_cuda
         if self.on:
-            self.name = _CFG_NAMES[forced - 1 if forced else lib.svb_conv1d_pick_cfg(int(cout_g), int(nq_max), int(nz))]
-            self.name = self.name.replace("svb_conv1d_mfma_kernel", family)
+            if family.startswith("svb_conv1d_wgrad"):
+                self.name = family
+            else:
+                self.name = _CFG_NAMES[forced - 1 if forced else lib.svb_conv1d_pick_cfg(int(cout_g), int(nq_max), int(nz))]
+                self.name = self.name.replace("svb_conv1d_mfma_kernel", family)
             self.flops = flops
+            self.tag = tag
             self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self.e0.record()
 
     def done(self):
         if self.on:
             self.e1.record()
-            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+            PROFILE.append((self.name, self.flops, self.e0, self.e1, self.tag))
 
 
 def _ptr(t):
@@ -170,7 +174,7 @@ def conv1d_forward(x, pa, cout, k, stride=1, pad=0, dil=1, groups=1, out=None, *
                                                       tout, k, stride, pad, dil, C.byref(e), st), "svb_conv1d_forward_bf16x3")
             e.force_cfg = _tuned_cfg(("qf", B, cin, cout, groups, tin, k, stride, pad, dil), launch)
         probe = _ConvProbe(lib, x, cout // groups, tout, 2.0 * B * cout * tout * (cin // groups) * k, B * groups, e.force_cfg,
-                           "svb_conv1d_bf16x3_kernel")
+                           "svb_conv1d_bf16x3_kernel", tag=("fwd", B, cin, cout, groups, tin, k, stride, dil))
         L.check(lib.svb_conv1d_forward_bf16x3(_ptr(x), _ptr(pa.hi), _ptr(pa.lo), _ptr(y), B, cin, cout, groups, tin, tout, k,
                                               stride, pad, dil, C.byref(e), st), "svb_conv1d_forward_bf16x3")
         probe.done()
@@ -183,7 +187,8 @@ def conv1d_forward(x, pa, cout, k, stride=1, pad=0, dil=1, groups=1, out=None, *
             L.check(lib.svb_conv1d_forward(_ptr(x), _ptr(pa), _ptr(y), B, cin, cout, groups, tin, tout, k, stride, pad,
                                            dil, C.byref(e), st), "svb_conv1d_forward")
         e.force_cfg = _tuned_cfg(("f", B, cin, cout, groups, tin, k, stride, pad, dil), launch)
-    probe = _ConvProbe(lib, x, cout // groups, tout, 2.0 * B * cout * tout * (cin // groups) * k, B * groups, e.force_cfg)
+    probe = _ConvProbe(lib, x, cout // groups, tout, 2.0 * B * cout * tout * (cin // groups) * k, B * groups, e.force_cfg,
+                       tag=("fwd", B, cin, cout, groups, tin, k, stride, dil))
     L.check(lib.svb_conv1d_forward(_ptr(x), _ptr(pa), _ptr(y), B, cin, cout, groups, tin, tout, k, stride, pad, dil,
                                    C.byref(e), st), "svb_conv1d_forward")
     probe.done()
@@ -207,7 +212,8 @@ def conv1d_transposed(x, pb, cout, tout, k, stride=1, pad=0, dil=1, groups=1, ou
                         "svb_conv1d_transposed_bf16x3")
             e.force_cfg = _tuned_cfg(("qt", B, cin, cout, groups, tin, tout, k, stride, pad, dil), launch)
         probe = _ConvProbe(lib, x, cout // groups, -(-tout // stride), 2.0 * B * cin * tin * (cout // groups) * k,
-                           B * groups * stride, e.force_cfg, "svb_conv1d_bf16x3_kernel")
+                           B * groups * stride, e.force_cfg, "svb_conv1d_bf16x3_kernel",
+                           tag=("convT", B, cin, cout, groups, tin, k, stride, dil))
         L.check(lib.svb_conv1d_transposed_bf16x3(_ptr(x), _ptr(pb.hi), _ptr(pb.lo), _ptr(y), B, cin, cout, groups, tin, tout,
                                                  k, stride, pad, dil, C.byref(e), st), "svb_conv1d_transposed_bf16x3")
         probe.done()
@@ -219,7 +225,7 @@ def conv1d_transposed(x, pb, cout, tout, k, stride=1, pad=0, dil=1, groups=1, ou
                                               pad, dil, C.byref(e), st), "svb_conv1d_transposed")
         e.force_cfg = _tuned_cfg(("t", B, cin, cout, groups, tin, tout, k, stride, pad, dil), launch)
     probe = _ConvProbe(lib, x, cout // groups, -(-tout // stride), 2.0 * B * cin * tin * (cout // groups) * k,
-                       B * groups * stride, e.force_cfg)
+                       B * groups * stride, e.force_cfg, tag=("convT", B, cin, cout, groups, tin, k, stride, dil))
     L.check(lib.svb_conv1d_transposed(_ptr(x), _ptr(pb), _ptr(y), B, cin, cout, groups, tin, tout, k, stride, pad, dil,
                                       C.byref(e), st), "svb_conv1d_transposed")
     probe.done()
@@ -242,17 +248,23 @@ def conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0
     nfl = 0
     if (WGRAD_BF16X3 if bf16x3 is None else bf16x3) and sx == 1:
         nfl = lib.svb_conv1d_wgrad_bf16x3_workspace_floats(B, ca, cb, groups, ta, k, dil, C.byref(ns))
+    wflops = 2.0 * B * ca * ta * (cb // groups) * k
     if nfl:
         part = torch.empty((nfl,), device=a.device, dtype=torch.float32)
+        probe = _ConvProbe(lib, a, 0, 0, wflops, family="svb_conv1d_wgrad_bf16x3_kernel",
+                           tag=("wgrad", B, ca, cb, groups, ta, k, sx, dil))
         L.check(lib.svb_conv1d_wgrad_bf16x3(_ptr(a), _ptr(b), _ptr(part), B, ca, cb, groups, ta, tb, k, pad, dil,
                                             _ptr(a_gate), float(a_slope), _ptr(b_gate), float(b_slope), ns.value, st),
                 "svb_conv1d_wgrad_bf16x3")
+        probe.done()
     else:
         nfl = lib.svb_conv1d_wgrad_workspace_floats(B, ca, cb, groups, ta, k, sx, C.byref(ns))
         part = torch.empty((nfl,), device=a.device, dtype=torch.float32)
+        probe = _ConvProbe(lib, a, 0, 0, wflops, family="svb_conv1d_wgrad_kernel", tag=("wgrad", B, ca, cb, groups, ta, k, sx, dil))
         L.check(lib.svb_conv1d_wgrad(_ptr(a), _ptr(b), _ptr(part), B, ca, cb, groups, ta, tb, k, sx, pad, dil,
                                      _ptr(a_gate), float(a_slope), _ptr(b_gate), float(b_slope), ns.value, st),
                 "svb_conv1d_wgrad")
+        probe.done()
     rows, rowlen = ca, (cb // groups) * k
     wn = g is not None
     if accumulate_into is not None and not wn:
@@ -365,23 +377,36 @@ def conv2d_out_hw(H, W, KH, KW, SH, SW, PH, PW):
     return (H + 2 * PH - KH) // SH + 1, (W + 2 * PW - KW) // SW + 1
 
 
-def im2col(x, KH, KW, SH, SW, PH, PW):
-    """x [B,C,H,W] -> cols [B, C*KH*KW, Ho*Wo]."""
+def im2col(x, KH, KW, SH, SW, PH, PW, fold_batch=False):
+    """x [B,C,H,W] (any batch/channel strides over contiguous H x W planes) -> cols [B, C*KH*KW, Ho*Wo], or with
+    fold_batch [1, C*KH*KW, B*Ho*Wo] (batch folded into the position axis)."""
     _f32(x)
-    lib, st = _prep(x)
     B, Cc, H, W = x.shape
+    if x.stride(3) != 1 or x.stride(2) != W:
+        x = x.contiguous()
+    lib, st = _prep_strided(x)
     Ho, Wo = conv2d_out_hw(H, W, KH, KW, SH, SW, PH, PW)
-    cols = torch.empty((B, Cc * KH * KW, Ho * Wo), device=x.device, dtype=torch.float32)
-    L.check(lib.svb_im2col(_ptr(x), _ptr(cols), B, Cc, H, W, KH, KW, SH, SW, PH, PW, Ho, Wo, st), "svb_im2col")
+    Kr, Lp = Cc * KH * KW, Ho * Wo
+    if fold_batch:
+        cols = torch.empty((1, Kr, B * Lp), device=x.device, dtype=torch.float32)
+        csb, csk = Lp, B * Lp
+    else:
+        cols = torch.empty((B, Kr, Lp), device=x.device, dtype=torch.float32)
+        csb, csk = Kr * Lp, Lp
+    L.check(lib.svb_im2col(_ptr(x), _ptr(cols), B, Cc, H, W, KH, KW, SH, SW, PH, PW, Ho, Wo, x.stride(0), x.stride(1),
+                           csb, csk, st), "svb_im2col")
     return cols, Ho, Wo
 
 
-def col2im(dcols, B, Cc, H, W, KH, KW, SH, SW, PH, PW):
+def col2im(dcols, B, Cc, H, W, KH, KW, SH, SW, PH, PW, fold_batch=False):
+    """inverse scatter of im2col (gather form): dcols [B, C*KH*KW, Ho*Wo] (or folded [1, C*KH*KW, B*Ho*Wo]) -> dx [B,C,H,W]."""
     _f32(dcols)
     lib, st = _prep(dcols)
     Ho, Wo = conv2d_out_hw(H, W, KH, KW, SH, SW, PH, PW)
+    Kr, Lp = Cc * KH * KW, Ho * Wo
+    csb, csk = (Lp, B * Lp) if fold_batch else (Kr * Lp, Lp)
     dx = torch.empty((B, Cc, H, W), device=dcols.device, dtype=torch.float32)
-    L.check(lib.svb_col2im(_ptr(dcols), _ptr(dx), B, Cc, H, W, KH, KW, SH, SW, PH, PW, Ho, Wo, st), "svb_col2im")
+    L.check(lib.svb_col2im(_ptr(dcols), _ptr(dx), B, Cc, H, W, KH, KW, SH, SW, PH, PW, Ho, Wo, csb, csk, st), "svb_col2im")
     return dx
 
 

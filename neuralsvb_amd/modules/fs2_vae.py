@@ -138,10 +138,9 @@ class GlobalFVAE(nn.Module):
             raise NotImplementedError("run_model always passes infer=False (svb_vae_task.py:148; SURVEY Appendix A.1)")
         z_q, m_q, logs_q, mask_sqz = self.encoder(x, x_mask, g_sqz, eps)
         x_recon = self.decoder(z_q, x_mask, g)
-        with torch.no_grad():  # positivity guard of vae_models.py:24-30
+        with torch.no_grad():  # positivity guard of vae_models.py:24-30 (unconditional select: no device->host sync)
             bad = ~(logs_q.exp() > 0)
-        if bad.any():
-            logs_q = torch.where(bad, torch.zeros_like(logs_q), logs_q)
+        logs_q = torch.where(bad, torch.zeros_like(logs_q), logs_q)
         kl = 0.5 * (torch.exp(2 * logs_q) + m_q ** 2 - 1.0) - logs_q    # KL(N(m, e^logs) || N(0,1))
         loss_kl = (kl * mask_sqz).sum() / mask_sqz.sum() / z_q.shape[1]
         return x_recon, loss_kl, None, m_q, logs_q, mask_sqz, z_q

@@ -50,12 +50,18 @@ class Discriminator(nn.Module):
         self.discriminator.conv_layers = nn.ModuleList(
             [_critic_tower(tl, freq_length, kernel, c_in, hidden_size, norm_type, reduction) for tl in self.time_lengths])
 
-    def forward(self, x, cond=None, start_frames_wins=None):
+    def forward(self, x, cond=None, start_frames_wins=None, starts_dev=None, longest=None):
         """x [B,T,n_mels] (or [B,1,T,n_mels]).  Returns {'y': [B,1,W] or None, 'y_c': None, 'h': fmaps,
-        'start_frames_wins': [[s]*B per window]}."""
+        'start_frames_wins': [[s]*B per window]}.
+
+        `longest` (max number of non-zero frames over the batch) and `start_frames_wins` may be supplied by a caller
+        that already knows them on the host (the task draws the step's window starts up front, in the reference's
+        order), which removes the device->host sync of :190.  `starts_dev` (int64 [n_windows], device) makes the window
+        crop a device-side gather so that the call can be replayed from a captured hipGraph with fresh starts."""
         if x.dim() == 3:
             x = x[:, None]
-        longest = int(x.sum([1, -1]).ne(0).int().sum(-1).max().item())
+        if longest is None:
+            longest = int(x.sum([1, -1]).ne(0).int().sum(-1).max().item())
         starts = list(start_frames_wins) if start_frames_wins is not None else [None] * len(self.time_lengths)
         scores, fmaps = [], []
         for w, (tower, wl) in enumerate(zip(self.discriminator.conv_layers, self.time_lengths)):
@@ -63,8 +69,11 @@ class Discriminator(nn.Module):
                 continue
             if starts[w] is None:
                 starts[w] = [int(np.random.randint(low=0, high=longest - wl + 1))] * x.size(0)
-            s = starts[w][0]
-            h = x[:, :, s:s + wl]
+            if starts_dev is not None:
+                h = x.index_select(2, starts_dev[w] + torch.arange(wl, device=x.device))
+            else:
+                s = starts[w][0]
+                h = x[:, :, s:s + wl]
             for blk in tower.model:
                 conv = blk[0]     # Conv2d 3x3 s2 p1 + LeakyReLU(0.2): im2col + HIP implicit-GEMM kernel, fused epilogue
                 h = SF.conv2d_lrelu(h, conv.weight, conv.bias, conv.stride[0], conv.padding[0], 0.2)

@@ -128,7 +128,7 @@ class MleSVBVAE(nn.Module):
                 z_map = z_a
             else:
                 z_map = self.z_mapping_function(z_a, ca["h_style"])
-            prof_dist = torch.distributions.Normal(m_p, logs_p.exp())
+            prof_dist = torch.distributions.Normal(m_p, logs_p.exp(), validate_args=False)   # no host-side constraint check (sync)
             out["mle"] = -prof_dist.log_prob(z_map).sum() / z_map.shape[0] / z_map.shape[1]
             idx = a2p_alignment[:, None, :].expand(-1, self.hidden_size, -1)          # gather along time (svb_vae.py:285,298)
             cond = self._cond_sum(cp["h_pitch"], torch.gather(ca["h_content"], 2, idx),

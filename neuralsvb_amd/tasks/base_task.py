@@ -149,7 +149,9 @@ class BaseTask(nn.Module):
                           resume_from_checkpoint=hparams.get("resume_from_checkpoint", 0), amp=hparams["amp"],
                           monitor_key=hparams["valid_monitor_key"], monitor_mode=hparams["valid_monitor_mode"],
                           num_ckpt_keep=hparams["num_ckpt_keep"], save_best=hparams["save_best"], seed=hparams["seed"],
-                          debug=hparams["debug"])
+                          debug=hparams["debug"], hip_graph=hparams.get("hip_graph", False),
+                          hip_graph_warmup=hparams.get("hip_graph_warmup", 2),
+                          hip_graph_max_shapes=hparams.get("hip_graph_max_shapes", 4))
         if not hparams["infer"]:
             trainer.fit(cls)
         else:

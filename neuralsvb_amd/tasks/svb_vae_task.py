@@ -40,6 +40,8 @@ class SVBVAEMleTask(BaseTask):
             self.loss_and_lambda[name] = float(lbd) if lbd else 1.0
         self.vocoder = None
         self.model_out = self.model_out_gt = None
+        self._step_rand = None          # host randoms of the current step, drawn up front by begin_step()
+        self._rand_dev = None           # their device copies (static buffers; hipGraph replay reads them)
 
     # ------------------------------------------------------------------ model / optimizers
     def build_tts_model(self):
@@ -118,11 +120,83 @@ class SVBVAEMleTask(BaseTask):
     def get_corresponding_gtmel(way, sample):
         return sample["mels"] if way in ("a2a", "p2a") else sample["prof_mels"]
 
+    # ------------------------------------------------------------------ host randoms of a step
+    def _disc_plan(self, global_step):
+        """[(optimizer_idx, way), ...] of the critic calls one training step makes, in execution order."""
+        disc_start = hparams["mel_gan"] and global_step > hparams["disc_start_steps"] and hparams["lambda_mel_adv"] > 0
+        phase, ways = self.phase_of(global_step)
+        plan = []
+        if phase in (1, 2) and disc_start:
+            plan += [(0, w) for w in ways]
+            if global_step % hparams["disc_interval"] == 0:
+                plan += [(1, w) for w in ways for _ in ("real", "fake")]
+        elif phase == 3 and not hparams["cross_way_no_disc_loss"]:
+            plan += [(2, w) for w in ways]
+        return phase, plan
+
+    def begin_step(self, sample, global_step, stage_device=False):
+        """Draw the step's host-side randoms up front, in the reference's order: the speaker-embedding pick of run_model
+        (svb_vae_task.py:124), then per critic call one window start per window length (multi_window_disc.py:144-148,
+        high = longest - window + 1).  `longest` comes from the batch's host-side lengths, so neither the draw nor the
+        critic needs a device->host sync.  With stage_device the values are also written to static device tensors
+        (read by the captured hipGraphs)."""
+        phase, plan = self._disc_plan(global_step)
+        runs_model = phase in (1, 2) or phase == 3
+        rand = {"spk": int(np.random.randint(1, sample["multi_spk_emb"].shape[1])) if runs_model else 0, "disc": [],
+                "cursor": 0, "structure": []}
+        wins = self.mel_disc.time_lengths if hparams["mel_gan"] else []
+        for _, way in plan:
+            lens = sample["mel_lengths"] if way in ("a2a", "p2a") else sample["prof_mel_lengths"]
+            longest = int(lens.max())
+            starts = [[int(np.random.randint(low=0, high=longest - wl + 1))] * sample["mels"].shape[0] if longest - wl >= 0
+                      else None for wl in wins]
+            rand["disc"].append({"starts": starts, "longest": longest})
+            rand["structure"].append(tuple(s is not None for s in starts))
+        self._step_rand = rand
+        if stage_device:
+            dev = self.model.z_mapping_function.parameters().__next__().device
+            n_calls, n_win = 8, max(len(wins), 1)
+            if self._rand_dev is None:
+                self._rand_dev = {"spk": torch.zeros(1, dtype=torch.long, device=dev),
+                                  "starts": torch.zeros(n_calls, n_win, dtype=torch.long, device=dev)}
+            host = torch.zeros(n_calls, n_win, dtype=torch.long)
+            for i, d in enumerate(rand["disc"][:n_calls]):
+                for w, s in enumerate(d["starts"]):
+                    host[i, w] = s[0] if s is not None else 0
+            self._rand_dev["starts"].copy_(host, non_blocking=True)
+            self._rand_dev["spk"].fill_(rand["spk"])
+            rand["dev"] = True
+        return rand
+
+    def end_step(self):
+        self._step_rand = None
+
+    def graph_key(self, global_step):
+        """Everything host-side that shapes the launch sequence of a step (a captured graph is only replayed for an equal key)."""
+        phase, plan = self._disc_plan(global_step)
+        r = self._step_rand
+        return (phase, tuple(plan), tuple(r["structure"]) if r else None)
+
+    def _critic(self, x):
+        r = self._step_rand
+        if r is None or r["cursor"] >= len(r["disc"]):
+            return self.mel_disc(x, None)
+        d = r["disc"][r["cursor"]]
+        dev = self._rand_dev["starts"][r["cursor"]] if r.get("dev") else None
+        r["cursor"] += 1
+        return self.mel_disc(x, None, start_frames_wins=d["starts"], starts_dev=dev, longest=d["longest"])
+
     # ------------------------------------------------------------------ model run (svb_vae_task.py:120-165)
     def run_model(self, model, sample, concurrent_ways, return_output=False, infer=False, disable_map=False, **inject):
         model.vc_asr.eval()
-        idx = 0 if infer else np.random.randint(1, sample["multi_spk_emb"].shape[1])
-        spk = sample["multi_spk_emb"][:, idx, :]
+        r = self._step_rand
+        if infer:
+            spk = sample["multi_spk_emb"][:, 0, :]
+        elif r is not None and r.get("dev"):
+            spk = sample["multi_spk_emb"].index_select(1, self._rand_dev["spk"])[:, 0, :]
+        else:
+            idx = r["spk"] if r is not None else np.random.randint(1, sample["multi_spk_emb"].shape[1])
+            spk = sample["multi_spk_emb"][:, idx, :]
         output = model(amateur_mel=sample["mels"], prof_mel=sample["prof_mels"], amateur_pitch=sample["pitch"],
                        prof_pitch=sample["prof_pitch"], amateur_spk_id=spk, prof_spk_id=spk,
                        a2p_alignment=sample["a2p_f0_alignment"], p2a_alignment=None, infer=False,
@@ -138,14 +212,14 @@ class SVBVAEMleTask(BaseTask):
 
     # ------------------------------------------------------------------ GAN helpers (svb_para.py:118-170)
     def gen_cheat_disc(self, way, model_out, log_outputs, loss_weights):
-        p_ = self.mel_disc(model_out[way]["mel_out"], None)["y"]
+        p_ = self._critic(model_out[way]["mel_out"])["y"]
         if p_ is not None:
             log_outputs[f"{way}_a"] = self.mse_loss_fn(p_, torch.ones_like(p_))
             loss_weights[f"{way}_a"] = hparams["lambda_mel_adv"]
 
     def disc_judge_gen(self, way, sample, log_outputs):
-        p = self.mel_disc(self.get_corresponding_gtmel(way, sample), None)["y"]
-        p_ = self.mel_disc(self.model_out_gt[way]["mel_out"], None)["y"]
+        p = self._critic(self.get_corresponding_gtmel(way, sample))["y"]
+        p_ = self._critic(self.model_out_gt[way]["mel_out"])["y"]
         if p_ is not None:
             log_outputs[f"{way}_r"] = self.mse_loss_fn(p, torch.ones_like(p))
             log_outputs[f"{way}_f"] = self.mse_loss_fn(p_, torch.zeros_like(p_))
@@ -169,6 +243,18 @@ class SVBVAEMleTask(BaseTask):
                 self.model_out = {w: {k: v.detach() for k, v in o.items() if isinstance(v, torch.Tensor)}
                                   for w, o in model_out.items()}
                 self.model_out_gt = self.model_out
+                if self._step_rand is not None and self._step_rand.get("dev"):
+                    # hipGraph mode: the critic pass (possibly another graph) reads the generated mels from fixed buffers
+                    if not hasattr(self, "_gen_mel_buf"):
+                        self._gen_mel_buf = {}
+                    gt = {}
+                    for w, o in self.model_out.items():
+                        buf = self._gen_mel_buf.get(w)
+                        if buf is None or buf.shape != o["mel_out"].shape:
+                            buf = self._gen_mel_buf[w] = torch.empty_like(o["mel_out"])
+                        buf.copy_(o["mel_out"])
+                        gt[w] = {"mel_out": buf}
+                    self.model_out_gt = gt
                 if disc_start:
                     for way in ways:
                         self.gen_cheat_disc(way, model_out, log_outputs, loss_weights)
@@ -188,7 +274,7 @@ class SVBVAEMleTask(BaseTask):
                     log_outputs[f"{way}_mle"] = cross["mle"]
                     loss_weights[f"{way}_mle"] = hparams["lambda_mle"]
                     if not hparams["cross_way_no_disc_loss"]:
-                        p_ = self.mel_disc(cross["mel_out"], None)["y"]
+                        p_ = self._critic(cross["mel_out"])["y"]
                         if p_ is not None:
                             log_outputs[f"{way}_a"] = self.mse_loss_fn(p_, torch.ones_like(p_))
                             loss_weights[f"{way}_a"] = hparams["lambda_mel_adv"]

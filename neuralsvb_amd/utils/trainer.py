@@ -13,7 +13,12 @@ MI355X-first differences (none changes results):
     (no SyncBN, as in the reference) and rank 0's buffers are broadcast before evaluation / checkpointing;
   * launch: `torchrun --nproc-per-node N` (RANK/LOCAL_RANK/WORLD_SIZE) or, like the reference, self-spawn when
     CUDA_VISIBLE_DEVICES lists several devices;
-  * loss terms are only synchronised to the host when they are logged.
+  * loss terms are only synchronised to the host when they are logged;
+  * `hip_graph: true`: the forward+backward of each optimizer pass is captured once per (batch shape, phase) into a
+    hipGraph and replayed -- the step issues ~3500 kernel launches, which costs the host ~37 ms per step when issued
+    one by one from Python, more than the GPU needs to execute them.  Host-side randoms (window starts, speaker pick)
+    are drawn up front in the reference's order and read by the graph from device buffers; all-reduce, clipping and
+    the optimizer step stay outside the graph.
 """
 import copy
 import logging
@@ -86,7 +91,7 @@ class Trainer:
     def __init__(self, work_dir, accumulate_grad_batches=1, max_updates=160000, print_nan_grads=False,
                  val_check_interval=2000, num_sanity_val_steps=5, amp=False, tb_log_interval=10, monitor_key="val_loss",
                  monitor_mode="min", num_ckpt_keep=5, save_best=True, resume_from_checkpoint=0, seed=1234, debug=False,
-                 **_):
+                 hip_graph=False, hip_graph_warmup=2, hip_graph_max_shapes=4, **_):
         if work_dir:
             os.makedirs(work_dir, exist_ok=True)
         self.work_dir = work_dir
@@ -96,6 +101,9 @@ class Trainer:
         self.resume_from_checkpoint = resume_from_checkpoint if resume_from_checkpoint > 0 else None
         self.seed, self.debug, self.amp = seed, debug, amp
         self.task, self.optimizers, self.grad_sync = None, [], []
+        # hipGraph replay of each optimizer pass's forward+backward (fixed-shape batches; see _graphed_forward_backward)
+        self.hip_graph, self.hip_graph_warmup, self.hip_graph_max_shapes = bool(hip_graph), hip_graph_warmup, hip_graph_max_shapes
+        self._static, self._graphs, self._graph_pool, self._graph_stream = {}, {}, None, None
         self.testing = False
         self.global_step = self.current_epoch = 0
         self.monitor_key, self.num_ckpt_keep, self.save_best = monitor_key, num_ckpt_keep, save_best
@@ -264,12 +272,85 @@ class Trainer:
                 break
         task.on_train_end()
 
+    def _static_batch(self, batch):
+        """hipGraph mode: the batch lives in fixed device buffers (one set per distinct shape signature)."""
+        sig = tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(batch.items()) if isinstance(v, torch.Tensor))
+        bufs = self._static.get(sig)
+        if bufs is None:
+            if len(self._static) >= self.hip_graph_max_shapes:
+                return None, None
+            bufs = {k: torch.empty(v.shape, dtype=v.dtype, device=self.device) for k, v in batch.items()
+                    if isinstance(v, torch.Tensor)}
+            self._static[sig] = bufs
+        out = dict(batch)
+        for k, b in bufs.items():
+            b.copy_(batch[k], non_blocking=True)
+            out[k] = b
+        return sig, out
+
+    def _forward_backward(self, batch, batch_idx, opt_idx):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(self.amp) and self.on_gpu):
+            out = self.task.training_step(batch, batch_idx, opt_idx)
+        loss = out["loss"]
+        if loss is not None:
+            loss = loss / self.accumulate_grad_batches
+            if loss.requires_grad:
+                loss.backward()
+        return out
+
+    def _graphed_forward_backward(self, sig, batch, batch_idx, opt_idx):
+        """Forward + backward of one optimizer pass as a captured hipGraph (captured after `hip_graph_warmup` eager
+        runs of the same key -- kernel autotuning and lazy initialisation happen there -- then replayed).  The
+        optimizer step, gradient clipping and the data-parallel all-reduce stay outside the graph."""
+        key = (sig, opt_idx, self.task.graph_key(self.global_step), self.task.training)
+        ent = self._graphs.setdefault(key, {"seen": 0, "graph": None, "out": None})
+        if ent["graph"] is not None:
+            ent["graph"].replay()
+            return ent["out"]
+        if ent["seen"] < max(self.hip_graph_warmup, 1) or ent.get("idle"):
+            ent["seen"] += 1
+            out = self._forward_backward(batch, batch_idx, opt_idx)
+            ent["idle"] = out["loss"] is None          # this optimizer has nothing to do in this phase: nothing to capture
+            return out
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, pool=self._graph_pool, stream=self._graph_stream):
+            out = self._forward_backward(batch, batch_idx, opt_idx)
+        if self._graph_pool is None:
+            self._graph_pool = graph.pool()
+        ent["graph"], ent["out"] = graph, out
+        graph.replay()                      # capture only records: this replay is the step's actual execution
+        return out
+
     def run_training_batch(self, batch_idx, batch):
         """One step = every non-None optimizer in order (reference :269-342)."""
         if batch is None:
             return {}, {}
+        if self.hip_graph and self.on_gpu:
+            # hipGraph mode works on ONE side stream throughout (eager warm-up runs, capture, replay, optimizer): the
+            # autograd AccumulateGrad nodes must live on the stream that is captured, never on the default stream.
+            if self._graph_stream is None:
+                self._graph_stream = torch.cuda.Stream(self.device)
+            ambient = torch.cuda.current_stream(self.device)
+            self._graph_stream.wait_stream(ambient)        # batch tensors / evaluation / checkpoint reads issued there
+            with torch.cuda.stream(self._graph_stream):
+                ret = self._run_training_batch(batch_idx, batch)
+            ambient.wait_stream(self._graph_stream)        # whoever reads losses or weights next does so on that stream
+            return ret
+        return self._run_training_batch(batch_idx, batch)
+
+    def _run_training_batch(self, batch_idx, batch):
         task = self.task
-        batch = move_to_device(batch, self.device)            # once per step
+        graph_mode = self.hip_graph and self.on_gpu
+        if hasattr(task, "begin_step"):
+            task.begin_step(batch, self.global_step, stage_device=graph_mode)   # host randoms (batch still on the host)
+        sig = None
+        if graph_mode:
+            sig, sbatch = self._static_batch(batch)
+            graph_mode = sig is not None
+            batch = sbatch if graph_mode else batch
+        if not graph_mode:
+            batch = move_to_device(batch, self.device)            # once per step
         pbar, tb = {}, {}
         multi = len(self.optimizers) > 1
         for opt_idx, optimizer in enumerate(self.optimizers):
@@ -281,14 +362,12 @@ class Trainer:
                 for g in optimizer.param_groups:
                     for p in g["params"]:
                         p.requires_grad = True
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(self.amp) and self.on_gpu):
-                out = task.training_step(batch, batch_idx, opt_idx)
-            loss = out["loss"]
-            if loss is None:
+            if graph_mode:
+                out = self._graphed_forward_backward(sig, batch, batch_idx, opt_idx)
+            else:
+                out = self._forward_backward(batch, batch_idx, opt_idx)
+            if out["loss"] is None:
                 continue
-            loss = loss / self.accumulate_grad_batches
-            if loss.requires_grad:
-                loss.backward()
             pbar.update(out["progress_bar"])
             tb.update(out["tb_log"])
             if self.print_nan_grads:
@@ -303,6 +382,8 @@ class Trainer:
                 optimizer.step()
                 sync.zero()
                 task.on_after_optimization(self.current_epoch, batch_idx, optimizer, opt_idx)
+        if hasattr(task, "end_step"):
+            task.end_step()
         return pbar, tb
 
     # ------------------------------------------------------------------ checkpoints (reference :347-436)

@@ -70,8 +70,8 @@ def test_phase2_training_step_matches_cpu_oracle(dev, tmp_path):
         starts = []
         orig_fwd = task.mel_disc.forward
 
-        def rec(x, cond=None, start_frames_wins=None, _o=orig_fwd):
-            r = _o(x, cond, start_frames_wins)
+        def rec(x, cond=None, start_frames_wins=None, _o=orig_fwd, **kw):
+            r = _o(x, cond, start_frames_wins, **kw)
             starts.append([list(s) for s in r["start_frames_wins"]])
             return r
         task.mel_disc.forward = rec
@@ -113,3 +113,38 @@ def test_phase2_training_step_matches_cpu_oracle(dev, tmp_path):
     assert set(ck.keys()) == {"epoch", "global_step", "checkpoint_callback_best", "optimizer_states", "state_dict"}
     assert set(ck["state_dict"].keys()) == {"model", "mel_disc"} and len(ck["optimizer_states"]) == 3
     assert "vae_model.encoder.wn.in_layers.0.weight_g" in ck["state_dict"]["model"]
+
+
+@pytest.mark.gpu
+def test_hipgraph_replay_matches_eager_steps(gpu_only, tmp_path):
+    """Trainer hip_graph mode (forward+backward of each optimizer pass captured once, then replayed with fresh host randoms
+    staged to device buffers) must produce the same losses and weights as issuing every launch eagerly."""
+    dev = gpu_only
+    results = {}
+    for mode in ("eager", "graph"):
+        task, trainer, batch, hp = _setup(tmp_path / mode, dev)
+        trainer.hip_graph, trainer.hip_graph_warmup = mode == "graph", 1
+        for m in task.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        g = torch.Generator().manual_seed(3)
+        L = hp["latent_size"]
+        eps_a, eps_p = torch.randn(2, L, 1, generator=g).to(dev), torch.randn(2, L, 1, generator=g).to(dev)
+        orig_run = task.run_model
+        task.run_model = lambda *a, _o=orig_run, **k: _o(*a, eps_a2a=eps_a, eps_p2p=eps_p, **k)
+        host_lens = {k: batch[k].cpu() for k in ("mel_lengths", "prof_mel_lengths")}
+        logs = []
+        for step in range(1, 7):
+            np.random.seed(200 + step)
+            task.global_step = trainer.global_step = step
+            pbar, _ = trainer.run_training_batch(0, dict(batch, **host_lens))
+            logs.append({k: float(v) for k, v in pbar.items() if isinstance(v, torch.Tensor)})
+        if mode == "graph":
+            assert sum(1 for e in trainer._graphs.values() if e["graph"] is not None) == 2   # gen pass + critic pass
+        results[mode] = (logs, {k: v.detach().clone() for k, v in task.state_dict().items() if v.is_floating_point()})
+    for step, (le, lg) in enumerate(zip(results["eager"][0], results["graph"][0])):
+        assert le.keys() == lg.keys()
+        for k in le:
+            assert abs(le[k] - lg[k]) <= 1e-5 * max(1.0, abs(le[k])), (step, k, le[k], lg[k])
+    for k, v in results["eager"][1].items():
+        assert torch.allclose(v, results["graph"][1][k], rtol=1e-4, atol=1e-6), k
