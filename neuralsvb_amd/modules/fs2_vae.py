@@ -65,8 +65,11 @@ class GlobalFVAEEncoder(nn.Module):
             Conv1d(c2, c2, 3, stride=2), nn.ReLU(), nn.BatchNorm1d(c2),
             Conv1d(c2, c2, 3, stride=2))
 
-    def forward(self, x, x_mask, g, eps=None):
-        """x [B,80,T], x_mask [B,T], g [B,gin,T/4]; eps: optional injected N(0,1) draw (vae_models.py:96-105)."""
+    def forward(self, x, x_mask, g, eps=None, groups=1):
+        """x [B,80,T], x_mask [B,T], g [B,gin,T/4]; eps: optional injected N(0,1) draw (vae_models.py:96-105).
+        groups > 1: the batch is `groups` independent calls stacked along dim 0 (the a2a and p2p ways run as one wide
+        launch sequence); the train-mode BatchNorms then normalise -- and update their running statistics -- per group,
+        in order, exactly as the separate calls would."""
         n = len(self.pre_net)
         m = None
         for i, (conv, s) in enumerate(zip(self.pre_net, self.strides)):
@@ -78,8 +81,8 @@ class GlobalFVAEEncoder(nn.Module):
         x = self.wn(x, m, g)                      # output already masked; the reference's extra `* x_mask` is idempotent
         x = self.out_proj(x)
         p = self.poolings
-        x = p[2](p[0](x, out_act=SF.ACT_RELU))
-        x = p[5](p[3](x, out_act=SF.ACT_RELU))
+        x = bn_groups(p[2], p[0](x, out_act=SF.ACT_RELU), groups)
+        x = bn_groups(p[5], p[3](x, out_act=SF.ACT_RELU), groups)
         x = p[6](x)
         x = x.mean(-1, keepdim=True)
         m_q, logs_q = torch.split(x, self.latent_channels, dim=1)
@@ -87,6 +90,13 @@ class GlobalFVAEEncoder(nn.Module):
             eps = torch.randn_like(m_q)
         z = m_q + eps * torch.exp(logs_q)
         return z, m_q, logs_q, m[:, None, :]
+
+
+def bn_groups(bn, x, groups):
+    """BatchNorm over each of `groups` equal batch slices separately (see GlobalFVAEEncoder.forward)."""
+    if groups == 1:
+        return bn(x)
+    return torch.cat([bn(c) for c in x.chunk(groups, 0)], 0)
 
 
 def conv_len(t, s):
@@ -128,21 +138,24 @@ class GlobalFVAE(nn.Module):
         self.decoder = GlobalFVAEDecoder(latent_size, hidden_channels, in_out_channels, kernel_size, dec_n_layers,
                                          gin_channels, strides=strides)
 
-    def forward(self, x=None, x_mask=None, g=None, infer=False, eps=None):
+    def forward(self, x=None, x_mask=None, g=None, infer=False, eps=None, groups=1):
         """x [B,80,T]; x_mask [B,T]; g [B,gin,T]  ->  (x_recon, kl, z_p=None, m_q, logs_q, x_mask_sqz, z_q)
-        (TMPFVAE.forward, vae_models.py:12-41)."""
+        (TMPFVAE.forward, vae_models.py:12-41).  groups > 1: `groups` stacked independent calls, kl is [groups]."""
         g_sqz = g
         for c in self.g_pre_net:
             g_sqz = c(g_sqz)
         if infer:
             raise NotImplementedError("run_model always passes infer=False (svb_vae_task.py:148; SURVEY Appendix A.1)")
-        z_q, m_q, logs_q, mask_sqz = self.encoder(x, x_mask, g_sqz, eps)
+        z_q, m_q, logs_q, mask_sqz = self.encoder(x, x_mask, g_sqz, eps, groups)
         x_recon = self.decoder(z_q, x_mask, g)
         with torch.no_grad():  # positivity guard of vae_models.py:24-30 (unconditional select: no device->host sync)
             bad = ~(logs_q.exp() > 0)
         logs_q = torch.where(bad, torch.zeros_like(logs_q), logs_q)
         kl = 0.5 * (torch.exp(2 * logs_q) + m_q ** 2 - 1.0) - logs_q    # KL(N(m, e^logs) || N(0,1))
-        loss_kl = (kl * mask_sqz).sum() / mask_sqz.sum() / z_q.shape[1]
+        if groups == 1:
+            loss_kl = (kl * mask_sqz).sum() / mask_sqz.sum() / z_q.shape[1]
+        else:
+            loss_kl = ((kl * mask_sqz).reshape(groups, -1).sum(1) / mask_sqz.reshape(groups, -1).sum(1)) / z_q.shape[1]
         return x_recon, loss_kl, None, m_q, logs_q, mask_sqz, z_q
 
 

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import functional as SF
-from .fs2_vae import GlobalFVAE, GlobalLatentMap
+from .fs2_vae import GlobalFVAE, GlobalLatentMap, bn_groups
 from .layers import Conv1d, LinearNCT
 from .vc_asr import VCASR
 
@@ -80,16 +80,17 @@ class MleSVBVAE(nn.Module):
                                     enc_n_layers=hp["fvae_enc_n_layers"], dec_n_layers=hp["fvae_dec_n_layers"],
                                     gin_channels=H, use_prior_glow=False, strides=[4])
         self.z_mapping_function = GlobalLatentMap(hp["latent_size"])
+        self.stack_ways = bool(hp.get("stack_ways", True))     # see forward()
 
     # ---- conditioning (svb_vae.py:60-86); all tensors NCT --------------------------------------------------------
-    def prepare_condition(self, mels_content, pitch, spk_ids):
+    def prepare_condition(self, mels_content, pitch, spk_ids, groups=1):
         T = pitch.shape[1]
         h_pitch = self.pitch_encoder(self.pitch_embed(pitch).transpose(1, 2).contiguous())
         h = self.vc_asr(mels_content)["h_content"].detach()
         for m in self.upsample_layer:
             if isinstance(m, nn.Sequential):
                 h = F.interpolate(h, scale_factor=m[0].scale_factor, mode="nearest")
-                h = m[3](m[1](h, out_act=SF.ACT_RELU))
+                h = bn_groups(m[3], m[1](h, out_act=SF.ACT_RELU), groups)
             else:
                 h = m(h)
         h_content = h[:, :, :mels_content.shape[1]]
@@ -99,10 +100,10 @@ class MleSVBVAE(nn.Module):
     def _cond_sum(self, h_pitch, h_content, h_style):
         return self.encoded_embed_proj(torch.cat([h_pitch, h_content, h_style], 1))
 
-    def normal_vae(self, tgt_mel, c, eps=None):
+    def normal_vae(self, tgt_mel, c, eps=None, groups=1):
         cond = self._cond_sum(c["h_pitch"], c["h_content"], c["h_style"])
         mel_out, kl, z_p, m_q, logs_q, mask_sqz, z_q = self.vae_model(
-            tgt_mel.transpose(1, 2).contiguous(), c["tgt_nonpadding"], g=cond, eps=eps)
+            tgt_mel.transpose(1, 2).contiguous(), c["tgt_nonpadding"], g=cond, eps=eps, groups=groups)
         return {"mel_out": mel_out.transpose(1, 2), "kl": kl, "z_p": z_p, "m_q": m_q, "logs_q": logs_q,
                 "x_mask_sqz": mask_sqz, "z_q": z_q}
 
@@ -112,13 +113,31 @@ class MleSVBVAE(nn.Module):
         N(0,1) draws of the encoder (vae_models.py:104) for parity tests."""
         ways = kwargs["concurrent_ways"]
         ret = {}
-        ca = self.prepare_condition(amateur_mel, amateur_pitch, amateur_spk_id)
-        cp = self.prepare_condition(prof_mel, prof_pitch, prof_spk_id)
+        eps_a, eps_p = kwargs.get("eps_a2a"), kwargs.get("eps_p2p")
+        stacked = (self.stack_ways and amateur_mel.shape == prof_mel.shape and amateur_pitch.shape == prof_pitch.shape
+                   and (eps_a is None) == (eps_p is None))
+        if stacked:
+            # The two voices share every weight and are independent per clip: run them as ONE launch sequence on the
+            # stacked batch [amateur; professional] (half the launches, twice the work per launch).  The only
+            # batch-coupled layers on the path, the train-mode BatchNorms, are applied per half (bn_groups).
+            B = amateur_mel.shape[0]
+            c2 = self.prepare_condition(torch.cat([amateur_mel, prof_mel]), torch.cat([amateur_pitch, prof_pitch]),
+                                        torch.cat([amateur_spk_id, prof_spk_id]), groups=2)
+            ca, cp = {k: v[:B] for k, v in c2.items()}, {k: v[B:] for k, v in c2.items()}
+        else:
+            ca = self.prepare_condition(amateur_mel, amateur_pitch, amateur_spk_id)
+            cp = self.prepare_condition(prof_mel, prof_pitch, prof_spk_id)
         self._last_conds = (ca, cp)
-        if "a2a" in ways:
-            ret["a2a"] = self.normal_vae(amateur_mel, ca, kwargs.get("eps_a2a"))
-        if "p2p" in ways:
-            ret["p2p"] = self.normal_vae(prof_mel, cp, kwargs.get("eps_p2p"))
+        if stacked and "a2a" in ways and "p2p" in ways:
+            o2 = self.normal_vae(torch.cat([amateur_mel, prof_mel]), c2, None if eps_a is None else torch.cat([eps_a, eps_p]),
+                                 groups=2)
+            for i, way in enumerate(("a2a", "p2p")):
+                ret[way] = {k: (None if v is None else (v[i] if k == "kl" else v[i * B:(i + 1) * B])) for k, v in o2.items()}
+        else:
+            if "a2a" in ways:
+                ret["a2a"] = self.normal_vae(amateur_mel, ca, eps_a)
+            if "p2p" in ways:
+                ret["p2p"] = self.normal_vae(prof_mel, cp, eps_p)
         if "a2p" in ways:
             out = {}
             z_a = ret["a2a"]["z_q"]
