@@ -94,10 +94,13 @@ int svb_conv1d_wgrad(const float* a, const float* b, float* part, int B, int CA,
 size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB, int groups, int TA, int k, int dil, int* nsplit_out);
 int svb_conv1d_wgrad_bf16x3(const float* a, const float* b, float* part, int B, int CA, int CB, int groups, int TA, int TB,
                             int k, int pad, int dil, const float* a_gate, float a_slope, const float* b_gate,
-                            float b_slope, int nsplit, void* stream);
-/* Stage 2: reduce partials (+ WeightNorm backward: dv, dg from dW).  rows = d0, rowlen = d1*k.              */
+                            float b_slope, int nsplit, float* bias_part, void* stream);
+/* bias_part (optional, [nsplit][CA] floats): per-split row sums of the gated A operand -- with A = dy these are the bias
+ * gradient partials (reference: autograd of the `bias` argument of F.conv1d); svb_wgrad_reduce sums them into db.     */
+/* Stage 2: reduce partials (+ WeightNorm backward: dv, dg from dW).  rows = d0, rowlen = d1*k.
+ * bias_part/db (optional): also sum the [nsplit][rows] bias-gradient partials of stage 1 into db[rows].     */
 int svb_wgrad_reduce(const float* part, int nsplit, const float* v, const float* g, float* dv, float* dg, int rows,
-                     int rowlen, int weight_norm, int accumulate, void* stream);
+                     int rowlen, int weight_norm, int accumulate, const float* bias_part, float* db, void* stream);
 /* db[c] = sum_{b,t} dy[b,c,t] * gate'(gate[b,c,t])                                                          */
 int svb_bias_grad(const float* dy, const float* gate, float slope, float* db, int B, int C, int T, void* stream);
 

@@ -423,22 +423,57 @@ __global__ __launch_bounds__(256) void svb_conv1d_wgrad_kernel(SvbWgradArgs a) {
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void svb_wgrad_reduce_kernel(const float* part, int nsplit, size_t split_stride,
                                                                const float* v, const float* gnorm, float* dv, float* dg,
-                                                               int rowlen, int weight_norm, int accumulate) {
+                                                               int rowlen, int weight_norm, int accumulate,
+                                                               const float* bias_part, float* db, int rows, int vec) {
     __shared__ float red[8];
     const int row = blockIdx.x;
     const size_t base = (size_t)row * rowlen;
     float dot = 0.f, vv = 0.f;
-    for (int e = threadIdx.x; e < rowlen; e += 256) {
-        float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += part[(size_t)sp * split_stride + base + e];
-        if (weight_norm) {
-            const float ve = v[base + e];
-            dot += ve * s;
-            vv += ve * ve;
-            dv[base + e] = s;  // finalised below
-        } else {
-            dv[base + e] = accumulate ? dv[base + e] + s : s;
+    if (vec) {
+        for (int e = threadIdx.x * 4; e < rowlen; e += 1024) {
+            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+            int sp = 0;
+            for (; sp + 1 < nsplit; sp += 2) {
+                const float4 p0 = *reinterpret_cast<const float4*>(part + (size_t)sp * split_stride + base + e);
+                const float4 p1 = *reinterpret_cast<const float4*>(part + (size_t)(sp + 1) * split_stride + base + e);
+                s0.x += p0.x; s0.y += p0.y; s0.z += p0.z; s0.w += p0.w;
+                s1.x += p1.x; s1.y += p1.y; s1.z += p1.z; s1.w += p1.w;
+            }
+            if (sp < nsplit) {
+                const float4 p0 = *reinterpret_cast<const float4*>(part + (size_t)sp * split_stride + base + e);
+                s0.x += p0.x; s0.y += p0.y; s0.z += p0.z; s0.w += p0.w;
+            }
+            float4 sv = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+            float4* dst = reinterpret_cast<float4*>(dv + base + e);
+            if (weight_norm) {
+                const float4 ve = *reinterpret_cast<const float4*>(v + base + e);
+                dot += ve.x * sv.x + ve.y * sv.y + ve.z * sv.z + ve.w * sv.w;
+                vv += ve.x * ve.x + ve.y * ve.y + ve.z * ve.z + ve.w * ve.w;
+            } else if (accumulate) {
+                const float4 o = *dst;
+                sv.x += o.x; sv.y += o.y; sv.z += o.z; sv.w += o.w;
+            }
+            *dst = sv;                                        // weight_norm: finalised below
         }
+    } else {
+        for (int e = threadIdx.x; e < rowlen; e += 256) {
+            float s = 0.f;
+            for (int sp = 0; sp < nsplit; ++sp) s += part[(size_t)sp * split_stride + base + e];
+            if (weight_norm) {
+                const float ve = v[base + e];
+                dot += ve * s;
+                vv += ve * ve;
+                dv[base + e] = s;  // finalised below
+            } else {
+                dv[base + e] = accumulate ? dv[base + e] + s : s;
+            }
+        }
+    }
+    if (bias_part) {      // bias-gradient partials written by the stage-1 kernel: [nsplit][rows]
+        float b = 0.f;
+        for (int sp = threadIdx.x; sp < nsplit; sp += 256) b += bias_part[(size_t)sp * rows + row];
+        b = svb_block_sum<256>(b, red);
+        if (threadIdx.x == 0) db[row] = b;
     }
     if (!weight_norm) return;
     dot = svb_block_sum<256>(dot, red);
@@ -705,11 +740,15 @@ extern "C" int svb_conv1d_wgrad(const float* a_t, const float* b_t, float* part,
 }
 
 extern "C" int svb_wgrad_reduce(const float* part, int nsplit, const float* v, const float* g, float* dv, float* dg,
-                                int rows, int rowlen, int weight_norm, int accumulate, void* stream) {
+                                int rows, int rowlen, int weight_norm, int accumulate, const float* bias_part, float* db,
+                                void* stream) {
     if (!part || !dv || rows <= 0 || rowlen <= 0 || nsplit <= 0) return SVB_ERR_ARG;
     if (weight_norm && (!v || !g || !dg)) return SVB_ERR_ARG;
+    if (bias_part && !db) return SVB_ERR_ARG;
+    // 16-byte loads when every row of every operand is 16-byte aligned
+    const int vec = (rowlen & 3) == 0 && (((uintptr_t)part | (uintptr_t)dv | (uintptr_t)v) & 15) == 0;
     hipLaunchKernelGGL(svb_wgrad_reduce_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, part, nsplit,
-                       (size_t)rows * rowlen, v, g, dv, dg, rowlen, weight_norm, accumulate);
+                       (size_t)rows * rowlen, v, g, dv, dg, rowlen, weight_norm, accumulate, bias_part, db, rows, vec);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }

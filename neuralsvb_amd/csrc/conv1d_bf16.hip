@@ -506,6 +506,7 @@ struct SvbWgradQArgs {
     const float* a;
     const float* b;
     float* part;
+    float* bias_part;   // optional [nsplit][CA]: per-split sums of the (gated) A rows = bias-gradient partials when A = dy
     const float* a_gate;
     const float* b_gate;
     float a_slope, b_slope;
@@ -573,6 +574,10 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
 
     float ar[8][2], br[8][2], bx[SVBQ_WG_NXIT][2];
     const int srow = tid >> 5, spair = tid & 31;            // staging role: row srow + 8*it, pair spair
+    const bool do_bias = a.bias_part != nullptr && bt == 0 && tgi == 0;
+    float bsum[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) bsum[rr] = 0.f;
     const float* a_base = a.a + (size_t)g * a.CA_g * a.TA;
     const float* ag_base = a.a_gate ? a.a_gate + (size_t)g * a.CA_g * a.TA : nullptr;
     const float* b_base = a.b + (size_t)g * a.CB_g * a.TB;
@@ -613,6 +618,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
         for (int rr = 0; rr < 8; ++rr) {
             const int r = srow + 8 * rr;
             unsigned hi, lo;
+            bsum[rr] += ar[rr][0] + ar[rr][1];
             svbq_split2(ar[rr][0], ar[rr][1], hi, lo);
             A_hi[r * a.pa + spair] = hi; A_lo[r * a.pa + spair] = lo;
             svbq_split2(br[rr][0], br[rr][1], hi, lo);
@@ -729,6 +735,16 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
             }
         }
     }
+    if (do_bias) {        // row sums of this split's A tiles: the 32 lanes of a half-wave staged one row
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            float v = bsum[rr];
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+            const int r = srow + 8 * rr;
+            if (spair == 0 && (a0 + r) < a.CA_g) a.bias_part[(size_t)blockIdx.y * a.CA + g * a.CA_g + a0 + r] = v;
+        }
+    }
 }
 
 static int wgq_tgw(int k) { return k <= 5 ? k : (k % 5 == 0 ? 5 : (svb_cdiv(k, 4) <= svb_cdiv(k, 5) ? 4 : 5)); }
@@ -770,12 +786,13 @@ static void wgq_launch(const SvbWgradQArgs& a, dim3 grid, size_t lds, hipStream_
 
 extern "C" int svb_conv1d_wgrad_bf16x3(const float* a_t, const float* b_t, float* part, int B, int CA, int CB, int groups,
                                        int TA, int TB, int k, int pad, int dil, const float* a_gate, float a_slope,
-                                       const float* b_gate, float b_slope, int nsplit, void* stream) {
+                                       const float* b_gate, float b_slope, int nsplit, float* bias_part, void* stream) {
     if (!a_t || !b_t || !part || B <= 0 || groups <= 0 || CA % groups || CB % groups || k <= 0 || k > SVB_MAX_TAPS ||
         dil <= 0 || nsplit <= 0)
         return SVB_ERR_ARG;
     SvbWgradQArgs a;
     a.a = a_t; a.b = b_t; a.part = part; a.a_gate = a_gate; a.b_gate = b_gate; a.a_slope = a_slope; a.b_slope = b_slope;
+    a.bias_part = bias_part;
     a.B = B; a.CA = CA; a.CB = CB; a.G = groups; a.CA_g = CA / groups; a.CB_g = CB / groups; a.TA = TA; a.TB = TB;
     a.k = k; a.off0 = -pad; a.dil = dil;
     const int tgw = wgq_tgw(k);

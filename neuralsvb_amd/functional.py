@@ -80,15 +80,20 @@ class _Conv1dFn(torch.autograd.Function):
                                      in_gate=yact, in_slope=a_slope,
                                      out_gate=x if in_slope is not None else None,
                                      out_gate_slope=in_slope if in_slope is not None else 0.0)
+        want_b = ctx.has_bias and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[1]:
             r = K.conv1d_wgrad(dy, x, k, stride, pad, dil, groups, a_gate=yact, a_slope=a_slope,
                                b_gate=x if in_slope is not None else None,
-                               b_slope=in_slope if in_slope is not None else 0.0, v=v if g is not None else None, g=g)
+                               b_slope=in_slope if in_slope is not None else 0.0, v=v if g is not None else None, g=g,
+                               want_bias=want_b)
+            if want_b:
+                r, db = r[:-1], r[-1]
+                r = r if g is not None else r[0]
             if g is not None:
                 dv, dg = r
             else:
                 dv = r
-        if ctx.has_bias and ctx.needs_input_grad[3]:
+        elif want_b:
             db = K.bias_grad(dy, yact, a_slope)
         return dx, dv, dg, db, d_res, None, None
 
@@ -228,33 +233,30 @@ class _WNStackFn(torch.autograd.Function):
             else:
                 drs, dxm = K.wn_res_skip_bwd(dx_next, dout, mask, want_dxm=True)
             # res/skip 1x1 conv
-            r = K.conv1d_wgrad(drs, acts, 1, v=rs_v if rs_g is not None else None, g=rs_g)
+            r = K.conv1d_wgrad(drs, acts, 1, v=rs_v if rs_g is not None else None, g=rs_g, want_bias=True)
             p = 6 + 6 * i
             if rs_g is not None:
-                grads[p + 3], grads[p + 4] = r
+                grads[p + 3], grads[p + 4], grads[p + 5] = r
             else:
-                grads[p + 3] = r
-            grads[p + 5] = K.bias_grad(drs)
+                grads[p + 3], grads[p + 5] = r
             dacts = K.conv1d_transposed(drs, pb_rs, C, acts.shape[2], 1)
             dxin = K.wn_gate_bwd(xin, G, dacts, i * 2 * C, dg=dG)
-            r = K.conv1d_wgrad(dxin, x_i, ks, 1, pad, dil, v=in_v if in_g is not None else None, g=in_g)
+            r = K.conv1d_wgrad(dxin, x_i, ks, 1, pad, dil, v=in_v if in_g is not None else None, g=in_g, want_bias=True)
             if in_g is not None:
-                grads[p + 0], grads[p + 1] = r
+                grads[p + 0], grads[p + 1], grads[p + 2] = r
             else:
-                grads[p + 0] = r
-            grads[p + 2] = K.bias_grad(dxin)
+                grads[p + 0], grads[p + 2] = r
             if i > 0 or ctx.needs_input_grad[3]:
                 dx_next = K.conv1d_transposed(dxin, pb_in, C, x_i.shape[2], ks, 1, pad, dil, residual=dxm)
             else:
                 dx_next = None
         grads[0] = dx_next
         if G is not None:
-            r = K.conv1d_wgrad(dG, gcond, 1, v=cond_v if cond_g is not None else None, g=cond_g)
+            r = K.conv1d_wgrad(dG, gcond, 1, v=cond_v if cond_g is not None else None, g=cond_g, want_bias=True)
             if cond_g is not None:
-                grads[3], grads[4] = r
+                grads[3], grads[4], grads[5] = r
             else:
-                grads[3] = r
-            grads[5] = K.bias_grad(dG)
+                grads[3], grads[5] = r
             if ctx.needs_input_grad[5]:
                 grads[2] = K.conv1d_transposed(dG, cond_pb, gcond.shape[1], gcond.shape[2], 1)
         return (None, None, None) + tuple(grads)
@@ -357,9 +359,12 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dcols = K.conv1d_transposed(dy, pb, C * KH * KW, B * Ho * Wo, 1, in_gate=yact, in_slope=a_slope)
             dx = K.col2im(dcols, B, C, H, W, KH, KW, stride, stride, pad, pad, fold_batch=True)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = K.conv1d_wgrad(dy, cols, 1, a_gate=yact, a_slope=a_slope).view(cout, C, KH, KW)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            r = K.conv1d_wgrad(dy, cols, 1, a_gate=yact, a_slope=a_slope, want_bias=want_b)
+            dw, db = r if want_b else (r, None)
+            dw = dw.view(cout, C, KH, KW)
+        elif want_b:
             db = K.bias_grad(dy, yact, a_slope)
         return dx, dw, db, None
 

@@ -236,10 +236,12 @@ WGRAD_BF16X3 = False      # set by functional.set_precision: stride-1 weight gra
 
 
 def conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0, b_gate=None, b_slope=0.0,
-                 v=None, g=None, accumulate_into=None, bf16x3=None):
+                 v=None, g=None, accumulate_into=None, bf16x3=None, want_bias=False):
     """dW[ca, cb/groups, k] = sum_{n,q} a[n,ca,q] * b[n,cb,q*sx + j*dil - pad].
 
-    With (v, g) given returns (dv, dg) of the weight-normalised parametrisation instead of dW."""
+    With (v, g) given returns (dv, dg) of the weight-normalised parametrisation instead of dW.  want_bias: also return
+    db[ca] = sum_{n,q} a[n,ca,q] (gated) -- the bias gradient when a = dy -- as the last element of the result; on the
+    bf16x3 path it comes out of the same two launches."""
     _f32(a, b, a_gate, b_gate, v, g)
     lib, st = _prep(a, b, a_gate, b_gate, v, g, accumulate_into)
     B, ca, ta = a.shape
@@ -253,13 +255,15 @@ def conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0
         part = torch.empty((nfl,), device=a.device, dtype=torch.float32)
         probe = _ConvProbe(lib, a, 0, 0, wflops, family="svb_conv1d_wgrad_bf16x3_kernel",
                            tag=("wgrad", B, ca, cb, groups, ta, k, sx, dil))
+        bias_part = torch.empty((ns.value, ca), device=a.device, dtype=torch.float32) if want_bias else None
         L.check(lib.svb_conv1d_wgrad_bf16x3(_ptr(a), _ptr(b), _ptr(part), B, ca, cb, groups, ta, tb, k, pad, dil,
-                                            _ptr(a_gate), float(a_slope), _ptr(b_gate), float(b_slope), ns.value, st),
-                "svb_conv1d_wgrad_bf16x3")
+                                            _ptr(a_gate), float(a_slope), _ptr(b_gate), float(b_slope), ns.value,
+                                            _ptr(bias_part), st), "svb_conv1d_wgrad_bf16x3")
         probe.done()
     else:
         nfl = lib.svb_conv1d_wgrad_workspace_floats(B, ca, cb, groups, ta, k, sx, C.byref(ns))
         part = torch.empty((nfl,), device=a.device, dtype=torch.float32)
+        bias_part = None
         probe = _ConvProbe(lib, a, 0, 0, wflops, family="svb_conv1d_wgrad_kernel", tag=("wgrad", B, ca, cb, groups, ta, k, sx, dil))
         L.check(lib.svb_conv1d_wgrad(_ptr(a), _ptr(b), _ptr(part), B, ca, cb, groups, ta, tb, k, sx, pad, dil,
                                      _ptr(a_gate), float(a_slope), _ptr(b_gate), float(b_slope), ns.value, st),
@@ -274,9 +278,15 @@ def conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0
         dw = torch.empty((ca, cb // groups, k), device=a.device, dtype=torch.float32)
         acc = 0
     dg = torch.empty_like(g) if wn else None
+    db = torch.empty((ca,), device=a.device, dtype=torch.float32) if bias_part is not None else None
     L.check(lib.svb_wgrad_reduce(_ptr(part), ns.value, _ptr(v), _ptr(g), _ptr(dw), _ptr(dg), rows, rowlen, int(wn),
-                                 acc, st), "svb_wgrad_reduce")
-    return (dw, dg) if wn else dw
+                                 acc, _ptr(bias_part), _ptr(db), st), "svb_wgrad_reduce")
+    res = (dw, dg) if wn else dw
+    if want_bias:
+        if db is None:
+            db = bias_grad(a, a_gate, a_slope)
+        return (dw, dg, db) if wn else (dw, db)
+    return res
 
 
 def bias_grad(dy, gate=None, slope=0.0):

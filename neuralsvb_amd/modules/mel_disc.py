@@ -85,3 +85,32 @@ class Discriminator(nn.Module):
         if len(scores) == len(self.time_lengths):
             y = torch.stack(scores, -1) if self.reduction == "stack" else sum(scores)
         return {"y": y, "y_c": None, "h": fmaps, "start_frames_wins": starts}
+
+    def forward_many(self, calls):
+        """Several independent critic calls -- [(x, start_frames_wins, starts_dev, longest), ...] with equal shapes and all
+        windows present -- as ONE pass per tower over the stacked crops [n*B,1,wl,80].  Every layer of the tower is
+        per-clip (Conv2d, LeakyReLU, Dropout2d, InstanceNorm2d), so each call's scores equal those of a separate
+        forward() (with Dropout2d off; with it on only the order of the mask draws differs).  Returns one result dict per
+        call ('h' holds the stacked feature maps and is shared)."""
+        xs = [c[0][:, None] if c[0].dim() == 3 else c[0] for c in calls]
+        B = xs[0].size(0)
+        scores, fmaps = [], []
+        for w, (tower, wl) in enumerate(zip(self.discriminator.conv_layers, self.time_lengths)):
+            crops = []
+            for x, (_, starts, starts_dev, _) in zip(xs, calls):
+                if starts_dev is not None:
+                    crops.append(x.index_select(2, starts_dev[w] + torch.arange(wl, device=x.device)))
+                else:
+                    s = starts[w][0]
+                    crops.append(x[:, :, s:s + wl])
+            h = torch.cat(crops, 0)
+            for blk in tower.model:
+                conv = blk[0]
+                h = SF.conv2d_lrelu(h, conv.weight, conv.bias, conv.stride[0], conv.padding[0], 0.2)
+                for m in list(blk)[2:]:
+                    h = m(h)
+                fmaps.append(h)
+            scores.append(tower.adv_layer(h.flatten(1)))
+        y = torch.stack(scores, -1) if self.reduction == "stack" else sum(scores)
+        return [{"y": y[i * B:(i + 1) * B], "y_c": None, "h": fmaps, "start_frames_wins": list(c[1])}
+                for i, c in enumerate(calls)]

@@ -177,6 +177,23 @@ class SVBVAEMleTask(BaseTask):
         r = self._step_rand
         return (phase, tuple(plan), tuple(r["structure"]) if r else None)
 
+    def _critic_many(self, xs):
+        """The critic on several mel batches at once (one stacked pass per tower) when the step's window starts were drawn
+        up front and every window fits; otherwise one call after the other.  -> list of y."""
+        r = self._step_rand
+        n = len(xs)
+        if (hparams.get("stack_critic_calls", True) and r is not None and r["cursor"] + n <= len(r["disc"]) and n > 1
+                and all(x.shape == xs[0].shape for x in xs)
+                and all(all(s is not None for s in d["starts"]) for d in r["disc"][r["cursor"]:r["cursor"] + n])):
+            calls = []
+            for x in xs:
+                d = r["disc"][r["cursor"]]
+                dev = self._rand_dev["starts"][r["cursor"]] if r.get("dev") else None
+                r["cursor"] += 1
+                calls.append((x, d["starts"], dev, d["longest"]))
+            return [o["y"] for o in self.mel_disc.forward_many(calls)]
+        return [self._critic(x)["y"] for x in xs]
+
     def _critic(self, x):
         r = self._step_rand
         if r is None or r["cursor"] >= len(r["disc"]):
@@ -256,14 +273,22 @@ class SVBVAEMleTask(BaseTask):
                         gt[w] = {"mel_out": buf}
                     self.model_out_gt = gt
                 if disc_start:
-                    for way in ways:
-                        self.gen_cheat_disc(way, model_out, log_outputs, loss_weights)
+                    for way, p_ in zip(ways, self._critic_many([model_out[w]["mel_out"] for w in ways])):
+                        if p_ is not None:       # gen_cheat_disc (svb_para.py:118-131), all ways in one critic pass
+                            log_outputs[f"{way}_a"] = self.mse_loss_fn(p_, torch.ones_like(p_))
+                            loss_weights[f"{way}_a"] = hparams["lambda_mel_adv"]
         elif optimizer_idx == 1:
             if phase in (1, 2):
                 self.model.z_mapping_function.eval()
                 if disc_start and self.global_step % hparams["disc_interval"] == 0:
-                    for way in ways:
-                        self.disc_judge_gen(way, sample, log_outputs)
+                    xs = [x for way in ways for x in (self.get_corresponding_gtmel(way, sample),
+                                                      self.model_out_gt[way]["mel_out"])]
+                    ys = self._critic_many(xs)   # disc_judge_gen (svb_para.py:133-170): real, fake per way, one pass
+                    for i, way in enumerate(ways):
+                        p, p_ = ys[2 * i], ys[2 * i + 1]
+                        if p_ is not None:
+                            log_outputs[f"{way}_r"] = self.mse_loss_fn(p, torch.ones_like(p))
+                            log_outputs[f"{way}_f"] = self.mse_loss_fn(p_, torch.zeros_like(p_))
         elif optimizer_idx == 2:
             if phase == 3:
                 self.model.eval()

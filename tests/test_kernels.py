@@ -380,9 +380,10 @@ def test_conv1d_wgrad_bf16x3(dev, case):
     y = oops.conv1d(x, w, None, 1, pad, dil, G)
     dy = torch.randn(y.shape, generator=g)
     y.backward(dy)
-    dw = K.conv1d_wgrad(dy.to(dev), x.to(dev), k, 1, pad, dil, G, bf16x3=True)
+    dw, db = K.conv1d_wgrad(dy.to(dev), x.to(dev), k, 1, pad, dil, G, bf16x3=True, want_bias=True)
     assert dw.shape == w.shape
     assert rel_err(dw, w.grad) < 6e-5
+    assert rel_err(db, dy.sum((0, 2))) < 1e-5          # bias-gradient partials fused into the same two launches
 
 
 def test_conv1d_wgrad_bf16x3_gates_and_weight_norm(dev):
@@ -395,7 +396,9 @@ def test_conv1d_wgrad_bf16x3_gates_and_weight_norm(dev):
     y = torch.relu(oops.conv1d(F.leaky_relu(x, 0.1), w, None, 1, 1))
     dy = torch.randn(y.shape, generator=g_)
     y.backward(dy)
-    dv, dg = K.conv1d_wgrad(dy.to(dev), x.to(dev), k, 1, 1, 1, 1, a_gate=y.detach().to(dev), a_slope=0.0,
-                            b_gate=x.to(dev), b_slope=0.1, v=v.detach().to(dev), g=gn.detach().to(dev), bf16x3=True)
+    dv, dg, db = K.conv1d_wgrad(dy.to(dev), x.to(dev), k, 1, 1, 1, 1, a_gate=y.detach().to(dev), a_slope=0.0,
+                                b_gate=x.to(dev), b_slope=0.1, v=v.detach().to(dev), g=gn.detach().to(dev), bf16x3=True,
+                                want_bias=True)
     assert rel_err(dv, v.grad) < 1e-4
     assert rel_err(dg, gn.grad) < 1e-4
+    assert rel_err(db, (dy * (y > 0)).sum((0, 2))) < 1e-5

@@ -66,21 +66,21 @@ def test_phase2_training_step_matches_cpu_oracle(dev, tmp_path):
     g = torch.Generator().manual_seed(3)
     for step in (1, 2):
         eps_a, eps_p = torch.randn(B, L, 1, generator=g), torch.randn(B, L, 1, generator=g)
-        # record the discriminator window starts and the speaker-embedding pick of the HIP step
+        # record the discriminator window starts of the HIP step (drawn up front by task.begin_step)
         starts = []
-        orig_fwd = task.mel_disc.forward
+        orig_begin = task.begin_step
 
-        def rec(x, cond=None, start_frames_wins=None, _o=orig_fwd, **kw):
-            r = _o(x, cond, start_frames_wins, **kw)
-            starts.append([list(s) for s in r["start_frames_wins"]])
+        def rec(*a, _o=orig_begin, **kw):
+            r = _o(*a, **kw)
+            starts.extend([list(s) for s in d["starts"]] for d in r["disc"])
             return r
-        task.mel_disc.forward = rec
+        task.begin_step = rec
         orig_run = task.run_model
         task.run_model = lambda *a, **k: orig_run(*a, eps_a2a=eps_a.to(dev), eps_p2p=eps_p.to(dev), **k)
         np.random.seed(100 + step)
         task.global_step = trainer.global_step = step
         pbar, _ = trainer.run_training_batch(0, batch)
-        task.mel_disc.forward, task.run_model = orig_fwd, orig_run
+        task.begin_step, task.run_model = orig_begin, orig_run
         np.random.seed(100 + step)
         spk_idx = np.random.randint(1, 5)
         assert len(starts) == 6
