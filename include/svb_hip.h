@@ -26,7 +26,7 @@ int svb_abi_version(void);
  *                                                          in_gate == saved y -> activation backward)
  *   out_gate' = 1 where out_gate > 0 else out_gate_slope  (data-gradient through a fused input LeakyReLU)
  * Any pointer may be NULL (term skipped).  out_act: 0 none, 1 ReLU, 2 LeakyReLU(out_slope), 3 tanh.
- * force_cfg: 0 = auto tile choice, 1..5 = force tile configuration (tests).                              */
+ * force_cfg: 0 = auto tile choice, 1..5 (bf16x3 variants: 1..7) = force tile configuration.                              */
 typedef struct SvbConvEpilogue {
     const float* bias;      /* [Cout] */
     const float* in_gate;   /* same shape as x */

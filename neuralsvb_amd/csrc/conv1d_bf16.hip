@@ -36,10 +36,15 @@ struct SvbConvQArgs {
     int B, Cin, Cout, G, Cin_g, Cout_g, Tin, Tout;
     int sx, out_stride;
     int w_tap_slabs, w_g_slabs, w_slab_rows, w_goff_m, kchunks;
-    int tg, kch, xrows, fast_x, xit;   // xit: 128-position groups per chunk on the register-staged path (1 or 2)
+    int tg, kch, xrows, fast_x, xit;   // xit: 128-position groups per chunk on the register-staged path (1..3)
     int w_floats16, x_floats16;   // LDS carve sizes in 16-byte units (one of hi/lo each)
     int force_cfg;
 };
+
+// load base[byte_off]: `base` wave-uniform, byte_off a 32-bit per-lane offset (scalar-base + vector-offset addressing)
+__device__ __forceinline__ float svbq_ld(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 
 typedef __bf16 svbq_bf2 __attribute__((ext_vector_type(2)));
 typedef float svbq_f2 __attribute__((ext_vector_type(2)));
@@ -67,12 +72,13 @@ __device__ __forceinline__ void svbq_split8(const float* v, uint4& hi, uint4& lo
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-template <int WM, int WN, int NT, int SLB>
+template <int WM, int WN, int NT, int SLB, bool GATE>
 __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs a, SvbConvPlan p) {
     constexpr int BM = 32 * WM, BN = 32 * WN * NT;
     constexpr int WTASKS = SLB * BM * 2;                 // 16-byte units per (hi|lo) weight tile
     constexpr int WU = (2 * WTASKS + 255) / 256;         // per-thread units, hi and lo together
     static_assert(WM * WN == 4, "256 threads = 4 waves");
+    static_assert(WTASKS % 256 == 0, "a staging unit index u addresses either the hi or the lo weight array");
     HIP_DYNAMIC_SHARED(uint4, dyn_smem)
     uint4* w_hi = dyn_smem;
     uint4* w_lo = w_hi + a.w_floats16;
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     const int m_base = mtile * BM;
     const int m_valid = min(BM, a.Cout_g - m_base);
     const float* xb = a.x + ((size_t)b * a.Cin + (size_t)g * a.Cin_g) * a.Tin;
-    const float* gb = a.in_gate ? a.in_gate + ((size_t)b * a.Cin + (size_t)g * a.Cin_g) * a.Tin : nullptr;
+    const float* gb = GATE ? a.in_gate + ((size_t)b * a.Cin + (size_t)g * a.Cin_g) * a.Tin : nullptr;
     const int tap_step = ntap > 1 ? (p.tap_w[t0 + 1] - p.tap_w[t0]) : 0;
     const size_t slab_elems = (size_t)a.w_slab_rows * 16;                      // bf16 per slab
     const size_t w_off0 = ((size_t)p.tap_w[t0 < SVB_MAX_TAPS ? t0 : 0] * a.w_tap_slabs + (size_t)g * a.w_g_slabs) * slab_elems +
@@ -137,7 +143,9 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
 
     uint4 wr[WU];
     float xr[SVBQ_XUNITS][8];
-    const int xsh = a.xit - 1;                             // unit u -> chunk u >> xsh, position group u & xsh
+    int u_c[SVBQ_XUNITS], u_it[SVBQ_XUNITS];               // unit u -> (chunk u / xit, 128-position group u % xit)
+#pragma unroll
+    for (int u = 0; u < SVBQ_XUNITS; ++u) { u_c[u] = u / a.xit; u_it[u] = u - u_c[u] * a.xit; }
 
     auto load_w = [&](int kc0, int tg0) {
         const int nt_here = min(a.tg, ntap - tg0);
@@ -145,12 +153,14 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
         const size_t base16 = (w_off0 + ((size_t)tg0 * tap_step * a.w_tap_slabs + (size_t)kc0) * slab_elems) / 8;
         const uint4* src_hi = reinterpret_cast<const uint4*>(a.wq_hi) + base16;
         const uint4* src_lo = reinterpret_cast<const uint4*>(a.wq_lo) + base16;
+        // branch-free: units that are not part of this phase read slot 0 (always in bounds) and are never consumed, so
+        // every load of the phase is in flight before the first wait
 #pragma unroll
         for (int u = 0; u < WU; ++u) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (w_t[u] < nt_here && w_c[u] < kch_here)
-                v = ((u * 256 + tid) < WTASKS ? src_hi : src_lo)[w_src[u]];
-            wr[u] = v;
+            const bool ok = w_t[u] < nt_here && w_c[u] < kch_here;
+            const uint4* sp = (u * 256) < WTASKS ? src_hi : src_lo;
+            const uint4 t = sp[ok ? w_src[u] : 0];
+            wr[u] = t;
         }
     };
     auto store_w = [&](int tg0) {
@@ -159,25 +169,34 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
         for (int u = 0; u < WU; ++u)
             if (w_t[u] < nt_here) w_hi[w_dst[u]] = wr[u];       // w_dst already carries the hi/lo array offset
     };
+    // hoisted per-thread staging invariants: the position part of each unit's offset and its validity do not depend
+    // on the channel chunk, so a load is one scalar-base + vector-offset instruction with no per-element address math
+    unsigned x_off[SVBQ_XUNITS];      // BYTE offset (32-bit, zero-extended onto a wave-uniform base pointer)
+    bool x_ok[SVBQ_XUNITS];
+#pragma unroll
+    for (int u = 0; u < SVBQ_XUNITS; ++u) {
+        const int i = xp0 + 128 * u_it[u];
+        const int pos = lo_pos + i;
+        x_ok[u] = i < span && pos >= 0 && pos < a.Tin;
+        x_off[u] = x_ok[u] ? 4u * (unsigned)(xh * 8 * a.Tin + pos) : 0u;
+    }
+    // register-staged path: phases whose chunks are all full 16-channel chunks (a ragged last chunk takes stage_x_slow)
+    auto phase_fast = [&](int kc0) { return a.fast_x && (kc0 + min(a.kch, a.kchunks - kc0)) * 16 <= a.Cin_g; };
     auto load_x = [&](int kc0) {
         const int kch_here = min(a.kch, a.kchunks - kc0);
 #pragma unroll
         for (int u = 0; u < SVBQ_XUNITS; ++u) {
-            const int c = u >> xsh, it = u & xsh;
+            const int c = u_c[u];
             if (c < kch_here) {
-                const int ch0 = (kc0 + c) * 16 + xh * 8;
-                const int i = xp0 + 128 * it;
-                const int pos = lo_pos + i;
-                const bool pv = i < span && pos >= 0 && pos < a.Tin;
+                const int chb = (kc0 + c) * 16;                           // wave-uniform
+                const float* pc = xb + (size_t)chb * a.Tin;
+                // branch-free: out-of-range lanes read element 0 of the channel row and are zeroed when staged
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float v = 0.f;
-                    if (pv && ch0 + e < a.Cin_g) {
-                        const size_t off = (size_t)(ch0 + e) * a.Tin + pos;
-                        v = xb[off];
-                        if (gb) v *= svb_gate(gb[off], a.in_slope);
-                    }
-                    xr[u][e] = v;
+                for (int e = 0; e < 8; ++e) xr[u][e] = svbq_ld(pc + (size_t)e * a.Tin, x_off[u]);
+                if (GATE) {
+                    const float* gc = gb + (size_t)chb * a.Tin;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xr[u][e] *= svb_gate(svbq_ld(gc + (size_t)e * a.Tin, x_off[u]), a.in_slope);
                 }
             }
         }
@@ -186,18 +205,19 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
         const int kch_here = min(a.kch, a.kchunks - kc0);
 #pragma unroll
         for (int u = 0; u < SVBQ_XUNITS; ++u) {
-            const int c = u >> xsh, it = u & xsh;
-            const int i = xp0 + 128 * it;
+            const int c = u_c[u];
+            const int i = xp0 + 128 * u_it[u];
             if (c < kch_here && i < span) {
                 uint4 hi, lo;
                 svbq_split8(xr[u], hi, lo);
+                if (!x_ok[u]) { hi = make_uint4(0u, 0u, 0u, 0u); lo = hi; }
                 const int d = (c * a.xrows + i) * 3 + xh;
                 x_hi[d] = hi;
                 x_lo[d] = lo;
             }
         }
     };
-    auto stage_x_slow = [&](int kc0) {      // wide (strided) spans: direct, unpipelined
+    auto stage_x_slow = [&](int kc0) {      // wide (strided) spans and ragged channel tails: direct, unpipelined
         const int kch_here = min(a.kch, a.kchunks - kc0);
         for (int c = 0; c < kch_here; ++c) {
             const int ch0 = (kc0 + c) * 16 + xh * 8;
@@ -222,19 +242,22 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
             }
         }
     };
+    const int wbase = (wm * 32 + l31) * 3 + kb;
+    int xbase[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) xbase[n] = ((wn * NT + n) * 32 + l31) * a.sx * 3 + kb;
     auto compute = [&](int kc0, int tg0) {
         const int nt_here = min(a.tg, ntap - tg0);
         const int kch_here = min(a.kch, a.kchunks - kc0);
         for (int c = 0; c < kch_here; ++c) {
             for (int t = 0; t < nt_here; ++t) {
-                const int wrow = ((t * a.kch + c) * BM + wm * 32 + l31) * 3 + kb;
-                const uint4 ah_u = w_hi[wrow], al_u = w_lo[wrow];
+                const int woff = (t * a.kch + c) * BM * 3;                                      // scalar
+                const int xoff = (c * a.xrows + __builtin_amdgcn_readfirstlane(tap_lds[tg0 + t])) * 3;   // scalar
+                const uint4 ah_u = w_hi[wbase + woff], al_u = w_lo[wbase + woff];
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&ah_u), al = *reinterpret_cast<const bf16x8*>(&al_u);
-                const int toff = tap_lds[tg0 + t];
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const int xrow = (c * a.xrows + ((wn * NT + n) * 32 + l31) * a.sx + toff) * 3 + kb;
-                    const uint4 bh_u = x_hi[xrow], bl_u = x_lo[xrow];
+                    const uint4 bh_u = x_hi[xbase[n] + xoff], bl_u = x_lo[xbase[n] + xoff];
                     const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&bh_u), bl = *reinterpret_cast<const bf16x8*>(&bl_u);
                     acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
                     acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
@@ -247,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     int kc0 = 0, tg0 = 0;
     if (ntap > 0) {
         __syncthreads();
-        if (a.fast_x) { load_x(0); store_x(0); } else { stage_x_slow(0); }
+        if (phase_fast(0)) { load_x(0); store_x(0); } else { stage_x_slow(0); }
         load_w(0, 0);
         store_w(0);
         __syncthreads();
@@ -256,13 +279,13 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
             if (ntg >= ntap) { ntg = 0; nkc = kc0 + a.kch; }
             const bool has_next = nkc < a.kchunks;
             if (has_next) {
-                if (ntg == 0 && a.fast_x) load_x(nkc);
+                if (ntg == 0 && phase_fast(nkc)) load_x(nkc);
                 load_w(nkc, ntg);
             }
             compute(kc0, tg0);
             if (!has_next) break;
             __syncthreads();
-            if (ntg == 0) { if (a.fast_x) store_x(nkc); else stage_x_slow(nkc); }
+            if (ntg == 0) { if (phase_fast(nkc)) store_x(nkc); else stage_x_slow(nkc); }
             store_w(ntg);
             __syncthreads();
             kc0 = nkc; tg0 = ntg;
@@ -334,12 +357,13 @@ __global__ __launch_bounds__(256) void svb_weight_pack_bf16x3_kernel(const float
 
 // ==================================================================================================================
 struct QCfg { int BM, BN; };
-static const QCfg kQCfgs[5] = {{64, 128}, {128, 96}, {128, 128}, {64, 64}, {32, 128}};
+#define SVBQ_NCFG 7
+static const QCfg kQCfgs[SVBQ_NCFG] = {{64, 128}, {128, 96}, {128, 128}, {64, 64}, {32, 128}, {64, 192}, {64, 256}};
 
 static int q_pick(int cout_g, int nq_max, long nz) {
     long best_cost = -1;
     int best = 0;
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < 5; ++i) {       // the wide-N tiles (5, 6) are only picked by measurement (force_cfg)
         const long mt = svb_cdiv(cout_g, kQCfgs[i].BM), qt = svb_cdiv(nq_max, kQCfgs[i].BN);
         const long area = (long)kQCfgs[i].BM * kQCfgs[i].BN;
         const long cost = ((mt * qt * nz + 255) / 256) * area;
@@ -351,13 +375,24 @@ static int q_pick(int cout_g, int nq_max, long nz) {
     return best;
 }
 
+template <int WM, int WN, int NT, int SLB, bool GATE>
+static void q_launch_kernel(const SvbConvQArgs& a, const SvbConvPlan& p, dim3 grid, size_t lds, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_bf16x3_kernel<WM, WN, NT, SLB, GATE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((svb_conv1d_bf16x3_kernel<WM, WN, NT, SLB, GATE>), grid, dim3(256), lds, stream, a, p);
+}
+
 template <int WM, int WN, int NT, int SLB>
 static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_off_max, int ntap_max, hipStream_t stream) {
     constexpr int BM = 32 * WM, BN = 32 * WN * NT;
     const int span_max = (BN - 1) * a.sx + span_off_max + 1;
     a.xrows = span_max;
-    a.fast_x = span_max <= 256 ? 1 : 0;
-    a.xit = span_max > 128 && a.fast_x ? 2 : 1;
+    a.fast_x = span_max <= 128 * 3 ? 1 : 0;
+    a.xit = a.fast_x ? svb_cdiv(span_max, 128) : 1;
     a.kchunks = svb_cdiv(a.Cin_g, 16);
     // phase = tg taps x kch chunks, tg*kch <= SLB slabs, kch*xit <= SVBQ_XUNITS, LDS budget ~78 KB (2 blocks per CU)
     a.tg = ntap_max < 1 ? 1 : (ntap_max > SLB ? SLB : ntap_max);
@@ -372,14 +407,9 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     a.kch = kch;
     a.w_floats16 = a.tg * a.kch * BM * 3;
     a.x_floats16 = a.kch * a.xrows * 3;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_bf16x3_kernel<WM, WN, NT, SLB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
     dim3 grid(a.G * svb_cdiv(a.Cout_g, BM), svb_cdiv(nq_max, BN), a.B * p.n_phase);
-    hipLaunchKernelGGL((svb_conv1d_bf16x3_kernel<WM, WN, NT, SLB>), grid, dim3(256), lds_bytes(a.kch), stream, a, p);
+    if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, true>(a, p, grid, lds_bytes(a.kch), stream);
+    else q_launch_kernel<WM, WN, NT, SLB, false>(a, p, grid, lds_bytes(a.kch), stream);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
@@ -395,13 +425,15 @@ static int q_dispatch(SvbConvQArgs& a, const SvbConvPlan& p, hipStream_t stream)
     if (nq_max <= 0) return SVB_OK;
     if ((long)a.B * p.n_phase > 65535) return SVB_ERR_UNSUPPORTED;
     int cfg = q_pick(a.Cout_g, nq_max, (long)a.B * p.n_phase * a.G);
-    if (a.force_cfg >= 0 && a.force_cfg < 5) cfg = a.force_cfg;
+    if (a.force_cfg >= 0 && a.force_cfg < SVBQ_NCFG) cfg = a.force_cfg;
     switch (cfg) {
         case 0: return q_launch<2, 2, 2, 8>(a, p, nq_max, span_off_max, ntap_max, stream);
         case 1: return q_launch<4, 1, 3, 5>(a, p, nq_max, span_off_max, ntap_max, stream);
         case 2: return q_launch<4, 1, 4, 5>(a, p, nq_max, span_off_max, ntap_max, stream);
         case 3: return q_launch<2, 2, 1, 8>(a, p, nq_max, span_off_max, ntap_max, stream);
-        default: return q_launch<1, 4, 1, 8>(a, p, nq_max, span_off_max, ntap_max, stream);
+        case 4: return q_launch<1, 4, 1, 8>(a, p, nq_max, span_off_max, ntap_max, stream);
+        case 5: return q_launch<2, 2, 3, 8>(a, p, nq_max, span_off_max, ntap_max, stream);
+        default: return q_launch<2, 2, 4, 8>(a, p, nq_max, span_off_max, ntap_max, stream);
     }
 }
 

@@ -17,7 +17,9 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PROFILE = None
 _CFG_NAMES = ["svb_conv1d_mfma_kernel<2,2,2,*,80> (64x128)", "svb_conv1d_mfma_kernel<4,1,3,*,80> (128x96)",
               "svb_conv1d_mfma_kernel<4,1,4,*,80> (128x128)", "svb_conv1d_mfma_kernel<2,2,1,*,80> (64x64)",
-              "svb_conv1d_mfma_kernel<1,4,1,*,80> (32x128)"]
+              "svb_conv1d_mfma_kernel<1,4,1,*,80> (32x128)", "svb_conv1d_mfma_kernel<2,2,3,*,80> (64x192)",
+              "svb_conv1d_mfma_kernel<2,2,4,*,80> (64x256)"]
+_NCFG_Q = 7      # tile configurations of the bf16x3 kernel (the fp32 kernel has the first 5)
 
 
 # ---- per-shape tile autotuning ("measure, don't guess"): the first time a conv signature is seen on the GPU all five
@@ -26,14 +28,14 @@ AUTOTUNE = os.environ.get("SVB_AUTOTUNE", "1") != "0"
 _TUNED = {}
 
 
-def _tuned_cfg(sig, launch):
-    """launch(force_cfg) enqueues the kernel once.  Returns the cached/measured best force_cfg (1..5) or 0 (heuristic)."""
+def _tuned_cfg(sig, launch, ncfg=5):
+    """launch(force_cfg) enqueues the kernel once.  Returns the cached/measured best force_cfg (1..ncfg) or 0 (heuristic)."""
     if not AUTOTUNE or PROFILE is not None:
         return _TUNED.get(sig, 0)
     best = _TUNED.get(sig)
     if best is None:
         times = []
-        for cfg in range(1, 6):
+        for cfg in range(1, ncfg + 1):
             launch(cfg)                                   # warm (also validates the configuration)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -42,7 +44,7 @@ def _tuned_cfg(sig, launch):
             e1.record()
             e1.synchronize()
             times.append(e0.elapsed_time(e1))
-        best = 1 + min(range(5), key=lambda i: times[i])
+        best = 1 + min(range(ncfg), key=lambda i: times[i])
         _TUNED[sig] = best
     return best
 
@@ -172,7 +174,7 @@ def conv1d_forward(x, pa, cout, k, stride=1, pad=0, dil=1, groups=1, out=None, *
                 e.force_cfg = cfg
                 L.check(lib.svb_conv1d_forward_bf16x3(_ptr(x), _ptr(pa.hi), _ptr(pa.lo), _ptr(y), B, cin, cout, groups, tin,
                                                       tout, k, stride, pad, dil, C.byref(e), st), "svb_conv1d_forward_bf16x3")
-            e.force_cfg = _tuned_cfg(("qf", B, cin, cout, groups, tin, k, stride, pad, dil), launch)
+            e.force_cfg = _tuned_cfg(("qf", B, cin, cout, groups, tin, k, stride, pad, dil), launch, _NCFG_Q)
         probe = _ConvProbe(lib, x, cout // groups, tout, 2.0 * B * cout * tout * (cin // groups) * k, B * groups, e.force_cfg,
                            "svb_conv1d_bf16x3_kernel", tag=("fwd", B, cin, cout, groups, tin, k, stride, dil))
         L.check(lib.svb_conv1d_forward_bf16x3(_ptr(x), _ptr(pa.hi), _ptr(pa.lo), _ptr(y), B, cin, cout, groups, tin, tout, k,
@@ -210,7 +212,7 @@ def conv1d_transposed(x, pb, cout, tout, k, stride=1, pad=0, dil=1, groups=1, ou
                 L.check(lib.svb_conv1d_transposed_bf16x3(_ptr(x), _ptr(pb.hi), _ptr(pb.lo), _ptr(y), B, cin, cout, groups, tin,
                                                          tout, k, stride, pad, dil, C.byref(e), st),
                         "svb_conv1d_transposed_bf16x3")
-            e.force_cfg = _tuned_cfg(("qt", B, cin, cout, groups, tin, tout, k, stride, pad, dil), launch)
+            e.force_cfg = _tuned_cfg(("qt", B, cin, cout, groups, tin, tout, k, stride, pad, dil), launch, _NCFG_Q)
         probe = _ConvProbe(lib, x, cout // groups, -(-tout // stride), 2.0 * B * cin * tin * (cout // groups) * k,
                            B * groups * stride, e.force_cfg, "svb_conv1d_bf16x3_kernel",
                            tag=("convT", B, cin, cout, groups, tin, k, stride, dil))

@@ -340,7 +340,7 @@ def test_conv1d_bf16x3_forward_dgrad(dev, case):
     assert rel_err(dx, xr.grad) < 6e-5
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
 def test_conv1d_bf16x3_tile_configs_and_convt(dev, cfg):
     g = torch.Generator().manual_seed(cfg)
     B, Cin, Cout, T, k, s, pad = 2, 40, 72, 37, 8, 4, 2
@@ -402,3 +402,20 @@ def test_conv1d_wgrad_bf16x3_gates_and_weight_norm(dev):
     assert rel_err(dv, v.grad) < 1e-4
     assert rel_err(dg, gn.grad) < 1e-4
     assert rel_err(db, (dy * (y > 0)).sum((0, 2))) < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [6, 7])
+def test_conv1d_bf16x3_wide_tiles_three_position_groups(dev, cfg):
+    """64x192 / 64x256 tiles on a long sequence: the register-staged x path with up to 3 groups of 128 positions."""
+    g = torch.Generator().manual_seed(cfg)
+    B, Cin, Cout, T, k = 1, 24, 40, 300, 5
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) * 0.2
+    ref = oops.conv1d(x, w, None, 1, 2)
+    qa, qb = K.weight_pack_q(w.to(dev), None, 1)
+    y = K.conv1d_forward(x.to(dev), qa, Cout, k, 1, 2, 1, 1, force_cfg=cfg)
+    assert rel_err(y, ref) < 6e-5
+    dy = torch.randn(ref.shape, generator=g)
+    dref = torch.autograd.grad(oops.conv1d(x.requires_grad_(True), w, None, 1, 2), x, dy)[0]
+    dx = K.conv1d_transposed(dy.to(dev), qb, Cin, T, k, 1, 2, 1, 1, force_cfg=cfg)
+    assert rel_err(dx, dref) < 6e-5
