@@ -574,7 +574,7 @@ __device__ __forceinline__ unsigned svbq_funnel(unsigned hi, unsigned lo, unsign
     return (unsigned)((((unsigned long long)hi << 32) | lo) >> sh);
 }
 
-template <int TGW, int DIL>
+template <int TGW, int DIL, bool GATED>
 __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgradQArgs a) {
     HIP_DYNAMIC_SHARED(unsigned, wg_smem)
     unsigned* A_hi = wg_smem;
@@ -611,37 +611,87 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) bsum[rr] = 0.f;
     const float* a_base = a.a + (size_t)g * a.CA_g * a.TA;
-    const float* ag_base = a.a_gate ? a.a_gate + (size_t)g * a.CA_g * a.TA : nullptr;
+    const float* ag_base = GATED && a.a_gate ? a.a_gate + (size_t)g * a.CA_g * a.TA : nullptr;
     const float* b_base = a.b + (size_t)g * a.CB_g * a.TB;
-    const float* bg_base = a.b_gate ? a.b_gate + (size_t)g * a.CB_g * a.TB : nullptr;
+    const float* bg_base = GATED && a.b_gate ? a.b_gate + (size_t)g * a.CB_g * a.TB : nullptr;
+
+    // ---- staging, branch-free: per-thread row offsets and masks are hoisted; per chunk only the (clamped) position
+    // changes.  Out-of-range rows / positions read a valid element and are zeroed when written to LDS, so all loads of a
+    // chunk are in flight before the first wait.
+    unsigned a_roff[8], b_roff[8];        // byte offsets of this thread's 8 A rows / 8 B rows
+    unsigned a_rmask = 0, b_rmask = 0;    // bit rr: row valid
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = srow + 8 * rr;
+        const bool av = (a0 + r) < a.CA_g, bv = (b0 + r) < a.CB_g;
+        a_roff[rr] = 4u * (unsigned)((av ? a0 + r : a0) * a.TA);
+        b_roff[rr] = 4u * (unsigned)((bv ? b0 + r : b0) * a.TB);
+        a_rmask |= (av ? 1u : 0u) << rr;
+        b_rmask |= (bv ? 1u : 0u) << rr;
+    }
+    unsigned x_roff[SVBQ_WG_NXIT];        // extra Bt pairs (beyond the first 32 of a row): row offset, pair, validity
+    int x_pr[SVBQ_WG_NXIT], x_r[SVBQ_WG_NXIT];
+    bool x_rv[SVBQ_WG_NXIT], x_on[SVBQ_WG_NXIT];
+#pragma unroll
+    for (int e = 0; e < SVBQ_WG_NXIT; ++e) {
+        const int task = tid + 256 * e;
+        x_on[e] = task < 64 * nxp;
+        const int r = x_on[e] ? task / nxp : 0;
+        x_r[e] = r;
+        x_pr[e] = 32 + (x_on[e] ? task - r * nxp : 0);
+        x_rv[e] = (b0 + r) < a.CB_g;
+        x_roff[e] = 4u * (unsigned)((x_rv[e] ? b0 + r : b0) * a.TB);
+    }
+    bool a_ok0, a_ok1, b_ok0, b_ok1, xk0[SVBQ_WG_NXIT], xk1[SVBQ_WG_NXIT];     // position validity of the staged chunk
 
     auto load_tiles = [&](int chunk) {
         const int bb = chunk / a.chunks_per_b;
         const int q0 = (chunk - bb * a.chunks_per_b) * SVBQ_WG_QC;
         const int lo = q0 + min_off;
+        const float* ab = a_base + (size_t)bb * a.CA * a.TA;               // wave-uniform bases
+        const float* bbp = b_base + (size_t)bb * a.CB * a.TB;
+        const int qa = q0 + 2 * spair, pb0 = lo + 2 * spair;
+        a_ok0 = qa < a.TA; a_ok1 = qa + 1 < a.TA;
+        b_ok0 = pb0 >= 0 && pb0 < a.TB; b_ok1 = pb0 + 1 >= 0 && pb0 + 1 < a.TB;
+        const unsigned ao0 = 4u * (unsigned)min(qa, a.TA - 1), ao1 = 4u * (unsigned)min(qa + 1, a.TA - 1);
+        const unsigned bo0 = 4u * (unsigned)min(max(pb0, 0), a.TB - 1), bo1 = 4u * (unsigned)min(max(pb0 + 1, 0), a.TB - 1);
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
-            const int r = srow + 8 * rr;
-            {
-                const size_t roff = ((size_t)bb * a.CA + a0 + r) * a.TA;
-                svbq_load2(a_base + roff, ag_base ? ag_base + roff : nullptr, a.a_slope, q0 + 2 * spair, a.TA,
-                           (a0 + r) < a.CA_g, ar[rr][0], ar[rr][1]);
-            }
-            {
-                const size_t roff = ((size_t)bb * a.CB + b0 + r) * a.TB;
-                svbq_load2(b_base + roff, bg_base ? bg_base + roff : nullptr, a.b_slope, lo + 2 * spair, a.TB,
-                           (b0 + r) < a.CB_g, br[rr][0], br[rr][1]);
-            }
+            ar[rr][0] = svbq_ld(ab, a_roff[rr] + ao0);
+            ar[rr][1] = svbq_ld(ab, a_roff[rr] + ao1);
+            br[rr][0] = svbq_ld(bbp, b_roff[rr] + bo0);
+            br[rr][1] = svbq_ld(bbp, b_roff[rr] + bo1);
         }
 #pragma unroll
         for (int e = 0; e < SVBQ_WG_NXIT; ++e) {
-            const int task = tid + 256 * e;
-            bx[e][0] = 0.f; bx[e][1] = 0.f;
-            if (task < 64 * nxp) {
-                const int r = task / nxp, pr = 32 + task - r * nxp;
-                const size_t roff = ((size_t)bb * a.CB + b0 + r) * a.TB;
-                svbq_load2(b_base + roff, bg_base ? bg_base + roff : nullptr, a.b_slope, lo + 2 * pr, a.TB,
-                           (b0 + r) < a.CB_g, bx[e][0], bx[e][1]);
+            const int p0 = lo + 2 * x_pr[e];
+            xk0[e] = x_on[e] && x_rv[e] && p0 >= 0 && p0 < a.TB;
+            xk1[e] = x_on[e] && x_rv[e] && p0 + 1 >= 0 && p0 + 1 < a.TB;
+            bx[e][0] = svbq_ld(bbp, x_roff[e] + 4u * (unsigned)min(max(p0, 0), a.TB - 1));
+            bx[e][1] = svbq_ld(bbp, x_roff[e] + 4u * (unsigned)min(max(p0 + 1, 0), a.TB - 1));
+        }
+        if (GATED) {
+            if (ag_base) {
+                const float* gp = ag_base + (size_t)bb * a.CA * a.TA;
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    ar[rr][0] *= svb_gate(svbq_ld(gp, a_roff[rr] + ao0), a.a_slope);
+                    ar[rr][1] *= svb_gate(svbq_ld(gp, a_roff[rr] + ao1), a.a_slope);
+                }
+            }
+            if (bg_base) {
+                const float* gp = bg_base + (size_t)bb * a.CB * a.TB;
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    br[rr][0] *= svb_gate(svbq_ld(gp, b_roff[rr] + bo0), a.b_slope);
+                    br[rr][1] *= svb_gate(svbq_ld(gp, b_roff[rr] + bo1), a.b_slope);
+                }
+#pragma unroll
+                for (int e = 0; e < SVBQ_WG_NXIT; ++e) {
+                    const int p0 = lo + 2 * x_pr[e];
+                    bx[e][0] *= svb_gate(svbq_ld(gp, x_roff[e] + 4u * (unsigned)min(max(p0, 0), a.TB - 1)), a.b_slope);
+                    bx[e][1] *= svb_gate(svbq_ld(gp, x_roff[e] + 4u * (unsigned)min(max(p0 + 1, 0), a.TB - 1)), a.b_slope);
+                }
             }
         }
     };
@@ -649,21 +699,22 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             const int r = srow + 8 * rr;
+            const bool av = (a_rmask >> rr) & 1u, bv = (b_rmask >> rr) & 1u;
+            const float a0v = av && a_ok0 ? ar[rr][0] : 0.f, a1v = av && a_ok1 ? ar[rr][1] : 0.f;
+            const float b0v = bv && b_ok0 ? br[rr][0] : 0.f, b1v = bv && b_ok1 ? br[rr][1] : 0.f;
             unsigned hi, lo;
-            bsum[rr] += ar[rr][0] + ar[rr][1];
-            svbq_split2(ar[rr][0], ar[rr][1], hi, lo);
+            bsum[rr] += a0v + a1v;
+            svbq_split2(a0v, a1v, hi, lo);
             A_hi[r * a.pa + spair] = hi; A_lo[r * a.pa + spair] = lo;
-            svbq_split2(br[rr][0], br[rr][1], hi, lo);
+            svbq_split2(b0v, b1v, hi, lo);
             B_hi[r * a.pb + spair] = hi; B_lo[r * a.pb + spair] = lo;
         }
 #pragma unroll
         for (int e = 0; e < SVBQ_WG_NXIT; ++e) {
-            const int task = tid + 256 * e;
-            if (task < 64 * nxp) {
-                const int r = task / nxp, pr = 32 + task - r * nxp;
+            if (x_on[e]) {
                 unsigned hi, lo;
-                svbq_split2(bx[e][0], bx[e][1], hi, lo);
-                B_hi[r * a.pb + pr] = hi; B_lo[r * a.pb + pr] = lo;
+                svbq_split2(xk0[e] ? bx[e][0] : 0.f, xk1[e] ? bx[e][1] : 0.f, hi, lo);
+                B_hi[x_r[e] * a.pb + x_pr[e]] = hi; B_lo[x_r[e] * a.pb + x_pr[e]] = lo;
             }
         }
     };
@@ -802,18 +853,27 @@ extern "C" size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB
     return (size_t)ns * slab;
 }
 
-template <int TGW>
-static void wgq_launch(const SvbWgradQArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+template <int TGW, int DIL, bool GATED>
+static void wgq_launch_kernel(const SvbWgradQArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_wgrad_bf16x3_kernel<TGW, 1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_wgrad_bf16x3_kernel<TGW, 0>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_wgrad_bf16x3_kernel<TGW, DIL, GATED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (a.dil == 1) hipLaunchKernelGGL((svb_conv1d_wgrad_bf16x3_kernel<TGW, 1>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((svb_conv1d_wgrad_bf16x3_kernel<TGW, 0>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((svb_conv1d_wgrad_bf16x3_kernel<TGW, DIL, GATED>), grid, dim3(256), lds, st, a);
+}
+
+template <int TGW>
+static void wgq_launch(const SvbWgradQArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    const bool gated = a.a_gate || a.b_gate;
+    if (a.dil == 1) {
+        if (gated) wgq_launch_kernel<TGW, 1, true>(a, grid, lds, st);
+        else wgq_launch_kernel<TGW, 1, false>(a, grid, lds, st);
+    } else {
+        if (gated) wgq_launch_kernel<TGW, 0, true>(a, grid, lds, st);
+        else wgq_launch_kernel<TGW, 0, false>(a, grid, lds, st);
+    }
 }
 
 extern "C" int svb_conv1d_wgrad_bf16x3(const float* a_t, const float* b_t, float* part, int B, int CA, int CB, int groups,
