@@ -101,3 +101,27 @@ def test_mle_svb_vae_gradients_match_oracle(dev):
         worst = max(worst, rel)
         assert rel < 2e-3, (k, rel)
     print("worst relative grad error", worst)
+
+
+@pytest.mark.gpu
+def test_mle_svb_vae_bf16x3_mel_l1_against_reference_golden(gpu_only):
+    """`conv_precision: bf16x3` (the bench's arithmetic): mel-L1 of the generated mels against the unmodified reference's
+    golden output must stay within BASELINE.json's tolerance (<= 1e-4); pure bf16 operands give ~1e-2."""
+    from neuralsvb_amd import functional as SF
+    dev = gpu_only
+    d = np.load(os.path.join(G, "vae_mle.npz"))
+    model, _ = build_model(dev)
+    model.train()
+    SF.set_precision("bf16x3")
+    try:
+        with torch.no_grad():
+            out = model(amateur_mel=t(d["mels"]).to(dev), prof_mel=t(d["prof_mels"]).to(dev),
+                        amateur_pitch=t(d["pitch"]).to(dev), prof_pitch=t(d["prof_pitch"]).to(dev),
+                        amateur_spk_id=t(d["spk"]).to(dev), prof_spk_id=t(d["spk"]).to(dev),
+                        a2p_alignment=t(d["a2p_alignment"]).to(dev), infer=False, concurrent_ways=["a2a", "p2p", "a2p"],
+                        eps_a2a=t(d["eps_a2a"]).to(dev), eps_p2p=t(d["eps_p2p"]).to(dev))
+    finally:
+        SF.set_precision("fp32")
+    for way in ("a2a", "p2p", "a2p"):
+        l1 = (out[way]["mel_out"].cpu() - t(d[f"{way}.mel_out"])).abs().mean().item()
+        assert l1 <= 1e-4, (way, l1)
