@@ -80,6 +80,10 @@ int svb_conv1d_transposed_bf16x3(const float* x, const unsigned short* qb_hi, co
                                  int Cin, int Cout, int groups, int Tin, int Tout, int k, int stride, int pad, int dil,
                                  const SvbConvEpilogue* epi, void* stream);
 
+/* Debug hook (tools/stage_timing.py): when set to a device buffer of 64*32*8 uint64, the bf16x3 conv kernel's first 64
+ * workgroups record shader-clock stamps around the phases of their K loop.  NULL (default) disables it.          */
+void svb_debug_set_timing_buffer(void* buf);
+
 /* Weight gradient, stage 1 (split-K partials): part[s][a][b][j] += A[n,a,q] * Bt[n,b,q*sx + j*dil - pad].
  * Conv1d: A = dy (CA=Cout), Bt = x (CB=Cin); ConvTranspose1d: A = x (CA=Cin), Bt = dy (CB=Cout).
  * a_gate/b_gate: optional activation-derivative gates (see SvbConvEpilogue).  Workspace = floats returned by
@@ -88,12 +92,14 @@ size_t svb_conv1d_wgrad_workspace_floats(int B, int CA, int CB, int groups, int 
 int svb_conv1d_wgrad(const float* a, const float* b, float* part, int B, int CA, int CB, int groups, int TA, int TB,
                      int k, int sx, int pad, int dil, const float* a_gate, float a_slope, const float* b_gate,
                      float b_slope, int nsplit, void* stream);
-/* The same stage 1 for stride-1 convs on the bf16 matrix cores (bf16x3 split, see above).  The workspace query returns 0
- * floats (and nsplit 0) for shapes outside its envelope ((taps per pass - 1)*dil > 23): use svb_conv1d_wgrad then.
+/* The same stage 1 on the bf16 matrix cores (bf16x3 split, see above).  Strided convs (sx > 1, dil 1) are decomposed
+ * into sx stride-1 problems over the phase subsequences of Bt.  The workspace query returns 0 floats (and nsplit 0) for
+ * shapes outside its envelope (sx 1: (taps per pass - 1)*dil > 23; sx > 1: dil != 1): use svb_conv1d_wgrad then.
  * Partials have the same layout, so svb_wgrad_reduce finishes either.                                           */
-size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB, int groups, int TA, int k, int dil, int* nsplit_out);
+size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB, int groups, int TA, int k, int sx, int pad, int dil,
+                                                int* nsplit_out);
 int svb_conv1d_wgrad_bf16x3(const float* a, const float* b, float* part, int B, int CA, int CB, int groups, int TA, int TB,
-                            int k, int pad, int dil, const float* a_gate, float a_slope, const float* b_gate,
+                            int k, int sx, int pad, int dil, const float* a_gate, float a_slope, const float* b_gate,
                             float b_slope, int nsplit, float* bias_part, void* stream);
 /* bias_part (optional, [nsplit][CA] floats): per-split row sums of the gated A operand -- with A = dy these are the bias
  * gradient partials (reference: autograd of the `bias` argument of F.conv1d); svb_wgrad_reduce sums them into db.     */

@@ -35,8 +35,9 @@ SIGNATURES = {
     "svb_conv1d_transposed_bf16x3": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),
     "svb_conv1d_wgrad_workspace_floats": (SZ, [I, I, I, I, I, I, I, C.POINTER(I)]),
     "svb_conv1d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, P, F, P, F, I, P]),
-    "svb_conv1d_wgrad_bf16x3_workspace_floats": (SZ, [I, I, I, I, I, I, I, C.POINTER(I)]),
-    "svb_conv1d_wgrad_bf16x3": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P, F, P, F, I, P, P]),
+    "svb_conv1d_wgrad_bf16x3_workspace_floats": (SZ, [I, I, I, I, I, I, I, I, I, C.POINTER(I)]),
+    "svb_conv1d_wgrad_bf16x3": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, P, F, P, F, I, P, P]),
+    "svb_debug_set_timing_buffer": (None, [P]),
     "svb_wgrad_reduce": (I, [P, I, P, P, P, P, I, I, I, I, P, P, P]),
     "svb_bias_grad": (I, [P, P, F, P, I, I, I, P]),
     "svb_wn_gate_fwd": (I, [P, P, P, I, I, I, I, I, P]),

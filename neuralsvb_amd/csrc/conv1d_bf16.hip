@@ -39,7 +39,16 @@ struct SvbConvQArgs {
     int tg, kch, xrows, fast_x, xit;   // xit: 128-position groups per chunk on the register-staged path (1..3)
     int w_floats16, x_floats16;   // LDS carve sizes in 16-byte units (one of hi/lo each)
     int force_cfg;
+    unsigned long long* dbg;      // optional per-phase cycle stamps (svb_debug_set_timing_buffer; tools/stage_timing.py)
 };
+
+static unsigned long long* g_svbq_dbg = nullptr;
+extern "C" void svb_debug_set_timing_buffer(void* p) { g_svbq_dbg = (unsigned long long*)p; }
+#define SVBQ_DBG_BLOCKS 64
+#define SVBQ_DBG_STAGES 32
+#define SVBQ_STAMP(slot)                                                                                            \
+    if (a.dbg && tid == 0 && wgid < SVBQ_DBG_BLOCKS && dbg_stage < SVBQ_DBG_STAGES)                                  \
+        a.dbg[((size_t)wgid * SVBQ_DBG_STAGES + dbg_stage) * 8 + (slot)] = __builtin_readcyclecounter();
 
 // load base[byte_off]: `base` wave-uniform, byte_off a 32-bit per-lane offset (scalar-base + vector-offset addressing)
 __device__ __forceinline__ float svbq_ld(const float* base, unsigned byte_off) {
@@ -268,27 +277,37 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     };
 
     int kc0 = 0, tg0 = 0;
+    int dbg_stage = 0;
     if (ntap > 0) {
         __syncthreads();
+        SVBQ_STAMP(6)
         if (phase_fast(0)) { load_x(0); store_x(0); } else { stage_x_slow(0); }
         load_w(0, 0);
         store_w(0);
         __syncthreads();
+        SVBQ_STAMP(7)
         while (true) {
             int ntg = tg0 + a.tg, nkc = kc0;
             if (ntg >= ntap) { ntg = 0; nkc = kc0 + a.kch; }
             const bool has_next = nkc < a.kchunks;
+            SVBQ_STAMP(0)
             if (has_next) {
                 if (ntg == 0 && phase_fast(nkc)) load_x(nkc);
                 load_w(nkc, ntg);
             }
+            SVBQ_STAMP(1)
             compute(kc0, tg0);
+            SVBQ_STAMP(2)
             if (!has_next) break;
             __syncthreads();
+            SVBQ_STAMP(3)
             if (ntg == 0) { if (phase_fast(nkc)) store_x(nkc); else stage_x_slow(nkc); }
             store_w(ntg);
+            SVBQ_STAMP(4)
             __syncthreads();
+            SVBQ_STAMP(5)
             kc0 = nkc; tg0 = ntg;
+            ++dbg_stage;
         }
     }
 
@@ -426,15 +445,21 @@ static int q_dispatch(SvbConvQArgs& a, const SvbConvPlan& p, hipStream_t stream)
     if ((long)a.B * p.n_phase > 65535) return SVB_ERR_UNSUPPORTED;
     int cfg = q_pick(a.Cout_g, nq_max, (long)a.B * p.n_phase * a.G);
     if (a.force_cfg >= 0 && a.force_cfg < SVBQ_NCFG) cfg = a.force_cfg;
-    switch (cfg) {
-        case 0: return q_launch<2, 2, 2, 8>(a, p, nq_max, span_off_max, ntap_max, stream);
-        case 1: return q_launch<4, 1, 3, 5>(a, p, nq_max, span_off_max, ntap_max, stream);
-        case 2: return q_launch<4, 1, 4, 5>(a, p, nq_max, span_off_max, ntap_max, stream);
-        case 3: return q_launch<2, 2, 1, 8>(a, p, nq_max, span_off_max, ntap_max, stream);
-        case 4: return q_launch<1, 4, 1, 8>(a, p, nq_max, span_off_max, ntap_max, stream);
-        case 5: return q_launch<2, 2, 3, 8>(a, p, nq_max, span_off_max, ntap_max, stream);
-        default: return q_launch<2, 2, 4, 8>(a, p, nq_max, span_off_max, ntap_max, stream);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int rc;
+        switch (cfg) {
+            case 0: rc = q_launch<2, 2, 2, 8>(a, p, nq_max, span_off_max, ntap_max, stream); break;
+            case 1: rc = q_launch<4, 1, 3, 5>(a, p, nq_max, span_off_max, ntap_max, stream); break;
+            case 2: rc = q_launch<4, 1, 4, 5>(a, p, nq_max, span_off_max, ntap_max, stream); break;
+            case 3: rc = q_launch<2, 2, 1, 8>(a, p, nq_max, span_off_max, ntap_max, stream); break;
+            case 4: rc = q_launch<1, 4, 1, 8>(a, p, nq_max, span_off_max, ntap_max, stream); break;
+            case 5: rc = q_launch<2, 2, 3, 8>(a, p, nq_max, span_off_max, ntap_max, stream); break;
+            default: rc = q_launch<2, 2, 4, 8>(a, p, nq_max, span_off_max, ntap_max, stream); break;
+        }
+        if (rc != SVB_ERR_UNSUPPORTED || cfg == 3) return rc;
+        cfg = 3;        // strided convs with very wide input spans: the narrowest tile has the smallest LDS footprint
     }
+    return SVB_ERR_UNSUPPORTED;
 }
 
 static void q_fill(SvbConvQArgs& a, const SvbConvEpilogue* e) {
@@ -448,6 +473,7 @@ static void q_fill(SvbConvQArgs& a, const SvbConvEpilogue* e) {
     a.residual = e ? e->residual : nullptr;
     a.mask = e ? e->mask : nullptr;
     a.force_cfg = e ? e->force_cfg - 1 : -1;
+    a.dbg = g_svbq_dbg;
 }
 
 extern "C" int svb_weight_pack_bf16x3(const float* v, const float* g, unsigned short* qa_hi, unsigned short* qa_lo,
@@ -543,9 +569,14 @@ struct SvbWgradQArgs {
     const float* b_gate;
     float a_slope, b_slope;
     int B, CA, CB, G, CA_g, CB_g, TA, TB;
-    int k, off0, dil;
+    int k, off0, dil, sx;
     int n_tg, a_tiles, b_tiles, chunks_per_b, total_chunks, nsplit;
     int pa, pb;   // LDS row pitches in dwords (2 * odd)
+    // tap groups.  Stride 1: group i = taps [i*TGW, ...), Bt position of tile index t: q0 + off0 + j0*dil + t.
+    // Stride s > 1 (dil 1): taps are grouped by phase r = (j - pad) mod s; within a phase the strided gather
+    // q*s + j - pad = (q + o_j)*s + r is a stride-1 walk over the phase-r subsequence of Bt, so a group is a stride-1
+    // problem on positions (q0 + o0 + t)*s + r with weight taps j0, j0 + s, j0 + 2s, ...
+    short tg_j0[SVB_MAX_TAPS], tg_ntap[SVB_MAX_TAPS], tg_r[SVB_MAX_TAPS], tg_o0[SVB_MAX_TAPS];
 };
 
 #define SVBQ_WG_QC 64
@@ -592,9 +623,10 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
     const int at = idx % a.a_tiles;
     const int g = idx / a.a_tiles;
     const int a0 = at * 64, b0 = bt * 64;
-    const int j0 = tgi * TGW;
-    const int ntap = min(TGW, a.k - j0);
-    const int min_off = a.off0 + j0 * a.dil;
+    const int j0 = a.tg_j0[tgi];
+    const int ntap = a.tg_ntap[tgi];
+    const int min_off = a.tg_o0[tgi];                        // first Bt tile index, in units of the (phase) sequence
+    const int ph_r = a.tg_r[tgi];
     const int span = SVBQ_WG_QC + (ntap - 1) * a.dil;
     const int nxp = (span + 1) / 2 - 32;                    // Bt pairs beyond the first 32 of a row
 
@@ -650,11 +682,12 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
         const int lo = q0 + min_off;
         const float* ab = a_base + (size_t)bb * a.CA * a.TA;               // wave-uniform bases
         const float* bbp = b_base + (size_t)bb * a.CB * a.TB;
-        const int qa = q0 + 2 * spair, pb0 = lo + 2 * spair;
+        const int qa = q0 + 2 * spair;
+        const int pb0 = (lo + 2 * spair) * a.sx + ph_r, pb1 = pb0 + a.sx;          // Bt positions of the pair
         a_ok0 = qa < a.TA; a_ok1 = qa + 1 < a.TA;
-        b_ok0 = pb0 >= 0 && pb0 < a.TB; b_ok1 = pb0 + 1 >= 0 && pb0 + 1 < a.TB;
+        b_ok0 = pb0 >= 0 && pb0 < a.TB; b_ok1 = pb1 >= 0 && pb1 < a.TB;
         const unsigned ao0 = 4u * (unsigned)min(qa, a.TA - 1), ao1 = 4u * (unsigned)min(qa + 1, a.TA - 1);
-        const unsigned bo0 = 4u * (unsigned)min(max(pb0, 0), a.TB - 1), bo1 = 4u * (unsigned)min(max(pb0 + 1, 0), a.TB - 1);
+        const unsigned bo0 = 4u * (unsigned)min(max(pb0, 0), a.TB - 1), bo1 = 4u * (unsigned)min(max(pb1, 0), a.TB - 1);
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             ar[rr][0] = svbq_ld(ab, a_roff[rr] + ao0);
@@ -664,11 +697,11 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
         }
 #pragma unroll
         for (int e = 0; e < SVBQ_WG_NXIT; ++e) {
-            const int p0 = lo + 2 * x_pr[e];
+            const int p0 = (lo + 2 * x_pr[e]) * a.sx + ph_r, p1 = p0 + a.sx;
             xk0[e] = x_on[e] && x_rv[e] && p0 >= 0 && p0 < a.TB;
-            xk1[e] = x_on[e] && x_rv[e] && p0 + 1 >= 0 && p0 + 1 < a.TB;
+            xk1[e] = x_on[e] && x_rv[e] && p1 >= 0 && p1 < a.TB;
             bx[e][0] = svbq_ld(bbp, x_roff[e] + 4u * (unsigned)min(max(p0, 0), a.TB - 1));
-            bx[e][1] = svbq_ld(bbp, x_roff[e] + 4u * (unsigned)min(max(p0 + 1, 0), a.TB - 1));
+            bx[e][1] = svbq_ld(bbp, x_roff[e] + 4u * (unsigned)min(max(p1, 0), a.TB - 1));
         }
         if (GATED) {
             if (ag_base) {
@@ -688,9 +721,9 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
                 }
 #pragma unroll
                 for (int e = 0; e < SVBQ_WG_NXIT; ++e) {
-                    const int p0 = lo + 2 * x_pr[e];
+                    const int p0 = (lo + 2 * x_pr[e]) * a.sx + ph_r, p1 = p0 + a.sx;
                     bx[e][0] *= svb_gate(svbq_ld(gp, x_roff[e] + 4u * (unsigned)min(max(p0, 0), a.TB - 1)), a.b_slope);
-                    bx[e][1] *= svb_gate(svbq_ld(gp, x_roff[e] + 4u * (unsigned)min(max(p0 + 1, 0), a.TB - 1)), a.b_slope);
+                    bx[e][1] *= svb_gate(svbq_ld(gp, x_roff[e] + 4u * (unsigned)min(max(p1, 0), a.TB - 1)), a.b_slope);
                 }
             }
         }
@@ -814,7 +847,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
                 const int al = a0 + wm * 32 + row;
                 const int bl = b0 + wn * 32 + l31;
                 if (al < a.CA_g && bl < a.CB_g)
-                    part[((size_t)(g * a.CA_g + al) * a.CB_g + bl) * a.k + (j0 + t)] = acc[t][r];
+                    part[((size_t)(g * a.CA_g + al) * a.CB_g + bl) * a.k + (j0 + t * a.sx)] = acc[t][r];
             }
         }
     }
@@ -832,15 +865,49 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
 
 static int wgq_tgw(int k) { return k <= 5 ? k : (k % 5 == 0 ? 5 : (svb_cdiv(k, 4) <= svb_cdiv(k, 5) ? 4 : 5)); }
 
+// Tap groups of a weight gradient (see SvbWgradQArgs).  Returns the number of groups (0 = outside the envelope) and the
+// taps-per-group template width in *tgw_out.
+static int wgq_groups(int k, int sx, int pad, int dil, int* tgw_out, short* j0, short* ntap, short* r, short* o0) {
+    if (sx > 1 && dil != 1) return 0;
+    int n = 0;
+    if (sx == 1) {
+        const int tgw = wgq_tgw(k);
+        if (((tgw - 1) * dil + 1) / 2 > 4 * SVBQ_WG_NXIT) return 0;
+        for (int j = 0; j < k; j += tgw, ++n) {
+            if (j0) { j0[n] = (short)j; ntap[n] = (short)(k - j < tgw ? k - j : tgw); r[n] = 0; o0[n] = (short)(j * dil - pad); }
+        }
+        *tgw_out = tgw;
+        return n;
+    }
+    const int tgw = wgq_tgw(svb_cdiv(k, sx));
+    for (int ph = 0; ph < sx; ++ph) {
+        int first = -1, cnt = 0;                              // taps j with (j - pad) mod sx == ph: first, first+sx, ...
+        for (int j = 0; j < k; ++j)
+            if ((((j - pad) % sx) + sx) % sx == ph) { if (first < 0) first = j; ++cnt; }
+        for (int i = 0; i < cnt; i += tgw, ++n) {
+            if (n >= SVB_MAX_TAPS) return 0;
+            if (j0) {
+                const int jj = first + i * sx;
+                j0[n] = (short)jj; ntap[n] = (short)(cnt - i < tgw ? cnt - i : tgw); r[n] = (short)ph;
+                o0[n] = (short)((jj - pad - ph) / sx);       // exact: (jj - pad - ph) is a multiple of sx
+            }
+        }
+    }
+    *tgw_out = tgw;
+    return n;
+}
+
 // 0 floats (and *nsplit = 0) when the shape is outside this kernel's envelope: the caller uses svb_conv1d_wgrad.
-extern "C" size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB, int groups, int TA, int k, int dil,
-                                                           int* nsplit_out) {
+extern "C" size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB, int groups, int TA, int k, int sx, int pad,
+                                                           int dil, int* nsplit_out) {
     if (nsplit_out) *nsplit_out = 0;
-    if (B <= 0 || groups <= 0 || CA % groups || CB % groups || k <= 0 || k > SVB_MAX_TAPS || dil <= 0 || TA <= 0) return 0;
-    const int tgw = wgq_tgw(k);
-    if (((tgw - 1) * dil + 1) / 2 > 4 * SVBQ_WG_NXIT) return 0;
+    if (B <= 0 || groups <= 0 || CA % groups || CB % groups || k <= 0 || k > SVB_MAX_TAPS || dil <= 0 || TA <= 0 || sx <= 0)
+        return 0;
+    int tgw = 0;
+    const int n_tg = wgq_groups(k, sx, pad, dil, &tgw, nullptr, nullptr, nullptr, nullptr);
+    if (n_tg <= 0) return 0;
     const int CA_g = CA / groups, CB_g = CB / groups;
-    const long tiles = (long)groups * svb_cdiv(CA_g, 64) * svb_cdiv(CB_g, 64) * svb_cdiv(k, tgw);
+    const long tiles = (long)groups * svb_cdiv(CA_g, 64) * svb_cdiv(CB_g, 64) * n_tg;
     const long chunks = (long)B * svb_cdiv(TA, SVBQ_WG_QC);
     const long slab = (long)CA * CB_g * k;
     long ns_cap = 512 / tiles;                                   // one resident wave of blocks at 2 per CU
@@ -877,19 +944,19 @@ static void wgq_launch(const SvbWgradQArgs& a, dim3 grid, size_t lds, hipStream_
 }
 
 extern "C" int svb_conv1d_wgrad_bf16x3(const float* a_t, const float* b_t, float* part, int B, int CA, int CB, int groups,
-                                       int TA, int TB, int k, int pad, int dil, const float* a_gate, float a_slope,
+                                       int TA, int TB, int k, int sx, int pad, int dil, const float* a_gate, float a_slope,
                                        const float* b_gate, float b_slope, int nsplit, float* bias_part, void* stream) {
     if (!a_t || !b_t || !part || B <= 0 || groups <= 0 || CA % groups || CB % groups || k <= 0 || k > SVB_MAX_TAPS ||
-        dil <= 0 || nsplit <= 0)
+        dil <= 0 || nsplit <= 0 || sx <= 0)
         return SVB_ERR_ARG;
     SvbWgradQArgs a;
     a.a = a_t; a.b = b_t; a.part = part; a.a_gate = a_gate; a.b_gate = b_gate; a.a_slope = a_slope; a.b_slope = b_slope;
     a.bias_part = bias_part;
     a.B = B; a.CA = CA; a.CB = CB; a.G = groups; a.CA_g = CA / groups; a.CB_g = CB / groups; a.TA = TA; a.TB = TB;
-    a.k = k; a.off0 = -pad; a.dil = dil;
-    const int tgw = wgq_tgw(k);
-    if (((tgw - 1) * dil + 1) / 2 > 4 * SVBQ_WG_NXIT) return SVB_ERR_UNSUPPORTED;
-    a.n_tg = svb_cdiv(k, tgw);
+    a.k = k; a.off0 = -pad; a.dil = dil; a.sx = sx;
+    int tgw = 0;
+    a.n_tg = wgq_groups(k, sx, pad, dil, &tgw, a.tg_j0, a.tg_ntap, a.tg_r, a.tg_o0);
+    if (a.n_tg <= 0) return SVB_ERR_UNSUPPORTED;
     a.a_tiles = svb_cdiv(a.CA_g, 64); a.b_tiles = svb_cdiv(a.CB_g, 64);
     a.chunks_per_b = svb_cdiv(TA, SVBQ_WG_QC); a.total_chunks = B * a.chunks_per_b;
     if (nsplit > a.total_chunks) return SVB_ERR_ARG;

@@ -250,15 +250,15 @@ def conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0
     _, cb, tb = b.shape
     ns = C.c_int(0)
     nfl = 0
-    if (WGRAD_BF16X3 if bf16x3 is None else bf16x3) and sx == 1:
-        nfl = lib.svb_conv1d_wgrad_bf16x3_workspace_floats(B, ca, cb, groups, ta, k, dil, C.byref(ns))
+    if WGRAD_BF16X3 if bf16x3 is None else bf16x3:
+        nfl = lib.svb_conv1d_wgrad_bf16x3_workspace_floats(B, ca, cb, groups, ta, k, sx, pad, dil, C.byref(ns))
     wflops = 2.0 * B * ca * ta * (cb // groups) * k
     if nfl:
         part = torch.empty((nfl,), device=a.device, dtype=torch.float32)
         probe = _ConvProbe(lib, a, 0, 0, wflops, family="svb_conv1d_wgrad_bf16x3_kernel",
                            tag=("wgrad", B, ca, cb, groups, ta, k, sx, dil))
         bias_part = torch.empty((ns.value, ca), device=a.device, dtype=torch.float32) if want_bias else None
-        L.check(lib.svb_conv1d_wgrad_bf16x3(_ptr(a), _ptr(b), _ptr(part), B, ca, cb, groups, ta, tb, k, pad, dil,
+        L.check(lib.svb_conv1d_wgrad_bf16x3(_ptr(a), _ptr(b), _ptr(part), B, ca, cb, groups, ta, tb, k, sx, pad, dil,
                                             _ptr(a_gate), float(a_slope), _ptr(b_gate), float(b_slope), ns.value,
                                             _ptr(bias_part), st), "svb_conv1d_wgrad_bf16x3")
         probe.done()

@@ -357,6 +357,31 @@ def test_conv1d_bf16x3_tile_configs_and_convt(dev, cfg):
     assert rel_err(dx, dref) < 6e-5
 
 
+WGQ_STRIDED = [
+    # B, Cin, Cout, G, T, k, s, pad
+    (2, 6, 10, 2, 137, 3, 2, 1),         # grouped + strided
+    (1, 16, 24, 1, 264, 8, 4, 2),        # pre-net family k8 s4 p2 (fs2_vae.py:109-114)
+    (1, 32, 32, 4, 400, 41, 4, 20),      # MSD grouped k41 s4 (hifigan.py:264-266): 4 phases x 3 tap groups
+    (3, 5, 3, 1, 229, 5, 3, 2),          # MPD stride 3 (hifigan.py:202-215)
+    (2, 8, 8, 1, 150, 4, 4, 0),          # k = s (ConvTranspose-style upsampling weight gradient)
+]
+
+
+@pytest.mark.parametrize("case", WGQ_STRIDED)
+def test_conv1d_wgrad_bf16x3_strided(dev, case):
+    """Strided weight gradient = `stride` stride-1 problems over the phase subsequences of the input."""
+    B, Cin, Cout, G, T, k, s, pad = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, Cin, T, generator=g)
+    w = (torch.randn(Cout, Cin // G, k, generator=g) * 0.2).requires_grad_(True)
+    y = oops.conv1d(x, w, None, s, pad, 1, G)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dw, db = K.conv1d_wgrad(dy.to(dev), x.to(dev), k, s, pad, 1, G, bf16x3=True, want_bias=True)
+    assert rel_err(dw, w.grad) < 6e-5
+    assert rel_err(db, dy.sum((0, 2))) < 1e-5
+
+
 WGQ_CASES = [
     # B, Cin, Cout, G, T, k, pad, dil
     (2, 8, 16, 1, 50, 5, 2, 1),

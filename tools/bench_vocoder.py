@@ -54,7 +54,8 @@ def train(B=64, L=8192, steps=10, warmup=3):
         trainer.run_training_batch(0, batch)
     s = timed(step, warmup, steps)
     print(json.dumps({"metric": "vocoder train step (G+MPD+MSD), config #3", "ms_per_step": s * 1e3,
-                      "audio_seconds_per_sec": B * L / 24000.0 / s, "batch": B, "segment": L, "dtype": "f32"}))
+                      "audio_seconds_per_sec": B * L / 24000.0 / s, "batch": B, "segment": L,
+                      "dtype": __import__("neuralsvb_amd.functional", fromlist=["PRECISION"]).PRECISION}))
 
 
 def infer(B=32, seconds=10.0, steps=3, warmup=1):
@@ -87,8 +88,12 @@ def infer(B=32, seconds=10.0, steps=3, warmup=1):
     s = timed(run, warmup, steps)
     audio = B * T * 128 / 24000.0
     print(json.dumps({"metric": "end-to-end inference (VAE 3 ways + 5 vocoder passes), config #5", "s_per_batch": s,
-                      "rtf": s / audio, "audio_seconds_per_sec": audio / s, "batch": B, "clip_seconds": T * 128 / 24000.0}))
+                      "rtf": s / audio, "audio_seconds_per_sec": audio / s, "batch": B, "clip_seconds": T * 128 / 24000.0,
+                      "dtype": __import__("neuralsvb_amd.functional", fromlist=["PRECISION"]).PRECISION}))
 
 
 if __name__ == "__main__":
+    from neuralsvb_amd import functional as SF
+    PREC = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"
+    SF.set_precision(PREC)
     {"train": train, "infer": infer}[sys.argv[1] if len(sys.argv) > 1 else "train"]()

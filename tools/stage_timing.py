@@ -1,0 +1,40 @@
+"""Where do the cycles of one bf16x3 conv workgroup go?  (GPU only; uses the svb_debug_set_timing_buffer hook.)"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neuralsvb_amd import _lib as L  # noqa: E402
+from neuralsvb_amd import kernels as K  # noqa: E402
+
+B, Cin, Cout, T, k, cfg = [int(v) for v in (sys.argv[1:7] if len(sys.argv) > 6 else (32, 192, 384, 1124, 5, 2))]
+dev = torch.device("cuda:0")
+x = torch.randn(B, Cin, T, device=dev)
+w = torch.randn(Cout, Cin, k, device=dev) * 0.05
+qa, _ = K.weight_pack_q(w, None, 1)
+pad = (k - 1) // 2
+for _ in range(3):
+    K.conv1d_forward(x, qa, Cout, k, 1, pad, 1, 1, force_cfg=cfg)
+buf = torch.zeros(64 * 32 * 8, dtype=torch.int64, device=dev)
+lib = L.get_lib()
+lib.svb_debug_set_timing_buffer(buf.data_ptr())
+K.conv1d_forward(x, qa, Cout, k, 1, pad, 1, 1, force_cfg=cfg)
+torch.cuda.synchronize()
+lib.svb_debug_set_timing_buffer(None)
+t = buf.cpu().numpy().reshape(64, 32, 8).astype(np.int64)
+names = ["issue loads", "compute (MFMA loop)", "barrier 1", "stage to LDS", "barrier 2"]
+rows = []
+for blk in range(64):
+    for st in range(32):
+        s = t[blk, st]
+        if s[0] and s[5]:
+            rows.append([s[1] - s[0], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[5] - s[4]])
+rows = np.array(rows)
+print(f"shape B{B} {Cin}->{Cout} k{k} T{T} cfg {cfg}: {len(rows)} (block, stage) samples; cycles mean / median")
+for i, n in enumerate(names):
+    print(f"  {n:22s} {rows[:, i].mean():9.0f} {np.median(rows[:, i]):9.0f}")
+print(f"  {'stage total':22s} {rows.sum(1).mean():9.0f}")
+pro = [(t[b, 0, 7] - t[b, 0, 6]) for b in range(64) if t[b, 0, 7]]
+print(f"  prologue (first tiles)  {np.mean(pro):9.0f}")
