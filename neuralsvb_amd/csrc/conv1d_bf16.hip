@@ -251,6 +251,26 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
             }
         }
     };
+    // ---- WN == 1 tiles ("direct-A"): every wave owns 32 weight rows and all BN columns, so its MFMA A operands
+    // (row l31, 16-byte half kb of each (tap, chunk) slab) are exactly one coalesced 1-KiB global read per slab -- no LDS
+    // staging, no ds_write, no LDS read for the weights.  The fragments of phase s+1 are loaded into the registers of
+    // phase s right after their last use (rolling prefetch), so they have a whole phase to arrive.
+    constexpr bool DIRECT_A = WN == 1;
+    uint4 wfh[SLB], wfl[SLB];
+    const int wf_row = wm * 32 + l31;
+    const int wf_lane16 = (wf_row < m_valid ? wf_row : 0) * 2 + kb;                 // 16-byte units inside a slab
+    auto load_wf = [&](int i, int kc0, int tg0) {          // slab i = (tap i / kch, chunk i % kch) of phase (kc0, tg0)
+        const int nt_here = min(a.tg, ntap - tg0);
+        const int kch_here = min(a.kch, a.kchunks - kc0);
+        const int t = i / a.kch, c = i - t * a.kch;
+        if (t < nt_here && c < kch_here) {                 // wave-uniform
+            const size_t base16 = (w_off0 + ((size_t)(tg0 + t) * tap_step * a.w_tap_slabs + (size_t)(kc0 + c)) * slab_elems) / 8;
+            const uint4 th = (reinterpret_cast<const uint4*>(a.wq_hi) + base16)[wf_lane16];
+            const uint4 tl = (reinterpret_cast<const uint4*>(a.wq_lo) + base16)[wf_lane16];
+            wfh[i] = th;
+            wfl[i] = tl;
+        }
+    };
     const int wbase = (wm * 32 + l31) * 3 + kb;
     int xbase[NT];
 #pragma unroll
@@ -276,9 +296,67 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
         }
     };
 
+    // direct-A compute: slabs unrolled (static fragment registers); after a slab's MFMAs its registers are refilled
+    // with the same slab of the next phase
+    auto compute_direct = [&](int kc0, int tg0, bool has_next, int nkc, int ntg) {
+        const int nt_here = min(a.tg, ntap - tg0);
+        const int kch_here = min(a.kch, a.kchunks - kc0);
+#pragma unroll
+        for (int i = 0; i < SLB; ++i) {
+            const int t = i / a.kch, c = i - t * a.kch;
+            if (t < nt_here && c < kch_here) {
+                const int xoff = (c * a.xrows + p.tap_off[t0 + tg0 + t] - min_off) * 3;        // scalar
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&wfh[i]), al = *reinterpret_cast<const bf16x8*>(&wfl[i]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const uint4 bh_u = x_hi[xbase[n] + xoff], bl_u = x_lo[xbase[n] + xoff];
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&bh_u), bl = *reinterpret_cast<const bf16x8*>(&bl_u);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
+                }
+            }
+            if (has_next) load_wf(i, nkc, ntg);
+        }
+    };
+
     int kc0 = 0, tg0 = 0;
     int dbg_stage = 0;
-    if (ntap > 0) {
+    if (DIRECT_A) {
+        if (ntap > 0) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < SLB; ++i) load_wf(i, 0, 0);
+            if (phase_fast(0)) { load_x(0); store_x(0); } else { stage_x_slow(0); }
+            __syncthreads();
+            while (true) {
+                int ntg = tg0 + a.tg, nkc = kc0;
+                if (ntg >= ntap) { ntg = 0; nkc = kc0 + a.kch; }
+                const bool has_next = nkc < a.kchunks;
+                const bool new_x = has_next && ntg == 0;
+                const bool fastn = new_x && phase_fast(nkc);
+                SVBQ_STAMP(0)
+                // all weight fragments of this phase were requested a phase ago: drain them here, so that the x loads
+                // issued next are the only outstanding requests and no MFMA waits behind them (vmcnt counts in order)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                if (fastn) load_x(nkc);
+                SVBQ_STAMP(1)
+                compute_direct(kc0, tg0, has_next, nkc, ntg);
+                SVBQ_STAMP(2)
+                if (!has_next) break;
+                if (new_x) {                                   // the x tile changes: all waves must be done reading it
+                    __syncthreads();
+                    SVBQ_STAMP(3)
+                    if (fastn) store_x(nkc); else stage_x_slow(nkc);
+                    SVBQ_STAMP(4)
+                    __syncthreads();
+                    SVBQ_STAMP(5)
+                }
+                kc0 = nkc; tg0 = ntg;
+                ++dbg_stage;
+            }
+        }
+    } else if (ntap > 0) {
         __syncthreads();
         SVBQ_STAMP(6)
         if (phase_fast(0)) { load_x(0); store_x(0); } else { stage_x_slow(0); }
@@ -420,11 +498,12 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     if (kch > kch_cap) kch = kch_cap;
     if (kch > a.kchunks) kch = a.kchunks;
     if (kch < 1) kch = 1;
-    auto lds_bytes = [&](int kc) { return (size_t)2 * (a.tg * kc * BM + kc * a.xrows) * 48 + SVB_MAX_TAPS * 4; };
+    // (WN == 1 tiles read their weight fragments straight from global memory: no weight tile in LDS)
+    auto lds_bytes = [&](int kc) { return (size_t)2 * ((WN == 1 ? 0 : a.tg * kc * BM) + kc * a.xrows) * 48 + SVB_MAX_TAPS * 4; };
     while (kch > 1 && lds_bytes(kch) > 78 * 1024) --kch;
     if (lds_bytes(kch) > 150 * 1024) return SVB_ERR_UNSUPPORTED;
     a.kch = kch;
-    a.w_floats16 = a.tg * a.kch * BM * 3;
+    a.w_floats16 = WN == 1 ? 0 : a.tg * a.kch * BM * 3;
     a.x_floats16 = a.kch * a.xrows * 3;
     dim3 grid(a.G * svb_cdiv(a.Cout_g, BM), svb_cdiv(nq_max, BN), a.B * p.n_phase);
     if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, true>(a, p, grid, lds_bytes(a.kch), stream);
