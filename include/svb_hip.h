@@ -104,7 +104,9 @@ int svb_conv1d_wgrad_bf16x3(const float* a, const float* b, float* part, int B, 
 /* bias_part (optional, [nsplit][CA] floats): per-split row sums of the gated A operand -- with A = dy these are the bias
  * gradient partials (reference: autograd of the `bias` argument of F.conv1d); svb_wgrad_reduce sums them into db.     */
 /* Stage 2: reduce partials (+ WeightNorm backward: dv, dg from dW).  rows = d0, rowlen = d1*k.
- * bias_part/db (optional): also sum the [nsplit][rows] bias-gradient partials of stage 1 into db[rows].     */
+ * bias_part/db (optional): also sum the [nsplit][rows] bias-gradient partials of stage 1 into db[rows].
+ * accumulate: add into dv / dg / db instead of overwriting them (gradients written straight into `.grad` buffers); with
+ * weight_norm this needs 16-byte aligned rows and rowlen <= 4096 (SVB_ERR_UNSUPPORTED otherwise).                */
 int svb_wgrad_reduce(const float* part, int nsplit, const float* v, const float* g, float* dv, float* dg, int rows,
                      int rowlen, int weight_norm, int accumulate, const float* bias_part, float* db, void* stream);
 /* db[c] = sum_{b,t} dy[b,c,t] * gate'(gate[b,c,t])                                                          */

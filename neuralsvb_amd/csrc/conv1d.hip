@@ -429,21 +429,46 @@ __global__ __launch_bounds__(256) void svb_wgrad_reduce_kernel(const float* part
     const int row = blockIdx.x;
     const size_t base = (size_t)row * rowlen;
     float dot = 0.f, vv = 0.f;
+    float4 sreg[4];                                           // vec path: this thread's first 4 summed float4s of the row
+    auto sum_splits = [&](int e) {
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+        int sp = 0;
+        for (; sp + 1 < nsplit; sp += 2) {
+            const float4 p0 = *reinterpret_cast<const float4*>(part + (size_t)sp * split_stride + base + e);
+            const float4 p1 = *reinterpret_cast<const float4*>(part + (size_t)(sp + 1) * split_stride + base + e);
+            s0.x += p0.x; s0.y += p0.y; s0.z += p0.z; s0.w += p0.w;
+            s1.x += p1.x; s1.y += p1.y; s1.z += p1.z; s1.w += p1.w;
+        }
+        if (sp < nsplit) {
+            const float4 p0 = *reinterpret_cast<const float4*>(part + (size_t)sp * split_stride + base + e);
+            s0.x += p0.x; s0.y += p0.y; s0.z += p0.z; s0.w += p0.w;
+        }
+        return make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    };
     if (vec) {
-        for (int e = threadIdx.x * 4; e < rowlen; e += 1024) {
-            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-            int sp = 0;
-            for (; sp + 1 < nsplit; sp += 2) {
-                const float4 p0 = *reinterpret_cast<const float4*>(part + (size_t)sp * split_stride + base + e);
-                const float4 p1 = *reinterpret_cast<const float4*>(part + (size_t)(sp + 1) * split_stride + base + e);
-                s0.x += p0.x; s0.y += p0.y; s0.z += p0.z; s0.w += p0.w;
-                s1.x += p1.x; s1.y += p1.y; s1.z += p1.z; s1.w += p1.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                         // elements [0, 4096): kept in registers
+            const int e = threadIdx.x * 4 + j * 1024;
+            sreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < rowlen) {
+                float4 sv = sum_splits(e);
+                if (weight_norm) {
+                    const float4 ve = *reinterpret_cast<const float4*>(v + base + e);
+                    dot += ve.x * sv.x + ve.y * sv.y + ve.z * sv.z + ve.w * sv.w;
+                    vv += ve.x * ve.x + ve.y * ve.y + ve.z * ve.z + ve.w * ve.w;
+                    sreg[j] = sv;
+                } else {
+                    float4* dst = reinterpret_cast<float4*>(dv + base + e);
+                    if (accumulate) {
+                        const float4 o = *dst;
+                        sv.x += o.x; sv.y += o.y; sv.z += o.z; sv.w += o.w;
+                    }
+                    *dst = sv;
+                }
             }
-            if (sp < nsplit) {
-                const float4 p0 = *reinterpret_cast<const float4*>(part + (size_t)sp * split_stride + base + e);
-                s0.x += p0.x; s0.y += p0.y; s0.z += p0.z; s0.w += p0.w;
-            }
-            float4 sv = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+        }
+        for (int e = threadIdx.x * 4 + 4096; e < rowlen; e += 1024) {      // longer rows: dv is the scratch (no accumulate with WN)
+            float4 sv = sum_splits(e);
             float4* dst = reinterpret_cast<float4*>(dv + base + e);
             if (weight_norm) {
                 const float4 ve = *reinterpret_cast<const float4*>(v + base + e);
@@ -453,7 +478,7 @@ __global__ __launch_bounds__(256) void svb_wgrad_reduce_kernel(const float* part
                 const float4 o = *dst;
                 sv.x += o.x; sv.y += o.y; sv.z += o.z; sv.w += o.w;
             }
-            *dst = sv;                                        // weight_norm: finalised below
+            *dst = sv;
         }
     } else {
         for (int e = threadIdx.x; e < rowlen; e += 256) {
@@ -463,7 +488,7 @@ __global__ __launch_bounds__(256) void svb_wgrad_reduce_kernel(const float* part
                 const float ve = v[base + e];
                 dot += ve * s;
                 vv += ve * ve;
-                dv[base + e] = s;  // finalised below
+                dv[base + e] = s;  // finalised below (no accumulate on this path: the host rejects it)
             } else {
                 dv[base + e] = accumulate ? dv[base + e] + s : s;
             }
@@ -473,7 +498,7 @@ __global__ __launch_bounds__(256) void svb_wgrad_reduce_kernel(const float* part
         float b = 0.f;
         for (int sp = threadIdx.x; sp < nsplit; sp += 256) b += bias_part[(size_t)sp * rows + row];
         b = svb_block_sum<256>(b, red);
-        if (threadIdx.x == 0) db[row] = b;
+        if (threadIdx.x == 0) db[row] = accumulate ? db[row] + b : b;
     }
     if (!weight_norm) return;
     dot = svb_block_sum<256>(dot, red);
@@ -482,8 +507,27 @@ __global__ __launch_bounds__(256) void svb_wgrad_reduce_kernel(const float* part
     const float gg = gnorm[row];
     const float sa = gg / nrm;
     const float sb = gg * dot / (nrm * nrm * nrm);
-    if (threadIdx.x == 0) dg[row] = dot / nrm;
-    for (int e = threadIdx.x; e < rowlen; e += 256) dv[base + e] = sa * dv[base + e] - sb * v[base + e];
+    if (threadIdx.x == 0) dg[row] = accumulate ? dg[row] + dot / nrm : dot / nrm;
+    if (vec) {
+        auto finish = [&](int e, const float4& sv) {
+            float4* dst = reinterpret_cast<float4*>(dv + base + e);
+            const float4 ve = *reinterpret_cast<const float4*>(v + base + e);
+            float4 o = make_float4(sa * sv.x - sb * ve.x, sa * sv.y - sb * ve.y, sa * sv.z - sb * ve.z, sa * sv.w - sb * ve.w);
+            if (accumulate) {
+                const float4 old = *dst;
+                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            }
+            *dst = o;
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = threadIdx.x * 4 + j * 1024;
+            if (e < rowlen) finish(e, sreg[j]);
+        }
+        for (int e = threadIdx.x * 4 + 4096; e < rowlen; e += 1024) finish(e, *reinterpret_cast<const float4*>(dv + base + e));
+    } else {
+        for (int e = threadIdx.x; e < rowlen; e += 256) dv[base + e] = sa * dv[base + e] - sb * v[base + e];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -747,6 +791,8 @@ extern "C" int svb_wgrad_reduce(const float* part, int nsplit, const float* v, c
     if (bias_part && !db) return SVB_ERR_ARG;
     // 16-byte loads when every row of every operand is 16-byte aligned
     const int vec = (rowlen & 3) == 0 && (((uintptr_t)part | (uintptr_t)dv | (uintptr_t)v) & 15) == 0;
+    // accumulating into dv with WeightNorm needs the summed row in registers (dv is not free to be scratch)
+    if (weight_norm && accumulate && !(vec && rowlen <= 4096)) return SVB_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(svb_wgrad_reduce_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, part, nsplit,
                        (size_t)rows * rowlen, v, g, dv, dg, rowlen, weight_norm, accumulate, bias_part, db, rows, vec);
     SVB_CHECK_LAUNCH();

@@ -29,6 +29,21 @@ def set_precision(mode):
     K.WGRAD_BF16X3 = mode == "bf16x3"
 
 
+DIRECT_GRADS = True      # weight/bias gradients of leaf parameters that already own a `.grad` buffer are accumulated into
+                         # it by the reduce kernel itself (autograd gets None and skips its `grad += new` pass)
+
+
+def _gbuf(p):
+    if not DIRECT_GRADS or p is None or not p.is_leaf or p.grad is None:
+        return None
+    gb = p.grad
+    return gb if (gb.dtype == torch.float32 and gb.is_contiguous() and gb.shape == p.shape) else None
+
+
+def _sinks(v, g, b):
+    return (_gbuf(v), _gbuf(g), _gbuf(b))
+
+
 def _c(t):
     return None if t is None else t.contiguous()
 
@@ -60,13 +75,13 @@ class _Conv1dFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.pb = pb
-        ctx.save_for_backward(x, v, g, mask, y if out_act != ACT_NONE else None)
+        ctx.save_for_backward(x, v, g, mask, y if out_act != ACT_NONE else None, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         stride, pad, dil, groups, in_slope, out_act, out_slope = ctx.cfg
-        x, v, g, mask, yact = ctx.saved_tensors
+        x, v, g, mask, yact, bias_p = ctx.saved_tensors
         pb = ctx.pb
         dy = dy.contiguous()
         if mask is not None:
@@ -85,7 +100,7 @@ class _Conv1dFn(torch.autograd.Function):
             r = K.conv1d_wgrad(dy, x, k, stride, pad, dil, groups, a_gate=yact, a_slope=a_slope,
                                b_gate=x if in_slope is not None else None,
                                b_slope=in_slope if in_slope is not None else 0.0, v=v if g is not None else None, g=g,
-                               want_bias=want_b)
+                               want_bias=want_b, sinks=_sinks(v, g, bias_p if want_b else None))
             if want_b:
                 r, db = r[:-1], r[-1]
                 r = r if g is not None else r[0]
@@ -205,6 +220,7 @@ class _WNStackFn(torch.autograd.Function):
             flat += [saved_x[i], saved_xin[i], saved_acts[i]]
             flat += [_c(t) for t in layers[i]]
         ctx.packs = (cond_pb, packs_b)
+        ctx.cond_b = cond_b          # (only consulted for its `.grad` buffer in backward)
         ctx.save_for_backward(*flat)
         return out
 
@@ -213,6 +229,7 @@ class _WNStackFn(torch.autograd.Function):
         n_layers, ks, dr, C = ctx.meta
         sv = ctx.saved_tensors
         mask, gcond, G, cond_v, cond_g = sv[:5]
+        cond_b = ctx.cond_b
         cond_pb, packs_b = ctx.packs
         dout = dout.contiguous()
         if mask is not None:
@@ -233,7 +250,8 @@ class _WNStackFn(torch.autograd.Function):
             else:
                 drs, dxm = K.wn_res_skip_bwd(dx_next, dout, mask, want_dxm=True)
             # res/skip 1x1 conv
-            r = K.conv1d_wgrad(drs, acts, 1, v=rs_v if rs_g is not None else None, g=rs_g, want_bias=True)
+            r = K.conv1d_wgrad(drs, acts, 1, v=rs_v if rs_g is not None else None, g=rs_g, want_bias=True,
+                               sinks=_sinks(rs_v, rs_g, rs_b))
             p = 6 + 6 * i
             if rs_g is not None:
                 grads[p + 3], grads[p + 4], grads[p + 5] = r
@@ -241,7 +259,8 @@ class _WNStackFn(torch.autograd.Function):
                 grads[p + 3], grads[p + 5] = r
             dacts = K.conv1d_transposed(drs, pb_rs, C, acts.shape[2], 1)
             dxin = K.wn_gate_bwd(xin, G, dacts, i * 2 * C, dg=dG)
-            r = K.conv1d_wgrad(dxin, x_i, ks, 1, pad, dil, v=in_v if in_g is not None else None, g=in_g, want_bias=True)
+            r = K.conv1d_wgrad(dxin, x_i, ks, 1, pad, dil, v=in_v if in_g is not None else None, g=in_g, want_bias=True,
+                               sinks=_sinks(in_v, in_g, in_b))
             if in_g is not None:
                 grads[p + 0], grads[p + 1], grads[p + 2] = r
             else:
@@ -252,7 +271,8 @@ class _WNStackFn(torch.autograd.Function):
                 dx_next = None
         grads[0] = dx_next
         if G is not None:
-            r = K.conv1d_wgrad(dG, gcond, 1, v=cond_v if cond_g is not None else None, g=cond_g, want_bias=True)
+            r = K.conv1d_wgrad(dG, gcond, 1, v=cond_v if cond_g is not None else None, g=cond_g, want_bias=True,
+                               sinks=_sinks(cond_v, cond_g, cond_b))
             if cond_g is not None:
                 grads[3], grads[4], grads[5] = r
             else:

@@ -238,12 +238,15 @@ WGRAD_BF16X3 = False      # set by functional.set_precision: stride-1 weight gra
 
 
 def conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0, b_gate=None, b_slope=0.0,
-                 v=None, g=None, accumulate_into=None, bf16x3=None, want_bias=False):
+                 v=None, g=None, accumulate_into=None, bf16x3=None, want_bias=False, sinks=None):
     """dW[ca, cb/groups, k] = sum_{n,q} a[n,ca,q] * b[n,cb,q*sx + j*dil - pad].
 
     With (v, g) given returns (dv, dg) of the weight-normalised parametrisation instead of dW.  want_bias: also return
     db[ca] = sum_{n,q} a[n,ca,q] (gated) -- the bias gradient when a = dy -- as the last element of the result; on the
-    bf16x3 path it comes out of the same two launches."""
+    bf16x3 path it comes out of the same two launches.
+
+    sinks = (grad_v, grad_g, grad_b): existing gradient buffers (e.g. `param.grad`) to ACCUMULATE into; outputs that
+    went into a sink are returned as None (the caller hands None to autograd, which skips its own `grad += new`)."""
     _f32(a, b, a_gate, b_gate, v, g)
     lib, st = _prep(a, b, a_gate, b_gate, v, g, accumulate_into)
     B, ca, ta = a.shape
@@ -273,22 +276,34 @@ def conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0
         probe.done()
     rows, rowlen = ca, (cb // groups) * k
     wn = g is not None
-    if accumulate_into is not None and not wn:
-        dw = accumulate_into
-        acc = 1
+    sv, sg, sb = sinks if sinks is not None else (None, None, None)
+    sink = (sv is not None and accumulate_into is None and (not wn or sg is not None)
+            and (bias_part is None or sb is not None))
+    if sink and wn:      # the accumulate-with-WeightNorm reduce needs 16-byte rows that fit the thread's registers
+        sink = rowlen % 4 == 0 and rowlen <= 4096 and sv.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
+    if sink:
+        dw, dg, acc = sv, (sg if wn else None), 1
+        db = sb if bias_part is not None else None
     else:
-        dw = torch.empty((ca, cb // groups, k), device=a.device, dtype=torch.float32)
-        acc = 0
-    dg = torch.empty_like(g) if wn else None
-    db = torch.empty((ca,), device=a.device, dtype=torch.float32) if bias_part is not None else None
+        if accumulate_into is not None and not wn:
+            dw, acc = accumulate_into, 1
+        else:
+            dw, acc = torch.empty((ca, cb // groups, k), device=a.device, dtype=torch.float32), 0
+        dg = torch.empty_like(g) if wn else None
+        db = torch.empty((ca,), device=a.device, dtype=torch.float32) if bias_part is not None else None
     L.check(lib.svb_wgrad_reduce(_ptr(part), ns.value, _ptr(v), _ptr(g), _ptr(dw), _ptr(dg), rows, rowlen, int(wn),
                                  acc, _ptr(bias_part), _ptr(db), st), "svb_wgrad_reduce")
-    res = (dw, dg) if wn else dw
+    if sink:
+        dw = dg = None
+        db = None if bias_part is not None else db
     if want_bias:
-        if db is None:
+        if bias_part is None:
             db = bias_grad(a, a_gate, a_slope)
+            if sink and sb is not None:
+                sb.add_(db)
+                db = None
         return (dw, dg, db) if wn else (dw, db)
-    return res
+    return (dw, dg) if wn else dw
 
 
 def bias_grad(dy, gate=None, slope=0.0):

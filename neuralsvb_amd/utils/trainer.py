@@ -55,13 +55,13 @@ class FlatGradSync:
     def __init__(self, params, world_size, group=None):
         self.params = [p for p in params]
         self.world_size, self.group = world_size, group
-        n = sum(p.numel() for p in self.params)
+        n = sum((p.numel() + 3) // 4 * 4 for p in self.params)        # every view starts 16-byte aligned (vector kernels)
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+            off += (p.numel() + 3) // 4 * 4
 
     def zero(self):
         self.flat.zero_()

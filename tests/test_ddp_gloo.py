@@ -51,7 +51,7 @@ def _worker(rank, world, port, emu_lib, out):
     loss = (y * dys).sum() / xs.shape[0]                          # per-rank mean over its clips
     loss.backward()
     sync.all_reduce()
-    res = {"grad": sync.flat.clone().numpy(), "w": torch.cat([p.detach().flatten() for p in params]).numpy()}
+    res = {"grad": torch.cat([p.grad.flatten() for p in params]).numpy(), "w": torch.cat([p.detach().flatten() for p in params]).numpy()}
     if rank == 0:
         # single-process reference on the whole batch with stock torch ops
         v, gn, b = (p.detach().clone().requires_grad_(True) for p in params)
