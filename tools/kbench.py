@@ -72,7 +72,7 @@ def main():
         errq = ((yq - ref).abs().max() / ref.abs().max()).item()
         t_qf = timeit(lambda: K.conv1d_forward(x, qa, Cout, k, s, pad, dil, G, bias=bias), args.iters)
         t_qd = timeit(lambda: K.conv1d_transposed(dy, qb, Cin, T, k, s, pad, dil, G), args.iters)
-        t_qw = timeit(lambda: K.conv1d_wgrad(dy, x, k, s, pad, dil, G, bf16x3=True), args.iters) if s == 1 else float("nan")
+        t_qw = timeit(lambda: K.conv1d_wgrad(dy, x, k, s, pad, dil, G, bf16x3=True), args.iters)
         row = dict(name=name, gflop=flops / 1e9, err=err, fwd_ms=t_f * 1e3, fwd_tf=flops / t_f / 1e12,
                    dgrad_ms=t_d * 1e3, dgrad_tf=flops / t_d / 1e12, wgrad_ms=t_w * 1e3, wgrad_tf=flops / t_w / 1e12,
                    pack_ms=t_p * 1e3, fwd_frac=flops / t_f / PEAK_F32, q_err=errq, q_fwd_ms=t_qf * 1e3,
