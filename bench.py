@@ -29,7 +29,7 @@ PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense p
 PEAK_BF16_MFMA = 2.5e15    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak (no sparsity)
 
 
-def build_task(args, rank, world, device, tmp):
+def build_task(args, rank, world, device, tmp, extra_hparams=""):
     from neuralsvb_amd.utils.hparams import set_hparams, hparams
     from neuralsvb_amd.utils import synth
     cfg = os.path.join(ROOT, "egs/datasets/audio/PopBuTFy/vae_global_mle_eng.yaml")
@@ -37,12 +37,14 @@ def build_task(args, rank, world, device, tmp):
     set_hparams(config=cfg, exp_name="", print_hparams=False,
                 hparams_str=f"audio_sample_rate={args.sample_rate},fmax={args.sample_rate // 2},max_sentences={args.batch},"
                             f"max_tokens=100000,ds_workers=0,num_sanity_val_steps=0,endless_ds=False,"
-                            f"conv_precision={args.precision}")
+                            f"conv_precision={args.precision}" + extra_hparams)
     hparams["binary_data_dir"], hparams["pretrain_asr_ckpt"], hparams["work_dir"] = data_dir, asr_dir, ""
     hparams["amp"] = bool(args.bf16)
     torch.manual_seed(1234 + rank)
     np.random.seed(1234)
-    synth.write_binary_dataset(data_dir, hparams, synth.mel_fn_hip(hparams, device), n_train=args.batch, n_valid=1,
+    # weak scaling: the reference's loader builds global batches of max_sentences x world clips and rank r takes
+    # every world-th one (tasks/tts/tts.py:93-96), so the synthetic set holds batch x world clips
+    synth.write_binary_dataset(data_dir, hparams, synth.mel_fn_hip(hparams, device), n_train=args.batch * world, n_valid=1,
                                seconds=args.seconds)
     synth.write_fake_asr_ckpt(asr_dir, 60 + 10, hparams)
     from neuralsvb_amd.tasks.svb_vae_task import SVBVAEMleTask
@@ -54,6 +56,7 @@ def build_task(args, rank, world, device, tmp):
     task.train()
     loader = task.build_dataloader(task.dataset_cls("train", False), False, hparams["max_tokens"], args.batch)
     host = next(iter(loader))
+    assert host["mels"].shape[0] == args.batch, (host["mels"].shape, args.batch, world)     # per-GPU batch is fixed
     batch = move_to_device(host, device)                       # inputs resident in HBM before the timed region
     for k in ("mel_lengths", "prof_mel_lengths"):              # clip lengths stay host-side too (no sync to read them)
         batch[k] = host[k]

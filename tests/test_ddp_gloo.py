@@ -89,3 +89,39 @@ def test_batch_sharding_rule():
     assert all(len(a) == len(b) for a, b in zip(*shards))
     flat = sorted(i for r in range(world) for b in shards[r] for i in b)
     assert flat == sorted(i for b in kept for i in b)             # disjoint cover of the kept batches
+
+
+def _bench_worker(rank, world, port, emu_lib, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import argparse
+    import sys
+    import tempfile
+    sys.path.insert(0, ROOT)
+    from neuralsvb_amd import _lib
+    _lib._LIB, _lib._LIB_IS_EMU = _lib.bind(emu_lib), True     # test harness: CPU lane emulator
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = argparse.Namespace(batch=2, seconds=0.71, sample_rate=24000, bf16=False, precision="fp32", graph=False)
+    small = (",hidden_size=32,fvae_enc_dec_hidden=32,latent_size=16,fvae_enc_n_layers=2,fvae_dec_n_layers=2,"
+             "mel_disc_hidden_size=16,warmup_updates=4")
+    with tempfile.TemporaryDirectory() as tmp:
+        task, trainer, batch, hp = bench.build_task(args, rank, world, torch.device("cpu"), tmp, extra_hparams=small)
+        assert trainer.use_ddp and trainer.world_size == world
+        assert batch["mels"].shape[0] == args.batch                   # weak scaling: per-rank batch is --batch
+        bench.run_steps(trainer, task, batch, 1, 1)
+        w = torch.cat([p.detach().flatten() for p in task.gen_params + task.disc_params])
+    np.save(os.path.join(out, f"b{rank}.npy"), w.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_multi_rank_path_two_ranks_gloo(tmp_path, _emu_lib):
+    """bench.py's own N > 1 path (what the driver launches with torchrun) on 2 gloo ranks: batch x world synthetic clips,
+    per-rank batch = --batch, DDP start-up broadcast, one full phase-2 step with the flat all-reduce; the replicas must
+    hold identical weights afterwards."""
+    from tests.conftest import EMU_LIB
+    port = _free_port()
+    mp.spawn(_bench_worker, args=(2, port, EMU_LIB, str(tmp_path)), nprocs=2, join=True)
+    w0, w1 = np.load(tmp_path / "b0.npy"), np.load(tmp_path / "b1.npy")
+    assert np.isfinite(w0).all() and np.array_equal(w0, w1)
