@@ -9,6 +9,8 @@ conv1d / conv_transpose1d carry the fusions the reference expresses as separate 
 wn_stack is the whole gated conv stack `WN.forward` (fs2_vae.py:61-91) as ONE autograd node with a hand-scheduled
 backward, so no intermediate is kept that the backward does not need.
 """
+import weakref
+
 import torch
 
 from . import kernels as K
@@ -48,10 +50,47 @@ def _c(t):
     return None if t is None else t.contiguous()
 
 
+PACK_CACHE = True        # reuse a weight's packed image while the weight is known to be unchanged
+PACK_EPOCH = None        # None: nobody tells us when trainable weights change -> only weights that cannot train are cached.
+                         # An int: the Trainer bumps it (note_weights_updated) after every optimizer step / weight load.
+_PACKS = {}
+
+
+def note_weights_updated():
+    """Called by whoever modifies trainable weights in place (Trainer: optimizer.step, restore, broadcast)."""
+    global PACK_EPOCH
+    PACK_EPOCH = 0 if PACK_EPOCH is None else PACK_EPOCH + 1
+
+
 def _pack(v, g, groups=1, want_a=True, want_b=True):
-    if PRECISION == "bf16x3":
-        return K.weight_pack_q(v, g, groups, want_a, want_b)
-    return K.weight_pack(v, g, want_a, want_b)
+    """Packed (and WeightNorm-ed) image(s) of a conv weight in the kernel's operand layouts, cached while the weight is
+    unchanged.  Weights that cannot train (requires_grad False and no grad buffer: the frozen PPG encoder) are keyed on
+    tensor identity, storage pointer and autograd version counter.  Trainable weights are only reused inside one "weight
+    epoch" announced by the Trainer (e.g. the critic between the generator pass and the critic pass of a step), never
+    across an optimizer step, and never while a hipGraph is being captured (a hit would record no pack kernel)."""
+    def make(a, b):
+        if PRECISION == "bf16x3":
+            return K.weight_pack_q(v, g, groups, a, b)
+        return K.weight_pack(v, g, a, b)
+    if not PACK_CACHE or not v.is_leaf or (g is not None and not g.is_leaf):
+        return make(want_a, want_b)
+    trainable = v.requires_grad or v.grad is not None or (g is not None and (g.requires_grad or g.grad is not None))
+    if trainable and (PACK_EPOCH is None or (v.is_cuda and torch.cuda.is_current_stream_capturing())):
+        return make(want_a, want_b)
+    key = (id(v), id(g) if g is not None else 0, groups, PRECISION)
+    ver = (v._version, g._version if g is not None else 0, v.data_ptr(), PACK_EPOCH if trainable else -1)
+    ent = _PACKS.get(key)
+    if ent is not None and ent["v"]() is v and ent["ver"] == ver and (ent["g"] is None or ent["g"]() is g):
+        pa, pb = ent["packs"]
+        if (pa is not None or not want_a) and (pb is not None or not want_b):
+            return (pa if want_a else None), (pb if want_b else None)
+        na, nb = make(want_a and pa is None, want_b and pb is None)        # the missing layout only
+        ent["packs"] = (pa if pa is not None else na, pb if pb is not None else nb)
+        pa, pb = ent["packs"]
+        return (pa if want_a else None), (pb if want_b else None)
+    packs = make(want_a, want_b)
+    _PACKS[key] = {"v": weakref.ref(v), "g": weakref.ref(g) if g is not None else None, "ver": ver, "packs": packs}
+    return packs
 
 
 class _Conv1dFn(torch.autograd.Function):

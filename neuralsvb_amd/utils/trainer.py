@@ -36,6 +36,11 @@ from .ckpt_utils import get_all_ckpts, get_last_checkpoint
 from .hparams import hparams
 
 
+def _note_weights_updated():
+    from .. import functional as SF          # weight images packed for the kernels are stale after an in-place update
+    SF.note_weights_updated()
+
+
 def move_to_device(batch, device):
     def mv(v):
         if isinstance(v, torch.Tensor):
@@ -188,6 +193,7 @@ class Trainer:
             self._broadcast_module_state(params=True)
             dist.barrier()
         task.testing = self.testing
+        _note_weights_updated()               # from here on this Trainer announces every in-place weight update
         if self.proc_rank == 0 and self.work_dir:
             self.logger = _make_writer(os.path.join(self.work_dir, "lightning_logs", "version_lastest"))
         task.logger = self.logger
@@ -211,6 +217,8 @@ class Trainer:
             for t in ts:
                 if t.is_floating_point() or t.dtype in (torch.int64, torch.int32):
                     dist.broadcast(t, 0)
+        if params:
+            _note_weights_updated()
 
     # ------------------------------------------------------------------ evaluation
     def run_evaluation(self, test=False):
@@ -380,6 +388,7 @@ class Trainer:
                 sync.all_reduce()
                 task.on_before_optimization(opt_idx)
                 optimizer.step()
+                _note_weights_updated()
                 sync.zero()
                 task.on_after_optimization(self.current_epoch, batch_idx, optimizer, opt_idx)
         if hasattr(task, "end_step"):
@@ -395,6 +404,7 @@ class Trainer:
         else:
             for k, v in sd.items():
                 getattr(task, k).load_state_dict(v)
+        _note_weights_updated()
         self.best_val_results = checkpoint["checkpoint_callback_best"]
         self.global_step = checkpoint["global_step"]
         self.current_epoch = checkpoint["epoch"]
