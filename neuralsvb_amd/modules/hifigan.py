@@ -202,11 +202,17 @@ class MultiPeriodDiscriminator(nn.Module):
         self.discriminators = nn.ModuleList([DiscriminatorP(p, use_cond=use_cond, c_in=c_in) for p in (2, 3, 5, 7, 11)])
 
     def forward(self, y, y_hat, mel=None):
+        """Real and generated audio go through each period discriminator as ONE stacked batch (every layer is a
+        weight-normalised conv + LeakyReLU, i.e. per clip), then the outputs are split: identical results, half the
+        launches, twice the work per launch."""
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        B = y.shape[0]
+        both = torch.cat([y, y_hat], 0)
+        mel2 = None if mel is None else torch.cat([mel, mel], 0)
         for d in self.discriminators:
-            r, fr = d(y, mel)
-            g, fg = d(y_hat, mel)
-            y_d_rs.append(r); fmap_rs.append(fr); y_d_gs.append(g); fmap_gs.append(fg)
+            o, fm = d(both, mel2)
+            y_d_rs.append(o[:B]); y_d_gs.append(o[B:])
+            fmap_rs.append([f[:B] for f in fm]); fmap_gs.append([f[B:] for f in fm])
         return y_d_rs, y_d_gs, fmap_rs, fmap_gs
 
 
@@ -280,11 +286,19 @@ class MultiScaleDiscriminator(nn.Module):
 
     def forward(self, y, y_hat, mel=None):
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        B = y.shape[0]
         for i, d in enumerate(self.discriminators):
             if i != 0:
                 y, y_hat = self.meanpools[i - 1](y), self.meanpools[i - 1](y_hat)
-            r, fr = d(y.contiguous(), mel)
-            g, fg = d(y_hat.contiguous(), mel)
+            if i == 0:
+                # spectral norm runs one power iteration per forward call (buffers updated in place): the reference's
+                # real and generated calls see different sigma estimates, so this scale keeps its two separate calls
+                r, fr = d(y.contiguous(), mel)
+                g, fg = d(y_hat.contiguous(), mel)
+            else:   # weight-normalised scales: real and generated stacked into one batch (per-clip layers only)
+                o, fm = d(torch.cat([y, y_hat], 0), None if mel is None else torch.cat([mel, mel], 0))
+                r, g = o[:B], o[B:]
+                fr, fg = [f[:B] for f in fm], [f[B:] for f in fm]
             y_d_rs.append(r); fmap_rs.append(fr); y_d_gs.append(g); fmap_gs.append(fg)
         return y_d_rs, y_d_gs, fmap_rs, fmap_gs
 
