@@ -140,6 +140,12 @@ int svb_layernorm_nct_fwd(const float* x, const float* gamma, const float* beta,
 int svb_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* mean, const float* rstd,
                       float* dx, float* dgamma_part, float* dbeta_part, int rows, int C, int n_part, void* stream);
 
+/* ---- Relative-position self-attention glue of the frozen conformer PPG encoder (reference
+ * modules/commons/espnet_transformer_attn.py:125-186): attn = masked softmax over keys of (ac + rel_shift(bd)) * scale,
+ * ac = (q+u) k^T and bd = (q+v) p^T both [B,H,T,T]; keep [B,T] (1 = real frame, 0 = padding); T <= 2048.        */
+int svb_relpos_softmax(const float* ac, const float* bd, const float* keep, float* attn, int B, int H, int T, float scale,
+                       void* stream);
+
 /* ---- im2col / col2im for small strided Conv2d layers (reference modules/fastspeech/multi_window_disc.py:14-31).
  * The column matrix is addressed as cols[b*cols_sb + row*cols_sk + pos] (row = (c,jh,jw), pos = ho*Wo+wo): per clip
  * ([B][K][L]: cols_sb = K*L, cols_sk = L) or with the batch folded into the position axis ([K][B*L]: cols_sb = L,

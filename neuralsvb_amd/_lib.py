@@ -45,6 +45,7 @@ SIGNATURES = {
     "svb_wn_res_skip_bwd": (I, [P, P, P, P, P, I, I, I, P]),
     "svb_wn_res_skip": (I, [P, P, P, P, P, P, I, I, I, I, P]),
     "svb_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
+    "svb_relpos_softmax": (I, [P, P, P, P, I, I, I, F, P]),
     "svb_layernorm_nct_fwd": (I, [P, P, P, P, I, I, I, F, P]),
     "svb_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
     "svb_im2col": (I, [P, P] + [I] * 12 + [C.c_long] * 4 + [P]),

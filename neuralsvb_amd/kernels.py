@@ -375,6 +375,16 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, save_stats=False):
     return (y, mean, rstd) if save_stats else y
 
 
+def relpos_softmax(ac, bd, keep, scale):
+    """attn = masked softmax_j((ac + rel_shift(bd)) * scale); ac, bd [B,H,T,T]; keep [B,T] float (1 = real frame)."""
+    _f32(ac, bd, keep)
+    lib, st = _prep(ac, bd, keep)
+    B, H, T, _ = ac.shape
+    out = torch.empty_like(ac)
+    L.check(lib.svb_relpos_softmax(_ptr(ac), _ptr(bd), _ptr(keep), _ptr(out), B, H, T, float(scale), st), "svb_relpos_softmax")
+    return out
+
+
 def layernorm_nct_fwd(x, gamma, beta, eps=1e-5):
     """LayerNorm over dim 1 of [B, C, T]."""
     _f32(x, gamma, beta)

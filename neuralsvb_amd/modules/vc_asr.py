@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import functional as SF
+from .. import kernels as K
 from .layers import Conv1d, LinearNCT, LayerNormNCT, attach_opaque
 
 
@@ -67,11 +68,8 @@ class RelPositionMultiHeadedAttention(nn.Module):
         q_v = (q + self.pos_bias_v[None, :, :, None]).transpose(-1, -2)
         ac = torch.matmul(q_u, k)                                   # [B,h,T,T]
         bd = torch.matmul(q_v, p)
-        bd = F.pad(bd, (1, 0)).view(B, h, T + 1, T)[:, :, 1:].reshape(B, h, T, T)   # rel_shift :125-148
-        scores = (ac + bd) / math.sqrt(dk)
-        drop = ~mask[:, None, None, :]
-        scores = scores.masked_fill(drop, torch.finfo(torch.float32).min)
-        attn = torch.softmax(scores, dim=-1).masked_fill(drop, 0.0)
+        # rel_shift (:125-148) + add + 1/sqrt(dk) + key mask + softmax + mask: one HIP kernel, one pass over [B,h,T,T]
+        attn = K.relpos_softmax(ac, bd.expand(B, h, T, T).contiguous(), mask.float().contiguous(), 1.0 / math.sqrt(dk))
         o = torch.matmul(v, attn.transpose(-1, -2)).reshape(B, D, T)
         return self.linear_out(o)
 

@@ -444,3 +444,21 @@ def test_conv1d_bf16x3_wide_tiles_three_position_groups(dev, cfg):
     dref = torch.autograd.grad(oops.conv1d(x.requires_grad_(True), w, None, 1, 2), x, dy)[0]
     dx = K.conv1d_transposed(dy.to(dev), qb, Cin, T, k, 1, 2, 1, 1, force_cfg=cfg)
     assert rel_err(dx, dref) < 6e-5
+
+
+@pytest.mark.parametrize("T", [37, 130])
+def test_relpos_softmax_matches_espnet_rel_shift(dev, T):
+    """svb_relpos_softmax against the reference's op sequence (espnet_transformer_attn.py:125-186): legacy rel_shift via
+    pad/view/slice, add, 1/sqrt(dk), masked_fill(min), softmax, masked_fill(0)."""
+    g = torch.Generator().manual_seed(T)
+    B, H, dk = 2, 3, 16
+    ac = torch.randn(B, H, T, T, generator=g) * 3
+    bd = torch.randn(B, H, T, T, generator=g) * 3
+    keep = torch.ones(B, T)
+    keep[1, T - 5:] = 0
+    x = F.pad(bd, (1, 0)).view(B, H, T + 1, T)[:, :, 1:].reshape(B, H, T, T)
+    scores = (ac + x) / (dk ** 0.5)
+    drop = ~(keep.bool())[:, None, None, :]
+    ref = torch.softmax(scores.masked_fill(drop, torch.finfo(torch.float32).min), -1).masked_fill(drop, 0.0)
+    out = K.relpos_softmax(ac.to(dev), bd.to(dev), keep.to(dev), 1.0 / dk ** 0.5)
+    assert (out.cpu() - ref).abs().max().item() < 2e-6
