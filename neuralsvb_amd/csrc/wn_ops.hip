@@ -188,23 +188,38 @@ __global__ __launch_bounds__(256) void svb_layernorm_bwd_kernel(const float* x, 
 }
 
 
-// LayerNorm over the channel dim of an NCT tensor.  Block = 64 time columns x 4 channel groups: lanes run along t
-// (coalesced 256-byte row segments), the 4 waves split the channels and combine their moments through LDS.
-// Shifted single-pass moments (shift = channel 0) + one normalise pass: 2 reads + 1 write of x.
+// LayerNorm over the channel dim of an NCT tensor.  Block = 32 time columns x 8 channel groups (a wave covers two
+// 128-byte row segments per load); each thread keeps its C/8 values in registers (all loads in flight at once, x is
+// read ONCE), the groups combine their shifted moments through LDS.  1 read + 1 write of x.
+#define SVB_LN_MAXV 48          /* register-resident values per thread: C <= 384 (larger C re-reads x) */
 __global__ __launch_bounds__(256) void svb_layernorm_nct_fwd_kernel(const float* x, const float* gamma, const float* beta,
                                                                     float* y, int B, int C, int T, float eps) {
-    __shared__ float s_sum[4][64];
-    __shared__ float s_sq[4][64];
-    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
-    const int tiles = (T + 63) / 64;
-    const int b = blockIdx.x / tiles, t = (blockIdx.x % tiles) * 64 + tl;
+    __shared__ float s_sum[8][32];
+    __shared__ float s_sq[8][32];
+    const int tl = threadIdx.x & 31, cg = threadIdx.x >> 5;
+    const int tiles = (T + 31) / 32;
+    const int b = blockIdx.x / tiles, t = (blockIdx.x % tiles) * 32 + tl;
     const bool ok = t < T;
     const float* xc = x + (size_t)b * C * T + (ok ? t : 0);
     float* yc = y + (size_t)b * C * T + (ok ? t : 0);
-    const float x0 = ok ? xc[0] : 0.f;
+    const float x0 = xc[0];                                   // shift (any finite value of the column works)
+    const bool inreg = C <= 8 * SVB_LN_MAXV;
+    float v[SVB_LN_MAXV];
     float s = 0.f, ss = 0.f;
-    if (ok) {
-        for (int c = cg; c < C; c += 4) {
+    if (inreg) {
+#pragma unroll
+        for (int i = 0; i < SVB_LN_MAXV; ++i) {
+            const int c = cg + 8 * i;
+            v[i] = c < C ? xc[(size_t)c * T] : x0;
+        }
+#pragma unroll
+        for (int i = 0; i < SVB_LN_MAXV; ++i) {
+            const float d = v[i] - x0;                        // channels beyond C contribute d = 0
+            s += d;
+            ss = fmaf(d, d, ss);
+        }
+    } else {
+        for (int c = cg; c < C; c += 8) {
             const float d = xc[(size_t)c * T] - x0;
             s += d;
             ss = fmaf(d, d, ss);
@@ -213,14 +228,27 @@ __global__ __launch_bounds__(256) void svb_layernorm_nct_fwd_kernel(const float*
     s_sum[cg][tl] = s;
     s_sq[cg][tl] = ss;
     __syncthreads();
-    s = s_sum[0][tl] + s_sum[1][tl] + s_sum[2][tl] + s_sum[3][tl];
-    ss = s_sq[0][tl] + s_sq[1][tl] + s_sq[2][tl] + s_sq[3][tl];
+    s = 0.f; ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { s += s_sum[q][tl]; ss += s_sq[q][tl]; }
     const float md = s / (float)C;
     const float var = fmaxf(ss / (float)C - md * md, 0.f);
     const float mu = x0 + md;
     const float rs = 1.f / sqrtf(var + eps);
-    if (ok) {
-        for (int c = cg; c < C; c += 4) {
+    if (!ok) return;
+    if (inreg) {
+#pragma unroll
+        for (int i = 0; i < SVB_LN_MAXV; ++i) {
+            const int c = cg + 8 * i;
+            if (c < C) {
+                float o = (v[i] - mu) * rs;
+                if (gamma) o *= gamma[c];
+                if (beta) o += beta[c];
+                yc[(size_t)c * T] = o;
+            }
+        }
+    } else {
+        for (int c = cg; c < C; c += 8) {
             float o = (xc[(size_t)c * T] - mu) * rs;
             if (gamma) o *= gamma[c];
             if (beta) o += beta[c];
@@ -304,7 +332,7 @@ extern "C" int svb_layernorm_bwd(const float* x, const float* gamma, const float
 extern "C" int svb_layernorm_nct_fwd(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T,
                                      float eps, void* stream) {
     if (!x || !y || B <= 0 || C <= 0 || T <= 0) return SVB_ERR_ARG;
-    hipLaunchKernelGGL(svb_layernorm_nct_fwd_kernel, dim3(B * ((T + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+    hipLaunchKernelGGL(svb_layernorm_nct_fwd_kernel, dim3(B * ((T + 31) / 32)), dim3(256), 0, (hipStream_t)stream, x, gamma,
                        beta, y, B, C, T, eps);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
