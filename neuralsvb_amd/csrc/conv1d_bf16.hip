@@ -661,25 +661,6 @@ struct SvbWgradQArgs {
 #define SVBQ_WG_QC 64
 #define SVBQ_WG_NXIT 3
 
-__device__ __forceinline__ void svbq_load2(const float* base, const float* gate, float slope, int pos, int T, bool rv,
-                                           float& v0, float& v1) {
-    v0 = 0.f; v1 = 0.f;
-    if (!rv) return;
-    if (pos >= 0 && pos + 1 < T) {
-        float2 t;
-        __builtin_memcpy(&t, base + pos, 8);
-        v0 = t.x; v1 = t.y;
-        if (gate) {
-            float2 gt;
-            __builtin_memcpy(&gt, gate + pos, 8);
-            v0 *= svb_gate(gt.x, slope); v1 *= svb_gate(gt.y, slope);
-        }
-    } else {
-        if (pos >= 0 && pos < T) { v0 = base[pos]; if (gate) v0 *= svb_gate(gate[pos], slope); }
-        if (pos + 1 >= 0 && pos + 1 < T) { v1 = base[pos + 1]; if (gate) v1 *= svb_gate(gate[pos + 1], slope); }
-    }
-}
-
 __device__ __forceinline__ unsigned svbq_funnel(unsigned hi, unsigned lo, unsigned sh) {
     return (unsigned)((((unsigned long long)hi << 32) | lo) >> sh);
 }

@@ -19,7 +19,8 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = K.ACT_NONE, K.ACT_RELU, K.ACT_LRELU, K
 
 
 # Conv arithmetic: "fp32" = exact fp32 on v_mfma_f32_32x32x2_f32 (parity mode, default);
-# "bf16x3" = fp32-class operand split on the bf16 matrix cores (forward + data-gradient; weight gradients stay fp32).
+# "bf16x3" = fp32-class operand split on the bf16 matrix cores (forward, data gradient and weight gradient); storage and
+# accumulation stay fp32.
 PRECISION = "fp32"
 
 
