@@ -53,14 +53,34 @@ def _c(t):
 
 PACK_CACHE = True        # reuse a weight's packed image while the weight is known to be unchanged
 PACK_EPOCH = None        # None: nobody tells us when trainable weights change -> only weights that cannot train are cached.
-                         # An int: the Trainer bumps it (note_weights_updated) after every optimizer step / weight load.
+                         # An int (only while a Trainer-managed training step is running): bumped by the Trainer at the
+                         # start of the step and after every optimizer step (note_weights_updated); end_weight_epoch()
+                         # puts it back to None when the step returns.
 _PACKS = {}
 
 
+_EPOCH_COUNTER = 0       # monotonic: an epoch number is never reused, so an image packed in an earlier step can never hit
+
+
+def begin_weight_epoch():
+    """Trainer, at the start of a training step: from here until end_weight_epoch() every in-place update of trainable
+    weights is announced through note_weights_updated()."""
+    global PACK_EPOCH, _EPOCH_COUNTER
+    _EPOCH_COUNTER += 1
+    PACK_EPOCH = _EPOCH_COUNTER
+
+
 def note_weights_updated():
-    """Called by whoever modifies trainable weights in place (Trainer: optimizer.step, restore, broadcast)."""
+    """Trainable weights were modified in place (optimizer step, restore, broadcast): start a fresh epoch if one is open."""
+    global PACK_EPOCH, _EPOCH_COUNTER
+    if PACK_EPOCH is not None:
+        _EPOCH_COUNTER += 1
+        PACK_EPOCH = _EPOCH_COUNTER
+
+
+def end_weight_epoch():
     global PACK_EPOCH
-    PACK_EPOCH = 0 if PACK_EPOCH is None else PACK_EPOCH + 1
+    PACK_EPOCH = None
 
 
 def _pack(v, g, groups=1, want_a=True, want_b=True):

@@ -193,7 +193,6 @@ class Trainer:
             self._broadcast_module_state(params=True)
             dist.barrier()
         task.testing = self.testing
-        _note_weights_updated()               # from here on this Trainer announces every in-place weight update
         if self.proc_rank == 0 and self.work_dir:
             self.logger = _make_writer(os.path.join(self.work_dir, "lightning_logs", "version_lastest"))
         task.logger = self.logger
@@ -348,6 +347,14 @@ class Trainer:
         return self._run_training_batch(batch_idx, batch)
 
     def _run_training_batch(self, batch_idx, batch):
+        from .. import functional as SF
+        SF.begin_weight_epoch()               # packed weight images may be reused inside this step (until the next update)
+        try:
+            return self._run_training_batch_body(batch_idx, batch)
+        finally:
+            SF.end_weight_epoch()             # outside a managed step trainable weights are never served from the cache
+
+    def _run_training_batch_body(self, batch_idx, batch):
         task = self.task
         graph_mode = self.hip_graph and self.on_gpu
         if hasattr(task, "begin_step"):

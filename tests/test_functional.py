@@ -220,3 +220,45 @@ def test_wn_stack_bf16x3_mode(dev):
     for la, lb in zip(ld, lr):
         for a, b in zip(la, lb):
             assert rel_err(a.grad, b.grad) < 3e-4
+
+
+def test_weight_pack_cache_semantics(dev):
+    """Packed weight images: frozen weights are packed once; trainable weights are repacked on every call unless a
+    Trainer-managed weight epoch is open, and an epoch bump (optimizer step) invalidates them."""
+    from neuralsvb_amd import kernels as K
+    calls = {"n": 0}
+    orig = K.weight_pack
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    K.weight_pack = counting
+    try:
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(1, 4, 20, generator=g).to(dev)
+        frozen = torch.nn.Parameter((torch.randn(6, 4, 3, generator=g) * 0.3).to(dev), requires_grad=False)
+        train = torch.nn.Parameter((torch.randn(6, 4, 3, generator=g) * 0.3).to(dev))
+        SF.end_weight_epoch()
+        y0 = SF.conv1d(x, frozen, None, 1, 1)
+        SF.conv1d(x, frozen, None, 1, 1)
+        assert calls["n"] == 1                                   # frozen: second call served from the cache
+        with torch.no_grad():
+            frozen.mul_(2.0)                                     # in-place update bumps the version counter
+        y1 = SF.conv1d(x, frozen, None, 1, 1)
+        assert calls["n"] == 2 and torch.allclose(y1, 2 * y0, rtol=1e-5, atol=1e-6)
+        n = calls["n"]
+        SF.conv1d(x, train, None, 1, 1); SF.conv1d(x, train, None, 1, 1)
+        assert calls["n"] == n + 2                               # trainable, no epoch: always repacked
+        SF.begin_weight_epoch()
+        SF.conv1d(x, train, None, 1, 1); SF.conv1d(x, train, None, 1, 1)
+        assert calls["n"] == n + 3                               # inside an epoch: packed once
+        SF.note_weights_updated()
+        SF.conv1d(x, train, None, 1, 1)
+        assert calls["n"] == n + 4                               # optimizer step announced: repacked
+        SF.end_weight_epoch()
+        SF.begin_weight_epoch()                                  # next training step: epoch numbers are never reused
+        SF.conv1d(x, train, None, 1, 1)
+        assert calls["n"] == n + 5
+    finally:
+        K.weight_pack = orig
+        SF.end_weight_epoch()
