@@ -18,7 +18,7 @@
 #include "svb_common.h"
 #include "conv1d.h"
 
-template <int WM, int WN, int NT, int RPW, int WS_ROWS>
+template <int WM, int WN, int NT, int RPW, int WS_ROWS, bool GATE>
 __global__ __launch_bounds__(256, 2) void svb_conv1d_mfma_kernel(SvbConvArgs a, SvbConvPlan p) {
     constexpr int BM = 32 * WM, BN = 32 * WN * NT;
     // RPW: x rows staged per wave per chunk (kc <= 4*RPW)
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_mfma_kernel(SvbConvArgs a, 
     const int m_base = mtile * BM;
     const int m_valid = min(BM, a.Cout_g - m_base);
     const float* xb = a.x + ((size_t)b * a.Cin + (size_t)g * a.Cin_g) * a.Tin;
-    const float* gb = a.in_gate ? a.in_gate + ((size_t)b * a.Cin + (size_t)g * a.Cin_g) * a.Tin : nullptr;
+    const float* gb = GATE ? a.in_gate + ((size_t)b * a.Cin + (size_t)g * a.Cin_g) * a.Tin : nullptr;
     const float* wbase = a.wp + (size_t)g * a.w_goff_k * a.w_ld + (size_t)g * a.w_goff_m + m_base;
 
     // ---- register staging (all global loads of a stage are issued before any LDS store) ----------------------
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_mfma_kernel(SvbConvArgs a, 
         const int i = lane + 64 * jj;
         const int pos = lo + i;
         xok[jj] = i < span && pos >= 0 && pos < a.Tin;
-        xsrc[jj] = pos;
+        xsrc[jj] = xok[jj] ? pos : 0;                     // out-of-range lanes read element 0 and are zeroed when staged
         xdst[jj] = (a.sx == 1) ? i : (i % a.sx) * a.ph_len + i / a.sx;
     }
     const int tap_step = ntap > 1 ? (p.tap_w[t0 + 1] - p.tap_w[t0]) : 0;   // tap slabs form an arithmetic progression
@@ -100,25 +100,23 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_mfma_kernel(SvbConvArgs a, 
         woff[u] = ok ? (p.tap_w[t0 + min(t, max(ntap - 1, 0))] * a.w_tap_stride + c * a.w_ld + col) : 0;
     }
 
+    // Branch-free loads: every load of a stage is issued unconditionally (invalid rows / lanes read a valid dummy element)
+    // and masked when the tile is written to LDS, so all of a stage's loads are in flight before the first wait.
     auto load_x = [&](int c0) {
         const int kc = min(a.kc, a.Cin_g - c0);
         const int kcp = (kc + 1) & ~1;
-        const float* xchunk = xb + (size_t)(c0 + wave) * a.Tin;
-        const float* gchunk = gb ? gb + (size_t)(c0 + wave) * a.Tin : nullptr;
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             const int r = wave + 4 * rr;
-            if (r < kcp) {
-                const bool rv = r < kc;
-                const float* xrow_p = xchunk + (size_t)(4 * rr) * a.Tin;
+            if (r < kcp) {                                     // wave-uniform
+                const size_t roff = r < kc ? (size_t)(c0 + r) * a.Tin : 0;
+                const float* xrow_p = xb + roff;
 #pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) {
-                    float v = 0.f;
-                    if (rv && xok[jj]) {
-                        v = xrow_p[xsrc[jj]];
-                        if (gchunk) v *= svb_gate(gchunk[(size_t)(4 * rr) * a.Tin + xsrc[jj]], a.in_slope);
-                    }
-                    xr[rr][jj] = v;
+                for (int jj = 0; jj < NJ; ++jj) xr[rr][jj] = xrow_p[xsrc[jj]];
+                if (GATE) {
+                    const float* grow_p = gb + roff;
+#pragma unroll
+                    for (int jj = 0; jj < NJ; ++jj) xr[rr][jj] *= svb_gate(grow_p[xsrc[jj]], a.in_slope);
                 }
             }
         }
@@ -131,9 +129,10 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_mfma_kernel(SvbConvArgs a, 
             const int r = wave + 4 * rr;
             if (r < kcp) {
                 float* xd = xs + r * a.xrow;
+                const bool rv = r < kc;
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj)
-                    if (lane + 64 * jj < span) xd[xdst[jj]] = xr[rr][jj];
+                    if (lane + 64 * jj < span) xd[xdst[jj]] = (rv && xok[jj]) ? xr[rr][jj] : 0.f;
             }
         }
     };
@@ -162,10 +161,10 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_mfma_kernel(SvbConvArgs a, 
         const float* wchunk = wbase + (size_t)c0 * a.w_ld + (size_t)tg * tap_step * a.w_tap_stride;
         if (a.w_vec) {
 #pragma unroll
-            for (int u = 0; u < WU; ++u) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (wtap[u] < nt_here && wch[u] < kc) v = *reinterpret_cast<const float4*>(wchunk + woff[u]);
-                wr[u] = v;
+            for (int u = 0; u < WU; ++u) {                    // unconditional; units outside the stage read offset 0
+                const bool ok = wtap[u] < nt_here && wch[u] < kc;
+                const float4 t = *reinterpret_cast<const float4*>(wchunk + (ok ? woff[u] : 0));
+                wr[u] = t;
             }
         } else {
 #pragma unroll
@@ -183,11 +182,13 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_mfma_kernel(SvbConvArgs a, 
             }
         }
     };
-    auto store_w = [&](int tg) {
+    auto store_w = [&](int c0, int tg) {
+        const int kc = min(a.kc, a.Cin_g - c0);
         const int nt_here = min(a.tg, ntap - tg);
 #pragma unroll
         for (int u = 0; u < WU; ++u)
-            if (wtap[u] < nt_here) *reinterpret_cast<float4*>(ws + (u * 256 + tid) * 4) = wr[u];
+            if (wtap[u] < nt_here)                             // rows past the chunk (odd-kc padding row) must be zero
+                *reinterpret_cast<float4*>(ws + (u * 256 + tid) * 4) = wch[u] < kc ? wr[u] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto compute = [&](int c0, int tg) {
         const int kc = min(a.kc, a.Cin_g - c0);
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_mfma_kernel(SvbConvArgs a, 
         __syncthreads();                                   // tap_lds visible
         if (a.fast_x) { load_x(0); store_x(0); } else { stage_x_slow(0); }
         load_w(0, 0);
-        store_w(0);
+        store_w(0, 0);
         __syncthreads();
         while (true) {
             int ntg = tg + a.tg, nc0 = c0;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_mfma_kernel(SvbConvArgs a, 
             if (!has_next) break;
             __syncthreads();
             if (ntg == 0) { if (a.fast_x) store_x(nc0); else stage_x_slow(nc0); }
-            store_w(ntg);
+            store_w(nc0, ntg);
             __syncthreads();
             c0 = nc0; tg = ntg;
         }
@@ -599,15 +600,21 @@ static int pick_cfg(int cout_g, int nq_max, long nz) {
     return best;
 }
 
-template <int WM, int WN, int NT, int RPW, int WS_ROWS>
-static int launch_one(SvbConvArgs& a, const SvbConvPlan& p, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+template <int WM, int WN, int NT, int RPW, int WS_ROWS, bool GATE>
+static void launch_one_g(const SvbConvArgs& a, const SvbConvPlan& p, dim3 grid, size_t lds_bytes, hipStream_t stream) {
     static bool attr_set = false;   // allow > 64 KiB of dynamic LDS (wide strided tiles); set once per instantiation
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_mfma_kernel<WM, WN, NT, RPW, WS_ROWS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_mfma_kernel<WM, WN, NT, RPW, WS_ROWS, GATE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((svb_conv1d_mfma_kernel<WM, WN, NT, RPW, WS_ROWS>), grid, dim3(256), lds_bytes, stream, a, p);
+    hipLaunchKernelGGL((svb_conv1d_mfma_kernel<WM, WN, NT, RPW, WS_ROWS, GATE>), grid, dim3(256), lds_bytes, stream, a, p);
+}
+
+template <int WM, int WN, int NT, int RPW, int WS_ROWS>
+static int launch_one(SvbConvArgs& a, const SvbConvPlan& p, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+    if (a.in_gate) launch_one_g<WM, WN, NT, RPW, WS_ROWS, true>(a, p, grid, lds_bytes, stream);
+    else launch_one_g<WM, WN, NT, RPW, WS_ROWS, false>(a, p, grid, lds_bytes, stream);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
