@@ -132,3 +132,43 @@ def test_mle_svb_vae_bf16x3_mel_l1_against_reference_golden(gpu_only):
     pooled = sum(v.sum().item() for v in diffs.values()) / sum(v.numel() for v in diffs.values())
     assert pooled <= 1e-4, (pooled, l1s)
     assert max(l1s.values()) <= 3e-4, l1s
+
+
+def test_stacked_voices_equal_separate_calls(dev):
+    """`stack_ways`: the a2a and p2p ways as one stacked launch sequence must give what two separate calls give --
+    outputs, gradients, and the running statistics of the train-mode BatchNorms (updated per half, in order).  Small dims."""
+    import copy
+    from neuralsvb_amd.modules.svb_vae import MleSVBVAE
+    hp = dict(HP, hidden_size=32, fvae_enc_dec_hidden=32, latent_size=16, fvae_enc_n_layers=1, fvae_dec_n_layers=1,
+              asr_enc_layers=1)
+    torch.manual_seed(0)
+    m1 = MleSVBVAE(70, hp).to(dev)
+    # spk_proj of the latent map is hard-wired to 256 channels in the reference; it is not on the a2a / p2p ways
+    m2 = copy.deepcopy(m1)
+    m1.stack_ways, m2.stack_ways = True, False
+    m1.train(); m2.train()
+    g = torch.Generator().manual_seed(1)
+    B, T = 2, 64            # T/4 = 16 frames survive the encoder's three stride-2 pooling convs
+    mels = [(torch.randn(B, T, 80, generator=g) * 0.5 - 2).to(dev) for _ in range(2)]
+    pitch = [torch.randint(1, 255, (B, T), generator=g).to(dev) for _ in range(2)]
+    spk = (torch.randn(B, 256, generator=g) / 16).to(dev)
+    eps = [torch.randn(B, hp["latent_size"], 1, generator=g).to(dev) for _ in range(2)]
+    outs = []
+    for m in (m1, m2):
+        o = m(amateur_mel=mels[0], prof_mel=mels[1], amateur_pitch=pitch[0], prof_pitch=pitch[1], amateur_spk_id=spk,
+              prof_spk_id=spk, a2p_alignment=None, infer=False, concurrent_ways=["a2a", "p2p"], eps_a2a=eps[0], eps_p2p=eps[1])
+        loss = sum(o[w]["kl"] + (o[w]["mel_out"] - tg).abs().mean() for w, tg in (("a2a", mels[0]), ("p2p", mels[1])))
+        loss.backward()
+        outs.append(o)
+    for w in ("a2a", "p2p"):
+        for k in ("mel_out", "kl", "m_q", "logs_q", "z_q"):
+            a, b = outs[0][w][k], outs[1][w][k]
+            assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item()), (w, k)
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if p2.grad is None:
+            assert p1.grad is None, k
+            continue
+        assert (p1.grad - p2.grad).abs().max().item() <= 2e-4 * max(1e-3, p2.grad.abs().max().item()), k
+    for (k, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
+        if b1.is_floating_point():
+            assert torch.allclose(b1, b2, rtol=1e-5, atol=1e-6), k          # BatchNorm running_mean / running_var
