@@ -49,6 +49,6 @@ def test_stacked_critic_calls_equal_separate_calls(dev):
     loss_many = sum(((o["y"] - 1) ** 2).mean() * (i + 1) for i, o in enumerate(many))
     grads_many = torch.autograd.grad(loss_many, xs + list(disc.parameters()))
     for a, b in zip(sep, many):
-        assert (a - b["y"]).abs().max().item() < 1e-5
+        assert (a - b["y"]).abs().max().item() < 5e-5 * max(1.0, a.abs().max().item())
     for a, b in zip(grads_sep, grads_many):
-        assert (a - b).abs().max().item() <= 1e-5 * max(1.0, a.abs().max().item())
+        assert (a - b).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item())

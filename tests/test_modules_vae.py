@@ -163,12 +163,12 @@ def test_stacked_voices_equal_separate_calls(dev):
     for w in ("a2a", "p2p"):
         for k in ("mel_out", "kl", "m_q", "logs_q", "z_q"):
             a, b = outs[0][w][k], outs[1][w][k]
-            assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item()), (w, k)
+            assert (a - b).abs().max().item() <= 5e-5 * max(1.0, b.abs().max().item()), (w, k)
     for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         if p2.grad is None:
             assert p1.grad is None, k
             continue
-        assert (p1.grad - p2.grad).abs().max().item() <= 2e-4 * max(1e-3, p2.grad.abs().max().item()), k
+        assert (p1.grad - p2.grad).abs().max().item() <= 5e-4 * max(1e-3, p2.grad.abs().max().item()), k
     for (k, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
         if b1.is_floating_point():
-            assert torch.allclose(b1, b2, rtol=1e-5, atol=1e-6), k          # BatchNorm running_mean / running_var
+            assert torch.allclose(b1, b2, rtol=1e-4, atol=1e-5), k          # BatchNorm running_mean / running_var
