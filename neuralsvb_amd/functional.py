@@ -32,13 +32,34 @@ def set_precision(mode):
     K.WGRAD_BF16X3 = mode == "bf16x3"
 
 
+class precision_scope:
+    """`with precision_scope("fp32"):` -- conv arithmetic of the forward ops issued inside (None: leave the global mode).
+    The data-gradient follows the forward's packed weights; weight gradients follow the global mode."""
+
+    def __init__(self, mode):
+        if mode not in (None, "fp32", "bf16x3"):
+            raise ValueError(mode)
+        self.mode = mode
+
+    def __enter__(self):
+        global PRECISION
+        self.prev = PRECISION
+        if self.mode is not None:
+            PRECISION = self.mode
+
+    def __exit__(self, *exc):
+        global PRECISION
+        PRECISION = self.prev
+        return False
+
+
 DIRECT_GRADS = True      # weight/bias gradients of leaf parameters that already own a `.grad` buffer are accumulated into
                          # it by the reduce kernel itself (autograd gets None and skips its `grad += new` pass)
 
 
 def _gbuf(p):
-    if not DIRECT_GRADS or p is None or not p.is_leaf or p.grad is None:
-        return None
+    if not DIRECT_GRADS or p is None or not p.is_leaf or p.grad is None or not p.requires_grad:
+        return None      # (a frozen parameter may still own a flat-buffer `.grad` view: never accumulate into it)
     gb = p.grad
     return gb if (gb.dtype == torch.float32 and gb.is_contiguous() and gb.shape == p.shape) else None
 
@@ -295,7 +316,11 @@ class _WNStackFn(torch.autograd.Function):
         if mask is not None:
             dout = dout * mask[:, None, :]
         grads = [None] * ctx.n_in
-        dG = torch.empty_like(G) if G is not None else None
+        need = ctx.needs_input_grad               # index 3 + t for tensors[t]
+        need_x, need_gcond = need[3], need[5]
+        need_cond_w = G is not None and any(need[6:9])
+        need_dG = G is not None and (need_cond_w or need_gcond)
+        dG = torch.empty_like(G) if need_dG else None
         dx_next = None  # gradient flowing into x_{i+1}
         for i in reversed(range(n_layers)):
             base = 5 + 9 * i
@@ -305,39 +330,47 @@ class _WNStackFn(torch.autograd.Function):
             dil = dr ** i
             pad = (ks * dil - dil) // 2
             last = i == n_layers - 1
+            p = 6 + 6 * i
+            need_in_w, need_rs_w = any(need[3 + p:6 + p]), any(need[6 + p:9 + p])
+            need_dx = i > 0 or need_x
             if last:
                 drs, dxm = dout, None
             else:
                 drs, dxm = K.wn_res_skip_bwd(dx_next, dout, mask, want_dxm=True)
             # res/skip 1x1 conv
-            r = K.conv1d_wgrad(drs, acts, 1, v=rs_v if rs_g is not None else None, g=rs_g, want_bias=True,
-                               sinks=_sinks(rs_v, rs_g, rs_b))
-            p = 6 + 6 * i
-            if rs_g is not None:
-                grads[p + 3], grads[p + 4], grads[p + 5] = r
-            else:
-                grads[p + 3], grads[p + 5] = r
+            if need_rs_w:           # (frozen weights -- e.g. the generator during the latent-map pass -- get no gradient)
+                r = K.conv1d_wgrad(drs, acts, 1, v=rs_v if rs_g is not None else None, g=rs_g, want_bias=True,
+                                   sinks=_sinks(rs_v, rs_g, rs_b))
+                if rs_g is not None:
+                    grads[p + 3], grads[p + 4], grads[p + 5] = r
+                else:
+                    grads[p + 3], grads[p + 5] = r
+            if not (need_in_w or need_dG or need_dx):
+                dx_next = None
+                continue
             dacts = K.conv1d_transposed(drs, pb_rs, C, acts.shape[2], 1)
             dxin = K.wn_gate_bwd(xin, G, dacts, i * 2 * C, dg=dG)
-            r = K.conv1d_wgrad(dxin, x_i, ks, 1, pad, dil, v=in_v if in_g is not None else None, g=in_g, want_bias=True,
-                               sinks=_sinks(in_v, in_g, in_b))
-            if in_g is not None:
-                grads[p + 0], grads[p + 1], grads[p + 2] = r
-            else:
-                grads[p + 0], grads[p + 2] = r
-            if i > 0 or ctx.needs_input_grad[3]:
+            if need_in_w:
+                r = K.conv1d_wgrad(dxin, x_i, ks, 1, pad, dil, v=in_v if in_g is not None else None, g=in_g, want_bias=True,
+                                   sinks=_sinks(in_v, in_g, in_b))
+                if in_g is not None:
+                    grads[p + 0], grads[p + 1], grads[p + 2] = r
+                else:
+                    grads[p + 0], grads[p + 2] = r
+            if need_dx:
                 dx_next = K.conv1d_transposed(dxin, pb_in, C, x_i.shape[2], ks, 1, pad, dil, residual=dxm)
             else:
                 dx_next = None
         grads[0] = dx_next
-        if G is not None:
-            r = K.conv1d_wgrad(dG, gcond, 1, v=cond_v if cond_g is not None else None, g=cond_g, want_bias=True,
-                               sinks=_sinks(cond_v, cond_g, cond_b))
-            if cond_g is not None:
-                grads[3], grads[4], grads[5] = r
-            else:
-                grads[3], grads[5] = r
-            if ctx.needs_input_grad[5]:
+        if need_dG:
+            if need_cond_w:
+                r = K.conv1d_wgrad(dG, gcond, 1, v=cond_v if cond_g is not None else None, g=cond_g, want_bias=True,
+                                   sinks=_sinks(cond_v, cond_g, cond_b))
+                if cond_g is not None:
+                    grads[3], grads[4], grads[5] = r
+                else:
+                    grads[3], grads[5] = r
+            if need_gcond:
                 grads[2] = K.conv1d_transposed(dG, cond_pb, gcond.shape[1], gcond.shape[2], 1)
         return (None, None, None) + tuple(grads)
 

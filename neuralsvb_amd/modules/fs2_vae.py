@@ -23,6 +23,7 @@ class WN(nn.Module):
             raise NotImplementedError("the hot path uses p_dropout=0 (fs2_vae.py:115,143)")
         self.hidden_channels, self.kernel_size, self.dilation_rate = hidden_channels, kernel_size, dilation_rate
         self.n_layers, self.gin_channels = n_layers, gin_channels
+        self.precision = None
         self.in_layers, self.res_skip_layers = nn.ModuleList(), nn.ModuleList()
         if gin_channels != 0:
             self.cond_layer = Conv1d(gin_channels, 2 * hidden_channels * n_layers, 1, weight_norm=True)
@@ -41,8 +42,9 @@ class WN(nn.Module):
         """x [B,C,T]; x_mask [B,T] (or None); g [B,gin,T].  Returns output * mask  (fs2_vae.py:61-91)."""
         layers = [self._p(a) + self._p(b) for a, b in zip(self.in_layers, self.res_skip_layers)]
         cond = self._p(self.cond_layer) if (g is not None and self.gin_channels != 0) else None
-        return SF.wn_stack(x, x_mask, g if cond is not None else None, cond, layers, self.kernel_size,
-                           self.dilation_rate)
+        with SF.precision_scope(self.precision):
+            return SF.wn_stack(x, x_mask, g if cond is not None else None, cond, layers, self.kernel_size,
+                               self.dilation_rate)
 
     def remove_weight_norm(self):
         for m in list(self.in_layers) + list(self.res_skip_layers) + ([self.cond_layer] if self.gin_channels else []):

@@ -25,6 +25,7 @@ class Conv1d(nn.Module):
         self.stride, self.padding, self.dilation, self.groups = stride, padding, dilation, groups
         self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
         self.is_weight_norm = weight_norm
+        self.precision = None           # None: the global conv_precision; "fp32" pins this layer (set_layer_precision)
         if weight_norm:
             w = ref.weight.data
             self.weight_g = nn.Parameter(w.flatten(1).norm(dim=1).view(-1, 1, 1))
@@ -34,6 +35,10 @@ class Conv1d(nn.Module):
         self.bias = ref.bias if bias else None
 
     def forward(self, x, in_slope=None, out_act=SF.ACT_NONE, out_slope=0.0, residual=None, mask=None):
+        with SF.precision_scope(self.precision):
+            return self._forward(x, in_slope, out_act, out_slope, residual, mask)
+
+    def _forward(self, x, in_slope, out_act, out_slope, residual, mask):
         if self.is_weight_norm:
             return SF.conv1d(x, self.weight_v, self.bias, self.stride, self.padding, self.dilation, self.groups,
                              weight_g=self.weight_g, in_slope=in_slope, out_act=out_act, out_slope=out_slope,
@@ -65,6 +70,7 @@ class ConvTranspose1d(nn.Module):
         self.stride, self.padding = stride, padding
         self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
         self.is_weight_norm = weight_norm
+        self.precision = None
         if weight_norm:
             w = ref.weight.data
             self.weight_g = nn.Parameter(w.flatten(1).norm(dim=1).view(-1, 1, 1))
@@ -74,6 +80,10 @@ class ConvTranspose1d(nn.Module):
         self.bias = ref.bias if bias else None
 
     def forward(self, x, in_slope=None, mask=None):
+        with SF.precision_scope(self.precision):
+            return self._forward(x, in_slope, mask)
+
+    def _forward(self, x, in_slope, mask):
         if self.is_weight_norm:
             return SF.conv_transpose1d(x, self.weight_v, self.bias, self.stride, self.padding, weight_g=self.weight_g,
                                        in_slope=in_slope, mask=mask)
@@ -102,9 +112,11 @@ class LinearNCT(nn.Module):
                 nn.init.constant_(ref.bias, 0.0)
         self.weight = ref.weight
         self.bias = ref.bias if bias else None
+        self.precision = None
 
     def forward(self, x, out_act=SF.ACT_NONE, mask=None):
-        return SF.conv1d(x, self.weight[:, :, None], self.bias, out_act=out_act, mask=mask)
+        with SF.precision_scope(self.precision):
+            return SF.conv1d(x, self.weight[:, :, None], self.bias, out_act=out_act, mask=mask)
 
 
 class LayerNormNCT(nn.Module):
@@ -134,3 +146,20 @@ def attach_opaque(root, dotted, shape, buffer=False, dtype=torch.float32):
         m.register_buffer(parts[-1], t)
     else:
         m.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
+
+
+def set_layer_precision(root, rules):
+    """rules: {module-name prefix: "fp32" | "bf16x3" | None}.  Pins the conv arithmetic of every layer below a prefix
+    (longest prefix wins); layers that match no prefix follow the global `conv_precision`."""
+    n = 0
+    for name, m in root.named_modules():
+        if not hasattr(m, "precision"):
+            continue
+        best = None
+        for pre in rules:
+            if (name == pre or name.startswith(pre + ".") or pre == "") and (best is None or len(pre) > len(best)):
+                best = pre
+        if best is not None:
+            m.precision = rules[best]
+            n += 1
+    return n

@@ -266,9 +266,12 @@ class SVBVAEMleTask(BaseTask):
                         self._gen_mel_buf = {}
                     gt = {}
                     for w, o in self.model_out.items():
-                        buf = self._gen_mel_buf.get(w)
-                        if buf is None or buf.shape != o["mel_out"].shape:
-                            buf = self._gen_mel_buf[w] = torch.empty_like(o["mel_out"])
+                        # one buffer per (way, shape), never freed: a captured graph has the address baked in, and the
+                        # Trainer keeps graphs of several batch shapes alive at once
+                        bkey = (w, tuple(o["mel_out"].shape))
+                        buf = self._gen_mel_buf.get(bkey)
+                        if buf is None:
+                            buf = self._gen_mel_buf[bkey] = torch.empty_like(o["mel_out"])
                         buf.copy_(o["mel_out"])
                         gt[w] = {"mel_out": buf}
                     self.model_out_gt = gt

@@ -52,13 +52,19 @@ def mel_fn_hip(hp, device):
 
 
 def build_items(n_items, seconds, hp, mel_fn, seed0=0):
+    """seconds: one clip length for all items, or a sequence (cycled) of per-item lengths (ragged batches)."""
     sr, hop = hp["audio_sample_rate"], hp["hop_size"]
+    ragged = not np.isscalar(seconds)
+    secs = [float(seconds[i % len(seconds)]) for i in range(n_items)] if ragged else [float(seconds)] * n_items
     wa, wp, twp = [], [], []
     for i in range(n_items):
-        a, _ = make_clip(seconds, sr, seed0 + i, warp=False, base=180.0 + 15 * (i % 8))
-        p, tw = make_clip(seconds, sr, seed0 + i, warp=True, base=180.0 + 15 * (i % 8))
+        a, _ = make_clip(secs[i], sr, seed0 + i, warp=False, base=180.0 + 15 * (i % 8))
+        p, tw = make_clip(secs[i], sr, seed0 + i, warp=True, base=180.0 + 15 * (i % 8))
         wa.append(a); wp.append(p); twp.append(tw)
-    mel_a, mel_p = mel_fn(np.stack(wa)), mel_fn(np.stack(wp))
+    if ragged:
+        mel_a, mel_p = [mel_fn(w[None])[0] for w in wa], [mel_fn(w[None])[0] for w in wp]
+    else:
+        mel_a, mel_p = mel_fn(np.stack(wa)), mel_fn(np.stack(wp))
     items = []
     rng = np.random.RandomState(seed0 + 77)
     for i in range(n_items):
@@ -74,7 +80,7 @@ def build_items(n_items, seconds, hp, mel_fn, seed0=0):
         items.append({"item_name": f"synth_{seed0 + i:05d}", "txt": "synthetic", "mel": mel_a[i], "prof_mel": mel_p[i],
                       "f0": f0_a, "prof_f0": f0_p, "pitch": pitch_utils.f0_to_coarse(f0_a),
                       "prof_pitch": pitch_utils.f0_to_coarse(f0_p), "a2p_f0_alignment": align,
-                      "multi_spk_emb": emb.astype(np.float32), "len": T, "sec": seconds})
+                      "multi_spk_emb": emb.astype(np.float32), "len": T, "sec": secs[i]})
     return items
 
 

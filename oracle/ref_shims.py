@@ -114,6 +114,19 @@ def install(chdir_to_reference: bool = False):
 
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
+    # The reference's `tasks/` has no __init__.py (namespace package); the product keeps a regular `tasks` package at the
+    # repo root for the drop-in dotted paths, and regular packages win over namespace packages whatever sys.path says.
+    # Pin the reference's directories explicitly for this (checker) process.
+    for top in ("tasks", "vocoders", "modules", "data_gen"):
+        ref_dir = os.path.join(REFERENCE_ROOT, top)
+        cur = sys.modules.get(top)
+        if os.path.isdir(ref_dir) and not os.path.exists(os.path.join(ref_dir, "__init__.py")) and \
+                (cur is None or ref_dir not in list(getattr(cur, "__path__", []))):
+            for k in [k for k in sys.modules if k == top or k.startswith(top + ".")]:
+                del sys.modules[k]
+            m = types.ModuleType(top)
+            m.__path__ = [ref_dir]
+            sys.modules[top] = m
     if chdir_to_reference:
         os.chdir(REFERENCE_ROOT)
 

@@ -86,6 +86,36 @@ def make_vae_inputs(B=2, T=64, lens=(64, 52), seed=0):
     return out
 
 
+BENCH_LENS = (1124, 1124, 1100, 1124, 1056, 1124, 1003, 1124, 1124, 960, 1124, 1088, 1124, 1124, 912, 1124)
+BENCH_FRAME_STRIDE = 8
+
+
+def vae_bench_shape(model):
+    """configs[1] shape (B=16 clips x T=1124 frames, ragged lengths): the reference forward of all three ways.
+    Inputs are regenerated from the seed by the test (make_vae_inputs is deterministic); the file keeps the injected
+    N(0,1) draws, input checksums, every BENCH_FRAME_STRIDE-th frame of each way's mel_out, the per-clip latent
+    statistics and the scalar terms."""
+    inp = make_vae_inputs(B=16, T=1124, lens=BENCH_LENS, seed=21)
+    rec = []
+    with record_rng(rec), torch.no_grad():
+        out = model(amateur_mel=inp["mels"], prof_mel=inp["prof_mels"], amateur_pitch=inp["pitch"],
+                    prof_pitch=inp["prof_pitch"], amateur_spk_id=inp["spk"], prof_spk_id=inp["spk"],
+                    a2p_alignment=inp["a2p_alignment"], p2a_alignment=None, infer=False,
+                    concurrent_ways=["a2a", "p2p", "a2p"], disable_map=False)
+    assert [k for k, _ in rec] == ["randn_like", "randn_like"]
+    save = {"eps_a2a": rec[0][1].numpy(), "eps_p2p": rec[1][1].numpy(), "lens": np.array(BENCH_LENS),
+            "frame_stride": np.array(BENCH_FRAME_STRIDE),
+            "input_checksum": np.array([float(inp[k].double().sum()) for k in ("mels", "prof_mels", "pitch", "prof_pitch", "spk",
+                                                                                "a2p_alignment")])}
+    for way in ("a2a", "p2p", "a2p"):
+        save[f"{way}.mel_out"] = out[way]["mel_out"][:, ::BENCH_FRAME_STRIDE].numpy()
+        save[f"{way}.mel_out_abs_mean"] = np.array(float(out[way]["mel_out"].double().abs().mean()))
+        for k in ("kl", "m_q", "logs_q", "z_q", "mle"):
+            if k in out[way] and isinstance(out[way][k], torch.Tensor):
+                save[f"{way}.{k}"] = out[way][k].numpy()
+    np.savez_compressed(os.path.join(HERE, "vae_mle_b16.npz"), **save)
+
+
 def main():
     torch.manual_seed(1234)
     torch.set_num_threads(8)
@@ -130,6 +160,7 @@ def main():
     mo, tg = out["a2a"]["mel_out"].detach(), inp["mels"]
     save["loss.ssim_map_a2a"] = ssim(mo[:, None] + 6.0, tg[:, None] + 6.0, size_average=False).numpy()
     np.savez_compressed(os.path.join(HERE, "vae_mle.npz"), **save)
+    vae_bench_shape(model)
 
     # ---------------- mel discriminator (G1), eval mode (Dropout2d off), fixed windows ----------------
     from modules.fastspeech.multi_window_disc import Discriminator

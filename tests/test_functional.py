@@ -262,3 +262,35 @@ def test_weight_pack_cache_semantics(dev):
     finally:
         K.weight_pack = orig
         SF.end_weight_epoch()
+
+
+def test_wn_stack_frozen_weights_receive_no_gradient(dev):
+    """Latent-map pass (svb_vae_task.py:634-661): the generator is frozen (requires_grad False) but keeps its flat-buffer
+    `.grad` views; the decoder WN backward must only produce dx -- nothing may be accumulated into the frozen grads."""
+    g_ = torch.Generator().manual_seed(77)
+    B, C, T, gin, n, ks = 2, 8, 37, 6, 2, 5
+    x = torch.randn(B, C, T, generator=g_)
+    gcond = torch.randn(B, gin, T, generator=g_)
+    cond = [torch.randn(2 * C * n, gin, 1, generator=g_) * 0.3, torch.rand(2 * C * n, 1, 1, generator=g_) + 0.5,
+            torch.randn(2 * C * n, generator=g_) * 0.1]
+    layers = []
+    for i in range(n):
+        rc = 2 * C if i < n - 1 else C
+        layers.append([torch.randn(2 * C, C, ks, generator=g_) * 0.3, torch.rand(2 * C, 1, 1, generator=g_) + 0.5,
+                       torch.randn(2 * C, generator=g_) * 0.1,
+                       torch.randn(rc, C, 1, generator=g_) * 0.3, torch.rand(rc, 1, 1, generator=g_) + 0.5,
+                       torch.randn(rc, generator=g_) * 0.1])
+    xr = x.clone().requires_grad_(True)
+    yr = _wn_ref(xr, None, gcond, cond, layers, ks)
+    dy = torch.randn(yr.shape, generator=g_)
+    yr.backward(dy)
+    xd = _leaf(x, dev)
+    frozen = [t.to(dev).requires_grad_(False) for t in cond] + [t.to(dev).requires_grad_(False) for lp in layers for t in lp]
+    for t in frozen:
+        t.grad = torch.zeros_like(t)          # FlatGradSync leaves such views on frozen parameters
+    cd, ld = frozen[:3], [frozen[3 + 6 * i: 9 + 6 * i] for i in range(n)]
+    y = SF.wn_stack(xd, None, gcond.to(dev), cd, ld, ks)
+    y.backward(dy.to(dev))
+    assert rel_err(xd.grad, xr.grad) < 5e-5
+    for t in frozen:
+        assert float(t.grad.abs().max()) == 0.0
