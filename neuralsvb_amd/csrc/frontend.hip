@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256) void svb_f0_to_coarse_f64_kernel(const double*
 __global__ __launch_bounds__(256) void svb_f0_to_coarse_f32_kernel(const float* f0, int64_t* out, int64_t n, float mel_min,
                                                                    float scale_num, float mel_range) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float m = 1127.f * logf(1.f + f0[i] / 700.f);
+        // correctly rounded fp32 log (evaluated in double): independent of the device's logf, equals the CPU reference's
+        float m = 1127.f * (float)log((double)(1.f + f0[i] / 700.f));
         if (m > 0.f) m = (m - mel_min) * scale_num / mel_range + 1.f;
         if (m <= 1.f) m = 1.f;
         if (m > 255.f) m = 255.f;

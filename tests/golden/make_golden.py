@@ -116,6 +116,47 @@ def vae_bench_shape(model):
     np.savez_compressed(os.path.join(HERE, "vae_mle_b16.npz"), **save)
 
 
+def grad_digest(t):
+    """[l2 norm, 24 evenly spaced elements] of a gradient tensor (float64)."""
+    g = t.detach().double().flatten()
+    idx = torch.linspace(0, g.numel() - 1, min(24, g.numel())).long()
+    return np.concatenate([[g.norm().item()], g[idx].numpy()])
+
+
+def hifigan_train_golden(mpd, msd, y, yh):
+    """V3/V4 in TRAIN mode + V5: one discriminator pass (discriminator_loss, backward -> parameter gradients) and one
+    generator pass (generator_loss + feature_loss, backward -> d/d y_hat), reference modules/hifigan/hifigan.py:202-365.
+    MSD scale 0 runs its spectral-norm power iteration on every forward (two per MSD call); the u / v buffers are first
+    converged with 10 train-mode forwards (procedural u, v start far from the dominant singular pair) and stored."""
+    from modules.hifigan.hifigan import discriminator_loss, feature_loss, generator_loss
+    mpd.train(); msd.train()
+    with torch.no_grad():
+        for _ in range(10):
+            msd(y, yh)
+    save = {}
+    for k, v in msd.state_dict().items():
+        if k.endswith("weight_u") or k.endswith("weight_v") and v.dim() == 1:
+            save[f"msd.buf0.{k}"] = v.numpy().copy()
+    for name, d in (("mpd", mpd), ("msd", msd)):
+        d.zero_grad()
+        y_d_rs, y_d_gs, _, _ = d(y, yh.detach())
+        lr_, lg_ = discriminator_loss(y_d_rs, y_d_gs)
+        (lr_ + lg_).backward()
+        save[f"{name}.d_loss"] = np.array([lr_.item(), lg_.item()])
+        for k, p_ in d.named_parameters():
+            save[f"{name}.dgrad.{k}"] = grad_digest(p_.grad)
+        yh2 = yh.clone().requires_grad_(True)
+        y_d_rs, y_d_gs, fmap_rs, fmap_gs = d(y, yh2)
+        la, lf = generator_loss(y_d_gs), feature_loss(fmap_rs, fmap_gs)
+        (la + lf).backward()
+        save[f"{name}.g_loss"] = np.array([la.item(), lf.item()])
+        save[f"{name}.g_grad_yhat"] = yh2.grad.numpy()
+    for k, v in msd.state_dict().items():
+        if k.endswith("weight_u") or k.endswith("weight_v") and v.dim() == 1:
+            save[f"msd.buf1.{k}"] = v.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "hifigan_train.npz"), **save)
+
+
 def main():
     torch.manual_seed(1234)
     torch.set_num_threads(8)
@@ -212,6 +253,7 @@ def main():
             save[f"{name}.fmap_g_stats"] = np.stack([fmap_stats(t) for fm in fmap_gs for t in fm])
             save[f"{name}.fmap_shapes"] = np.array([list(t.shape) + [0] * (4 - t.dim()) for fm in fmap_rs for t in fm])
     np.savez_compressed(os.path.join(HERE, "hifigan_disc.npz"), **save)
+    hifigan_train_golden(mpd, msd, y, yh)
 
     with open(os.path.join(HERE, "ref_state_keys.json"), "w") as f:
         json.dump(keys, f)

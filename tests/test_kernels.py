@@ -7,6 +7,8 @@ output scale (stated per test); integer outputs are compared exactly.
 """
 import math
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -290,8 +292,12 @@ def test_f0_to_coarse_bit_exact(dev):
     f32 = torch.from_numpy(f0.astype(np.float32))
     ref32 = ofe.f0_to_coarse(f32)
     out32 = K.f0_to_coarse(f32.to(dev))
-    assert (out32.cpu() != ref32).float().mean() < 1e-3  # fp32 log may differ by 1 ulp at a bin edge
-    assert (out32.cpu() - ref32).abs().max() <= 1
+    assert torch.equal(out32.cpu(), ref32)          # torch branch: correctly rounded fp32 log -> exact integers too
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "f0_to_coarse.npz"))      # the reference's own outputs
+    g32 = K.f0_to_coarse(torch.from_numpy(d["f0"].astype(np.float32)).to(dev))
+    assert np.array_equal(g32.cpu().numpy(), d["coarse_torch"])
+    g64 = K.f0_to_coarse(torch.from_numpy(d["f0"]).to(dev))
+    assert np.array_equal(g64.cpu().numpy(), d["coarse_np"])
 
 
 def test_ssim_map_forward_backward(dev):

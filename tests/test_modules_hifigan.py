@@ -127,3 +127,51 @@ def test_ingraph_mel_with_grad_matches_fused_kernel_and_oracle(dev):
     assert (fused.cpu() - ref.detach()).abs().max() < 2e-4
     m.backward(dm.to(dev))
     assert ((yd.grad.cpu() - y.grad).abs().max() / y.grad.abs().max()).item() < 2e-3
+
+
+@pytest.mark.parametrize("name", ["mpd", "msd"])
+def test_discriminators_train_mode_losses_and_gradients(dev, name):
+    """V3 / V4 in TRAIN mode + V5 against the unmodified reference (tests/golden/make_golden.py:hifigan_train_golden):
+    discriminator pass (discriminator_loss -> every parameter gradient), generator pass (generator_loss + feature_loss ->
+    d/d y_hat), and the spectral-norm power iteration of MSD scale 0 (u / v buffers after the four forwards)."""
+    _slow(dev)
+    from neuralsvb_amd.modules import hifigan as H
+    from tests.golden.make_golden import grad_digest
+    d = np.load(os.path.join(G, "hifigan_disc.npz"))
+    z = np.load(os.path.join(G, "hifigan_train.npz"))
+    if name == "mpd":
+        m = _load(H.MultiPeriodDiscriminator(), "MultiPeriodDiscriminator", "model_disc.mpd.")
+    else:
+        m = _load(H.MultiScaleDiscriminator(), "MultiScaleDiscriminator", "model_disc.msd.")
+        sd = m.state_dict()
+        for k in z.files:
+            if k.startswith("msd.buf0."):
+                sd[k[len("msd.buf0."):]].copy_(t(z[k]))
+    m = m.to(dev).train()
+    y, yh = t(d["y"]).to(dev), t(d["y_hat"]).to(dev)
+    m.zero_grad()
+    y_d_rs, y_d_gs, _, _ = m(y, yh)
+    lr_, lg_ = H.discriminator_loss(y_d_rs, y_d_gs)
+    (lr_ + lg_).backward()
+    assert np.allclose([lr_.item(), lg_.item()], z[f"{name}.d_loss"], rtol=2e-4, atol=1e-6), (lr_.item(), lg_.item(), z[f"{name}.d_loss"])
+    worst = 0.0
+    for k, p in m.named_parameters():
+        ref, got = z[f"{name}.dgrad.{k}"], grad_digest(p.grad.cpu())
+        rel = abs(got[0] - ref[0]) / max(ref[0], 1e-12)
+        worst = max(worst, rel)
+        assert rel < 3e-3, (k, got[0], ref[0])
+        rms = ref[0] / np.sqrt(p.numel())
+        assert np.abs(got[1:] - ref[1:]).max() <= 2e-2 * max(rms, np.abs(ref[1:]).max()), k
+    yh2 = yh.clone().requires_grad_(True)
+    y_d_rs, y_d_gs, fmap_rs, fmap_gs = m(y, yh2)
+    la, lf = H.generator_loss(y_d_gs), H.feature_loss(fmap_rs, fmap_gs)
+    (la + lf).backward()
+    assert np.allclose([la.item(), lf.item()], z[f"{name}.g_loss"], rtol=2e-4, atol=1e-6), (la.item(), lf.item(), z[f"{name}.g_loss"])
+    gref = t(z[f"{name}.g_grad_yhat"])
+    assert ((yh2.grad.cpu() - gref).abs().max() / gref.abs().max()).item() < 3e-3
+    if name == "msd":
+        sd = m.state_dict()
+        for k in z.files:
+            if k.startswith("msd.buf1."):
+                assert np.abs(sd[k[len("msd.buf1."):]].cpu().numpy() - z[k]).max() < 2e-5, k
+    print(name, "worst grad-norm rel err", worst)

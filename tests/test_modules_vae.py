@@ -62,12 +62,9 @@ def test_mle_svb_vae_forward_matches_reference_golden(dev):
             # latent statistics go through exp() and train-mode BatchNorm over very few positions: relative bound
             tol = 2e-4 * max(1.0, ref.abs().max().item()) if k in ("z_q", "m_q", "logs_q") else 3e-4
             assert err < tol, (way, k, err)
-    # north-star gate: mel-L1 vs reference <= 1e-4
-    diffs = {way: (out[way]["mel_out"].cpu() - t(d[f"{way}.mel_out"])).abs() for way in ("a2a", "p2p", "a2p")}
-    l1s = {way: v.mean().item() for way, v in diffs.items()}
-    pooled = sum(v.sum().item() for v in diffs.values()) / sum(v.numel() for v in diffs.values())
-    assert pooled <= 1e-4, (pooled, l1s)
-    assert max(l1s.values()) <= 3e-4, l1s
+    # north-star gate: mel-L1 vs reference <= 1e-4, for EACH way (fp32 MFMA arithmetic: measured 1.4e-6 .. 4.4e-6)
+    l1s = {way: (out[way]["mel_out"].cpu() - t(d[f"{way}.mel_out"])).abs().mean().item() for way in ("a2a", "p2p", "a2p")}
+    assert max(l1s.values()) <= 1e-4, l1s
     mle_ref = float(d["a2p.mle"])      # sum of ((z' - m_p)/sigma_p)^2 terms: relative bound
     assert abs(out["a2p"]["mle"].item() - mle_ref) < 5e-4 * max(1.0, abs(mle_ref)), (out["a2p"]["mle"].item(), mle_ref)
 
@@ -105,13 +102,58 @@ def test_mle_svb_vae_gradients_match_oracle(dev):
     print("worst relative grad error", worst)
 
 
+def _bench_shape_case():
+    """configs[1] shape: B=16 clips x T=1124 frames, ragged lengths (tests/golden/make_golden.py:vae_bench_shape)."""
+    import sys
+    sys.path.insert(0, G)
+    import make_golden as M
+    d = np.load(os.path.join(G, "vae_mle_b16.npz"))
+    inp = M.make_vae_inputs(B=16, T=1124, lens=tuple(int(x) for x in d["lens"]), seed=21)
+    chk = np.array([float(inp[k].double().sum()) for k in ("mels", "prof_mels", "pitch", "prof_pitch", "spk", "a2p_alignment")])
+    assert np.allclose(chk, d["input_checksum"], rtol=1e-12, atol=0), "regenerated inputs differ from the golden run's"
+    return d, inp
+
+
 @pytest.mark.gpu
-def test_mle_svb_vae_bf16x3_mel_l1_against_reference_golden(gpu_only):
-    """`conv_precision: bf16x3` (the bench's arithmetic): mel-L1 of the generated mels (all ways of the golden batch pooled)
-    against the unmodified reference's golden output must stay within BASELINE.json's tolerance (<= 1e-4); pure bf16
-    operands give ~1e-2.  Per way the split's rounding noise (~6x fp32's) lands at a2a 2e-5, a2p 8e-6 and p2p 0.9-1.9e-4
-    depending on tile choice: the golden batch has B = 2, so the encoder's train-mode BatchNorms normalise with the
-    statistics of two clips and amplify noise in the professional voice's global latent; each way is bounded at 3e-4."""
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_mle_svb_vae_bench_shape_mel_l1_per_way(gpu_only, precision):
+    """THE north-star parity gate, at the shape and in the arithmetic `bench.py` measures (BASELINE configs[1]: batch 16 x
+    6 s clips, T = 1124; `conv_precision: bf16x3`): mel-L1 of EACH way (a2a, p2p, a2p) against the unmodified reference's
+    CPU output <= 1e-4.  Measured on the MI355X: bf16x3 9.8e-6 per way, fp32 1.2e-6."""
+    from neuralsvb_amd import functional as SF
+    dev = gpu_only
+    d, inp = _bench_shape_case()
+    model, _ = build_model(dev)
+    model.train()
+    SF.set_precision(precision)
+    try:
+        with torch.no_grad():
+            out = model(amateur_mel=inp["mels"].to(dev), prof_mel=inp["prof_mels"].to(dev), amateur_pitch=inp["pitch"].to(dev),
+                        prof_pitch=inp["prof_pitch"].to(dev), amateur_spk_id=inp["spk"].to(dev), prof_spk_id=inp["spk"].to(dev),
+                        a2p_alignment=inp["a2p_alignment"].to(dev), infer=False, concurrent_ways=["a2a", "p2p", "a2p"],
+                        eps_a2a=t(d["eps_a2a"]).to(dev), eps_p2p=t(d["eps_p2p"]).to(dev))
+    finally:
+        SF.set_precision("fp32")
+    st = int(d["frame_stride"])
+    l1s = {w: (out[w]["mel_out"][:, ::st].cpu() - t(d[f"{w}.mel_out"])).abs().mean().item() for w in ("a2a", "p2p", "a2p")}
+    print(precision, l1s)
+    assert max(l1s.values()) <= (1e-4 if precision == "bf16x3" else 1e-5), (precision, l1s)
+    for w in ("a2a", "p2p"):
+        for k in ("m_q", "logs_q", "z_q"):
+            ref = t(d[f"{w}.{k}"])
+            assert (out[w][k].cpu() - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item()), (w, k)
+        assert abs(out[w]["kl"].item() - float(d[f"{w}.kl"])) <= 1e-4 * max(1.0, abs(float(d[f"{w}.kl"]))), w
+    mle_ref = float(d["a2p.mle"])
+    assert abs(out["a2p"]["mle"].item() - mle_ref) <= 5e-4 * max(1.0, abs(mle_ref))
+
+
+@pytest.mark.gpu
+def test_mle_svb_vae_bf16x3_small_golden(gpu_only):
+    """`conv_precision: bf16x3` on the B = 2 x T = 64 golden.  a2a and a2p meet the 1e-4 gate (2e-5, 8e-6).  The p2p way of
+    THIS input is ill-conditioned -- its encoder BatchNorms normalise over 6 .. 14 values, see
+    test_small_golden_p2p_is_ill_conditioned: the reference's own fp32 output moves by 1e-5 .. 2e-5 under a 1e-6 relative
+    input perturbation -- so the split's ~1e-5 relative rounding noise lands at 0.9e-4 .. 1.9e-4 there (tile-choice
+    dependent).  The gate proper is asserted per way at the bench's shape above."""
     from neuralsvb_amd import functional as SF
     dev = gpu_only
     d = np.load(os.path.join(G, "vae_mle.npz"))
@@ -127,11 +169,33 @@ def test_mle_svb_vae_bf16x3_mel_l1_against_reference_golden(gpu_only):
                         eps_a2a=t(d["eps_a2a"]).to(dev), eps_p2p=t(d["eps_p2p"]).to(dev))
     finally:
         SF.set_precision("fp32")
-    diffs = {way: (out[way]["mel_out"].cpu() - t(d[f"{way}.mel_out"])).abs() for way in ("a2a", "p2p", "a2p")}
-    l1s = {way: v.mean().item() for way, v in diffs.items()}
-    pooled = sum(v.sum().item() for v in diffs.values()) / sum(v.numel() for v in diffs.values())
-    assert pooled <= 1e-4, (pooled, l1s)
-    assert max(l1s.values()) <= 3e-4, l1s
+    l1s = {way: (out[way]["mel_out"].cpu() - t(d[f"{way}.mel_out"])).abs().mean().item() for way in ("a2a", "p2p", "a2p")}
+    assert l1s["a2a"] <= 1e-4 and l1s["a2p"] <= 1e-4, l1s
+    assert l1s["p2p"] <= 3e-4, l1s
+
+
+def test_small_golden_p2p_is_ill_conditioned():
+    """Evidence for the bound above, from the CPU oracle (pinned to the reference golden): a relative input perturbation of
+    1e-6 (a few fp32 ulps) moves the p2p mel of the B = 2 golden several times more than the a2a mel."""
+    d = np.load(os.path.join(G, "vae_mle.npz"))
+    sd = procedural.state_dict_for(KEYS["MleSVBVAE"], prefix="model.")
+    args = [t(d[k]) for k in ("mels", "prof_mels", "pitch", "prof_pitch", "spk", "a2p_alignment")]
+
+    def run(a):
+        with torch.no_grad():
+            ret, _, _ = R.mle_svb_vae(sd, *a, ["a2a", "p2p"], t(d["eps_a2a"]), t(d["eps_p2p"]), HP, training=True)
+        return {w: ret[w]["mel_out"] for w in ret}
+    base = run(args)
+    g = torch.Generator().manual_seed(0)
+    resp = {"a2a": 0.0, "p2p": 0.0}
+    for _ in range(3):
+        a = list(args)
+        a[0] = args[0] * (1 + 1e-6 * torch.randn(args[0].shape, generator=g))
+        a[1] = args[1] * (1 + 1e-6 * torch.randn(args[1].shape, generator=g))
+        o = run(a)
+        for w in resp:
+            resp[w] += (o[w] - base[w]).abs().mean().item() / 3
+    assert resp["p2p"] >= 8e-6 and resp["p2p"] >= 2.0 * resp["a2a"], resp
 
 
 def test_stacked_voices_equal_separate_calls(dev):
