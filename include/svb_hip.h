@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define SVB_ABI_VERSION 1
+#define SVB_ABI_VERSION 2
 int svb_abi_version(void);
 
 /* ---- fused conv epilogue / prologue description ------------------------------------------------------
@@ -36,6 +36,9 @@ typedef struct SvbConvEpilogue {
     float in_slope, out_slope, out_gate_slope;
     int out_act;
     int force_cfg;
+    const unsigned short* x_q; /* bf16x3 entry points only: optional Q image of x (svb_split_q layout).  When given (and
+                                * in_gate is NULL) the kernel stages its input tiles from it with plain 16-byte copies
+                                * instead of splitting fp32 x again in every consuming workgroup; results are bit-identical. */
 } SvbConvEpilogue;
 
 /* Weight pack (+ WeightNorm forward  w = g * v / ||v||, norm over all dims but 0).
@@ -116,18 +119,26 @@ int svb_bias_grad(const float* dy, const float* gate, float slope, float* db, in
  * gate fwd: acts[b,c,t] = tanh(xin[b,c,t] + g[b,goff+c,t]) * sigmoid(xin[b,C+c,t] + g[b,goff+C+c,t])
  * gate bwd: d_xin from d_acts; the same values are the gradient of g's slice and are optionally also written
  * into dg[b, g_off : g_off+2C, t] (dg has g_channels channels; dxin or dg may be NULL).                      */
-int svb_wn_gate_fwd(const float* xin, const float* g, float* acts, int B, int C, int T, int g_channels, int g_off,
-                    void* stream);
-int svb_wn_gate_bwd(const float* xin, const float* g, const float* dacts, float* dxin, float* dg, int B, int C, int T,
+int svb_wn_gate_fwd(const float* xin, const float* g, float* acts, unsigned short* acts_q, int B, int C, int T,
                     int g_channels, int g_off, void* stream);
+int svb_wn_gate_bwd(const float* xin, const float* g, const float* dacts, float* dxin, float* dg, unsigned short* dxin_q,
+                    int B, int C, int T, int g_channels, int g_off, void* stream);
+/* The *_q arguments of the four gated-stack kernels (all optional, NULL = skip): also emit the result's Q image (see
+ * svb_split_q) for the bf16x3 conv that consumes it next.  dxin_q / drs_q describe 2C-channel tensors and need C % 16 == 0. */
 /* res/skip update: x_new = (x + rs[:, :C]) * mask ; out_new = out + rs[:, C:]   (last layer: out += rs, x untouched;
  * rs then has C channels and x/x_new may be NULL).  In-place allowed (x_new == x, out_new == out).            */
 int svb_wn_res_skip(const float* x, const float* rs, const float* mask, const float* out, float* x_new, float* out_new,
-                    int B, int C, int T, int last, void* stream);
+                    unsigned short* x_new_q, int B, int C, int T, int last, void* stream);
 /* backward of the (non-last) res/skip update: drs[:, :C] = dx_new*mask, drs[:, C:] = dout, dxm = dx_new*mask
  * (dx_new NULL = zeros, dxm may be NULL).                                                                    */
-int svb_wn_res_skip_bwd(const float* dx_new, const float* dout, const float* mask, float* drs, float* dxm, int B, int C,
-                        int T, void* stream);
+int svb_wn_res_skip_bwd(const float* dx_new, const float* dout, const float* mask, float* drs, float* dxm,
+                        unsigned short* drs_q, int B, int C, int T, void* stream);
+
+/* ---- Pre-split activations ("Q image") for the bf16x3 convs: xq[b][chunk][t][0..15] = hi, [16..31] = lo of the 16
+ * channels of chunk `chunk` at position t (bf16; v = hi + lo, hi = rne(v), lo = rne(v - hi)); ceil(C/16) chunks, channels
+ * beyond C are zero; optional mask[b,t] multiplies x first.  xq: B * ceil(C/16) * T * 32 bf16, 16-byte aligned.
+ * Replaces the per-consumer fp32 -> bf16 split of the conv kernels (no reference counterpart: layout plumbing). */
+int svb_split_q(const float* x, const float* mask, unsigned short* xq, int B, int C, int T, void* stream);
 
 /* ---- LayerNorm over the channel (last) dim of [rows, C] (reference modules/fastspeech/conformer/layers.py:160-170,
  * conformer.py:30; torch.nn.LayerNorm eps 1e-5).                                                             */

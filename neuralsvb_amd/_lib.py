@@ -17,7 +17,7 @@ class SvbConvEpilogue(C.Structure):
         ("bias", C.c_void_p), ("in_gate", C.c_void_p), ("out_gate", C.c_void_p),
         ("residual", C.c_void_p), ("mask", C.c_void_p),
         ("in_slope", C.c_float), ("out_slope", C.c_float), ("out_gate_slope", C.c_float),
-        ("out_act", C.c_int), ("force_cfg", C.c_int),
+        ("out_act", C.c_int), ("force_cfg", C.c_int), ("x_q", C.c_void_p),
     ]
 
 
@@ -40,10 +40,11 @@ SIGNATURES = {
     "svb_debug_set_timing_buffer": (None, [P]),
     "svb_wgrad_reduce": (I, [P, I, P, P, P, P, I, I, I, I, P, P, P]),
     "svb_bias_grad": (I, [P, P, F, P, I, I, I, P]),
-    "svb_wn_gate_fwd": (I, [P, P, P, I, I, I, I, I, P]),
-    "svb_wn_gate_bwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),
-    "svb_wn_res_skip_bwd": (I, [P, P, P, P, P, I, I, I, P]),
-    "svb_wn_res_skip": (I, [P, P, P, P, P, P, I, I, I, I, P]),
+    "svb_wn_gate_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "svb_wn_gate_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    "svb_wn_res_skip_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
+    "svb_wn_res_skip": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
+    "svb_split_q": (I, [P, P, P, I, I, I, P]),
     "svb_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
     "svb_relpos_softmax": (I, [P, P, P, P, I, I, I, F, P]),
     "svb_layernorm_nct_fwd": (I, [P, P, P, P, I, I, I, F, P]),

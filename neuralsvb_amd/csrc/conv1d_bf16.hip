@@ -14,15 +14,18 @@
 //                    LDS stores, hi and lo)
 // 48-byte rows put the 16 lanes of every ds_read_b128 service group on 16 disjoint 4-bank windows.
 #include "svb_common.h"
+#include "svb_q.h"
 #include "conv1d.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define SVBQ_PITCH 24          /* bf16 elements per LDS row (16 used + 8 pad) = 48 bytes */
 #define SVBQ_XUNITS 4          /* register-staged x units per thread: (16-channel chunks per phase) x (128-position groups) */
+#define SVBQ_QUNITS 8          /* Q-input staging: 16-byte units per thread and phase */
 
 struct SvbConvQArgs {
     const float* x;
+    const unsigned short* xq;     // optional Q image of x (svb_q.h): staged with plain 16-byte copies
     const unsigned short* wq_hi;
     const unsigned short* wq_lo;
     const float* bias;
@@ -55,18 +58,6 @@ __device__ __forceinline__ float svbq_ld(const float* base, unsigned byte_off) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-typedef __bf16 svbq_bf2 __attribute__((ext_vector_type(2)));
-typedef float svbq_f2 __attribute__((ext_vector_type(2)));
-
-// two fp32 values -> packed bf16 pairs  hi = rne(v), lo = rne(v - hi)   (v_cvt_pk_bf16_f32 x2 + 3 VALU ops on gfx950)
-__device__ __forceinline__ void svbq_split2(float v0, float v1, unsigned& hi, unsigned& lo) {
-    const svbq_f2 v = {v0, v1};
-    const svbq_bf2 h = __builtin_convertvector(v, svbq_bf2);
-    const svbq_f2 hf = __builtin_convertvector(h, svbq_f2);
-    const svbq_bf2 l = __builtin_convertvector(v - hf, svbq_bf2);
-    __builtin_memcpy(&hi, &h, 4);
-    __builtin_memcpy(&lo, &l, 4);
-}
 __device__ __forceinline__ void svbq_split(float v, unsigned& hi, unsigned& lo) {
     unsigned h2, l2;
     svbq_split2(v, 0.f, h2, l2);
@@ -81,8 +72,11 @@ __device__ __forceinline__ void svbq_split8(const float* v, uint4& hi, uint4& lo
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-template <int WM, int WN, int NT, int SLB, bool GATE>
+// MODE 0: fp32 x, split while staging;  1: the same with the activation-derivative gate on the load;  2: x comes pre-split
+// (Q image): the tile is staged with 16-byte copies -- four consecutive lanes fetch the 64-byte row of one position.
+template <int WM, int WN, int NT, int SLB, int MODE>
 __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs a, SvbConvPlan p) {
+    constexpr bool GATE = MODE == 1, QIN = MODE == 2;
     constexpr int BM = 32 * WM, BN = 32 * WN * NT;
     constexpr int WTASKS = SLB * BM * 2;                 // 16-byte units per (hi|lo) weight tile
     constexpr int WU = (2 * WTASKS + 255) / 256;         // per-thread units, hi and lo together
@@ -251,6 +245,41 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
             }
         }
     };
+    // ---- Q-input staging (MODE 2).  Unit U = u*256 + tid -> (chunk c, position i, 16-byte part: hi0 hi1 lo0 lo1).
+    uint4 qr[QIN ? SVBQ_QUNITS : 1];
+    unsigned q_off[QIN ? SVBQ_QUNITS : 1];
+    int q_dst[QIN ? SVBQ_QUNITS : 1], q_c[QIN ? SVBQ_QUNITS : 1];
+    bool q_ok[QIN ? SVBQ_QUNITS : 1];
+    const unsigned short* xqb = nullptr;
+    if (QIN) {
+        const int kc_all = (a.Cin + 15) >> 4, kc_g = a.kchunks;               // (groups > 1 need Cin_g % 16 == 0: host)
+        xqb = a.xq + ((size_t)b * kc_all + (size_t)g * kc_g) * a.Tin * 32;
+        const int per_chunk = 4 * span;
+#pragma unroll
+        for (int u = 0; u < SVBQ_QUNITS; ++u) {
+            const int U = u * 256 + tid;
+            const int c = U / per_chunk, r = U - c * per_chunk;
+            const int i = r >> 2, part = r & 3;
+            const int pos = lo_pos + i;
+            q_c[u] = c < a.kch ? c : (1 << 20);
+            q_ok[u] = pos >= 0 && pos < a.Tin;
+            q_off[u] = (c < a.kch && q_ok[u]) ? (unsigned)((c * a.Tin + pos) * 64 + part * 16) : 0u;
+            q_dst[u] = ((part >> 1) ? a.x_floats16 : 0) + (c * a.xrows + i) * 3 + (part & 1);
+        }
+    }
+    auto load_xq = [&](int kc0) {
+        const int kch_here = min(a.kch, a.kchunks - kc0);
+        const char* base = reinterpret_cast<const char*>(xqb + (size_t)kc0 * a.Tin * 32);
+#pragma unroll
+        for (int u = 0; u < (QIN ? SVBQ_QUNITS : 0); ++u)       // branch-free: idle units read the first row of the phase
+            qr[u] = *reinterpret_cast<const uint4*>(base + (q_c[u] < kch_here ? q_off[u] : 0u));
+    };
+    auto store_xq = [&](int kc0) {
+        const int kch_here = min(a.kch, a.kchunks - kc0);
+#pragma unroll
+        for (int u = 0; u < (QIN ? SVBQ_QUNITS : 0); ++u)
+            if (q_c[u] < kch_here) x_hi[q_dst[u]] = q_ok[u] ? qr[u] : make_uint4(0u, 0u, 0u, 0u);
+    };
     // ---- WN == 1 tiles ("direct-A"): every wave owns 32 weight rows and all BN columns, so its MFMA A operands
     // (row l31, 16-byte half kb of each (tap, chunk) slab) are exactly one coalesced 1-KiB global read per slab -- no LDS
     // staging, no ds_write, no LDS read for the weights.  The fragments of phase s+1 are loaded into the registers of
@@ -327,19 +356,20 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < SLB; ++i) load_wf(i, 0, 0);
-            if (phase_fast(0)) { load_x(0); store_x(0); } else { stage_x_slow(0); }
+            if (QIN) { load_xq(0); store_xq(0); }
+            else if (phase_fast(0)) { load_x(0); store_x(0); } else { stage_x_slow(0); }
             __syncthreads();
             while (true) {
                 int ntg = tg0 + a.tg, nkc = kc0;
                 if (ntg >= ntap) { ntg = 0; nkc = kc0 + a.kch; }
                 const bool has_next = nkc < a.kchunks;
                 const bool new_x = has_next && ntg == 0;
-                const bool fastn = new_x && phase_fast(nkc);
+                const bool fastn = new_x && (QIN || phase_fast(nkc));
                 SVBQ_STAMP(0)
                 // all weight fragments of this phase were requested a phase ago: drain them here, so that the x loads
                 // issued next are the only outstanding requests and no MFMA waits behind them (vmcnt counts in order)
                 __builtin_amdgcn_s_waitcnt(0x0F70);
-                if (fastn) load_x(nkc);
+                if (fastn) { if (QIN) load_xq(nkc); else load_x(nkc); }
                 SVBQ_STAMP(1)
                 compute_direct(kc0, tg0, has_next, nkc, ntg);
                 SVBQ_STAMP(2)
@@ -347,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
                 if (new_x) {                                   // the x tile changes: all waves must be done reading it
                     __syncthreads();
                     SVBQ_STAMP(3)
-                    if (fastn) store_x(nkc); else stage_x_slow(nkc);
+                    if (QIN) store_xq(nkc); else if (fastn) store_x(nkc); else stage_x_slow(nkc);
                     SVBQ_STAMP(4)
                     __syncthreads();
                     SVBQ_STAMP(5)
@@ -359,7 +389,8 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     } else if (ntap > 0) {
         __syncthreads();
         SVBQ_STAMP(6)
-        if (phase_fast(0)) { load_x(0); store_x(0); } else { stage_x_slow(0); }
+        if (QIN) { load_xq(0); store_xq(0); }
+        else if (phase_fast(0)) { load_x(0); store_x(0); } else { stage_x_slow(0); }
         load_w(0, 0);
         store_w(0);
         __syncthreads();
@@ -370,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
             const bool has_next = nkc < a.kchunks;
             SVBQ_STAMP(0)
             if (has_next) {
-                if (ntg == 0 && phase_fast(nkc)) load_x(nkc);
+                if (ntg == 0) { if (QIN) load_xq(nkc); else if (phase_fast(nkc)) load_x(nkc); }
                 load_w(nkc, ntg);
             }
             SVBQ_STAMP(1)
@@ -379,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
             if (!has_next) break;
             __syncthreads();
             SVBQ_STAMP(3)
-            if (ntg == 0) { if (phase_fast(nkc)) store_x(nkc); else stage_x_slow(nkc); }
+            if (ntg == 0) { if (QIN) store_xq(nkc); else if (phase_fast(nkc)) store_x(nkc); else stage_x_slow(nkc); }
             store_w(ntg);
             SVBQ_STAMP(4)
             __syncthreads();
@@ -472,15 +503,15 @@ static int q_pick(int cout_g, int nq_max, long nz) {
     return best;
 }
 
-template <int WM, int WN, int NT, int SLB, bool GATE>
+template <int WM, int WN, int NT, int SLB, int MODE>
 static void q_launch_kernel(const SvbConvQArgs& a, const SvbConvPlan& p, dim3 grid, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_bf16x3_kernel<WM, WN, NT, SLB, GATE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_bf16x3_kernel<WM, WN, NT, SLB, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((svb_conv1d_bf16x3_kernel<WM, WN, NT, SLB, GATE>), grid, dim3(256), lds, stream, a, p);
+    hipLaunchKernelGGL((svb_conv1d_bf16x3_kernel<WM, WN, NT, SLB, MODE>), grid, dim3(256), lds, stream, a, p);
 }
 
 template <int WM, int WN, int NT, int SLB>
@@ -494,7 +525,10 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     // phase = tg taps x kch chunks, tg*kch <= SLB slabs, kch*xit <= SVBQ_XUNITS, LDS budget ~78 KB (2 blocks per CU)
     a.tg = ntap_max < 1 ? 1 : (ntap_max > SLB ? SLB : ntap_max);
     int kch = SLB / a.tg;
-    const int kch_cap = a.fast_x ? SVBQ_XUNITS / a.xit : 2;
+    // Q input: usable without an input gate, with whole 16-channel chunks per group, and when one chunk's span fits the
+    // per-thread unit budget
+    const bool qin = a.xq && !a.in_gate && (a.G == 1 || a.Cin_g % 16 == 0) && 4 * span_max <= SVBQ_QUNITS * 256;
+    const int kch_cap = qin ? (SVBQ_QUNITS * 256) / (4 * span_max) : (a.fast_x ? SVBQ_XUNITS / a.xit : 2);
     if (kch > kch_cap) kch = kch_cap;
     if (kch > a.kchunks) kch = a.kchunks;
     if (kch < 1) kch = 1;
@@ -506,8 +540,9 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     a.w_floats16 = WN == 1 ? 0 : a.tg * a.kch * BM * 3;
     a.x_floats16 = a.kch * a.xrows * 3;
     dim3 grid(a.G * svb_cdiv(a.Cout_g, BM), svb_cdiv(nq_max, BN), a.B * p.n_phase);
-    if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, true>(a, p, grid, lds_bytes(a.kch), stream);
-    else q_launch_kernel<WM, WN, NT, SLB, false>(a, p, grid, lds_bytes(a.kch), stream);
+    if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, 1>(a, p, grid, lds_bytes(a.kch), stream);
+    else if (qin) q_launch_kernel<WM, WN, NT, SLB, 2>(a, p, grid, lds_bytes(a.kch), stream);
+    else q_launch_kernel<WM, WN, NT, SLB, 0>(a, p, grid, lds_bytes(a.kch), stream);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
@@ -552,6 +587,7 @@ static void q_fill(SvbConvQArgs& a, const SvbConvEpilogue* e) {
     a.residual = e ? e->residual : nullptr;
     a.mask = e ? e->mask : nullptr;
     a.force_cfg = e ? e->force_cfg - 1 : -1;
+    a.xq = e ? e->x_q : nullptr;
     a.dbg = g_svbq_dbg;
 }
 

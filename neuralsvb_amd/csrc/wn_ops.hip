@@ -5,108 +5,267 @@
 // All are pure streaming kernels: 16-byte vector loads when rows are 16-byte aligned, grid-stride loops,
 // 64-wide wave reductions.  Roofline: HBM (bytes listed per kernel in DESIGN.md).
 #include "svb_common.h"
+#include <initializer_list>
+#include "svb_q.h"
 #include "../../include/svb_hip.h"
 
 extern "C" int svb_abi_version(void) { return SVB_ABI_VERSION; }
 
+// All four elementwise kernels of the gated stack (and svb_split_q) share one thread mapping: a thread owns VEC consecutive
+// positions of one (batch, 16-channel chunk) and walks the chunk's channels two at a time.  Loads / fp32 stores are
+// coalesced along t across the lanes of a wave (16-byte vectors when VEC == 4); the optional Q image (svb_q.h) of the
+// result leaves as VEC contiguous 64-byte rows per thread -- the consuming bf16x3 conv stages it with plain copies.
+#define SVB_EW_LOOP(total_)                                                                              \
+    for (long i_ = (long)blockIdx.x * 256 + threadIdx.x; i_ < (total_); i_ += (long)gridDim.x * 256)
+
 // acts[b,c,t] = tanh(xin[b,c,t]+g[b,goff+c,t]) * sigmoid(xin[b,C+c,t]+g[b,goff+C+c,t])
 template <int VEC>
-__global__ __launch_bounds__(256) void svb_wn_gate_fwd_kernel(const float* xin, const float* g, float* acts, int B, int C,
-                                                              int T, int gch, int goff) {
-    const int TV = T / VEC;
-    const long total = (long)B * C * TV;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int tv = (int)(i % TV);
-        const long bc = i / TV;
-        const int c = (int)(bc % C), b = (int)(bc / C);
-        const size_t xa = ((size_t)b * 2 * C + c) * T + (size_t)tv * VEC;
-        const size_t xb = xa + (size_t)C * T;
-        const size_t ga = ((size_t)b * gch + goff + c) * T + (size_t)tv * VEC;
-        const size_t gb = ga + (size_t)C * T;
-        const size_t oa = ((size_t)b * C + c) * T + (size_t)tv * VEC;
-        if (VEC == 4) {
-            float4 a = *reinterpret_cast<const float4*>(xin + xa);
-            float4 s = *reinterpret_cast<const float4*>(xin + xb);
-            if (g) {
-                const float4 ga4 = *reinterpret_cast<const float4*>(g + ga);
-                const float4 gb4 = *reinterpret_cast<const float4*>(g + gb);
-                a.x += ga4.x; a.y += ga4.y; a.z += ga4.z; a.w += ga4.w;
-                s.x += gb4.x; s.y += gb4.y; s.z += gb4.z; s.w += gb4.w;
+__global__ __launch_bounds__(256) void svb_wn_gate_fwd_kernel(const float* xin, const float* g, float* acts,
+                                                              unsigned short* acts_q, int B, int C, int T, int gch, int goff) {
+    const int TV = T / VEC, kc = (C + 15) / 16;
+    SVB_EW_LOOP((long)B * kc * TV) {
+        const int tv = (int)(i_ % TV);
+        const long bk = i_ / TV;
+        const int k = (int)(bk % kc), b = (int)(bk / kc);
+        const size_t t0 = (size_t)tv * VEC;
+        SvbQRows<VEC> q;
+        q.zero();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float o[2][VEC];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = k * 16 + 2 * e + h;
+#pragma unroll
+                for (int p = 0; p < VEC; ++p) o[h][p] = 0.f;
+                if (c < C) {
+                    const size_t xa = ((size_t)b * 2 * C + c) * T + t0, xb = xa + (size_t)C * T;
+                    float a[VEC], sv[VEC];
+                    svbq_ldv(xin + xa, a);
+                    svbq_ldv(xin + xb, sv);
+                    if (g) {
+                        const size_t ga = ((size_t)b * gch + goff + c) * T + t0, gb = ga + (size_t)C * T;
+                        float ag[VEC], sg[VEC];
+                        svbq_ldv(g + ga, ag);
+                        svbq_ldv(g + gb, sg);
+#pragma unroll
+                        for (int p = 0; p < VEC; ++p) { a[p] += ag[p]; sv[p] += sg[p]; }
+                    }
+#pragma unroll
+                    for (int p = 0; p < VEC; ++p) o[h][p] = tanhf(a[p]) * svb_sigmoid(sv[p]);
+                    svbq_stv(acts + ((size_t)b * C + c) * T + t0, o[h]);
+                }
             }
-            float4 o;
-            o.x = tanhf(a.x) * svb_sigmoid(s.x);
-            o.y = tanhf(a.y) * svb_sigmoid(s.y);
-            o.z = tanhf(a.z) * svb_sigmoid(s.z);
-            o.w = tanhf(a.w) * svb_sigmoid(s.w);
-            *reinterpret_cast<float4*>(acts + oa) = o;
-        } else {
-            float a = xin[xa], s = xin[xb];
-            if (g) { a += g[ga]; s += g[gb]; }
-            acts[oa] = tanhf(a) * svb_sigmoid(s);
+            if (acts_q) {
+#pragma unroll
+                for (int p = 0; p < VEC; ++p) q.put(p, e, o[0][p], o[1][p]);
+            }
         }
+        if (acts_q) q.store(acts_q, ((size_t)b * kc + k) * T + t0);
     }
 }
 
-// dxin[:, :C] = dacts * sig * (1 - tanh^2) ; dxin[:, C:] = dacts * tanh * sig * (1 - sig); optional copy into dg slice
+// dxin[:, :C] = dacts * sig * (1 - tanh^2) ; dxin[:, C:] = dacts * tanh * sig * (1 - sig); optional copy into dg slice;
+// optional Q image of dxin (2C channels; needs C % 16 == 0 so that both halves start on a chunk boundary)
+template <int VEC>
 __global__ __launch_bounds__(256) void svb_wn_gate_bwd_kernel(const float* xin, const float* g, const float* dacts,
-                                                              float* dxin, float* dg, int B, int C, int T, int gch,
-                                                              int goff) {
-    const long total = (long)B * C * T;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int t = (int)(i % T);
-        const long bc = i / T;
-        const int c = (int)(bc % C), b = (int)(bc / C);
-        const size_t xa = ((size_t)b * 2 * C + c) * T + t;
-        const size_t xb = xa + (size_t)C * T;
-        const size_t ga = ((size_t)b * gch + goff + c) * T + t;
-        const size_t gb = ga + (size_t)C * T;
-        float a = xin[xa], s = xin[xb];
-        if (g) { a += g[ga]; s += g[gb]; }
-        const float th = tanhf(a), sg = svb_sigmoid(s);
-        const float d = dacts[((size_t)b * C + c) * T + t];
-        const float da = d * sg * (1.f - th * th);
-        const float ds = d * th * sg * (1.f - sg);
-        if (dxin) { dxin[xa] = da; dxin[xb] = ds; }
-        if (dg) { dg[ga] = da; dg[gb] = ds; }
-    }
-}
-
-// x_new = (x + rs[:, :C]) * mask ; out_new = out + rs[:, C:]     (last: out_new = out + rs)
-__global__ __launch_bounds__(256) void svb_wn_res_skip_kernel(const float* x, const float* rs, const float* mask,
-                                                              const float* out, float* x_new, float* out_new, int B, int C,
-                                                              int T, int last) {
-    const long total = (long)B * C * T;
-    const int rc = last ? C : 2 * C;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int t = (int)(i % T);
-        const long bc = i / T;
-        const int c = (int)(bc % C), b = (int)(bc / C);
-        const size_t r0 = ((size_t)b * rc + c) * T + t;
-        const float o = out ? out[i] : 0.f;
-        if (last) {
-            out_new[i] = o + rs[r0];
-        } else {
-            const float m = mask ? mask[(size_t)b * T + t] : 1.f;
-            x_new[i] = (x[i] + rs[r0]) * m;
-            out_new[i] = o + rs[r0 + (size_t)C * T];
+                                                              float* dxin, float* dg, unsigned short* dxin_q, int B, int C,
+                                                              int T, int gch, int goff) {
+    const int TV = T / VEC, kc = (C + 15) / 16;
+    SVB_EW_LOOP((long)B * kc * TV) {
+        const int tv = (int)(i_ % TV);
+        const long bk = i_ / TV;
+        const int k = (int)(bk % kc), b = (int)(bk / kc);
+        const size_t t0 = (size_t)tv * VEC;
+        SvbQRows<VEC> qa, qs;
+        qa.zero();
+        qs.zero();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float da[2][VEC], ds[2][VEC];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = k * 16 + 2 * e + h;
+#pragma unroll
+                for (int p = 0; p < VEC; ++p) { da[h][p] = 0.f; ds[h][p] = 0.f; }
+                if (c < C) {
+                    const size_t xa = ((size_t)b * 2 * C + c) * T + t0, xb = xa + (size_t)C * T;
+                    const size_t ga = ((size_t)b * gch + goff + c) * T + t0, gb = ga + (size_t)C * T;
+                    float a[VEC], sv[VEC], d[VEC];
+                    svbq_ldv(xin + xa, a);
+                    svbq_ldv(xin + xb, sv);
+                    svbq_ldv(dacts + ((size_t)b * C + c) * T + t0, d);
+                    if (g) {
+                        float ag[VEC], sg[VEC];
+                        svbq_ldv(g + ga, ag);
+                        svbq_ldv(g + gb, sg);
+#pragma unroll
+                        for (int p = 0; p < VEC; ++p) { a[p] += ag[p]; sv[p] += sg[p]; }
+                    }
+#pragma unroll
+                    for (int p = 0; p < VEC; ++p) {
+                        const float th = tanhf(a[p]), sg = svb_sigmoid(sv[p]);
+                        da[h][p] = d[p] * sg * (1.f - th * th);
+                        ds[h][p] = d[p] * th * sg * (1.f - sg);
+                    }
+                    if (dxin) { svbq_stv(dxin + xa, da[h]); svbq_stv(dxin + xb, ds[h]); }
+                    if (dg) { svbq_stv(dg + ga, da[h]); svbq_stv(dg + gb, ds[h]); }
+                }
+            }
+            if (dxin_q) {
+#pragma unroll
+                for (int p = 0; p < VEC; ++p) { qa.put(p, e, da[0][p], da[1][p]); qs.put(p, e, ds[0][p], ds[1][p]); }
+            }
+        }
+        if (dxin_q) {
+            qa.store(dxin_q, ((size_t)b * 2 * kc + k) * T + t0);
+            qs.store(dxin_q, ((size_t)b * 2 * kc + kc + k) * T + t0);
         }
     }
 }
 
-// backward of res/skip: drs[:, :C] = dx_new * mask ; drs[:, C:] = dout ; dxm = dx_new * mask (contiguous copy)
+// x_new = (x + rs[:, :C]) * mask ; out_new = out + rs[:, C:]     (last: out_new = out + rs); optional Q image of x_new
+template <int VEC>
+__global__ __launch_bounds__(256) void svb_wn_res_skip_kernel(const float* x, const float* rs, const float* mask,
+                                                              const float* out, float* x_new, float* out_new,
+                                                              unsigned short* x_new_q, int B, int C, int T, int last) {
+    const int TV = T / VEC, kc = (C + 15) / 16;
+    const int rc = last ? C : 2 * C;
+    SVB_EW_LOOP((long)B * kc * TV) {
+        const int tv = (int)(i_ % TV);
+        const long bk = i_ / TV;
+        const int k = (int)(bk % kc), b = (int)(bk / kc);
+        const size_t t0 = (size_t)tv * VEC;
+        float m[VEC];
+#pragma unroll
+        for (int p = 0; p < VEC; ++p) m[p] = 1.f;
+        if (mask && !last) svbq_ldv(mask + (size_t)b * T + t0, m);
+        SvbQRows<VEC> q;
+        q.zero();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float xn[2][VEC];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = k * 16 + 2 * e + h;
+#pragma unroll
+                for (int p = 0; p < VEC; ++p) xn[h][p] = 0.f;
+                if (c < C) {
+                    const size_t i0 = ((size_t)b * C + c) * T + t0, r0 = ((size_t)b * rc + c) * T + t0;
+                    float o[VEC], ra[VEC];
+#pragma unroll
+                    for (int p = 0; p < VEC; ++p) o[p] = 0.f;
+                    if (out) svbq_ldv(out + i0, o);
+                    svbq_ldv(rs + r0, ra);
+                    if (last) {
+#pragma unroll
+                        for (int p = 0; p < VEC; ++p) o[p] += ra[p];
+                        svbq_stv(out_new + i0, o);
+                    } else {
+                        float xv[VEC], rb[VEC];
+                        svbq_ldv(x + i0, xv);
+                        svbq_ldv(rs + r0 + (size_t)C * T, rb);
+#pragma unroll
+                        for (int p = 0; p < VEC; ++p) { xn[h][p] = (xv[p] + ra[p]) * m[p]; o[p] += rb[p]; }
+                        svbq_stv(x_new + i0, xn[h]);
+                        svbq_stv(out_new + i0, o);
+                    }
+                }
+            }
+            if (x_new_q) {
+#pragma unroll
+                for (int p = 0; p < VEC; ++p) q.put(p, e, xn[0][p], xn[1][p]);
+            }
+        }
+        if (x_new_q) q.store(x_new_q, ((size_t)b * kc + k) * T + t0);
+    }
+}
+
+// backward of res/skip: drs[:, :C] = dx_new * mask ; drs[:, C:] = dout ; dxm = dx_new * mask (contiguous copy);
+// optional Q image of drs (2C channels, C % 16 == 0)
+template <int VEC>
 __global__ __launch_bounds__(256) void svb_wn_res_skip_bwd_kernel(const float* dx_new, const float* dout, const float* mask,
-                                                                  float* drs, float* dxm, int B, int C, int T) {
-    const long total = (long)B * C * T;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int t = (int)(i % T);
-        const long bc = i / T;
-        const int c = (int)(bc % C), b = (int)(bc / C);
-        const size_t r0 = ((size_t)b * 2 * C + c) * T + t;
-        const float m = mask ? mask[(size_t)b * T + t] : 1.f;
-        const float v = dx_new ? dx_new[i] * m : 0.f;
-        drs[r0] = v;
-        drs[r0 + (size_t)C * T] = dout[i];
-        if (dxm) dxm[i] = v;
+                                                                  float* drs, float* dxm, unsigned short* drs_q, int B,
+                                                                  int C, int T) {
+    const int TV = T / VEC, kc = (C + 15) / 16;
+    SVB_EW_LOOP((long)B * kc * TV) {
+        const int tv = (int)(i_ % TV);
+        const long bk = i_ / TV;
+        const int k = (int)(bk % kc), b = (int)(bk / kc);
+        const size_t t0 = (size_t)tv * VEC;
+        float m[VEC];
+#pragma unroll
+        for (int p = 0; p < VEC; ++p) m[p] = 1.f;
+        if (mask) svbq_ldv(mask + (size_t)b * T + t0, m);
+        SvbQRows<VEC> qa, qb;
+        qa.zero();
+        qb.zero();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float va[2][VEC], vb[2][VEC];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = k * 16 + 2 * e + h;
+#pragma unroll
+                for (int p = 0; p < VEC; ++p) { va[h][p] = 0.f; vb[h][p] = 0.f; }
+                if (c < C) {
+                    const size_t i0 = ((size_t)b * C + c) * T + t0, r0 = ((size_t)b * 2 * C + c) * T + t0;
+                    if (dx_new) {
+                        svbq_ldv(dx_new + i0, va[h]);
+#pragma unroll
+                        for (int p = 0; p < VEC; ++p) va[h][p] *= m[p];
+                    }
+                    svbq_ldv(dout + i0, vb[h]);
+                    svbq_stv(drs + r0, va[h]);
+                    svbq_stv(drs + r0 + (size_t)C * T, vb[h]);
+                    if (dxm) svbq_stv(dxm + i0, va[h]);
+                }
+            }
+            if (drs_q) {
+#pragma unroll
+                for (int p = 0; p < VEC; ++p) { qa.put(p, e, va[0][p], va[1][p]); qb.put(p, e, vb[0][p], vb[1][p]); }
+            }
+        }
+        if (drs_q) {
+            qa.store(drs_q, ((size_t)b * 2 * kc + k) * T + t0);
+            qb.store(drs_q, ((size_t)b * 2 * kc + kc + k) * T + t0);
+        }
+    }
+}
+
+// Q image of an fp32 [B][C][T] tensor (optionally of x * mask[b,t])
+template <int VEC>
+__global__ __launch_bounds__(256) void svb_split_q_kernel(const float* x, const float* mask, unsigned short* xq, int B, int C,
+                                                          int T) {
+    const int TV = T / VEC, kc = (C + 15) / 16;
+    SVB_EW_LOOP((long)B * kc * TV) {
+        const int tv = (int)(i_ % TV);
+        const long bk = i_ / TV;
+        const int k = (int)(bk % kc), b = (int)(bk / kc);
+        const size_t t0 = (size_t)tv * VEC;
+        float m[VEC];
+#pragma unroll
+        for (int p = 0; p < VEC; ++p) m[p] = 1.f;
+        if (mask) svbq_ldv(mask + (size_t)b * T + t0, m);
+        SvbQRows<VEC> q;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v[2][VEC];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = k * 16 + 2 * e + h;
+#pragma unroll
+                for (int p = 0; p < VEC; ++p) v[h][p] = 0.f;
+                if (c < C) {
+                    svbq_ldv(x + ((size_t)b * C + c) * T + t0, v[h]);
+#pragma unroll
+                    for (int p = 0; p < VEC; ++p) v[h][p] *= m[p];
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < VEC; ++p) q.put(p, e, v[0][p], v[1][p]);
+        }
+        q.store(xq, ((size_t)b * kc + k) * T + t0);
     }
 }
 
@@ -264,46 +423,73 @@ static inline int ew_grid(long total) {
     return (int)g;
 }
 
-extern "C" int svb_wn_gate_fwd(const float* xin, const float* g, float* acts, int B, int C, int T, int g_channels,
-                               int g_off, void* stream) {
+static inline bool ew_vec4(int T, std::initializer_list<const void*> ptrs) {
+    if (T % 4) return false;
+    for (const void* p : ptrs)
+        if ((uintptr_t)p % 16) return false;
+    return true;
+}
+#define SVB_EW_LAUNCH(kern, total_v4, total_v1, v4, ...)                                                              \
+    do {                                                                                                              \
+        if (v4) hipLaunchKernelGGL(kern<4>, dim3(ew_grid(total_v4)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);  \
+        else hipLaunchKernelGGL(kern<1>, dim3(ew_grid(total_v1)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);     \
+    } while (0)
+
+extern "C" int svb_wn_gate_fwd(const float* xin, const float* g, float* acts, unsigned short* acts_q, int B, int C, int T,
+                               int g_channels, int g_off, void* stream) {
     if (!xin || !acts || B <= 0 || C <= 0 || T <= 0) return SVB_ERR_ARG;
     if (g && (g_off < 0 || g_off + 2 * C > g_channels)) return SVB_ERR_ARG;
-    const bool v4 = (T % 4 == 0) && (((uintptr_t)xin | (uintptr_t)g | (uintptr_t)acts) % 16 == 0);
-    if (v4)
-        hipLaunchKernelGGL(svb_wn_gate_fwd_kernel<4>, dim3(ew_grid((long)B * C * (T / 4))), dim3(256), 0,
-                           (hipStream_t)stream, xin, g, acts, B, C, T, g_channels, g_off);
-    else
-        hipLaunchKernelGGL(svb_wn_gate_fwd_kernel<1>, dim3(ew_grid((long)B * C * T)), dim3(256), 0, (hipStream_t)stream,
-                           xin, g, acts, B, C, T, g_channels, g_off);
+    const long kc = (C + 15) / 16;
+    const bool v4 = ew_vec4(T, {xin, g, acts});
+    SVB_EW_LAUNCH(svb_wn_gate_fwd_kernel, (long)B * kc * (T / 4), (long)B * kc * T, v4, xin, g, acts, acts_q, B, C, T,
+                  g_channels, g_off);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
 
-extern "C" int svb_wn_gate_bwd(const float* xin, const float* g, const float* dacts, float* dxin, float* dg, int B, int C,
-                               int T, int g_channels, int g_off, void* stream) {
+extern "C" int svb_wn_gate_bwd(const float* xin, const float* g, const float* dacts, float* dxin, float* dg,
+                               unsigned short* dxin_q, int B, int C, int T, int g_channels, int g_off, void* stream) {
     if (!xin || !dacts || (!dxin && !dg) || B <= 0 || C <= 0 || T <= 0) return SVB_ERR_ARG;
     if ((g || dg) && (g_off < 0 || g_off + 2 * C > g_channels)) return SVB_ERR_ARG;
-    hipLaunchKernelGGL(svb_wn_gate_bwd_kernel, dim3(ew_grid((long)B * C * T)), dim3(256), 0, (hipStream_t)stream, xin, g,
-                       dacts, dxin, dg, B, C, T, g_channels, g_off);
+    if (dxin_q && C % 16) return SVB_ERR_ARG;
+    const long kc = (C + 15) / 16;
+    const bool v4 = ew_vec4(T, {xin, g, dacts, dxin, dg});
+    SVB_EW_LAUNCH(svb_wn_gate_bwd_kernel, (long)B * kc * (T / 4), (long)B * kc * T, v4, xin, g, dacts, dxin, dg, dxin_q, B, C,
+                  T, g_channels, g_off);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
 
 extern "C" int svb_wn_res_skip(const float* x, const float* rs, const float* mask, const float* out, float* x_new,
-                               float* out_new, int B, int C, int T, int last, void* stream) {
+                               float* out_new, unsigned short* x_new_q, int B, int C, int T, int last, void* stream) {
     if (!rs || !out_new || B <= 0 || C <= 0 || T <= 0) return SVB_ERR_ARG;
     if (!last && (!x || !x_new)) return SVB_ERR_ARG;
-    hipLaunchKernelGGL(svb_wn_res_skip_kernel, dim3(ew_grid((long)B * C * T)), dim3(256), 0, (hipStream_t)stream, x, rs,
-                       mask, out, x_new, out_new, B, C, T, last);
+    if (last && x_new_q) return SVB_ERR_ARG;
+    const long kc = (C + 15) / 16;
+    const bool v4 = ew_vec4(T, {x, rs, mask, out, x_new, out_new});
+    SVB_EW_LAUNCH(svb_wn_res_skip_kernel, (long)B * kc * (T / 4), (long)B * kc * T, v4, x, rs, mask, out, x_new, out_new,
+                  x_new_q, B, C, T, last);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
 
 extern "C" int svb_wn_res_skip_bwd(const float* dx_new, const float* dout, const float* mask, float* drs, float* dxm,
-                                   int B, int C, int T, void* stream) {
+                                   unsigned short* drs_q, int B, int C, int T, void* stream) {
     if (!dout || !drs || B <= 0 || C <= 0 || T <= 0) return SVB_ERR_ARG;
-    hipLaunchKernelGGL(svb_wn_res_skip_bwd_kernel, dim3(ew_grid((long)B * C * T)), dim3(256), 0, (hipStream_t)stream,
-                       dx_new, dout, mask, drs, dxm, B, C, T);
+    if (drs_q && C % 16) return SVB_ERR_ARG;
+    const long kc = (C + 15) / 16;
+    const bool v4 = ew_vec4(T, {dx_new, dout, mask, drs, dxm});
+    SVB_EW_LAUNCH(svb_wn_res_skip_bwd_kernel, (long)B * kc * (T / 4), (long)B * kc * T, v4, dx_new, dout, mask, drs, dxm,
+                  drs_q, B, C, T);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_split_q(const float* x, const float* mask, unsigned short* xq, int B, int C, int T, void* stream) {
+    if (!x || !xq || B <= 0 || C <= 0 || T <= 0) return SVB_ERR_ARG;
+    const long kc = (C + 15) / 16;
+    const bool v4 = ew_vec4(T, {x, mask});
+    SVB_EW_LAUNCH(svb_split_q_kernel, (long)B * kc * (T / 4), (long)B * kc * T, v4, x, mask, xq, B, C, T);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }

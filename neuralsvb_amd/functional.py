@@ -53,6 +53,10 @@ class precision_scope:
         return False
 
 
+USE_Q = True             # bf16x3 mode: producers inside the gated stack also emit the pre-split "Q" image of their result
+                         # (kernels.split_q layout); the consuming conv then stages its tiles with plain 16-byte copies
+
+
 DIRECT_GRADS = True      # weight/bias gradients of leaf parameters that already own a `.grad` buffer are accumulated into
                          # it by the reduce kernel itself (autograd gets None and skips its `grad += new` pass)
 
@@ -276,25 +280,35 @@ class _WNStackFn(torch.autograd.Function):
             G = K.conv1d_forward(gcond, pa, cond_v.shape[0], 1, bias=_c(cond_b))
         saved_x, saved_xin, saved_acts, packs_b = [], [], [], []
         out = None
+        useq = USE_Q and PRECISION == "bf16x3" and C % 16 == 0
+        xq = K.split_q(x) if useq else None
         for i, (in_v, in_g, in_b, rs_v, rs_g, rs_b) in enumerate(layers):
             dil = dilation_rate ** i
             pad = (kernel_size * dil - dil) // 2
             pa_in, pb_in = _pack(_c(in_v), _c(in_g))
-            xin = K.conv1d_forward(x, pa_in, 2 * C, kernel_size, 1, pad, dil, 1, bias=_c(in_b))
-            acts = K.wn_gate_fwd(xin, G, i * 2 * C)
+            xin = K.conv1d_forward(x, pa_in, 2 * C, kernel_size, 1, pad, dil, 1, bias=_c(in_b), x_q=xq)
+            acts_q = None
+            if useq:
+                acts, acts_q = K.wn_gate_fwd(xin, G, i * 2 * C, want_q=True)
+            else:
+                acts = K.wn_gate_fwd(xin, G, i * 2 * C)
             pa_rs, pb_rs = _pack(_c(rs_v), _c(rs_g))
             last = i == n_layers - 1
-            rs = K.conv1d_forward(acts, pa_rs, rs_v.shape[0], 1, bias=_c(rs_b))
+            rs = K.conv1d_forward(acts, pa_rs, rs_v.shape[0], 1, bias=_c(rs_b), x_q=acts_q)
             saved_x.append(x)
             saved_xin.append(xin)
             saved_acts.append(acts)
             packs_b.append((pb_in, pb_rs))
-            x_new, out = K.wn_res_skip(x, rs, mask, out, last)
+            if useq:
+                x_new, out, xq = K.wn_res_skip(x, rs, mask, out, last, want_q=True)
+            else:
+                x_new, out = K.wn_res_skip(x, rs, mask, out, last)
             if not last:
                 x = x_new
         if mask is not None:
             out = out * mask[:, None, :]
         ctx.meta = (n_layers, kernel_size, dilation_rate, C)
+        ctx.useq = useq
         ctx.n_in = len(tensors)
         flat = [mask, gcond, G, _c(cond_v), _c(cond_g)]
         for i in range(n_layers):
@@ -316,6 +330,7 @@ class _WNStackFn(torch.autograd.Function):
         if mask is not None:
             dout = dout * mask[:, None, :]
         grads = [None] * ctx.n_in
+        useq = ctx.useq
         need = ctx.needs_input_grad               # index 3 + t for tensors[t]
         need_x, need_gcond = need[3], need[5]
         need_cond_w = G is not None and any(need[6:9])
@@ -333,8 +348,13 @@ class _WNStackFn(torch.autograd.Function):
             p = 6 + 6 * i
             need_in_w, need_rs_w = any(need[3 + p:6 + p]), any(need[6 + p:9 + p])
             need_dx = i > 0 or need_x
+            drs_q = None
             if last:
                 drs, dxm = dout, None
+                if useq:
+                    drs_q = K.split_q(dout)
+            elif useq:
+                drs, dxm, drs_q = K.wn_res_skip_bwd(dx_next, dout, mask, want_dxm=True, want_q=True)
             else:
                 drs, dxm = K.wn_res_skip_bwd(dx_next, dout, mask, want_dxm=True)
             # res/skip 1x1 conv
@@ -348,8 +368,12 @@ class _WNStackFn(torch.autograd.Function):
             if not (need_in_w or need_dG or need_dx):
                 dx_next = None
                 continue
-            dacts = K.conv1d_transposed(drs, pb_rs, C, acts.shape[2], 1)
-            dxin = K.wn_gate_bwd(xin, G, dacts, i * 2 * C, dg=dG)
+            dacts = K.conv1d_transposed(drs, pb_rs, C, acts.shape[2], 1, x_q=drs_q)
+            dxin_q = None
+            if useq and need_dx:
+                dxin, dxin_q = K.wn_gate_bwd(xin, G, dacts, i * 2 * C, dg=dG, want_q=True)
+            else:
+                dxin = K.wn_gate_bwd(xin, G, dacts, i * 2 * C, dg=dG)
             if need_in_w:
                 r = K.conv1d_wgrad(dxin, x_i, ks, 1, pad, dil, v=in_v if in_g is not None else None, g=in_g, want_bias=True,
                                    sinks=_sinks(in_v, in_g, in_b))
@@ -358,7 +382,7 @@ class _WNStackFn(torch.autograd.Function):
                 else:
                     grads[p + 0], grads[p + 2] = r
             if need_dx:
-                dx_next = K.conv1d_transposed(dxin, pb_in, C, x_i.shape[2], ks, 1, pad, dil, residual=dxm)
+                dx_next = K.conv1d_transposed(dxin, pb_in, C, x_i.shape[2], ks, 1, pad, dil, residual=dxm, x_q=dxin_q)
             else:
                 dx_next = None
         grads[0] = dx_next

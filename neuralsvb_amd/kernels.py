@@ -104,8 +104,9 @@ def _f32(*ts):
 
 
 def make_epilogue(bias=None, in_gate=None, in_slope=0.0, out_act=ACT_NONE, out_slope=0.0, out_gate=None,
-                  out_gate_slope=0.0, residual=None, mask=None, force_cfg=0):
+                  out_gate_slope=0.0, residual=None, mask=None, force_cfg=0, x_q=None):
     e = L.SvbConvEpilogue()
+    e.x_q = _ptr(x_q)
     e.bias, e.in_gate, e.out_gate = _ptr(bias), _ptr(in_gate), _ptr(out_gate)
     e.residual, e.mask = _ptr(residual), _ptr(mask)
     e.in_slope, e.out_slope, e.out_gate_slope = float(in_slope), float(out_slope), float(out_gate_slope)
@@ -162,10 +163,13 @@ def weight_pack_q(v, g=None, groups=1, want_a=True, want_b=True):
 def conv1d_forward(x, pa, cout, k, stride=1, pad=0, dil=1, groups=1, out=None, **epi):
     q = isinstance(pa, PackedQ)
     _f32(x, None if q else pa)
-    tensors = [x, pa.hi if q else pa, out] + [epi.get(n) for n in ("bias", "in_gate", "out_gate", "residual", "mask")]
+    tensors = [x, pa.hi if q else pa, out] + [epi.get(n) for n in ("bias", "in_gate", "out_gate", "residual", "mask", "x_q")]
     lib, st = _prep(*tensors)
     B, cin, tin = x.shape
     tout = conv_out_len(tin, k, stride, pad, dil)
+    if not q:
+        epi.pop("x_q", None)
+    has_q = epi.get("x_q") is not None
     if q:
         y = out if out is not None else torch.empty((B, cout, tout), device=x.device, dtype=torch.float32)
         e = make_epilogue(**epi)
@@ -174,7 +178,7 @@ def conv1d_forward(x, pa, cout, k, stride=1, pad=0, dil=1, groups=1, out=None, *
                 e.force_cfg = cfg
                 L.check(lib.svb_conv1d_forward_bf16x3(_ptr(x), _ptr(pa.hi), _ptr(pa.lo), _ptr(y), B, cin, cout, groups, tin,
                                                       tout, k, stride, pad, dil, C.byref(e), st), "svb_conv1d_forward_bf16x3")
-            e.force_cfg = _tuned_cfg(("qf", B, cin, cout, groups, tin, k, stride, pad, dil), launch, _NCFG_Q)
+            e.force_cfg = _tuned_cfg(("qf", B, cin, cout, groups, tin, k, stride, pad, dil, has_q), launch, _NCFG_Q)
         probe = _ConvProbe(lib, x, cout // groups, tout, 2.0 * B * cout * tout * (cin // groups) * k, B * groups, e.force_cfg,
                            "svb_conv1d_bf16x3_kernel", tag=("fwd", B, cin, cout, groups, tin, k, stride, dil))
         L.check(lib.svb_conv1d_forward_bf16x3(_ptr(x), _ptr(pa.hi), _ptr(pa.lo), _ptr(y), B, cin, cout, groups, tin, tout, k,
@@ -200,9 +204,12 @@ def conv1d_forward(x, pa, cout, k, stride=1, pad=0, dil=1, groups=1, out=None, *
 def conv1d_transposed(x, pb, cout, tout, k, stride=1, pad=0, dil=1, groups=1, out=None, **epi):
     q = isinstance(pb, PackedQ)
     _f32(x, None if q else pb)
-    tensors = [x, pb.hi if q else pb, out] + [epi.get(n) for n in ("bias", "in_gate", "out_gate", "residual", "mask")]
+    tensors = [x, pb.hi if q else pb, out] + [epi.get(n) for n in ("bias", "in_gate", "out_gate", "residual", "mask", "x_q")]
     lib, st = _prep(*tensors)
     B, cin, tin = x.shape
+    if not q:
+        epi.pop("x_q", None)
+    has_q = epi.get("x_q") is not None
     y = out if out is not None else torch.empty((B, cout, tout), device=x.device, dtype=torch.float32)
     e = make_epilogue(**epi)
     if q:
@@ -212,7 +219,7 @@ def conv1d_transposed(x, pb, cout, tout, k, stride=1, pad=0, dil=1, groups=1, ou
                 L.check(lib.svb_conv1d_transposed_bf16x3(_ptr(x), _ptr(pb.hi), _ptr(pb.lo), _ptr(y), B, cin, cout, groups, tin,
                                                          tout, k, stride, pad, dil, C.byref(e), st),
                         "svb_conv1d_transposed_bf16x3")
-            e.force_cfg = _tuned_cfg(("qt", B, cin, cout, groups, tin, tout, k, stride, pad, dil), launch, _NCFG_Q)
+            e.force_cfg = _tuned_cfg(("qt", B, cin, cout, groups, tin, tout, k, stride, pad, dil, has_q), launch, _NCFG_Q)
         probe = _ConvProbe(lib, x, cout // groups, -(-tout // stride), 2.0 * B * cin * tin * (cout // groups) * k,
                            B * groups * stride, e.force_cfg, "svb_conv1d_bf16x3_kernel",
                            tag=("convT", B, cin, cout, groups, tin, k, stride, dil))
@@ -315,51 +322,70 @@ def bias_grad(dy, gate=None, slope=0.0):
     return db
 
 
-def wn_gate_fwd(xin, g=None, g_off=0):
+def q_empty(B, c, t, device):
+    """Uninitialised Q image buffer (svb_split_q layout) of a [B, c, t] fp32 tensor."""
+    return torch.empty((B, -(-c // 16), t, 32), device=device, dtype=torch.int16)
+
+
+def split_q(x, mask=None):
+    """fp32 [B,C,T] (optionally times mask [B,T]) -> its Q image: bf16 hi/lo rows for the bf16x3 convs' 16-byte staging."""
+    _f32(x, mask)
+    lib, st = _prep(x, mask)
+    B, c, t = x.shape
+    xq = q_empty(B, c, t, x.device)
+    L.check(lib.svb_split_q(_ptr(x), _ptr(mask), _ptr(xq), B, c, t, st), "svb_split_q")
+    return xq
+
+
+def wn_gate_fwd(xin, g=None, g_off=0, want_q=False):
     _f32(xin, g)
     lib, st = _prep(xin, g)
     B, c2, t = xin.shape
     c = c2 // 2
     acts = torch.empty((B, c, t), device=xin.device, dtype=torch.float32)
+    acts_q = q_empty(B, c, t, xin.device) if want_q else None
     gch = g.shape[1] if g is not None else 0
-    L.check(lib.svb_wn_gate_fwd(_ptr(xin), _ptr(g), _ptr(acts), B, c, t, gch, g_off, st), "svb_wn_gate_fwd")
-    return acts
+    L.check(lib.svb_wn_gate_fwd(_ptr(xin), _ptr(g), _ptr(acts), _ptr(acts_q), B, c, t, gch, g_off, st), "svb_wn_gate_fwd")
+    return (acts, acts_q) if want_q else acts
 
 
-def wn_gate_bwd(xin, g, dacts, g_off=0, dg=None, want_dxin=True):
+def wn_gate_bwd(xin, g, dacts, g_off=0, dg=None, want_dxin=True, want_q=False):
     _f32(xin, g, dacts, dg)
     lib, st = _prep(xin, g, dacts, dg)
     B, c2, t = xin.shape
     c = c2 // 2
     dxin = torch.empty_like(xin) if want_dxin else None
+    dxin_q = q_empty(B, c2, t, xin.device) if want_q else None
     gch = g.shape[1] if g is not None else (dg.shape[1] if dg is not None else 0)
-    L.check(lib.svb_wn_gate_bwd(_ptr(xin), _ptr(g), _ptr(dacts), _ptr(dxin), _ptr(dg), B, c, t, gch, g_off, st),
+    L.check(lib.svb_wn_gate_bwd(_ptr(xin), _ptr(g), _ptr(dacts), _ptr(dxin), _ptr(dg), _ptr(dxin_q), B, c, t, gch, g_off, st),
             "svb_wn_gate_bwd")
-    return dxin
+    return (dxin, dxin_q) if want_q else dxin
 
 
-def wn_res_skip(x, rs, mask, out, last):
-    """Returns (x_new, out_new); `out` may be None (first layer).  mask: [B, T] or None."""
+def wn_res_skip(x, rs, mask, out, last, want_q=False):
+    """Returns (x_new, out_new[, x_new_q]); `out` may be None (first layer).  mask: [B, T] or None."""
     _f32(x, rs, mask, out)
     lib, st = _prep(x, rs, mask, out)
     B, rc, t = rs.shape
     c = rc if last else rc // 2
     out_new = torch.empty((B, c, t), device=rs.device, dtype=torch.float32)
     x_new = None if last else torch.empty((B, c, t), device=rs.device, dtype=torch.float32)
-    L.check(lib.svb_wn_res_skip(_ptr(x), _ptr(rs), _ptr(mask), _ptr(out), _ptr(x_new), _ptr(out_new), B, c, t,
+    x_new_q = q_empty(B, c, t, rs.device) if (want_q and not last) else None
+    L.check(lib.svb_wn_res_skip(_ptr(x), _ptr(rs), _ptr(mask), _ptr(out), _ptr(x_new), _ptr(out_new), _ptr(x_new_q), B, c, t,
                                 int(last), st), "svb_wn_res_skip")
-    return x_new, out_new
+    return (x_new, out_new, x_new_q) if want_q else (x_new, out_new)
 
 
-def wn_res_skip_bwd(dx_new, dout, mask, want_dxm=True):
+def wn_res_skip_bwd(dx_new, dout, mask, want_dxm=True, want_q=False):
     _f32(dx_new, dout, mask)
     lib, st = _prep(dx_new, dout, mask)
     B, c, t = dout.shape
     drs = torch.empty((B, 2 * c, t), device=dout.device, dtype=torch.float32)
     dxm = torch.empty_like(dout) if want_dxm else None
-    L.check(lib.svb_wn_res_skip_bwd(_ptr(dx_new), _ptr(dout), _ptr(mask), _ptr(drs), _ptr(dxm), B, c, t, st),
+    drs_q = q_empty(B, 2 * c, t, dout.device) if want_q else None
+    L.check(lib.svb_wn_res_skip_bwd(_ptr(dx_new), _ptr(dout), _ptr(mask), _ptr(drs), _ptr(dxm), _ptr(drs_q), B, c, t, st),
             "svb_wn_res_skip_bwd")
-    return drs, dxm
+    return (drs, dxm, drs_q) if want_q else (drs, dxm)
 
 
 def layernorm_fwd(x, gamma, beta, eps=1e-5, save_stats=False):
