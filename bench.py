@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = try 8/16/32 threads and report the fastest")
+    ap.add_argument("--use-q", action="store_true", help="A/B switch: pre-split (Q image) activations inside the gated stacks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true",
@@ -191,6 +192,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    if args.use_q:
+        from neuralsvb_amd import functional as SF
+        SF.USE_Q = True
     with tempfile.TemporaryDirectory() as tmp:
         log("building synthetic dataset + task")
         task, trainer, batch, hp = build_task(args, rank, world, device, tmp)

@@ -53,8 +53,12 @@ class precision_scope:
         return False
 
 
-USE_Q = True             # bf16x3 mode: producers inside the gated stack also emit the pre-split "Q" image of their result
-                         # (kernels.split_q layout); the consuming conv then stages its tiles with plain 16-byte copies
+USE_Q = False            # bf16x3 mode, opt-in: producers inside the gated stack also emit the pre-split "Q" image of their
+                         # result (kernels.split_q layout) and the consuming conv stages its tiles with plain 16-byte copies.
+                         # Measured on the MI355X (profiles/r02_qbench.log): the convs gain 8-13 % (the split was ~10 % of a
+                         # K phase, not the bottleneck), the producers pay 8-20 us per launch for the extra 4 B/element, and
+                         # the step is unchanged (23.6 vs 23.5 ms) -- so it stays off until the gate / res-skip updates move
+                         # into the conv epilogues, where the Q image costs no extra pass.
 
 
 DIRECT_GRADS = True      # weight/bias gradients of leaf parameters that already own a `.grad` buffer are accumulated into

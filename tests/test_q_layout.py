@@ -103,3 +103,37 @@ def test_conv_from_q_image_is_bit_identical(dev, case):
         d0 = K.conv1d_transposed(dy, qb, cin, T, k, s, pad, dil, groups, residual=res, force_cfg=cfg)
         d1 = K.conv1d_transposed(dy, qb, cin, T, k, s, pad, dil, groups, residual=res, force_cfg=cfg, x_q=dyq)
         assert torch.equal(d0, d1), (case, cfg, (d0 - d1).abs().max().item())
+
+
+def test_gated_stack_with_q_images_is_bit_identical(dev):
+    """functional.USE_Q: the whole WN stack (forward, data gradients, weight gradients) gives identical bits either way."""
+    from neuralsvb_amd import functional as SF
+    g_ = torch.Generator().manual_seed(9)
+    B, C, T, gin, n, ks = 2, 16, 44, 20, 2, 5
+    x = torch.randn(B, C, T, generator=g_)
+    gcond = torch.randn(B, gin, T, generator=g_)
+    mask = (torch.rand(B, T, generator=g_) > 0.2).float()
+    cond = [torch.randn(2 * C * n, gin, 1, generator=g_) * 0.3, torch.rand(2 * C * n, 1, 1, generator=g_) + 0.5,
+            torch.randn(2 * C * n, generator=g_) * 0.1]
+    layers = []
+    for i in range(n):
+        rc = 2 * C if i < n - 1 else C
+        layers.append([torch.randn(2 * C, C, ks, generator=g_) * 0.3, torch.rand(2 * C, 1, 1, generator=g_) + 0.5,
+                       torch.randn(2 * C, generator=g_) * 0.1, torch.randn(rc, C, 1, generator=g_) * 0.3,
+                       torch.rand(rc, 1, 1, generator=g_) + 0.5, torch.randn(rc, generator=g_) * 0.1])
+    dy = torch.randn(B, C, T, generator=g_)
+    res = []
+    SF.set_precision("bf16x3")
+    try:
+        for useq in (False, True):
+            SF.USE_Q = useq
+            leaves = [t.clone().to(dev).requires_grad_(True) for t in [x, gcond] + cond + [t for lp in layers for t in lp]]
+            ld = [leaves[5 + 6 * i: 11 + 6 * i] for i in range(n)]
+            y = SF.wn_stack(leaves[0], mask.to(dev), leaves[1], leaves[2:5], ld, ks)
+            y.backward(dy.to(dev))
+            res.append([y.detach()] + [t.grad for t in leaves])
+    finally:
+        SF.USE_Q = False
+        SF.set_precision("fp32")
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

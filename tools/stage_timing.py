@@ -10,27 +10,36 @@ from neuralsvb_amd import _lib as L  # noqa: E402
 from neuralsvb_amd import kernels as K  # noqa: E402
 
 B, Cin, Cout, T, k, cfg = [int(v) for v in (sys.argv[1:7] if len(sys.argv) > 6 else (32, 192, 384, 1124, 5, 2))]
+USEQ = len(sys.argv) > 7 and sys.argv[7] == "q"
 dev = torch.device("cuda:0")
 x = torch.randn(B, Cin, T, device=dev)
 w = torch.randn(Cout, Cin, k, device=dev) * 0.05
 qa, _ = K.weight_pack_q(w, None, 1)
 pad = (k - 1) // 2
+xq = K.split_q(x) if USEQ else None
 for _ in range(3):
-    K.conv1d_forward(x, qa, Cout, k, 1, pad, 1, 1, force_cfg=cfg)
+    K.conv1d_forward(x, qa, Cout, k, 1, pad, 1, 1, force_cfg=cfg, x_q=xq)
 buf = torch.zeros(64 * 32 * 8, dtype=torch.int64, device=dev)
 lib = L.get_lib()
 lib.svb_debug_set_timing_buffer(buf.data_ptr())
-K.conv1d_forward(x, qa, Cout, k, 1, pad, 1, 1, force_cfg=cfg)
+K.conv1d_forward(x, qa, Cout, k, 1, pad, 1, 1, force_cfg=cfg, x_q=xq)
 torch.cuda.synchronize()
 lib.svb_debug_set_timing_buffer(None)
 t = buf.cpu().numpy().reshape(64, 32, 8).astype(np.int64)
-names = ["issue loads", "compute (MFMA loop)", "barrier 1", "stage to LDS", "barrier 2"]
+fast = bool((t[:, :, 3] > t[:, :, 0]).any() and (t[:, :, 3] < t[:, :, 1]).any())      # the pipelined loop stamps 0 3 1 2 4 5
+if fast:
+    names = ["wait weight frags", "issue x loads", "compute (MFMA loop)", "store next tile", "barrier"]
+else:
+    names = ["issue loads", "compute (MFMA loop)", "barrier 1", "stage to LDS", "barrier 2"]
 rows = []
 for blk in range(64):
     for st in range(32):
         s = t[blk, st]
         if s[0] and s[5]:
-            rows.append([s[1] - s[0], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[5] - s[4]])
+            if fast:
+                rows.append([s[3] - s[0], s[1] - s[3], s[2] - s[1], s[4] - s[2], s[5] - s[4]])
+            else:
+                rows.append([s[1] - s[0], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[5] - s[4]])
 rows = np.array(rows)
 print(f"shape B{B} {Cin}->{Cout} k{k} T{T} cfg {cfg}: {len(rows)} (block, stage) samples; cycles mean / median")
 for i, n in enumerate(names):
