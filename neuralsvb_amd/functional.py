@@ -76,6 +76,19 @@ def _sinks(v, g, b):
     return (_gbuf(v), _gbuf(g), _gbuf(b))
 
 
+GRAD_READY = None        # callable(param) or None.  Set by the Trainer's gradient exchange: parameters whose gradient a kernel
+                         # wrote straight into `.grad` never pass through autograd's AccumulateGrad (no hook fires), so the
+                         # backward functions announce them here once the reduce kernel that produced them is enqueued.
+
+
+def _notify(sinks, params, results):
+    """After a conv1d_wgrad call with sinks: a result that came back None went into its parameter's `.grad` -- announce it."""
+    if GRAD_READY is not None and sinks is not None:
+        for sk, p, r in zip(sinks, params, results):
+            if sk is not None and p is not None and r is None:
+                GRAD_READY(p)
+
+
 def _c(t):
     return None if t is None else t.contiguous()
 
@@ -186,10 +199,11 @@ class _Conv1dFn(torch.autograd.Function):
                                      out_gate_slope=in_slope if in_slope is not None else 0.0)
         want_b = ctx.has_bias and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[1]:
+            sk = _sinks(v, g, bias_p if want_b else None)
             r = K.conv1d_wgrad(dy, x, k, stride, pad, dil, groups, a_gate=yact, a_slope=a_slope,
                                b_gate=x if in_slope is not None else None,
                                b_slope=in_slope if in_slope is not None else 0.0, v=v if g is not None else None, g=g,
-                               want_bias=want_b, sinks=_sinks(v, g, bias_p if want_b else None))
+                               want_bias=want_b, sinks=sk)
             if want_b:
                 r, db = r[:-1], r[-1]
                 r = r if g is not None else r[0]
@@ -197,6 +211,7 @@ class _Conv1dFn(torch.autograd.Function):
                 dv, dg = r
             else:
                 dv = r
+            _notify(sk, (v, g, bias_p if want_b else None), (dv, dg if g is not None else 0, db if want_b else 0))
         elif want_b:
             db = K.bias_grad(dy, yact, a_slope)
         return dx, dv, dg, db, d_res, None, None
@@ -363,12 +378,13 @@ class _WNStackFn(torch.autograd.Function):
                 drs, dxm = K.wn_res_skip_bwd(dx_next, dout, mask, want_dxm=True)
             # res/skip 1x1 conv
             if need_rs_w:           # (frozen weights -- e.g. the generator during the latent-map pass -- get no gradient)
-                r = K.conv1d_wgrad(drs, acts, 1, v=rs_v if rs_g is not None else None, g=rs_g, want_bias=True,
-                                   sinks=_sinks(rs_v, rs_g, rs_b))
+                sk = _sinks(rs_v, rs_g, rs_b)
+                r = K.conv1d_wgrad(drs, acts, 1, v=rs_v if rs_g is not None else None, g=rs_g, want_bias=True, sinks=sk)
                 if rs_g is not None:
                     grads[p + 3], grads[p + 4], grads[p + 5] = r
                 else:
                     grads[p + 3], grads[p + 5] = r
+                _notify(sk, (rs_v, rs_g, rs_b), (grads[p + 3], grads[p + 4] if rs_g is not None else 0, grads[p + 5]))
             if not (need_in_w or need_dG or need_dx):
                 dx_next = None
                 continue
@@ -379,12 +395,14 @@ class _WNStackFn(torch.autograd.Function):
             else:
                 dxin = K.wn_gate_bwd(xin, G, dacts, i * 2 * C, dg=dG)
             if need_in_w:
+                sk = _sinks(in_v, in_g, in_b)
                 r = K.conv1d_wgrad(dxin, x_i, ks, 1, pad, dil, v=in_v if in_g is not None else None, g=in_g, want_bias=True,
-                                   sinks=_sinks(in_v, in_g, in_b))
+                                   sinks=sk)
                 if in_g is not None:
                     grads[p + 0], grads[p + 1], grads[p + 2] = r
                 else:
                     grads[p + 0], grads[p + 2] = r
+                _notify(sk, (in_v, in_g, in_b), (grads[p + 0], grads[p + 1] if in_g is not None else 0, grads[p + 2]))
             if need_dx:
                 dx_next = K.conv1d_transposed(dxin, pb_in, C, x_i.shape[2], ks, 1, pad, dil, residual=dxm, x_q=dxin_q)
             else:
@@ -392,12 +410,13 @@ class _WNStackFn(torch.autograd.Function):
         grads[0] = dx_next
         if need_dG:
             if need_cond_w:
-                r = K.conv1d_wgrad(dG, gcond, 1, v=cond_v if cond_g is not None else None, g=cond_g, want_bias=True,
-                                   sinks=_sinks(cond_v, cond_g, cond_b))
+                sk = _sinks(cond_v, cond_g, cond_b)
+                r = K.conv1d_wgrad(dG, gcond, 1, v=cond_v if cond_g is not None else None, g=cond_g, want_bias=True, sinks=sk)
                 if cond_g is not None:
                     grads[3], grads[4], grads[5] = r
                 else:
                     grads[3], grads[5] = r
+                _notify(sk, (cond_v, cond_g, cond_b), (grads[3], grads[4] if cond_g is not None else 0, grads[5]))
             if need_gcond:
                 grads[2] = K.conv1d_transposed(dG, cond_pb, gcond.shape[1], gcond.shape[2], 1)
         return (None, None, None) + tuple(grads)

@@ -54,25 +54,102 @@ def move_to_device(batch, device):
 
 
 class FlatGradSync:
-    """Gradients of one optimizer live in one contiguous fp32 buffer (param.grad are views of it), so the
-    data-parallel exchange is a single all-reduce and zeroing is a single memset."""
+    """Gradients of one optimizer live in one contiguous fp32 buffer (param.grad are views of it): zeroing is a single
+    memset and the data-parallel exchange works on contiguous BUCKETS of that buffer.
 
-    def __init__(self, params, world_size, group=None):
+    Overlap with backward (the reference gets it from torch DDP, utils/trainer.py:453-454): the buffer is cut into
+    buckets of ~bucket_bytes in parameter order; every gradient that becomes final during `loss.backward()` is announced
+    (autograd's post-accumulate hook, or functional.GRAD_READY for gradients the kernels write straight into `.grad`), and
+    when a bucket has seen as many announcements as the same pass produced in its first (recording) step, its all-reduce is
+    issued at once with async_op=True -- RCCL runs it on its own stream while the rest of backward keeps the compute
+    stream busy.  `finish()` (after backward) issues whatever is left, waits and averages.  A pass is identified by a key
+    (optimizer, phase, critic plan): the graph is static under a key, so the recorded counts are exact; an announcement
+    beyond the recorded count raises instead of silently reducing a half-accumulated bucket."""
+
+    def __init__(self, params, world_size, group=None, bucket_bytes=8 << 20, overlap=True):
         self.params = [p for p in params]
         self.world_size, self.group = world_size, group
         n = sum((p.numel() + 3) // 4 * 4 for p in self.params)        # every view starts 16-byte aligned (vector kernels)
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
-        off = 0
+        self.overlap = bool(overlap) and world_size > 1
+        self.buckets, self._bucket_of = [], {}
+        off = start = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self._bucket_of[p.grad.data_ptr()] = len(self.buckets)
             off += (p.numel() + 3) // 4 * 4
+            if (off - start) * 4 >= bucket_bytes:
+                self.buckets.append((start, off))
+                start = off
+        if off > start or not self.buckets:
+            self.buckets.append((start, off))
+        self._profiles = {}              # pass key -> announcements per bucket (recorded on the key's first step)
+        self._key = self._counts = self._expected = self._work = None
+        self.stats = {"launched_in_backward": 0, "launched_after": 0, "wait_s": 0.0, "passes": 0}
+        if self.overlap:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self.grad_ready)
 
     def zero(self):
         self.flat.zero_()
 
+    # ---- overlapped exchange ----------------------------------------------------------------------------------
+    def begin_pass(self, key):
+        """Call before the backward of an optimizer pass."""
+        if not self.overlap:
+            return
+        self._key = key
+        self._counts = [0] * len(self.buckets)
+        self._expected = self._profiles.get(key)
+        self._work = [None] * len(self.buckets)
+
+    def grad_ready(self, p):
+        if self._counts is None:
+            return
+        b = self._bucket_of.get(p.grad.data_ptr() if p.grad is not None else 0)
+        if b is None:
+            return
+        self._counts[b] += 1
+        if self._expected is not None:
+            if self._counts[b] == self._expected[b] and self._work[b] is None:
+                self._launch(b, True)
+            elif self._counts[b] > self._expected[b]:
+                raise RuntimeError(f"gradient bucket {b} of pass {self._key} received more gradient announcements than in "
+                                   f"its recording step: the autograd graph changed under an unchanged pass key")
+
+    def _launch(self, b, in_backward):
+        s, e = self.buckets[b]
+        self._work[b] = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.stats["launched_in_backward" if in_backward else "launched_after"] += 1
+
+    def finish(self):
+        """After backward: exchange the buckets that did not complete during it, wait for all, average."""
+        if self.world_size <= 1:
+            return
+        if not self.overlap or self._counts is None:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.div_(self.world_size)
+            return
+        if self._expected is None:
+            self._profiles[self._key] = list(self._counts)
+        for b in range(len(self.buckets)):
+            if self._work[b] is None:
+                self._launch(b, False)
+        import time as _t
+        t0 = _t.perf_counter()
+        for w in self._work:
+            w.wait()
+        self.stats["wait_s"] += _t.perf_counter() - t0
+        self.stats["passes"] += 1
+        self.flat.div_(self.world_size)
+        self._counts = self._work = None
+
     def all_reduce(self):
+        """Blocking exchange of the whole buffer (no overlap): kept for callers outside the Trainer's step."""
         if self.world_size > 1:
+            if self._counts is not None:
+                return self.finish()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(self.world_size)
 
@@ -184,7 +261,9 @@ class Trainer:
         if not self.testing:
             self.optimizers = task.configure_optimizers()
             self.first_epoch = True
-            self.grad_sync = [FlatGradSync([p for g in o.param_groups for p in g["params"]], self.world_size)
+            self.grad_sync = [FlatGradSync([p for g in o.param_groups for p in g["params"]], self.world_size,
+                                           bucket_bytes=int(hparams.get("ddp_bucket_mb", 8) * (1 << 20)),
+                                           overlap=hparams.get("ddp_overlap", True))
                               if o is not None else None for o in self.optimizers]
         if checkpoint is not None:
             self.restore_opt_state(checkpoint)
@@ -377,11 +456,26 @@ class Trainer:
                 for g in optimizer.param_groups:
                     for p in g["params"]:
                         p.requires_grad = True
-            if graph_mode:
-                out = self._graphed_forward_backward(sig, batch, batch_idx, opt_idx)
-            else:
-                out = self._forward_backward(batch, batch_idx, opt_idx)
+            sync = self.grad_sync[opt_idx] if opt_idx < len(self.grad_sync) else None
+            final_micro = (self.global_step + 1) % self.accumulate_grad_batches == 0
+            if sync is not None and not graph_mode and final_micro:
+                # overlapped exchange: buckets are all-reduced as their gradients become final during backward (only on the
+                # micro-batch that is followed by the optimizer step: earlier ones just accumulate locally)
+                from .. import functional as SF
+                key = (opt_idx, task.graph_key(self.global_step) if hasattr(task, "graph_key") else None)
+                sync.begin_pass(key)
+                SF.GRAD_READY = sync.grad_ready if sync.overlap else None
+            try:
+                if graph_mode:
+                    out = self._graphed_forward_backward(sig, batch, batch_idx, opt_idx)
+                else:
+                    out = self._forward_backward(batch, batch_idx, opt_idx)
+            finally:
+                if sync is not None and not graph_mode and final_micro:
+                    SF.GRAD_READY = None
             if out["loss"] is None:
+                if sync is not None:
+                    sync._counts = None          # nothing to exchange in this pass
                 continue
             pbar.update(out["progress_bar"])
             tb.update(out["tb_log"])
@@ -392,7 +486,7 @@ class Trainer:
                     sys.exit(0)
             if (self.global_step + 1) % self.accumulate_grad_batches == 0:
                 sync = self.grad_sync[opt_idx]
-                sync.all_reduce()
+                sync.finish()
                 task.on_before_optimization(opt_idx)
                 optimizer.step()
                 _note_weights_updated()

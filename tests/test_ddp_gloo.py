@@ -59,6 +59,36 @@ def _worker(rank, world, port, emu_lib, out):
         yr = torch.nn.functional.conv1d(x_full, w, b, 1, 1)
         ((yr * dy_full).sum() / 4).backward()
         res["ref"] = torch.cat([t.grad.flatten() for t in (v, gn, b)]).numpy()
+    # (d) bucketed exchange overlapped with backward: three passes under one key; the first records how many gradient
+    # announcements each bucket receives, from the second on buckets are all-reduced from inside backward
+    lin = torch.nn.Linear(6, 3)                                   # stock-autograd parameters (post-accumulate hook path)
+    for p in lin.parameters():
+        dist.broadcast(p.data, 0)
+    params2 = [conv_v, conv_g, bias] + list(lin.parameters())
+    for p in params2:
+        p.grad = None
+    sync2 = FlatGradSync(params2, world, bucket_bytes=64, overlap=True)          # tiny buckets -> several of them
+    res["n_buckets"] = len(sync2.buckets)
+    res["ov_grad"], res["ov_ref"] = [], []
+    for it in range(3):
+        gi = torch.Generator().manual_seed(50 + it)
+        xf, df = torch.randn(4, 4, 20, generator=gi), torch.randn(4, 3, generator=gi)
+        sync2.zero()
+        sync2.begin_pass(("pass", 0))
+        SF.GRAD_READY = sync2.grad_ready
+        y = SF.conv1d(xf[rank::world], conv_v, bias, 1, 1, weight_g=conv_g)      # gradients written straight into .grad
+        loss = (lin(y.mean(-1)) * df[rank::world]).sum() / 2
+        loss.backward()
+        SF.GRAD_READY = None
+        sync2.finish()
+        res["ov_grad"].append(torch.cat([p.grad.flatten() for p in params2]).numpy().copy())
+        if rank == 0:
+            ps = [p.detach().clone().requires_grad_(True) for p in params2]
+            w = ps[0] * (ps[1] / ps[0].flatten(1).norm(dim=1).view(-1, 1, 1))
+            yr = torch.nn.functional.conv1d(xf, w, ps[2], 1, 1)
+            ((torch.nn.functional.linear(yr.mean(-1), ps[3], ps[4]) * df).sum() / 4).backward()
+            res["ov_ref"].append(torch.cat([t.grad.flatten() for t in ps]).numpy())
+    res["stats"] = dict(sync2.stats)
     np.save(os.path.join(out, f"r{rank}.npy"), res, allow_pickle=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -73,6 +103,14 @@ def test_flat_grad_allreduce_two_ranks_gloo(tmp_path, _emu_lib):
     assert np.array_equal(r0["w"], r1["w"])                       # identical replicas after broadcast
     assert np.array_equal(r0["grad"], r1["grad"])                 # identical averaged gradients on every rank
     assert np.abs(r0["grad"] - r0["ref"]).max() < 2e-5 * max(1.0, np.abs(r0["ref"]).max())
+    # bucketed + overlapped exchange == full-batch gradient on every rank, every pass
+    assert r0["n_buckets"] >= 3
+    for it in range(3):
+        assert np.array_equal(r0["ov_grad"][it], r1["ov_grad"][it])
+        assert np.abs(r0["ov_grad"][it] - r0["ov_ref"][it]).max() < 2e-5 * max(1.0, np.abs(r0["ov_ref"][it]).max()), it
+    st = r0["stats"]
+    assert st["passes"] == 3 and st["launched_after"] == r0["n_buckets"]           # recording pass: nothing overlapped
+    assert st["launched_in_backward"] == 2 * r0["n_buckets"]                       # passes 2 and 3: every bucket overlapped
 
 
 def test_batch_sharding_rule():
