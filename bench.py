@@ -8,8 +8,11 @@ resident in HBM before the timed region.  One sample (amateur+professional pair)
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the fp32-MFMA implicit-GEMM conv) and `cpu_baseline`
-(the oracle's CPU port of the same step, timed on this box's host cores on a bounded sample).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the implicit-GEMM conv; HIP events around every launch,
+`traffic` from the committed rocprofv3 PMC passes of tools/pmc_traffic.py when they cover that kernel and shape) and
+`cpu_baseline` (the oracle's CPU port of the same step at the same batch, timed on this box's host cores; the reference's
+own step is timed next to the port in tools/cpu_ref_vs_port.py where /root/reference exists).  N > 1 adds `comm` (RCCL ranks,
+gradient buckets overlapped with backward, exposed wait per pass).  `--workload vocoder|infer` = BASELINE configs[2] / [4].
 """
 import argparse
 import json
@@ -103,12 +106,52 @@ def conv_roofline(trainer, task, batch, steps, start_step, precision="fp32"):
     name, (fl, sec, cnt) = max(by_cfg.items(), key=lambda kv: kv[1][1])
     tot_fl = sum(v[0] for v in by_cfg.values())
     tot_s = sum(v[1] for v in by_cfg.values())
+    tags = {}
+    for nm, _, _, _, tag in rec:
+        if nm == name:
+            tags[tag] = tags.get(tag, 0) + 1
+    traffic, traffic_src = pmc_traffic(tags)
     return {"bound": "mfma", "kernel": name, "achieved": fl / sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-            "frac": fl / sec / peak, "traffic": None, "launches_per_step": cnt / steps,
+            "frac": fl / sec / peak, "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": sum(c * conv_alg_bytes(t) for t, c in tags.items()) / max(1, sum(tags.values())),
+            "launches_per_step": cnt / steps,
             "avg_launch_us": sec / cnt * 1e6, "gflop_per_launch": fl / cnt / 1e9,
             "mfma_macs_per_algorithmic_mac": mult, "frac_executed": mult * fl / sec / peak,
             "all_conv_kernels": {"achieved": tot_fl / tot_s / 1e12, "frac": tot_fl / tot_s / peak,
                                  "ms_per_step": tot_s / steps * 1e3, "launches_per_step": sum(v[2] for v in by_cfg.values()) / steps}}
+
+
+def conv_alg_bytes(tag):
+    """Algorithmic HBM bytes of one conv launch: input + output activations (fp32) + packed bf16 hi/lo weights, each once."""
+    op, B, ca, cb, G, T, k, s, dil = tag
+    if op == "fwd":
+        tout = (T + 2 * (dil * (k - 1) // 2) - dil * (k - 1) - 1) // s + 1
+        return 4.0 * B * (ca * T + cb * tout) + 4.0 * cb * (ca // G) * k
+    if op == "convT":
+        tout = (T - 1) * s + 1
+        return 4.0 * B * (ca * T + cb * tout) + 4.0 * ca * (cb // G) * k
+    return 4.0 * B * T * (ca + cb)
+
+
+def pmc_traffic(tag_counts):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r02_pmc_traffic.json, written by
+    tools/pmc_traffic.py on the MI355X: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, each calibrated
+    on a launch of known traffic with the same access pattern).  Launch-weighted over the shapes the kernel ran in this
+    step; (None, why) when the file does not cover at least 80 % of its launches."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, "no PMC file"
+    db = json.load(open(path)).get("shapes", {})
+    tot = n = 0
+    for tag, cnt in tag_counts.items():
+        ent = db.get(json.dumps(list(tag)))
+        if ent is not None:
+            tot += cnt * ent["hbm_bytes"]
+            n += cnt
+    allc = sum(tag_counts.values())
+    if n == 0 or n < 0.8 * allc:
+        return None, f"PMC file covers {n}/{allc} launches"
+    return tot / n, f"profiles/r02_pmc_traffic.json, {n}/{allc} launches covered"
 
 
 def cpu_baseline(task, batch, hp, args):
@@ -150,6 +193,159 @@ def cpu_baseline(task, batch, hp, args):
                       f"({avail} logical CPUs available)", "s_per_step": t}
 
 
+def bench_vocoder(args, device):
+    """BASELINE configs[2]: NSF-HifiGAN vocoder-only training step (G + MPD + MSD, two optimizer passes), B = 64 segments of
+    8192 samples @ 24 kHz, the composed HifiGanTask (the reference ships the modules and the YAML but no task)."""
+    from neuralsvb_amd import kernels as K
+    from neuralsvb_amd.modules.frontend import MelFrontend
+    from neuralsvb_amd.tasks.hifigan_task import HifiGanTask, default_hparams
+    from neuralsvb_amd.utils.hparams import hparams
+    from neuralsvb_amd.utils.trainer import Trainer
+    hparams.clear()
+    hparams.update(default_hparams())
+    hparams["conv_precision"] = args.precision
+    B, L, sr = 64, 8192, hparams["audio_sample_rate"]
+    trainer = Trainer(work_dir="", num_sanity_val_steps=0)
+    torch.manual_seed(0)
+    task = trainer.setup(HifiGanTask())
+    task.train()
+    g = torch.Generator().manual_seed(0)
+    t = torch.arange(L) / float(sr)
+    f0 = 150 + 200 * torch.rand(B, L // 128, generator=g)
+    f0[:, ::9] = 0.0
+    wav = 0.5 * torch.sin(2 * np.pi * 220 * t)[None].repeat(B, 1) + 0.05 * torch.randn(B, L, generator=g)
+    mel = MelFrontend(hparams, device).mel_spectrogram(wav.to(device))
+    batch = {"mels": mel, "wavs": wav[:, None].to(device), "f0": f0.to(device)}
+
+    def steps(n, s0):
+        for i in range(n):
+            task.global_step = trainer.global_step = s0 + i
+            trainer.run_training_batch(i, batch)
+    steps(args.warmup, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps(args.steps, 1 + args.warmup)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    K.PROFILE = []
+    steps(2, 1 + args.warmup + args.steps)
+    torch.cuda.synchronize()
+    rec, K.PROFILE = K.PROFILE, None
+    roof = _roofline_from_records(rec, 2, args.precision)
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle.vocoder_step_ref import vocoder_train_step
+        nb = 4
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        sd = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        a = (sd(task.model_gen), sd(task.model_disc["mpd"]), sd(task.model_disc["msd"]), mel[:nb].cpu(), wav[:nb, None], f0[:nb],
+             dict(hparams))
+        vocoder_train_step(*a)
+        tt = float(np.median([vocoder_train_step(*a) for _ in range(2)]))
+        cpu = {"value": nb * L / sr / tt, "unit": "audio-seconds/sec", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"oracle CPU port of the G+MPD+MSD step (forward + both backward passes, no optimizer update), "
+                         f"B={nb} x {L} samples, median of 2 after 1 warm-up, torch fp32", "s_per_step": tt}
+    return {"metric": "audio-seconds/sec per train step (NSF-HifiGAN vocoder-only, G+MPD+MSD)", "value": B * L / sr / dt,
+            "unit": "audio-seconds/sec", "ms_per_step": dt * 1e3,
+            "config": {"workload": f"configs[2]: NSF-HifiGAN vocoder-only training step (generator + MPD + MSD passes, AdamW), "
+                                   f"batch {B} x {L}-sample segments @ {sr} Hz, hop 128, composed HifiGanTask",
+                       "global_batch": B, "parallelism": "dp1", "random_init_weights": True}, "roofline": roof, "cpu_baseline": cpu}
+
+
+def bench_infer(args, device):
+    """BASELINE configs[4]: end-to-end inference PPG+pitch -> VAE mel (a2a, p2p, a2p) -> NSF-HifiGAN waveform (the three
+    conversions + the two ground-truth resyntheses tasks/infer.py writes), batch 32 x 10 s clips; RTF = seconds of compute
+    per second of (source) audio."""
+    from neuralsvb_amd import functional as SF
+    from neuralsvb_amd import kernels as K
+    from neuralsvb_amd.modules.hifigan import HifiGanGenerator
+    from neuralsvb_amd.modules.svb_vae import MleSVBVAE
+    from neuralsvb_amd.tasks.hifigan_task import default_hparams
+    from neuralsvb_amd.utils.hparams import hparams, set_hparams
+    set_hparams(config=os.path.join(ROOT, "egs/datasets/audio/PopBuTFy/vae_global_mle_eng.yaml"), exp_name="",
+                hparams_str="audio_sample_rate=24000,fmax=12000", print_hparams=False)
+    SF.set_precision(args.precision)
+    hifi = default_hparams()
+    B, seconds, sr = 32, 10.0, 24000
+    torch.manual_seed(0)
+    model = MleSVBVAE(70, hparams).to(device).eval()
+    gen = HifiGanGenerator(hifi)
+    gen.remove_weight_norm()
+    gen = gen.to(device).eval()
+    T = int(seconds * sr) // 128 // 4 * 4
+    g = torch.Generator().manual_seed(0)
+    mels = (torch.randn(B, T, 80, generator=g) * 0.8 - 3).to(device)
+    pitch = torch.randint(1, 255, (B, T), generator=g).to(device)
+    spk = (torch.randn(B, 256, generator=g) / 16).to(device)
+    al = torch.arange(T)[None].repeat(B, 1).to(device)
+    f0 = (150 + 200 * torch.rand(B, T, generator=g)).to(device)
+
+    @torch.no_grad()
+    def run():
+        out = model(amateur_mel=mels, prof_mel=mels, amateur_pitch=pitch, prof_pitch=pitch, amateur_spk_id=spk,
+                    prof_spk_id=spk, a2p_alignment=al, concurrent_ways=["a2a", "p2p", "a2p"])
+        for w in ("a2a", "p2p", "a2p"):
+            gen(out[w]["mel_out"].transpose(1, 2).contiguous(), f0)
+        gen(mels.transpose(1, 2).contiguous(), f0)
+        gen(mels.transpose(1, 2).contiguous(), f0)
+    for _ in range(max(1, args.warmup // 2)):
+        run()
+    torch.cuda.synchronize()
+    n = max(3, args.steps // 4)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    K.PROFILE = []
+    run()
+    torch.cuda.synchronize()
+    rec, K.PROFILE = K.PROFILE, None
+    roof = _roofline_from_records(rec, 1, args.precision)
+    audio = B * T * 128 / float(sr)
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle.vocoder_step_ref import infer_clip
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        msd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        gsd = {k: v.detach().cpu() for k, v in gen.state_dict().items()}
+        nb = 1
+        a = (msd, gsd, mels[:nb].cpu(), pitch[:nb].cpu(), spk[:nb].cpu(), al[:nb].cpu(), f0[:nb].cpu(), dict(hparams), hifi)
+        infer_clip(*a)
+        tt = infer_clip(*a)
+        cpu = {"value": nb * T * 128 / sr / tt, "unit": "audio-seconds/sec", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"oracle CPU port of the same pipeline on {nb} x {T * 128 / sr:.1f} s clip, second of two runs, torch fp32",
+               "s_per_batch": tt, "rtf": tt / (nb * T * 128 / sr)}
+    SF.set_precision("fp32")
+    return {"metric": "audio-seconds/sec, end-to-end inference (PPG+pitch -> VAE mel -> NSF-HifiGAN)", "value": audio / dt,
+            "unit": "audio-seconds/sec", "ms_per_step": dt * 1e3, "rtf": dt / audio,
+            "config": {"workload": f"configs[4]: end-to-end inference, VAE three ways + five NSF-HifiGAN passes, batch {B} x "
+                                   f"{T * 128 / sr:.2f} s clips @ {sr} Hz, hop 128, weight norm folded", "global_batch": B,
+                       "parallelism": "dp1", "random_init_weights": True}, "roofline": roof, "cpu_baseline": cpu}
+
+
+def _roofline_from_records(rec, steps, precision):
+    peak = PEAK_BF16_MFMA if precision == "bf16x3" else PEAK_F32_MFMA
+    mult = 3.0 if precision == "bf16x3" else 1.0
+    by = {}
+    for name, flops, e0, e1, tag in rec:
+        if name.startswith("svb_conv1d_wgrad"):
+            continue
+        d = by.setdefault(name, [0.0, 0.0, 0])
+        d[0] += flops
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += 1
+    if not by:
+        return None
+    name, (fl, sec, cnt) = max(by.items(), key=lambda kv: kv[1][1])
+    tot_fl, tot_s = sum(v[0] for v in by.values()), sum(v[1] for v in by.values())
+    return {"bound": "mfma", "kernel": name, "achieved": fl / sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+            "frac": fl / sec / peak, "traffic": None, "launches_per_step": cnt / steps, "avg_launch_us": sec / cnt * 1e6,
+            "mfma_macs_per_algorithmic_mac": mult, "frac_executed": mult * fl / sec / peak,
+            "all_conv_kernels": {"achieved": tot_fl / tot_s / 1e12, "frac": tot_fl / tot_s / peak,
+                                 "ms_per_step": tot_s / steps * 1e3}}
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -165,11 +361,14 @@ def main():
     ap.add_argument("--seconds", type=float, default=6.0)
     ap.add_argument("--sample-rate", type=int, default=24000)
     ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--workload", choices=["train", "vocoder", "infer"], default="train",
+                    help="train = BASELINE configs[1] (the headline metric); vocoder = configs[2] NSF-HifiGAN G+MPD+MSD train step, "
+                         "B=64 x 8192 samples; infer = configs[4] end-to-end inference 32 x 10 s (RTF)")
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="conv arithmetic: bf16x3 = bf16 matrix cores with an fp32-class operand split (BASELINE configs[1] names "
                          "bf16; mel-L1 against the reference golden <= 1e-4 is asserted by tests/test_modules_vae.py); "
                          "fp32 = fp32 MFMA, the exact parity mode")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = try 8/16/32 threads and report the fastest")
     ap.add_argument("--use-q", action="store_true", help="A/B switch: pre-split (Q image) activations inside the gated stacks")
@@ -191,6 +390,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.workload != "train":
+        assert world == 1, "the vocoder / inference workloads are single-GPU lines"
+        res = (bench_vocoder if args.workload == "vocoder" else bench_infer)(args, device)
+        res.update({"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+                    "vs_baseline": None, "data": "synthetic",
+                    "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32-class split, fp32 accumulate/storage)"})
+        print(json.dumps(res))
+        return
 
     if args.use_q:
         from neuralsvb_amd import functional as SF
@@ -220,6 +427,30 @@ def main():
         ms = dt / args.steps * 1e3
         log(f"{ms:.2f} ms/step")
         value = args.batch * args.seconds * world / (dt / args.steps)
+        # the same steps with the batch handed over as (pinned) HOST buffers: one H2D copy per step inside the timed region
+        # (SURVEY 8d's step definition; reported beside `value`, never as it)
+        from neuralsvb_amd.utils.trainer import move_to_device
+        host = {k: (v.cpu().pin_memory() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        n_h2d = max(5, args.steps // 2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n_h2d):
+            task.global_step = trainer.global_step = 1 + args.warmup + args.steps + i
+            hb = dict(host)
+            trainer.run_training_batch(i, hb)
+        torch.cuda.synchronize()
+        ms_h2d = (time.perf_counter() - t1) / n_h2d * 1e3
+        log(f"{ms_h2d:.2f} ms/step with the H2D copy of the batch inside the step")
+        comm = None
+        if world > 1:
+            st = [g.stats for g in trainer.grad_sync if g is not None]
+            passes = max(1, sum(x["passes"] for x in st))
+            comm = {"backend": "nccl (RCCL)", "ranks": dist.get_world_size(),
+                    "buckets_per_optimizer": [len(g.buckets) for g in trainer.grad_sync if g is not None],
+                    "bucket_mb": hp.get("ddp_bucket_mb", 8),
+                    "buckets_launched_in_backward": sum(x["launched_in_backward"] for x in st),
+                    "buckets_launched_after_backward": sum(x["launched_after"] for x in st),
+                    "exposed_wait_ms_per_pass": 1e3 * sum(x["wait_s"] for x in st) / passes}
         roof = cpu = None
         if rank == 0 and not args.no_roofline:
             roof = conv_roofline(trainer, task, batch, 3, 1 + args.warmup + args.steps, args.precision) if world == 1 else None
@@ -241,7 +472,8 @@ def main():
                                        f"{'hipGraph replay' if args.graph else 'eager launches'}, "
                                        f"hop 128, T={T}, 80-bin mel", "global_batch": args.batch * world,
                            "parallelism": f"dp{world}", "random_init_weights": True},
-                "roofline": roof, "cpu_baseline": cpu}))
+                "value_with_h2d": args.batch * args.seconds * world / (ms_h2d * 1e-3), "ms_per_step_with_h2d": ms_h2d,
+                "comm": comm, "roofline": roof, "cpu_baseline": cpu}))
     if world > 1:
         dist.destroy_process_group()
 

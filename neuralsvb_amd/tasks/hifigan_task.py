@@ -20,12 +20,26 @@ from ..utils.hparams import hparams
 from .base_task import BaseTask
 
 
+def default_hparams():
+    """egs/egs_bases/tts/vocoder/hifigan.yaml:1-37 with the hop-128 NSF generator of SURVEY Appendix D (the released
+    1012_hifigan_all_songs_nsf/config.yaml is not in the reference tree) -- what `egs/.../hifigan_nsf.yaml` resolves to."""
+    return dict(resblock="1", upsample_rates=[8, 4, 2, 2], upsample_kernel_sizes=[16, 8, 4, 4], upsample_initial_channel=512,
+                resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3, use_pitch_embed=True,
+                audio_sample_rate=24000, hop_size=128, fft_size=512, win_size=512, audio_num_mel_bins=80, fmin=50, fmax=12000,
+                adam_b1=0.8, adam_b2=0.99, use_fm_loss=False, use_ms_stft=False, lambda_mel=5.0, lambda_adv=1.0,
+                disc_start_steps=0, generator_grad_norm=10, discriminator_grad_norm=1,
+                generator_optimizer_params={"lr": 2e-4}, generator_scheduler_params={"step_size": 600, "gamma": 0.999},
+                discriminator_optimizer_params={"lr": 2e-4}, discriminator_scheduler_params={"step_size": 600, "gamma": 0.999})
+
+
 class HifiGanTask(BaseTask):
     def __init__(self):
         super().__init__()
         self._fe = None
 
     def build_model(self):
+        from .. import functional as SF
+        SF.set_precision(hparams.get("conv_precision", "fp32"))
         self.model_gen = HifiGanGenerator(hparams)
         self.model_disc = nn.ModuleDict()
         self.model_disc["mpd"] = MultiPeriodDiscriminator()

@@ -1,0 +1,63 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU ports (stock torch fp32) of BASELINE configs[2] and configs[4], used by bench.py's
+`cpu_baseline` leg of `--workload vocoder|infer` (kind "port") and by nothing in the product.
+
+vocoder_train_step: the composed NSF-HifiGAN GAN step of neuralsvb_amd/tasks/hifigan_task.py on the oracle's restatements
+of the reference modules (modules/hifigan/hifigan.py:105-169,202-325 and loss functions :328-365, mel_utils.py:45-79) --
+generator pass (mel L1 + adversarial terms, backward) + discriminator pass (backward); optimizer updates are left out (they
+are <1 % of the CPU time).  infer_clip: MleSVBVAE three ways + five generator passes on one clip, as tasks/infer.py does.
+"""
+import time
+
+import torch
+import torch.nn.functional as F
+
+from oracle import frontend as FE
+from oracle import modules_ref as R
+
+
+def vocoder_train_step(gen_sd, mpd_sd, msd_sd, mel, wav, f0, cfg, lambda_mel=5.0, lambda_adv=1.0):
+    """mel [B,80,frames], wav [B,1,L], f0 [B,frames].  Returns seconds spent."""
+    B, L = wav.shape[0], wav.shape[-1]
+    t0 = time.perf_counter()
+    def leafs(sd):
+        out = {}
+        for k, v in sd.items():
+            buf = k.endswith("weight_u") or (k.endswith("weight_v") and v.dim() == 1) or not v.is_floating_point()
+            out[k] = v if buf else v.clone().requires_grad_(True)
+        return out
+    gsd, psd, ssd = leafs(gen_sd), leafs(mpd_sd), leafs(msd_sd)
+    ri = torch.zeros(B, 9)
+    nz = torch.zeros(B, L, 9)
+    y_ = R.hifigan_generator(gsd, mel, f0, ri, nz, cfg)
+    hp = dict(fft_size=512, hop_size=cfg["hop_size"], win_size=512, num_mels=80, fmin=50, fmax=cfg["audio_sample_rate"] // 2,
+              sample_rate=cfg["audio_sample_rate"])
+    m_ = FE.mel_spectrogram_ingraph(y_[:, 0], **hp)
+    m = FE.mel_spectrogram_ingraph(wav[:, 0], **hp)
+    loss = F.l1_loss(m_, m.detach()) * lambda_mel
+    _, g1, _, _ = R.multi_period_disc(psd, wav, y_)
+    _, g2, _, _ = R.multi_scale_disc(ssd, wav, y_)
+    loss = loss + (R.generator_loss(g1) + R.generator_loss(g2)) * lambda_adv
+    loss.backward()
+    yd = y_.detach()
+    r1, f1, _, _ = R.multi_period_disc(psd, wav, yd)
+    r2, f2, _, _ = R.multi_scale_disc(ssd, wav, yd)
+    ld = sum(R.discriminator_loss(r1, f1)) + sum(R.discriminator_loss(r2, f2))
+    ld.backward()
+    return time.perf_counter() - t0
+
+
+@torch.no_grad()
+def infer_clip(model_sd, gen_sd, mels, pitch, spk, align, f0, hp, cfg):
+    """One batch of clips through the VAE (a2a, p2p, a2p) and five vocoder passes.  Returns seconds spent."""
+    B, T = pitch.shape
+    t0 = time.perf_counter()
+    eps = torch.zeros(B, hp["latent_size"], 1)
+    ret, _, _ = R.mle_svb_vae(model_sd, mels, mels, pitch, pitch, spk, align, ["a2a", "p2p", "a2p"], eps, eps, hp,
+                              training=False)
+    L = T * cfg["hop_size"]
+    ri, nz = torch.zeros(B, 9), torch.zeros(B, L, 9)
+    for w in ("a2a", "p2p", "a2p"):
+        R.hifigan_generator(gen_sd, ret[w]["mel_out"].transpose(1, 2), f0, ri, nz, cfg)
+    for _ in range(2):
+        R.hifigan_generator(gen_sd, mels.transpose(1, 2), f0, ri, nz, cfg)
+    return time.perf_counter() - t0
