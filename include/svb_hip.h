@@ -76,6 +76,16 @@ int svb_conv1d_transposed(const float* x, const float* wp, float* y, int B, int 
 int svb_weight_pack_bf16x3(const float* v, const float* g, unsigned short* qa_hi, unsigned short* qa_lo,
                            unsigned short* qb_hi, unsigned short* qb_lo, int d0, int d1, int k, int groups, int weight_norm,
                            void* stream);
+/* The same pack for MANY weights in one launch (e.g. every conv weight of an optimizer right after its step).  `descs` is a
+ * DEVICE array of n descriptors; row_start = number of d0 rows of all earlier descriptors (descs[0].row_start = 0),
+ * total_rows = sum of d0.  Replaces ~70 per-forward pack launches of a training step by one per optimizer step.      */
+typedef struct SvbPackDesc {
+    const float* v;
+    const float* g;               /* NULL without weight norm */
+    unsigned short *qa_hi, *qa_lo, *qb_hi, *qb_lo;   /* either layout may be NULL */
+    int d0, d1, k, groups, weight_norm, row_start;
+} SvbPackDesc;
+int svb_weight_pack_bf16x3_multi(const SvbPackDesc* descs, int n, int total_rows, void* stream);
 int svb_conv1d_forward_bf16x3(const float* x, const unsigned short* qa_hi, const unsigned short* qa_lo, float* y, int B,
                               int Cin, int Cout, int groups, int Tin, int Tout, int k, int stride, int pad, int dil,
                               const SvbConvEpilogue* epi, void* stream);
@@ -156,6 +166,14 @@ int svb_layernorm_bwd(const float* x, const float* gamma, const float* dy, const
  * ac = (q+u) k^T and bd = (q+v) p^T both [B,H,T,T]; keep [B,T] (1 = real frame, 0 = padding); T <= 2048.        */
 int svb_relpos_softmax(const float* ac, const float* bd, const float* keep, float* attn, int B, int H, int T, float scale,
                        void* stream);
+
+/* ---- Conformer convolution module between its pointwise convs, eval mode (reference
+ * modules/fastspeech/conformer/layers.py:47-63): out = Swish(BatchNorm_eval(depthwise_conv1d(GLU(y)))).  y [B, 2C, T],
+ * w [C][K] (K odd <= 63, padding (K-1)/2), bias [C] or NULL, BatchNorm weight / bias (NULL = 1 / 0), running mean / var,
+ * out [B, C, T].  Forward only (the PPG encoder is frozen).                                                        */
+int svb_glu_dwconv_bn_swish(const float* y, const float* w, const float* bias, const float* bn_w, const float* bn_b,
+                            const float* bn_mean, const float* bn_var, float eps, float* out, int B, int C, int T, int K,
+                            void* stream);
 
 /* ---- im2col / col2im for small strided Conv2d layers (reference modules/fastspeech/multi_window_disc.py:14-31).
  * The column matrix is addressed as cols[b*cols_sb + row*cols_sk + pos] (row = (c,jh,jw), pos = ho*Wo+wo): per clip

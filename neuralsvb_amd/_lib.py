@@ -21,6 +21,12 @@ class SvbConvEpilogue(C.Structure):
     ]
 
 
+class SvbPackDesc(C.Structure):
+    _fields_ = [("v", C.c_void_p), ("g", C.c_void_p), ("qa_hi", C.c_void_p), ("qa_lo", C.c_void_p), ("qb_hi", C.c_void_p),
+                ("qb_lo", C.c_void_p), ("d0", C.c_int), ("d1", C.c_int), ("k", C.c_int), ("groups", C.c_int),
+                ("weight_norm", C.c_int), ("row_start", C.c_int)]
+
+
 I, F, P, SZ, I64 = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_int64
 
 # name -> (restype, argtypes)   -- must mirror include/svb_hip.h exactly
@@ -31,6 +37,7 @@ SIGNATURES = {
     "svb_conv1d_transposed": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),
     "svb_conv1d_pick_cfg": (I, [I, I, I]),
     "svb_weight_pack_bf16x3": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    "svb_weight_pack_bf16x3_multi": (I, [P, I, I, P]),
     "svb_conv1d_forward_bf16x3": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),
     "svb_conv1d_transposed_bf16x3": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),
     "svb_conv1d_wgrad_workspace_floats": (SZ, [I, I, I, I, I, I, I, C.POINTER(I)]),
@@ -47,6 +54,7 @@ SIGNATURES = {
     "svb_split_q": (I, [P, P, P, I, I, I, P]),
     "svb_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
     "svb_relpos_softmax": (I, [P, P, P, P, I, I, I, F, P]),
+    "svb_glu_dwconv_bn_swish": (I, [P, P, P, P, P, P, P, F, P, I, I, I, I, P]),
     "svb_layernorm_nct_fwd": (I, [P, P, P, P, I, I, I, F, P]),
     "svb_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
     "svb_im2col": (I, [P, P] + [I] * 12 + [C.c_long] * 4 + [P]),

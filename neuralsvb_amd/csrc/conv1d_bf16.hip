@@ -450,12 +450,9 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
 //   qb[tap][G][ceil(d0g/16)][d1][16]        (k-dim = d0 within its group: ConvTranspose1d forward, Conv1d data-gradient)
 // Padding entries are never written: the caller zero-fills the buffers once.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void svb_weight_pack_bf16x3_kernel(const float* v, const float* gnorm, unsigned short* qa_hi,
-                                                                     unsigned short* qa_lo, unsigned short* qb_hi,
-                                                                     unsigned short* qb_lo, int d0, int d1, int k, int G,
-                                                                     int weight_norm) {
-    __shared__ float red[8];
-    const int row = blockIdx.x;
+__device__ __forceinline__ void svbq_pack_row(const float* v, const float* gnorm, unsigned short* qa_hi, unsigned short* qa_lo,
+                                              unsigned short* qb_hi, unsigned short* qb_lo, int d0, int d1, int k, int G,
+                                              int weight_norm, int row, float* red) {
     const int rowlen = d1 * k;
     const float* vr = v + (size_t)row * rowlen;
     float scale = 1.f;
@@ -481,6 +478,28 @@ __global__ __launch_bounds__(256) void svb_weight_pack_bf16x3_kernel(const float
             qb_hi[ib] = (unsigned short)hi; qb_lo[ib] = (unsigned short)lo;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void svb_weight_pack_bf16x3_kernel(const float* v, const float* gnorm, unsigned short* qa_hi,
+                                                                     unsigned short* qa_lo, unsigned short* qb_hi,
+                                                                     unsigned short* qb_lo, int d0, int d1, int k, int G,
+                                                                     int weight_norm) {
+    __shared__ float red[8];
+    svbq_pack_row(v, gnorm, qa_hi, qa_lo, qb_hi, qb_lo, d0, d1, k, G, weight_norm, blockIdx.x, red);
+}
+
+// Many weights in ONE launch (all convs of an optimizer after its step): block -> (tensor, row) through the descriptor
+// table's cumulative row counts.
+__global__ __launch_bounds__(256) void svb_weight_pack_bf16x3_multi_kernel(const SvbPackDesc* descs, int n) {
+    __shared__ float red[8];
+    int lo = 0, hi = n - 1;
+    const int r = blockIdx.x;
+    while (lo < hi) {                        // last descriptor with row_start <= r
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].row_start <= r) lo = mid; else hi = mid - 1;
+    }
+    const SvbPackDesc d = descs[lo];
+    svbq_pack_row(d.v, d.g, d.qa_hi, d.qa_lo, d.qb_hi, d.qb_lo, d.d0, d.d1, d.k, d.groups, d.weight_norm, r - d.row_start, red);
 }
 
 // ==================================================================================================================
@@ -599,6 +618,13 @@ extern "C" int svb_weight_pack_bf16x3(const float* v, const float* g, unsigned s
         return SVB_ERR_ARG;
     hipLaunchKernelGGL(svb_weight_pack_bf16x3_kernel, dim3(d0), dim3(256), 0, (hipStream_t)stream, v, g, qa_hi, qa_lo, qb_hi,
                        qb_lo, d0, d1, k, groups, weight_norm);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_weight_pack_bf16x3_multi(const SvbPackDesc* descs, int n, int total_rows, void* stream) {
+    if (!descs || n <= 0 || total_rows <= 0) return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_weight_pack_bf16x3_multi_kernel, dim3(total_rows), dim3(256), 0, (hipStream_t)stream, descs, n);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }

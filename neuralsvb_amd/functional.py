@@ -94,6 +94,8 @@ def _c(t):
 
 
 PACK_CACHE = True        # reuse a weight's packed image while the weight is known to be unchanged
+PACK_REGISTRY = True     # bf16x3 + Trainer-managed step: trainable conv weights keep PERSISTENT packed images that are refilled
+                         # by one multi-tensor launch per optimizer step (repack_registered) instead of one launch per conv call
 PACK_EPOCH = None        # None: nobody tells us when trainable weights change -> only weights that cannot train are cached.
                          # An int (only while a Trainer-managed training step is running): bumped by the Trainer at the
                          # start of the step and after every optimizer step (note_weights_updated); end_weight_epoch()
@@ -112,12 +114,81 @@ def begin_weight_epoch():
     PACK_EPOCH = _EPOCH_COUNTER
 
 
-def note_weights_updated():
-    """Trainable weights were modified in place (optimizer step, restore, broadcast): start a fresh epoch if one is open."""
+def note_weights_updated(params=None):
+    """Trainable weights were modified in place (optimizer step, restore, broadcast): start a fresh epoch if one is open.
+    `params` (optional): exactly the tensors that changed -- only their persistent bf16x3 images are marked stale."""
     global PACK_EPOCH, _EPOCH_COUNTER
     if PACK_EPOCH is not None:
         _EPOCH_COUNTER += 1
         PACK_EPOCH = _EPOCH_COUNTER
+    if params is None:
+        for e in _REG.values():
+            e.dirty = True
+    else:
+        ids = {id(p) for p in params}
+        for e in _REG.values():
+            if e.vid in ids or e.gid in ids:
+                e.dirty = True
+
+
+class _PackEntry:
+    """Persistent bf16x3 image of one trainable conv weight: buffers live as long as the weight, are refilled in place --
+    one by one on a miss, or all weights of an optimizer in ONE launch right after its step (repack_registered)."""
+    __slots__ = ("v", "g", "vid", "gid", "groups", "qa", "qb", "dirty", "ver")
+
+    def alive(self):
+        return self.v() is not None and (self.g is None or self.g() is not None)
+
+    def current_ver(self):
+        v, g = self.v(), (self.g() if self.g is not None else None)
+        return (v._version, g._version if g is not None else 0, v.data_ptr())
+
+
+_REG = {}                # (id(v), id(g) or 0, groups) -> _PackEntry
+_REG_TABLES = {}         # tuple of registry keys -> (descriptor table on the device, n, rows, layout signature)
+
+
+def _pack_registered(v, g, groups, want_a, want_b):
+    key = (id(v), id(g) if g is not None else 0, groups)
+    e = _REG.get(key)
+    if e is None or e.v() is not v or (g is not None and (e.g is None or e.g() is not g)):
+        e = _PackEntry()
+        e.v, e.g = weakref.ref(v), (weakref.ref(g) if g is not None else None)
+        e.vid, e.gid, e.groups = id(v), (id(g) if g is not None else 0), groups
+        e.qa = e.qb = None
+        e.dirty, e.ver = True, None
+        _REG[key] = e
+    need_a, need_b = want_a and e.qa is None, want_b and e.qb is None
+    if need_a or need_b:
+        na, nb = K.weight_pack_q_alloc(v, groups, need_a, need_b)
+        e.qa, e.qb = (na if need_a else e.qa), (nb if need_b else e.qb)
+        e.dirty = True
+    if e.dirty or e.ver != e.current_ver():
+        K.weight_pack_q_into(v, g, groups, e.qa, e.qb)
+        e.dirty, e.ver = False, e.current_ver()
+    return (e.qa if want_a else None), (e.qb if want_b else None)
+
+
+def repack_registered(params):
+    """After an optimizer step (Trainer): refill the persistent bf16x3 images of every registered conv weight among `params`
+    with ONE multi-tensor launch; the following forward passes find them current (no per-conv pack launches)."""
+    if PRECISION != "bf16x3" or not _REG:
+        return 0
+    ids = {id(p) for p in params}
+    keys = tuple(k for k, e in _REG.items() if (e.vid in ids or e.gid in ids) and e.alive() and (e.qa or e.qb))
+    if not keys:
+        return 0
+    ents = [_REG[k] for k in keys]
+    sig = tuple((e.current_ver()[2], e.qa is not None, e.qb is not None) for e in ents)
+    tab = _REG_TABLES.get(keys)
+    if tab is None or tab[3] != sig:
+        items = [(e.v(), e.g() if e.g is not None else None, e.groups, e.qa, e.qb) for e in ents]
+        tab = K.pack_desc_table(items, ents[0].v().device) + (sig,)
+        _REG_TABLES[keys] = tab
+    K.weight_pack_q_multi(tab[0], tab[1], tab[2])
+    for e in ents:
+        e.dirty, e.ver = False, e.current_ver()
+    return len(ents)
 
 
 def end_weight_epoch():
@@ -140,6 +211,8 @@ def _pack(v, g, groups=1, want_a=True, want_b=True):
     trainable = v.requires_grad or v.grad is not None or (g is not None and (g.requires_grad or g.grad is not None))
     if trainable and (PACK_EPOCH is None or (v.is_cuda and torch.cuda.is_current_stream_capturing())):
         return make(want_a, want_b)
+    if trainable and PRECISION == "bf16x3" and PACK_REGISTRY:
+        return _pack_registered(v, g, groups, want_a, want_b)
     key = (id(v), id(g) if g is not None else 0, groups, PRECISION)
     ver = (v._version, g._version if g is not None else 0, v.data_ptr(), PACK_EPOCH if trainable else -1)
     ent = _PACKS.get(key)

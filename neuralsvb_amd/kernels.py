@@ -160,6 +160,53 @@ def weight_pack_q(v, g=None, groups=1, want_a=True, want_b=True):
     return qa, qb
 
 
+def weight_pack_q_alloc(v, groups=1, want_a=True, want_b=True):
+    """Zero-filled persistent (qa, qb) buffers for weight v [d0, d1, k] (see weight_pack_q); filled by weight_pack_q_into /
+    weight_pack_q_multi."""
+    d0, d1, k = v.shape
+    d0g = d0 // groups
+    z = lambda n: torch.zeros((n,), device=v.device, dtype=torch.int16)
+    qa = qb = None
+    if want_a:
+        n = k * (-(-d1 // 16)) * d0 * 16
+        qa = PackedQ(z(n), z(n))
+    if want_b:
+        n = k * groups * (-(-d0g // 16)) * d1 * 16
+        qb = PackedQ(z(n), z(n))
+    return qa, qb
+
+
+def weight_pack_q_into(v, g, groups, qa, qb):
+    """(Re)pack v (weight-normalised with g when given) into existing buffers (either may be None)."""
+    _f32(v, g)
+    lib, st = _prep(v, g)
+    d0, d1, k = v.shape
+    L.check(lib.svb_weight_pack_bf16x3(_ptr(v), _ptr(g), _ptr(qa.hi) if qa else None, _ptr(qa.lo) if qa else None,
+                                       _ptr(qb.hi) if qb else None, _ptr(qb.lo) if qb else None, d0, d1, k, groups,
+                                       int(g is not None), st), "svb_weight_pack_bf16x3")
+
+
+def pack_desc_table(items, device):
+    """items: [(v, g, groups, qa, qb), ...] -> (device byte tensor holding the SvbPackDesc array, n, total_rows)."""
+    arr = (L.SvbPackDesc * len(items))()
+    rows = 0
+    for i, (v, g, groups, qa, qb) in enumerate(items):
+        d0, d1, k = v.shape
+        arr[i].v, arr[i].g = v.data_ptr(), (g.data_ptr() if g is not None else None)
+        arr[i].qa_hi, arr[i].qa_lo = (qa.hi.data_ptr(), qa.lo.data_ptr()) if qa else (None, None)
+        arr[i].qb_hi, arr[i].qb_lo = (qb.hi.data_ptr(), qb.lo.data_ptr()) if qb else (None, None)
+        arr[i].d0, arr[i].d1, arr[i].k, arr[i].groups = d0, d1, k, groups
+        arr[i].weight_norm, arr[i].row_start = int(g is not None), rows
+        rows += d0
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(device), len(items), rows
+
+
+def weight_pack_q_multi(table, n, total_rows):
+    lib, st = _prep(table)
+    L.check(lib.svb_weight_pack_bf16x3_multi(_ptr(table), n, total_rows, st), "svb_weight_pack_bf16x3_multi")
+
+
 def conv1d_forward(x, pa, cout, k, stride=1, pad=0, dil=1, groups=1, out=None, **epi):
     q = isinstance(pa, PackedQ)
     _f32(x, None if q else pa)
@@ -408,6 +455,19 @@ def relpos_softmax(ac, bd, keep, scale):
     B, H, T, _ = ac.shape
     out = torch.empty_like(ac)
     L.check(lib.svb_relpos_softmax(_ptr(ac), _ptr(bd), _ptr(keep), _ptr(out), B, H, T, float(scale), st), "svb_relpos_softmax")
+    return out
+
+
+def glu_dwconv_bn_swish(y, w, bias, bn_w, bn_b, bn_mean, bn_var, eps):
+    """Swish(BatchNorm_eval(depthwise_conv1d(GLU(y)))): y [B,2C,T], w [C,1,K] or [C,K] -> [B,C,T] (forward only)."""
+    w = w.reshape(w.shape[0], -1).contiguous()
+    _f32(y, w, bias, bn_w, bn_b, bn_mean, bn_var)
+    lib, st = _prep(y, w, bias, bn_w, bn_b, bn_mean, bn_var)
+    B, c2, t = y.shape
+    c = c2 // 2
+    out = torch.empty((B, c, t), device=y.device, dtype=torch.float32)
+    L.check(lib.svb_glu_dwconv_bn_swish(_ptr(y), _ptr(w), _ptr(bias), _ptr(bn_w), _ptr(bn_b), _ptr(bn_mean), _ptr(bn_var),
+                                        float(eps), _ptr(out), B, c, t, w.shape[1], st), "svb_glu_dwconv_bn_swish")
     return out
 
 

@@ -7,8 +7,8 @@ espnet_positional_embedding.py:89-112.  Same state_dict keys (incl. the never-ex
 kept as opaque frozen parameters so reference checkpoints load strictly).
 
 Forward-only (the task freezes it, svb_vae_task.py:558-561) and eval-mode (BatchNorm running stats, no dropout).
-All dense projections / FFN / k5 convs and the five LayerNorms per block run on the HIP kernels; the rel-pos
-attention products, softmax, GLU, the depthwise k31 conv and Swish stay on torch-ROCm ops this round.
+All dense projections / FFN / k5 convs, the five LayerNorms per block, the rel-pos softmax glue and the conv module's
+GLU + depthwise k31 + BatchNorm + Swish chain run on the HIP kernels; the three attention matrix products stay on rocBLAS.
 """
 import math
 
@@ -93,9 +93,15 @@ class ConvolutionModule(nn.Module):
         self.pointwise_conv2 = Conv1d(channels, channels, 1)
 
     def forward(self, x):
-        x = F.glu(self.pointwise_conv1(x), dim=1)
-        x = self.norm(self.depthwise_conv(x))
-        x = x * torch.sigmoid(x)
+        y = self.pointwise_conv1(x)
+        if self.training or self.norm.training:          # (never on the hot path: VCASR pins eval mode)
+            x = F.glu(y, dim=1)
+            x = self.norm(self.depthwise_conv(x))
+            x = x * torch.sigmoid(x)
+        else:                                            # GLU + depthwise k31 + folded BatchNorm + Swish: one HIP kernel
+            dw, bn = self.depthwise_conv, self.norm
+            x = K.glu_dwconv_bn_swish(y.contiguous(), dw.weight, dw.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                      bn.eps)
         return self.pointwise_conv2(x)
 
 

@@ -36,9 +36,11 @@ from .ckpt_utils import get_all_ckpts, get_last_checkpoint
 from .hparams import hparams
 
 
-def _note_weights_updated():
+def _note_weights_updated(params=None, repack=False):
     from .. import functional as SF          # weight images packed for the kernels are stale after an in-place update
-    SF.note_weights_updated()
+    SF.note_weights_updated(params)
+    if repack and params is not None:
+        SF.repack_registered(params)          # ... and refilled at once: one multi-tensor launch per optimizer step
 
 
 def move_to_device(batch, device):
@@ -489,7 +491,7 @@ class Trainer:
                 sync.finish()
                 task.on_before_optimization(opt_idx)
                 optimizer.step()
-                _note_weights_updated()
+                _note_weights_updated([p for g in optimizer.param_groups for p in g["params"]], repack=True)
                 sync.zero()
                 task.on_after_optimization(self.current_epoch, batch_idx, optimizer, opt_idx)
         if hasattr(task, "end_step"):

@@ -294,3 +294,64 @@ def test_wn_stack_frozen_weights_receive_no_gradient(dev):
     assert rel_err(xd.grad, xr.grad) < 5e-5
     for t in frozen:
         assert float(t.grad.abs().max()) == 0.0
+
+
+def test_persistent_weight_images_and_multi_tensor_repack(dev):
+    """bf16x3 + Trainer-managed step: trainable conv weights keep persistent packed images.  A silent in-place update (fused
+    AdamW does not bump version counters) is announced with note_weights_updated(params); repack_registered(params) refills
+    all of them with ONE launch; unrelated weights stay valid; a versioned update is caught without any announcement."""
+    from neuralsvb_amd import kernels as K
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 8, 30, generator=g).to(dev)
+    mk = lambda *s: torch.nn.Parameter((torch.randn(*s, generator=g) * 0.3).to(dev))
+    v1, g1, b1 = mk(12, 8, 3), torch.nn.Parameter((torch.rand(12, 1, 1, generator=g) + 0.5).to(dev)), mk(12)
+    v2 = mk(6, 8, 5)
+    counts = {"single": 0, "multi": 0}
+    o_into, o_multi = K.weight_pack_q_into, K.weight_pack_q_multi
+
+    def c_into(*a, **k):
+        counts["single"] += 1
+        return o_into(*a, **k)
+
+    def c_multi(*a, **k):
+        counts["multi"] += 1
+        return o_multi(*a, **k)
+    K.weight_pack_q_into, K.weight_pack_q_multi = c_into, c_multi
+
+    def fresh(v, gg, b, pad):
+        SF.end_weight_epoch()                          # no epoch: packed from scratch on every call
+        try:
+            return SF.conv1d(x, v, b, 1, pad, weight_g=gg).detach().clone()
+        finally:
+            SF.begin_weight_epoch()
+    SF.set_precision("bf16x3")
+    try:
+        SF.begin_weight_epoch()
+        y1 = SF.conv1d(x, v1, b1, 1, 1, weight_g=g1)
+        y2 = SF.conv1d(x, v2, None, 1, 2)
+        n0 = counts["single"]
+        assert torch.equal(SF.conv1d(x, v1, b1, 1, 1, weight_g=g1), y1) and counts["single"] == n0      # image reused
+        SF.end_weight_epoch()
+        SF.begin_weight_epoch()                                                # next step, nothing changed: still valid
+        assert torch.equal(SF.conv1d(x, v1, b1, 1, 1, weight_g=g1), y1) and counts["single"] == n0
+        v1.data.mul_(1.5)                                                      # silent update (no version bump)
+        g1.data.add_(0.25)
+        SF.note_weights_updated([v1, g1, b1])
+        assert SF.repack_registered([v1, g1, b1]) == 1 and counts["multi"] == 1
+        ya = SF.conv1d(x, v1, b1, 1, 1, weight_g=g1)
+        assert counts["single"] == n0 and torch.equal(ya, fresh(v1, g1, b1, 1)) and not torch.equal(ya, y1)
+        assert torch.equal(SF.conv1d(x, v2, None, 1, 2), y2) and counts["single"] == n0     # the other weight was not touched
+        with torch.no_grad():
+            v2.mul_(2.0)                                                       # versioned update, no announcement
+        yb = SF.conv1d(x, v2, None, 1, 2)
+        assert counts["single"] == n0 + 1 and torch.equal(yb, fresh(v2, None, None, 2))
+        # backward through the image (data gradient uses the second layout, allocated on demand)
+        xg = x.clone().requires_grad_(True)
+        SF.conv1d(xg, v1, b1, 1, 1, weight_g=g1).sum().backward()
+        assert xg.grad is not None and torch.isfinite(xg.grad).all()
+        SF.note_weights_updated([v1, g1, b1, v2])
+        assert SF.repack_registered([v1, g1, b1, v2]) == 2 and counts["multi"] == 2
+    finally:
+        K.weight_pack_q_into, K.weight_pack_q_multi = o_into, o_multi
+        SF.end_weight_epoch()
+        SF.set_precision("fp32")

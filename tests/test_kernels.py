@@ -468,3 +468,19 @@ def test_relpos_softmax_matches_espnet_rel_shift(dev, T):
     ref = torch.softmax(scores.masked_fill(drop, torch.finfo(torch.float32).min), -1).masked_fill(drop, 0.0)
     out = K.relpos_softmax(ac.to(dev), bd.to(dev), keep.to(dev), 1.0 / dk ** 0.5)
     assert (out.cpu() - ref).abs().max().item() < 2e-6
+
+
+def test_glu_dwconv_bn_swish(dev):
+    """Conformer conv module core (conformer/layers.py:47-63, eval): Swish(BN_eval(depthwise_conv1d_k31(GLU(y))))."""
+    g_ = torch.Generator().manual_seed(12)
+    for B, C, T, k in ((2, 24, 70, 31), (1, 8, 600, 31), (2, 5, 33, 7)):
+        y = torch.randn(B, 2 * C, T, generator=g_)
+        w = torch.randn(C, 1, k, generator=g_) * 0.2
+        b = torch.randn(C, generator=g_) * 0.1
+        bw, bb = 1 + 0.1 * torch.randn(C, generator=g_), 0.1 * torch.randn(C, generator=g_)
+        mean, var = 0.1 * torch.randn(C, generator=g_), torch.rand(C, generator=g_) + 0.5
+        u = F.glu(y, dim=1)
+        z = F.batch_norm(F.conv1d(u, w, b, padding=(k - 1) // 2, groups=C), mean, var, bw, bb, False, 0.1, 1e-5)
+        ref = z * torch.sigmoid(z)
+        out = K.glu_dwconv_bn_swish(y.to(dev), w.to(dev), b.to(dev), bw.to(dev), bb.to(dev), mean.to(dev), var.to(dev), 1e-5)
+        assert (out.cpu() - ref).abs().max() < 2e-5, (B, C, T, k)
