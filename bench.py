@@ -124,6 +124,8 @@ def conv_roofline(trainer, task, batch, steps, start_step, precision="fp32"):
 def conv_alg_bytes(tag):
     """Algorithmic HBM bytes of one conv launch: input + output activations (fp32) + packed bf16 hi/lo weights, each once."""
     op, B, ca, cb, G, T, k, s, dil = tag
+    if op == "taps":
+        return 4.0 * B * T * (ca + cb) + 4.0 * ca * cb * k
     if op == "fwd":
         tout = (T + 2 * (dil * (k - 1) // 2) - dil * (k - 1) - 1) // s + 1
         return 4.0 * B * (ca * T + cb * tout) + 4.0 * cb * (ca // G) * k

@@ -55,6 +55,16 @@ int svb_weight_pack(const float* v, const float* g, float* pa, float* pb, int d0
 int svb_conv1d_forward(const float* x, const float* wp, float* y, int B, int Cin, int Cout, int groups, int Tin,
                        int Tout, int k, int stride, int pad, int dil, const SvbConvEpilogue* epi, void* stream);
 
+/* Stride-1 conv with an arbitrary tap table (groups 1):  y[b,co,q] = sum_{ci,t} w[t][ci][co] x[b,ci,q + tap_off[t]], zero
+ * outside [0,Tin).  wp = a [ntaps][Cin][Cout] pack (pa of a [Cout][Cin][ntaps] weight; pb of it, with Cin/Cout swapped and
+ * the offsets negated, gives the data gradient).  Used for the mel critic's 3x3 stride-2 Conv2d (reference
+ * modules/fastspeech/multi_window_disc.py:14-31): after a space-to-depth of the input it is a 2x2 stride-1 conv, i.e. a 1-D
+ * conv over the row-padded flattened image with taps {-P-1, -P, -1, 0} -- no 9x im2col expansion.                      */
+int svb_conv1d_taps(const float* x, const float* wp, float* y, int B, int Cin, int Cout, int Tin, int Tout, int ntaps,
+                    const int* tap_off, const SvbConvEpilogue* epi, void* stream);
+int svb_conv1d_taps_bf16x3(const float* x, const unsigned short* q_hi, const unsigned short* q_lo, float* y, int B, int Cin,
+                           int Cout, int Tin, int Tout, int ntaps, const int* tap_off, const SvbConvEpilogue* epi, void* stream);
+
 /* Tile configuration (0..4) the conv launcher picks for Cout/groups output channels and nq_max output positions
  * per phase: {64x128, 128x96, 128x128, 64x64, 32x128} = svb_conv1d_mfma_kernel<2,2,2>, <4,1,3>, <4,1,4>, <2,2,1>, <1,4,1>.
  * (profiling aid: lets a caller name the kernel instantiation a launch used)                                   */
@@ -185,6 +195,13 @@ int svb_im2col(const float* x, float* cols, int B, int C, int H, int W, int KH, 
                int Ho, int Wo, long x_sb, long x_sc, long cols_sb, long cols_sk, void* stream);
 int svb_col2im(const float* dcols, float* dx, int B, int C, int H, int W, int KH, int KW, int SH, int SW, int PH, int PW,
                int Ho, int Wo, long cols_sb, long cols_sk, void* stream);
+
+/* Space-to-depth + zero border for the stride-2 3x3 Conv2d of the mel critic without im2col (see svb_conv1d_taps):
+ * out[(ph*2+pw)*C + c][n][i+1][j+1] = x[n][c][2i+ph][2j+pw], row 0 / column 0 of each plane zero; x addressed with element
+ * strides (n, c, h, w), out contiguous [4C][N][H/2+1][W/2+1]; H, W even.  _bwd: the inverse gather into a contiguous
+ * dx [N][C][H][W].                                                                                                  */
+int svb_s2d_pad(const float* x, float* out, int N, int C, int H, int W, long sn, long sc, long sh, long sw, void* stream);
+int svb_s2d_pad_bwd(const float* dout, float* dx, int N, int C, int H, int W, void* stream);
 
 /* ---- SSIM map of two [B, T, F] mel images (+bias), 11x11 gaussian sigma 1.5, zero padding, C1=1e-4, C2=9e-4
  * (reference modules/commons/ssim.py:331-351 via tasks/tts/fs2.py:166-175).  Inputs are addressed with element

@@ -36,6 +36,8 @@ SIGNATURES = {
     "svb_conv1d_forward": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),
     "svb_conv1d_transposed": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),
     "svb_conv1d_pick_cfg": (I, [I, I, I]),
+    "svb_conv1d_taps": (I, [P, P, P, I, I, I, I, I, I, C.POINTER(I), C.POINTER(SvbConvEpilogue), P]),
+    "svb_conv1d_taps_bf16x3": (I, [P, P, P, P, I, I, I, I, I, I, C.POINTER(I), C.POINTER(SvbConvEpilogue), P]),
     "svb_weight_pack_bf16x3": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
     "svb_weight_pack_bf16x3_multi": (I, [P, I, I, P]),
     "svb_conv1d_forward_bf16x3": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),
@@ -59,6 +61,8 @@ SIGNATURES = {
     "svb_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
     "svb_im2col": (I, [P, P] + [I] * 12 + [C.c_long] * 4 + [P]),
     "svb_col2im": (I, [P, P] + [I] * 12 + [C.c_long] * 2 + [P]),
+    "svb_s2d_pad": (I, [P, P, I, I, I, I, C.c_long, C.c_long, C.c_long, C.c_long, P]),
+    "svb_s2d_pad_bwd": (I, [P, P, I, I, I, I, P]),
     "svb_ssim_fwd": (I, [P, C.c_long, C.c_long, C.c_long, P, C.c_long, C.c_long, C.c_long, P, I, I, I, F, P]),
     "svb_ssim_bwd": (I, [P, C.c_long, C.c_long, C.c_long, P, C.c_long, C.c_long, C.c_long, P, P, P, I, I, I, F, P]),
     "svb_stft_mel": (I, [P, P, P, P, I, I, I, I, I, I, I, F, P]),

@@ -703,6 +703,32 @@ extern "C" int svb_conv1d_forward(const float* x, const float* wp, float* y, int
     return launch_conv(a, p, (hipStream_t)stream);
 }
 
+// Stride-1 conv with an arbitrary tap table: y[b,co,q] = sum_{ci,t} wp[t][ci][co] x[b,ci,q + tap_off[t]] (zero outside [0,Tin)).
+extern "C" int svb_conv1d_taps(const float* x, const float* wp, float* y, int B, int Cin, int Cout, int Tin, int Tout,
+                               int ntaps, const int* tap_off, const SvbConvEpilogue* epi, void* stream) {
+    if (!x || !wp || !y || !tap_off || B <= 0 || Cin <= 0 || Cout <= 0 || Tin <= 0 || Tout <= 0 || ntaps <= 0 ||
+        ntaps > SVB_MAX_TAPS)
+        return SVB_ERR_ARG;
+    SvbConvArgs a;
+    SvbConvPlan p;
+    memset(&p, 0, sizeof(p));
+    a.x = x; a.wp = wp; a.y = y;
+    fill_epilogue(a, epi);
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.G = 1; a.Cin_g = Cin; a.Cout_g = Cout;
+    a.Tin = Tin; a.Tout = Tout; a.sx = 1; a.out_stride = 1;
+    a.w_tap_stride = Cin * Cout; a.w_ld = Cout; a.w_goff_k = 0; a.w_goff_m = Cout;
+    p.n_phase = 1;
+    p.phase_start[0] = 0; p.phase_start[1] = ntaps;
+    int mn = tap_off[0], mx = tap_off[0];
+    for (int j = 0; j < ntaps; ++j) {
+        p.tap_off[j] = tap_off[j]; p.tap_w[j] = j;
+        if (tap_off[j] < mn) mn = tap_off[j];
+        if (tap_off[j] > mx) mx = tap_off[j];
+    }
+    p.phase_nq[0] = Tout; p.phase_out_base[0] = 0; p.phase_min_off[0] = mn; p.phase_span_off[0] = mx - mn;
+    return launch_conv(a, p, (hipStream_t)stream);
+}
+
 // y[b,co,pos] = sum_{ci,j : pos = t*stride - pad + j*dil} wp[j][ci][co] x[b,ci,t]   (gather form, no zero insertion)
 extern "C" int svb_conv1d_transposed(const float* x, const float* wp, float* y, int B, int Cin, int Cout, int groups,
                                      int Tin, int Tout, int k, int stride, int pad, int dil,

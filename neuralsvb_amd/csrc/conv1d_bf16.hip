@@ -651,6 +651,32 @@ extern "C" int svb_conv1d_forward_bf16x3(const float* x, const unsigned short* q
     return q_dispatch(a, p, (hipStream_t)stream);
 }
 
+extern "C" int svb_conv1d_taps_bf16x3(const float* x, const unsigned short* q_hi, const unsigned short* q_lo, float* y, int B,
+                                      int Cin, int Cout, int Tin, int Tout, int ntaps, const int* tap_off,
+                                      const SvbConvEpilogue* epi, void* stream) {
+    if (!x || !q_hi || !q_lo || !y || !tap_off || B <= 0 || Cin <= 0 || Cout <= 0 || Tin <= 0 || Tout <= 0 || ntaps <= 0 ||
+        ntaps > SVB_MAX_TAPS)
+        return SVB_ERR_ARG;
+    SvbConvQArgs a;
+    SvbConvPlan p;
+    memset(&p, 0, sizeof(p));
+    a.x = x; a.wq_hi = q_hi; a.wq_lo = q_lo; a.y = y;
+    q_fill(a, epi);
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.G = 1; a.Cin_g = Cin; a.Cout_g = Cout;
+    a.Tin = Tin; a.Tout = Tout; a.sx = 1; a.out_stride = 1;
+    a.w_tap_slabs = svb_cdiv(Cin, 16); a.w_g_slabs = 0; a.w_slab_rows = Cout; a.w_goff_m = Cout;
+    p.n_phase = 1;
+    p.phase_start[0] = 0; p.phase_start[1] = ntaps;
+    int mn = tap_off[0], mx = tap_off[0];
+    for (int j = 0; j < ntaps; ++j) {
+        p.tap_off[j] = tap_off[j]; p.tap_w[j] = j;
+        if (tap_off[j] < mn) mn = tap_off[j];
+        if (tap_off[j] > mx) mx = tap_off[j];
+    }
+    p.phase_nq[0] = Tout; p.phase_out_base[0] = 0; p.phase_min_off[0] = mn; p.phase_span_off[0] = mx - mn;
+    return q_dispatch(a, p, (hipStream_t)stream);
+}
+
 extern "C" int svb_conv1d_transposed_bf16x3(const float* x, const unsigned short* qb_hi, const unsigned short* qb_lo, float* y,
                                             int B, int Cin, int Cout, int groups, int Tin, int Tout, int k, int stride, int pad,
                                             int dil, const SvbConvEpilogue* epi, void* stream) {

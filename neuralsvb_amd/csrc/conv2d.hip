@@ -85,3 +85,63 @@ extern "C" int svb_col2im(const float* dcols, float* dx, int B, int C, int H, in
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Space-to-depth + zero border for the stride-2 3x3 convs WITHOUT the 9x im2col expansion.
+//   out[(ph*2+pw)*C + c][n][i+1][j+1] = x[n][c][2i+ph][2j+pw],   row 0 and column 0 of every (channel, clip) plane = 0
+// (x addressed with element strides; out contiguous [4C][N][Ho+1][Wo+1], Ho = H/2, Wo = W/2, H and W even).
+// A 3x3 stride-2 pad-1 conv of x is then a 2x2 stride-1 conv of `out`, i.e. a 1-D conv over the flattened planes of pitch
+// P = Wo+1 with taps {-P-1, -P, -1, 0} (svb_conv1d_taps): kernel row kh maps to (plane row offset, row phase) =
+// 0 -> (-1, 1), 1 -> (0, 0), 2 -> (0, 1), the same for columns.  Data moved: 1 read + 1 write of the activation.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void svb_s2d_pad_kernel(const float* x, float* out, int N, int C, int Ho, int Wo, long sn,
+                                                          long sc, long sh, long sw) {
+    const int P = Wo + 1, R = Ho + 1;
+    const long total = 4L * C * N * R * P;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int jp = (int)(i % P);
+        long r = i / P;
+        const int ip = (int)(r % R); r /= R;
+        const int n = (int)(r % N); r /= N;
+        const int c = (int)(r % C);
+        const int blk = (int)(r / C);
+        float v = 0.f;
+        if (ip > 0 && jp > 0) {
+            const int h = 2 * (ip - 1) + (blk >> 1), w = 2 * (jp - 1) + (blk & 1);
+            v = x[(long)n * sn + (long)c * sc + (long)h * sh + (long)w * sw];
+        }
+        out[i] = v;
+    }
+}
+
+// inverse gather: dx[n][c][h][w] (contiguous) = dout[((h&1)*2 + (w&1))*C + c][n][h/2 + 1][w/2 + 1]
+__global__ __launch_bounds__(256) void svb_s2d_pad_bwd_kernel(const float* dout, float* dx, int N, int C, int Ho, int Wo) {
+    const int P = Wo + 1, R = Ho + 1, H = 2 * Ho, W = 2 * Wo;
+    const long total = (long)N * C * H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int w = (int)(i % W);
+        long r = i / W;
+        const int h = (int)(r % H); r /= H;
+        const int c = (int)(r % C);
+        const int n = (int)(r / C);
+        const int blk = (h & 1) * 2 + (w & 1);
+        dx[i] = dout[((((long)blk * C + c) * N + n) * R + (h >> 1) + 1) * P + (w >> 1) + 1];
+    }
+}
+
+extern "C" int svb_s2d_pad(const float* x, float* out, int N, int C, int H, int W, long sn, long sc, long sh, long sw,
+                           void* stream) {
+    if (!x || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_s2d_pad_kernel, dim3(g1d(4L * C * N * (H / 2 + 1) * (W / 2 + 1))), dim3(256), 0, (hipStream_t)stream,
+                       x, out, N, C, H / 2, W / 2, sn, sc, sh, sw);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_s2d_pad_bwd(const float* dout, float* dx, int N, int C, int H, int W, void* stream) {
+    if (!dout || !dx || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_s2d_pad_bwd_kernel, dim3(g1d((long)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, dout, dx, N, C,
+                       H / 2, W / 2);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}

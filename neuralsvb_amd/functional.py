@@ -602,6 +602,96 @@ class _Conv2dFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _S2DPadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return K.s2d_pad(x)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return K.s2d_pad_bwd(dout.contiguous(), *ctx.shape)
+
+
+class _ConvTapsFn(torch.autograd.Function):
+    """Stride-1 conv with an arbitrary tap table (+ fused LeakyReLU): x [B,Cin,T], w [Cout,Cin,ntaps], y [B,Cout,T]."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, cfg):
+        offsets, slope = cfg
+        x, w = x.contiguous(), w.contiguous()
+        cout = w.shape[0]
+        pa, pb = _pack(w, None, 1, want_a=True, want_b=ctx.needs_input_grad[0])
+        y = K.conv1d_taps(x, pa, cout, offsets, bias=bias, out_act=ACT_LRELU if slope is not None else ACT_NONE,
+                          out_slope=slope if slope is not None else 0.0)
+        ctx.cfg, ctx.pb, ctx.has_bias = cfg, pb, bias is not None
+        ctx.save_for_backward(x if ctx.needs_input_grad[1] else None, y if slope is not None else None)
+        ctx.cin = x.shape[1]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        offsets, slope = ctx.cfg
+        x, yact = ctx.saved_tensors
+        dy = dy.contiguous()
+        a_slope = slope if slope is not None else 0.0
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = K.conv1d_taps(dy, ctx.pb, ctx.cin, [-o for o in offsets], in_gate=yact, in_slope=a_slope)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            parts, i = [], 0
+            while i < len(offsets):                      # runs of consecutive offsets = one dilation-1 weight-gradient call
+                n = 1
+                while i + n < len(offsets) and offsets[i + n] == offsets[i + n - 1] + 1:
+                    n += 1
+                r = K.conv1d_wgrad(dy, x, n, 1, -offsets[i], 1, 1, a_gate=yact, a_slope=a_slope, want_bias=want_b and i == 0)
+                if want_b and i == 0:
+                    r, db = r
+                parts.append(r)
+                i += n
+            dw = torch.cat(parts, 2) if len(parts) > 1 else parts[0]
+        elif want_b:
+            db = K.bias_grad(dy, yact, a_slope)
+        return dx, dw, db, None
+
+
+_S2_MAP = {}
+
+
+def _s2_weight(weight):
+    """[Cout,C,3,3] stride-2 kernel -> [Cout,4C,4]: the equivalent 2x2 stride-1 kernel over the space-to-depth planes
+    (channel block ph*2+pw, tap (di+1)*2+(dj+1) with kernel row kh -> (di, ph) = 0:(-1,1) 1:(0,0) 2:(0,1); 7 of the 16
+    (block, tap) slots have no kernel entry and stay zero)."""
+    dev = weight.device
+    m = _S2_MAP.get(dev)
+    if m is None:
+        idx = torch.zeros(4, 4, dtype=torch.long)
+        msk = torch.zeros(4, 4)
+        dp = {0: (-1, 1), 1: (0, 0), 2: (0, 1)}
+        for kh in range(3):
+            for kw in range(3):
+                (di, ph), (dj, pw) = dp[kh], dp[kw]
+                idx[ph * 2 + pw, (di + 1) * 2 + (dj + 1)] = kh * 3 + kw
+                msk[ph * 2 + pw, (di + 1) * 2 + (dj + 1)] = 1.0
+        m = _S2_MAP[dev] = (idx.flatten().to(dev), msk.flatten().to(dev))
+    cout, c = weight.shape[:2]
+    w16 = weight.reshape(cout, c, 9).index_select(2, m[0]) * m[1]               # [Cout, C, 16] (block, tap)
+    return w16.view(cout, c, 4, 4).permute(0, 2, 1, 3).reshape(cout, 4 * c, 4)
+
+
+CONV2D_S2D = True        # 3x3 stride-2 pad-1 Conv2d via space-to-depth + the tap-table conv (no 9x im2col expansion)
+
+
 def conv2d_lrelu(x, weight, bias, stride, padding, lrelu_slope=None):
-    """x [B,C,H,W]; weight [Cout,C,KH,KW]; returns leaky_relu(conv2d(x)) (or conv2d(x) when lrelu_slope is None)."""
+    """x [B,C,H,W]; weight [Cout,C,KH,KW]; returns leaky_relu(conv2d(x)) (or conv2d(x) when lrelu_slope is None).
+    Result: a [B,Cout,Ho,Wo] strided view of channel-major memory."""
+    N, C, H, W = x.shape
+    if (CONV2D_S2D and tuple(weight.shape[2:]) == (3, 3) and int(stride) == 2 and int(padding) == 1 and H % 2 == 0
+            and W % 2 == 0):
+        Ho, Wo = H // 2, W // 2
+        P = Wo + 1
+        x4 = _S2DPadFn.apply(x).view(1, 4 * C, N * (Ho + 1) * P)              # clips folded into one long position axis
+        y4 = _ConvTapsFn.apply(x4, _s2_weight(weight), bias, ((-P - 1, -P, -1, 0), lrelu_slope))
+        return y4.view(weight.shape[0], N, Ho + 1, P)[:, :, 1:, 1:].permute(1, 0, 2, 3)
     return _Conv2dFn.apply(x, weight, bias, (int(stride), int(padding), lrelu_slope))

@@ -248,6 +248,39 @@ def conv1d_forward(x, pa, cout, k, stride=1, pad=0, dil=1, groups=1, out=None, *
     return y
 
 
+def conv1d_taps(x, packed, cout, offsets, tout=None, **epi):
+    """Stride-1 conv with an arbitrary tap table: y[b,co,q] = sum_{ci,t} w[t][ci][co] x[b,ci,q+offsets[t]] (zero outside).
+    packed: pa of a [cout, cin, ntaps] weight (fp32 tensor or PackedQ)."""
+    q = isinstance(packed, PackedQ)
+    _f32(x, None if q else packed)
+    tensors = [x, packed.hi if q else packed] + [epi.get(n) for n in ("bias", "in_gate", "out_gate", "residual", "mask")]
+    lib, st = _prep(*tensors)
+    B, cin, tin = x.shape
+    tout = tin if tout is None else tout
+    y = torch.empty((B, cout, tout), device=x.device, dtype=torch.float32)
+    offs = (C.c_int * len(offsets))(*[int(o) for o in offsets])
+    e = make_epilogue(**epi)
+    nt = len(offsets)
+    sig = ("taps", q, B, cin, cout, tin, tout, tuple(int(o) for o in offsets))
+
+    def launch(cfg):
+        e.force_cfg = cfg
+        if q:
+            L.check(lib.svb_conv1d_taps_bf16x3(_ptr(x), _ptr(packed.hi), _ptr(packed.lo), _ptr(y), B, cin, cout, tin, tout, nt,
+                                               offs, C.byref(e), st), "svb_conv1d_taps_bf16x3")
+        else:
+            L.check(lib.svb_conv1d_taps(_ptr(x), _ptr(packed), _ptr(y), B, cin, cout, tin, tout, nt, offs, C.byref(e), st),
+                    "svb_conv1d_taps")
+    cfg = epi.get("force_cfg", 0)
+    if x.is_cuda and not cfg:
+        cfg = _tuned_cfg(sig, launch, _NCFG_Q if q else 5)
+    probe = _ConvProbe(lib, x, cout, tout, 2.0 * B * cout * tout * cin * nt, B, cfg,
+                       "svb_conv1d_bf16x3_kernel" if q else "svb_conv1d_mfma_kernel", tag=("taps", B, cin, cout, 1, tin, nt, 1, 1))
+    launch(cfg)
+    probe.done()
+    return y
+
+
 def conv1d_transposed(x, pb, cout, tout, k, stride=1, pad=0, dil=1, groups=1, out=None, **epi):
     q = isinstance(pb, PackedQ)
     _f32(x, None if q else pb)
@@ -530,6 +563,24 @@ def col2im(dcols, B, Cc, H, W, KH, KW, SH, SW, PH, PW, fold_batch=False):
     csb, csk = (Lp, B * Lp) if fold_batch else (Kr * Lp, Lp)
     dx = torch.empty((B, Cc, H, W), device=dcols.device, dtype=torch.float32)
     L.check(lib.svb_col2im(_ptr(dcols), _ptr(dx), B, Cc, H, W, KH, KW, SH, SW, PH, PW, Ho, Wo, csb, csk, st), "svb_col2im")
+    return dx
+
+
+def s2d_pad(x):
+    """x [N,C,H,W] (any strides, H and W even) -> [4C, N, H/2+1, W/2+1] space-to-depth planes with a zero top row / left column."""
+    _f32(x)
+    lib, st = _prep_strided(x)
+    N, Cc, H, W = x.shape
+    out = torch.empty((4 * Cc, N, H // 2 + 1, W // 2 + 1), device=x.device, dtype=torch.float32)
+    L.check(lib.svb_s2d_pad(_ptr(x), _ptr(out), N, Cc, H, W, *x.stride(), st), "svb_s2d_pad")
+    return out
+
+
+def s2d_pad_bwd(dout, N, Cc, H, W):
+    _f32(dout)
+    lib, st = _prep(dout)
+    dx = torch.empty((N, Cc, H, W), device=dout.device, dtype=torch.float32)
+    L.check(lib.svb_s2d_pad_bwd(_ptr(dout), _ptr(dx), N, Cc, H, W, st), "svb_s2d_pad_bwd")
     return dx
 
 
