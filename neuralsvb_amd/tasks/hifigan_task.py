@@ -14,10 +14,11 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..modules.frontend import MelFrontend
+from ..modules.stft_loss import MultiResolutionSTFTLoss
 from ..modules.hifigan import (HifiGanGenerator, MultiPeriodDiscriminator, MultiScaleDiscriminator, discriminator_loss,
                                feature_loss, generator_loss)
 from ..utils.hparams import hparams
-from .base_task import BaseTask
+from .base_task import BaseTask, data_loader
 
 
 def default_hparams():
@@ -35,7 +36,11 @@ def default_hparams():
 class HifiGanTask(BaseTask):
     def __init__(self):
         super().__init__()
+        from .vocoder_dataset import VocoderDataset
+        self.dataset_cls = VocoderDataset
         self._fe = None
+        self._inject = None          # tests: (rand_ini, noise) of the NSF source, so a CPU oracle can be fed the same draws
+        self.stft_loss = MultiResolutionSTFTLoss() if hparams.get("use_ms_stft", False) else None
 
     def build_model(self):
         from .. import functional as SF
@@ -67,8 +72,12 @@ class HifiGanTask(BaseTask):
         logs = {}
         adv = self.global_step >= hparams["disc_start_steps"]
         if optimizer_idx == 0:
-            y_ = self.model_gen(mel, f0)
+            inj = {} if self._inject is None else {"rand_ini": self._inject[0], "noise": self._inject[1]}
+            y_ = self.model_gen(mel, f0, **inj)
             logs["mel"] = F.l1_loss(self.mel(y_[:, 0]), self.mel(y[:, 0]).detach()) * hparams["lambda_mel"]
+            if self.stft_loss is not None:        # optional multi-resolution STFT terms (stft_loss.py:79-152)
+                sc, mag = self.stft_loss(y_[:, 0], y[:, 0])
+                logs["sc"], logs["mag"] = sc, mag
             self.y_ = y_.detach()
             if adv:
                 for name in ("mpd", "msd"):
@@ -92,3 +101,26 @@ class HifiGanTask(BaseTask):
 
     def on_after_optimization(self, epoch, batch_idx, optimizer, optimizer_idx):
         self.scheduler["gen" if optimizer_idx == 0 else "disc"].step()
+
+    # ------------------------------------------------------------------ validation / data
+    def validation_step(self, sample, batch_idx):
+        with torch.no_grad():
+            y_ = self.model_gen(sample["mels"], sample.get("f0"))
+            n = min(y_.shape[-1], sample["wavs"].shape[-1])
+            mel_l1 = F.l1_loss(self.mel(y_[:, 0, :n]), self.mel(sample["wavs"][:, 0, :n]))
+        return {"losses": {"mel": float(mel_l1)}, "total_loss": float(mel_l1), "nsamples": sample["nsamples"]}
+
+    @data_loader
+    def train_dataloader(self):
+        return self.build_dataloader(self.dataset_cls("train", True), True, max_sentences=hparams["max_sentences"],
+                                     endless=hparams.get("endless_ds", False), batch_by_size=False)
+
+    @data_loader
+    def val_dataloader(self):
+        return self.build_dataloader(self.dataset_cls("valid", False), False, max_sentences=hparams.get("max_valid_sentences", 1),
+                                     batch_by_size=False)
+
+    @data_loader
+    def test_dataloader(self):
+        return self.build_dataloader(self.dataset_cls("test", False), False, max_sentences=hparams.get("max_valid_sentences", 1),
+                                     batch_by_size=False)

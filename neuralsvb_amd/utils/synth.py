@@ -114,3 +114,23 @@ def write_fake_asr_ckpt(ckpt_dir, dict_size, hp):
         if v.is_floating_point() and v.dim() >= 2 and "asr_decoder" in k:
             v.copy_(torch.randn(v.shape, generator=g) * 0.02)
     torch.save({"state_dict": {"model": sd}}, os.path.join(ckpt_dir, "model_ckpt_steps_1.ckpt"))
+
+
+def write_vocoder_dataset(data_dir, hp, mel_fn, n_train=8, n_valid=2, seconds=1.0):
+    """Synthetic clips for the vocoder task (tasks/vocoder_dataset.py item schema): wav, its front-end mel, analytic f0."""
+    os.makedirs(data_dir, exist_ok=True)
+    sr, hop = hp["audio_sample_rate"], hp["hop_size"]
+    for prefix, n, seed0 in (("train", n_train, 0), ("valid", n_valid, 1000), ("test", n_valid, 2000)):
+        b = IndexedDatasetBuilder(os.path.join(data_dir, prefix))
+        lens = []
+        for i in range(n):
+            wav, tw = make_clip(seconds, sr, seed0 + i, base=170.0 + 20 * (i % 6))
+            mel = mel_fn(wav[None])[0]
+            T = mel.shape[0]
+            f0 = f0_contour((np.arange(T) * hop) / sr, 170.0 + 20 * (i % 6))
+            pad = np.zeros(max(0, T * hop - len(wav)), np.float32)
+            b.add_item({"item_name": f"voc_{seed0 + i:05d}", "mel": mel, "wav": np.concatenate([wav, pad])[:T * hop],
+                        "f0": f0.astype(np.float32), "len": T})
+            lens.append(T)
+        b.finalize()
+        np.save(os.path.join(data_dir, f"{prefix}_lengths.npy"), np.array(lens))

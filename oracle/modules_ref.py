@@ -374,11 +374,19 @@ def hifigan_generator(sd, mel, f0, rand_ini, noise, cfg, lrelu=0.1):
     return torch.tanh(x)
 
 
-def _spectral_w(sd, name):
-    """spectral_norm in eval mode: W / sigma with sigma = u^T W_mat v from the stored buffers."""
+def _spectral_w(sd, name, train=False):
+    """spectral_norm: W / sigma with sigma = u^T W_mat v from the stored buffers; in train mode one power iteration
+    (v = normalize(W^T u), u = normalize(W v), buffers updated in place) runs first, as torch.nn.utils.spectral_norm does on
+    every training forward (reference hifigan.py:261,294-296)."""
     w = sd[name + ".weight_orig"]
     wm = w.flatten(1)
-    sigma = torch.dot(sd[name + ".weight_u"], torch.mv(wm, sd[name + ".weight_v"]))
+    if train:
+        with torch.no_grad():
+            v = F.normalize(torch.mv(wm.t(), sd[name + ".weight_u"]), dim=0, eps=1e-12)
+            u = F.normalize(torch.mv(wm, v), dim=0, eps=1e-12)
+            sd[name + ".weight_v"].copy_(v)
+            sd[name + ".weight_u"].copy_(u)
+    sigma = torch.dot(sd[name + ".weight_u"].clone(), torch.mv(wm, sd[name + ".weight_v"].clone()))
     return w / sigma
 
 
@@ -399,10 +407,10 @@ def disc_period(sd, x, period, lrelu=0.1):
     return torch.flatten(x, 1, -1), fmap
 
 
-def disc_scale(sd, x, spectral, lrelu=0.1):
+def disc_scale(sd, x, spectral, lrelu=0.1, train=False):
     """DiscriminatorS.forward, hifigan.py:273-286."""
     cfgs = [(1, 7, 1), (2, 20, 4), (2, 20, 16), (4, 20, 16), (4, 20, 16), (1, 20, 16), (1, 2, 1)]
-    wf = (lambda n: _spectral_w(sd, n)) if spectral else (lambda n: _wnw(sd, n))
+    wf = (lambda n: _spectral_w(sd, n, train)) if spectral else (lambda n: _wnw(sd, n))
     fmap = []
     for i, (s, p, g) in enumerate(cfgs):
         x = F.leaky_relu(F.conv1d(x, wf(f"convs.{i}"), sd[f"convs.{i}.bias"], s, p, 1, g), lrelu)
@@ -424,15 +432,15 @@ def multi_period_disc(sd, y, y_hat, periods=(2, 3, 5, 7, 11)):
     return outs
 
 
-def multi_scale_disc(sd, y, y_hat):
-    """MultiScaleDiscriminator.forward, hifigan.py:309-325 (scale 0 spectral-norm, eval-mode sigma)."""
+def multi_scale_disc(sd, y, y_hat, train=False):
+    """MultiScaleDiscriminator.forward, hifigan.py:309-325 (scale 0 spectral-norm; train: power iteration per call)."""
     outs = ([], [], [], [])
     for i in range(3):
         if i != 0:
             y, y_hat = F.avg_pool1d(y, 4, 2, 1), F.avg_pool1d(y_hat, 4, 2, 1)
         d = sub(sd, f"discriminators.{i}.")
-        r, fr = disc_scale(d, y, i == 0)
-        g, fg = disc_scale(d, y_hat, i == 0)
+        r, fr = disc_scale(d, y, i == 0, train=train)
+        g, fg = disc_scale(d, y_hat, i == 0, train=train)
         for o, v in zip(outs, (r, g, fr, fg)):
             o.append(v)
     return outs
