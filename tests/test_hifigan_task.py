@@ -15,7 +15,7 @@ from oracle import frontend as ofe
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = os.path.join(ROOT, "egs/egs_bases/tts/vocoder/hifigan_nsf.yaml")
-SMALL = "upsample_initial_channel=32,max_samples=1024,max_sentences=2,ds_workers=0,num_sanity_val_steps=0,disc_start_steps=0,endless_ds=False"
+SMALL = "upsample_initial_channel=32,max_samples=2048,max_sentences=2,ds_workers=0,num_sanity_val_steps=0,disc_start_steps=0,endless_ds=False"
 
 
 def _mel_fn(hp):
