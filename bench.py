@@ -42,7 +42,7 @@ def build_task(args, rank, world, device, tmp, extra_hparams=""):
                             f"max_tokens=100000,ds_workers=0,num_sanity_val_steps=0,endless_ds=False,"
                             f"conv_precision={args.precision}" + extra_hparams)
     hparams["binary_data_dir"], hparams["pretrain_asr_ckpt"], hparams["work_dir"] = data_dir, asr_dir, ""
-    hparams["amp"] = bool(args.bf16)
+    hparams["amp"] = False
     torch.manual_seed(1234 + rank)
     np.random.seed(1234)
     # weak scaling: the reference's loader builds global batches of max_sentences x world clips and rank r takes
@@ -362,7 +362,6 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--seconds", type=float, default=6.0)
     ap.add_argument("--sample-rate", type=int, default=24000)
-    ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--workload", choices=["train", "vocoder", "infer"], default="train",
                     help="train = BASELINE configs[1] (the headline metric); vocoder = configs[2] NSF-HifiGAN G+MPD+MSD train step, "
                          "B=64 x 8192 samples; infer = configs[4] end-to-end inference 32 x 10 s (RTF)")
@@ -467,7 +466,7 @@ def main():
                 "metric": "audio-seconds/sec per train step (vae_global_mle_eng)", "value": value,
                 "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "bf16" if args.bf16 else ("f32" if args.precision == "fp32" else "bf16x3 (fp32-class split, fp32 accumulate/storage)"),
+                "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32-class split, fp32 accumulate/storage)",
                 "data": "synthetic",
                 "config": {"workload": "vae_global_mle_eng phase-2 train step (gen+disc passes), configs[1]: per-GPU "
                                        f"batch {args.batch} x {args.seconds:g} s synthetic clips @ {args.sample_rate} Hz, "

@@ -30,8 +30,8 @@ _TUNED = {}
 
 def _tuned_cfg(sig, launch, ncfg=5):
     """launch(force_cfg) enqueues the kernel once.  Returns the cached/measured best force_cfg (1..ncfg) or 0 (heuristic)."""
-    if not AUTOTUNE or PROFILE is not None:
-        return _TUNED.get(sig, 0)
+    if not AUTOTUNE or PROFILE is not None or torch.cuda.is_current_stream_capturing():
+        return _TUNED.get(sig, 0)        # (timing needs an event synchronise: never inside a hipGraph capture -> heuristic tile)
     best = _TUNED.get(sig)
     if best is None:
         times = []

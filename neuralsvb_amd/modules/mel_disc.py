@@ -53,7 +53,7 @@ class Discriminator(nn.Module):
             raise NotImplementedError("vae_global_mle_eng uses the unconditional critic only (use_cond_disc: false)")
         if reduction not in ("sum", "stack"):
             raise NotImplementedError(reduction)
-        self.time_lengths, self.reduction = list(time_lengths), reduction
+        self.time_lengths, self.reduction, self.norm_type = list(time_lengths), reduction, norm_type
         self.discriminator = nn.Module()
         self.discriminator.conv_layers = nn.ModuleList(
             [_critic_tower(tl, freq_length, kernel, c_in, hidden_size, norm_type, reduction) for tl in self.time_lengths])

@@ -182,7 +182,10 @@ class SVBVAEMleTask(BaseTask):
         up front and every window fits; otherwise one call after the other.  -> list of y."""
         r = self._step_rand
         n = len(xs)
-        if (hparams.get("stack_critic_calls", True) and r is not None and r["cursor"] + n <= len(r["disc"]) and n > 1
+        # (stacking is only an identity for per-clip layers: with disc_norm 'bn' the BatchNorm2d statistics would mix the
+        # real and generated batches, so those configurations keep the reference's separate calls)
+        if (hparams.get("stack_critic_calls", True) and self.mel_disc.norm_type == "in" and r is not None
+                and r["cursor"] + n <= len(r["disc"]) and n > 1
                 and all(x.shape == xs[0].shape for x in xs)
                 and all(all(s is not None for s in d["starts"]) for d in r["disc"][r["cursor"]:r["cursor"] + n])):
             calls = []

@@ -59,6 +59,12 @@ class FlatGradSync:
     """Gradients of one optimizer live in one contiguous fp32 buffer (param.grad are views of it): zeroing is a single
     memset and the data-parallel exchange works on contiguous BUCKETS of that buffer.
 
+    Difference from the reference's `optimizer.zero_grad()` (grads -> None): a parameter that receives no gradient in a pass
+    keeps a ZERO gradient here, so AdamW still applies its step to it (stale momentum decays towards zero, weight decay
+    acts).  Results are identical to the reference exactly when every parameter of an optimizer gets a gradient in each of
+    its passes -- true for the three optimizers of SVBVAEMleTask in every phase -- or when weight_decay == 0 and the
+    parameter never had a gradient before (its moments are zero).
+
     Overlap with backward (the reference gets it from torch DDP, utils/trainer.py:453-454): the buffer is cut into
     buckets of ~bucket_bytes in parameter order; every gradient that becomes final during `loss.backward()` is announced
     (autograd's post-accumulate hook, or functional.GRAD_READY for gradients the kernels write straight into `.grad`), and
@@ -184,6 +190,12 @@ class Trainer:
         self.print_nan_grads = print_nan_grads
         self.resume_from_checkpoint = resume_from_checkpoint if resume_from_checkpoint > 0 else None
         self.seed, self.debug, self.amp = seed, debug, amp
+        if amp:
+            # the reference's `amp` is fp16 autocast + GradScaler (utils/trainer.py:88,288,306-333); the HIP kernels take
+            # fp32 tensors only (their reduced-precision mode is `conv_precision: bf16x3`), so autocast would hand them
+            # bf16 inputs and fail deep inside a step -- refuse up front instead
+            raise NotImplementedError("amp is not supported by the MI355X kernels: use conv_precision=bf16x3 (fp32 storage, "
+                                      "bf16 matrix cores with an fp32-class operand split) instead of autocast")
         self.task, self.optimizers, self.grad_sync = None, [], []
         # hipGraph replay of each optimizer pass's forward+backward (fixed-shape batches; see _graphed_forward_backward)
         self.hip_graph, self.hip_graph_warmup, self.hip_graph_max_shapes = bool(hip_graph), hip_graph_warmup, hip_graph_max_shapes
