@@ -1,0 +1,55 @@
+"""Steady-state per-step kernel table from a rocprofv3 --kernel-trace CSV of `SVB_BENCH_MARKERS=1 python bench.py ...`:
+only the dispatches between the two marker (spin) kernels that bracket bench.py's timed region are counted, so warm-up,
+autotuning and MIOpen's find passes are excluded and sum(kernel time) <= wall.
+
+  python tools/trace_summary.py <kernel_trace.csv> <steps> [top]"""
+import csv
+import sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+steps = float(sys.argv[2])
+top = int(sys.argv[3]) if len(sys.argv) > 3 else 45
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+marks = [i for i, r in enumerate(rows) if "spin_kernel" in r["Kernel_Name"] or "sleep" in r["Kernel_Name"].lower()]
+if len(marks) >= 2:
+    rows = rows[marks[0] + 1:marks[1]]
+    note = "between the two marker kernels"
+else:
+    note = "NO MARKERS FOUND: whole trace"
+t0, t1 = int(rows[0]["Start_Timestamp"]), int(rows[-1]["End_Timestamp"])
+acc = defaultdict(lambda: [0, 0])
+busy = 0
+for r in rows:
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    acc[r["Kernel_Name"]][0] += d
+    acc[r["Kernel_Name"]][1] += 1
+    busy += d
+
+
+def group(nm):
+    low = nm.lower()
+    if "svb_" in nm:
+        return "svb (hand-written HIP)"
+    if nm.startswith("Cijk") or "rocblas" in low:
+        return "rocBLAS / hipBLASLt"
+    if "miopen" in low or "batchnorm" in low:
+        return "MIOpen"
+    if "rccl" in low or "nccl" in low:
+        return "RCCL"
+    return "torch (ATen)"
+
+
+groups = defaultdict(lambda: [0, 0])
+for nm, (d, c) in acc.items():
+    groups[group(nm)][0] += d
+    groups[group(nm)][1] += c
+wall = t1 - t0
+print(f"{len(rows)} dispatches {note}; span {wall / 1e6:.2f} ms = {wall / 1e6 / steps:.2f} ms/step over {steps:g} steps; "
+      f"sum of kernel durations {busy / 1e6 / steps:.2f} ms/step ({100.0 * busy / wall:.1f} % of the span); "
+      f"{len(rows) / steps:.0f} launches/step")
+for g, (d, c) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
+    print(f"  {g:26s} {d / 1e6 / steps:7.3f} ms/step {c / steps:7.1f} launches/step")
+print(f"{'ms/step':>9} {'calls/step':>10} {'avg us':>8}  kernel")
+for nm, (d, c) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:top]:
+    print(f"{d / 1e6 / steps:9.3f} {c / steps:10.1f} {d / c / 1e3:8.1f}  {nm[:110]}")
