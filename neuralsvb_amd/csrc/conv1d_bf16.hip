@@ -13,6 +13,7 @@
 //                    a thread loads 8 channels of one position with 8 coalesced dword loads and issues two 16-byte
 //                    LDS stores, hi and lo)
 // 48-byte rows put the 16 lanes of every ds_read_b128 service group on 16 disjoint 4-bank windows.
+#include <stdlib.h>
 #include "svb_common.h"
 #include "svb_q.h"
 #include "conv1d.h"
@@ -46,6 +47,7 @@ struct SvbConvQArgs {
 };
 
 static unsigned long long* g_svbq_dbg = nullptr;
+static const bool g_svbq_wg_narrow = getenv("SVB_WGRAD_NARROW") != nullptr;     // A/B switch: 64x64 weight-gradient tiles only
 extern "C" void svb_debug_set_timing_buffer(void* p) { g_svbq_dbg = (unsigned long long*)p; }
 #define SVBQ_DBG_BLOCKS 64
 #define SVBQ_DBG_STAGES 32
@@ -738,6 +740,7 @@ struct SvbWgradQArgs {
     int B, CA, CB, G, CA_g, CB_g, TA, TB;
     int k, off0, dil, sx;
     int n_tg, a_tiles, b_tiles, chunks_per_b, total_chunks, nsplit;
+    int at, bt;   // 32x32 accumulator tiles per wave along A / B rows (workgroup tile 64*at x 64*bt)
     int pa, pb;   // LDS row pitches in dwords (2 * odd)
     // tap groups.  Stride 1: group i = taps [i*TGW, ...), Bt position of tile index t: q0 + off0 + j0*dil + t.
     // Stride s > 1 (dil 1): taps are grouped by phase r = (j - pad) mod s; within a phase the strided gather
@@ -753,13 +756,15 @@ __device__ __forceinline__ unsigned svbq_funnel(unsigned hi, unsigned lo, unsign
     return (unsigned)((((unsigned long long)hi << 32) | lo) >> sh);
 }
 
-template <int TGW, int DIL, bool GATED>
+// AT x BT: 32x32 accumulator tiles per wave along the A rows / B rows (workgroup tile 64*AT x 64*BT).  Wide tiles raise the
+// MFMA work per staged element for the tap-poor gradients (1x1 convs: 12 MFMAs per wave and 64-position chunk at 1x1).
+template <int TGW, int DIL, bool GATED, int AT, int BT>
 __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgradQArgs a) {
     HIP_DYNAMIC_SHARED(unsigned, wg_smem)
     unsigned* A_hi = wg_smem;
-    unsigned* A_lo = A_hi + 64 * a.pa;
-    unsigned* B_hi = A_lo + 64 * a.pa;
-    unsigned* B_lo = B_hi + 64 * a.pb;
+    unsigned* A_lo = A_hi + 64 * AT * a.pa;
+    unsigned* B_hi = A_lo + 64 * AT * a.pa;
+    unsigned* B_lo = B_hi + 64 * BT * a.pb;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
@@ -770,7 +775,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
     const int bt = idx % a.b_tiles; idx /= a.b_tiles;
     const int at = idx % a.a_tiles;
     const int g = idx / a.a_tiles;
-    const int a0 = at * 64, b0 = bt * 64;
+    const int a0 = at * 64 * AT, b0 = bt * 64 * BT;
     const int j0 = a.tg_j0[tgi];
     const int ntap = a.tg_ntap[tgi];
     const int min_off = a.tg_o0[tgi];                        // first Bt tile index, in units of the (phase) sequence
@@ -778,18 +783,23 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
     const int span = SVBQ_WG_QC + (ntap - 1) * a.dil;
     const int nxp = (span + 1) / 2 - 32;                    // Bt pairs beyond the first 32 of a row
 
-    f32x16 acc[TGW];
+    f32x16 acc[AT][BT][TGW];
 #pragma unroll
-    for (int t = 0; t < TGW; ++t)
+    for (int ia = 0; ia < AT; ++ia)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int ib = 0; ib < BT; ++ib)
+#pragma unroll
+            for (int t = 0; t < TGW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ia][ib][t][r] = 0.f;
 
-    float ar[8][2], br[8][2], bx[SVBQ_WG_NXIT][2];
+    constexpr int RA = 8 * AT, RB = 8 * BT;                 // staged rows per thread (row = srow + 8 * rr)
+    float ar[RA][2], br[RB][2], bx[SVBQ_WG_NXIT][2];
     const int srow = tid >> 5, spair = tid & 31;            // staging role: row srow + 8*it, pair spair
     const bool do_bias = a.bias_part != nullptr && bt == 0 && tgi == 0;
-    float bsum[8];
+    float bsum[RA];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) bsum[rr] = 0.f;
+    for (int rr = 0; rr < RA; ++rr) bsum[rr] = 0.f;
     const float* a_base = a.a + (size_t)g * a.CA_g * a.TA;
     const float* ag_base = GATED && a.a_gate ? a.a_gate + (size_t)g * a.CA_g * a.TA : nullptr;
     const float* b_base = a.b + (size_t)g * a.CB_g * a.TB;
@@ -798,15 +808,20 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
     // ---- staging, branch-free: per-thread row offsets and masks are hoisted; per chunk only the (clamped) position
     // changes.  Out-of-range rows / positions read a valid element and are zeroed when written to LDS, so all loads of a
     // chunk are in flight before the first wait.
-    unsigned a_roff[8], b_roff[8];        // byte offsets of this thread's 8 A rows / 8 B rows
+    unsigned a_roff[RA], b_roff[RB];      // byte offsets of this thread's A rows / B rows
     unsigned a_rmask = 0, b_rmask = 0;    // bit rr: row valid
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
+    for (int rr = 0; rr < RA; ++rr) {
         const int r = srow + 8 * rr;
-        const bool av = (a0 + r) < a.CA_g, bv = (b0 + r) < a.CB_g;
+        const bool av = (a0 + r) < a.CA_g;
         a_roff[rr] = 4u * (unsigned)((av ? a0 + r : a0) * a.TA);
-        b_roff[rr] = 4u * (unsigned)((bv ? b0 + r : b0) * a.TB);
         a_rmask |= (av ? 1u : 0u) << rr;
+    }
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr) {
+        const int r = srow + 8 * rr;
+        const bool bv = (b0 + r) < a.CB_g;
+        b_roff[rr] = 4u * (unsigned)((bv ? b0 + r : b0) * a.TB);
         b_rmask |= (bv ? 1u : 0u) << rr;
     }
     unsigned x_roff[SVBQ_WG_NXIT];        // extra Bt pairs (beyond the first 32 of a row): row offset, pair, validity
@@ -815,7 +830,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
 #pragma unroll
     for (int e = 0; e < SVBQ_WG_NXIT; ++e) {
         const int task = tid + 256 * e;
-        x_on[e] = task < 64 * nxp;
+        x_on[e] = task < 64 * BT * nxp;
         const int r = x_on[e] ? task / nxp : 0;
         x_r[e] = r;
         x_pr[e] = 32 + (x_on[e] ? task - r * nxp : 0);
@@ -837,9 +852,12 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
         const unsigned ao0 = 4u * (unsigned)min(qa, a.TA - 1), ao1 = 4u * (unsigned)min(qa + 1, a.TA - 1);
         const unsigned bo0 = 4u * (unsigned)min(max(pb0, 0), a.TB - 1), bo1 = 4u * (unsigned)min(max(pb1, 0), a.TB - 1);
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
+        for (int rr = 0; rr < RA; ++rr) {
             ar[rr][0] = svbq_ld(ab, a_roff[rr] + ao0);
             ar[rr][1] = svbq_ld(ab, a_roff[rr] + ao1);
+        }
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
             br[rr][0] = svbq_ld(bbp, b_roff[rr] + bo0);
             br[rr][1] = svbq_ld(bbp, b_roff[rr] + bo1);
         }
@@ -855,7 +873,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
             if (ag_base) {
                 const float* gp = ag_base + (size_t)bb * a.CA * a.TA;
 #pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
+                for (int rr = 0; rr < RA; ++rr) {
                     ar[rr][0] *= svb_gate(svbq_ld(gp, a_roff[rr] + ao0), a.a_slope);
                     ar[rr][1] *= svb_gate(svbq_ld(gp, a_roff[rr] + ao1), a.a_slope);
                 }
@@ -863,7 +881,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
             if (bg_base) {
                 const float* gp = bg_base + (size_t)bb * a.CB * a.TB;
 #pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
+                for (int rr = 0; rr < RB; ++rr) {
                     br[rr][0] *= svb_gate(svbq_ld(gp, b_roff[rr] + bo0), a.b_slope);
                     br[rr][1] *= svb_gate(svbq_ld(gp, b_roff[rr] + bo1), a.b_slope);
                 }
@@ -878,15 +896,21 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
+        for (int rr = 0; rr < RA; ++rr) {
             const int r = srow + 8 * rr;
-            const bool av = (a_rmask >> rr) & 1u, bv = (b_rmask >> rr) & 1u;
+            const bool av = (a_rmask >> rr) & 1u;
             const float a0v = av && a_ok0 ? ar[rr][0] : 0.f, a1v = av && a_ok1 ? ar[rr][1] : 0.f;
-            const float b0v = bv && b_ok0 ? br[rr][0] : 0.f, b1v = bv && b_ok1 ? br[rr][1] : 0.f;
             unsigned hi, lo;
             bsum[rr] += a0v + a1v;
             svbq_split2(a0v, a1v, hi, lo);
             A_hi[r * a.pa + spair] = hi; A_lo[r * a.pa + spair] = lo;
+        }
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const int r = srow + 8 * rr;
+            const bool bv = (b_rmask >> rr) & 1u;
+            const float b0v = bv && b_ok0 ? br[rr][0] : 0.f, b1v = bv && b_ok1 ? br[rr][1] : 0.f;
+            unsigned hi, lo;
             svbq_split2(b0v, b1v, hi, lo);
             B_hi[r * a.pb + spair] = hi; B_lo[r * a.pb + spair] = lo;
         }
@@ -907,60 +931,69 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
     };
     auto compute = [&]() {
-        const unsigned* ahp = A_hi + (wm * 32 + l31) * a.pa + 16 * kb;
-        const unsigned* alp = A_lo + (wm * 32 + l31) * a.pa + 16 * kb;
-        const unsigned* bhp = B_hi + (wn * 32 + l31) * a.pb + 16 * kb;
-        const unsigned* blp = B_lo + (wn * 32 + l31) * a.pb + 16 * kb;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const uint2 ah0 = *reinterpret_cast<const uint2*>(ahp + 4 * s), ah1 = *reinterpret_cast<const uint2*>(ahp + 4 * s + 2);
-            const uint2 al0 = *reinterpret_cast<const uint2*>(alp + 4 * s), al1 = *reinterpret_cast<const uint2*>(alp + 4 * s + 2);
-            const uint4 ah = make_uint4(ah0.x, ah0.y, ah1.x, ah1.y);
-            const uint4 al = make_uint4(al0.x, al0.y, al1.x, al1.y);
-            if (DIL == 1) {
-                constexpr int NU2 = (4 + TGW / 2 + 1) / 2, NU = 2 * NU2;
-                unsigned uh[NU], ul[NU];
+            uint4 ahf[AT], alf[AT];
 #pragma unroll
-                for (int d = 0; d < NU2; ++d) {
-                    const uint2 th = *reinterpret_cast<const uint2*>(bhp + 4 * s + 2 * d);
-                    const uint2 tl = *reinterpret_cast<const uint2*>(blp + 4 * s + 2 * d);
-                    uh[2 * d] = th.x; uh[2 * d + 1] = th.y;
-                    ul[2 * d] = tl.x; ul[2 * d + 1] = tl.y;
-                }
+            for (int ia = 0; ia < AT; ++ia) {
+                const unsigned* ahp = A_hi + ((wm + 2 * ia) * 32 + l31) * a.pa + 16 * kb;
+                const unsigned* alp = A_lo + ((wm + 2 * ia) * 32 + l31) * a.pa + 16 * kb;
+                const uint2 ah0 = *reinterpret_cast<const uint2*>(ahp + 4 * s), ah1 = *reinterpret_cast<const uint2*>(ahp + 4 * s + 2);
+                const uint2 al0 = *reinterpret_cast<const uint2*>(alp + 4 * s), al1 = *reinterpret_cast<const uint2*>(alp + 4 * s + 2);
+                ahf[ia] = make_uint4(ah0.x, ah0.y, ah1.x, ah1.y);
+                alf[ia] = make_uint4(al0.x, al0.y, al1.x, al1.y);
+            }
 #pragma unroll
-                for (int t = 0; t < TGW; ++t) {
-                    if (t < ntap) {
-                        uint4 bh, bl;
-                        if (t & 1) {
-                            constexpr unsigned S16 = 16;
-                            const int o = t >> 1;
-                            bh = make_uint4(svbq_funnel(uh[o + 1], uh[o], S16), svbq_funnel(uh[o + 2], uh[o + 1], S16),
-                                            svbq_funnel(uh[o + 3], uh[o + 2], S16), svbq_funnel(uh[o + 4], uh[o + 3], S16));
-                            bl = make_uint4(svbq_funnel(ul[o + 1], ul[o], S16), svbq_funnel(ul[o + 2], ul[o + 1], S16),
-                                            svbq_funnel(ul[o + 3], ul[o + 2], S16), svbq_funnel(ul[o + 4], ul[o + 3], S16));
-                        } else {
-                            const int o = t >> 1;
-                            bh = make_uint4(uh[o], uh[o + 1], uh[o + 2], uh[o + 3]);
-                            bl = make_uint4(ul[o], ul[o + 1], ul[o + 2], ul[o + 3]);
-                        }
-                        mma3(ah, al, bh, bl, acc[t]);
+            for (int ib = 0; ib < BT; ++ib) {
+                const unsigned* bhp = B_hi + ((wn + 2 * ib) * 32 + l31) * a.pb + 16 * kb;
+                const unsigned* blp = B_lo + ((wn + 2 * ib) * 32 + l31) * a.pb + 16 * kb;
+                if (DIL == 1) {
+                    constexpr int NU2 = (4 + TGW / 2 + 1) / 2, NU = 2 * NU2;
+                    unsigned uh[NU], ul[NU];
+#pragma unroll
+                    for (int d = 0; d < NU2; ++d) {
+                        const uint2 th = *reinterpret_cast<const uint2*>(bhp + 4 * s + 2 * d);
+                        const uint2 tl = *reinterpret_cast<const uint2*>(blp + 4 * s + 2 * d);
+                        uh[2 * d] = th.x; uh[2 * d + 1] = th.y;
+                        ul[2 * d] = tl.x; ul[2 * d + 1] = tl.y;
                     }
-                }
-            } else {
 #pragma unroll
-                for (int t = 0; t < TGW; ++t) {
-                    if (t < ntap) {
-                        const int bp = 8 * s + t * a.dil;
-                        const int dw = bp >> 1;
-                        const unsigned sh = (unsigned)(bp & 1) * 16u;
-                        unsigned uh[5], ul[5];
+                    for (int t = 0; t < TGW; ++t) {
+                        if (t < ntap) {
+                            uint4 bh, bl;
+                            if (t & 1) {
+                                constexpr unsigned S16 = 16;
+                                const int o = t >> 1;
+                                bh = make_uint4(svbq_funnel(uh[o + 1], uh[o], S16), svbq_funnel(uh[o + 2], uh[o + 1], S16),
+                                                svbq_funnel(uh[o + 3], uh[o + 2], S16), svbq_funnel(uh[o + 4], uh[o + 3], S16));
+                                bl = make_uint4(svbq_funnel(ul[o + 1], ul[o], S16), svbq_funnel(ul[o + 2], ul[o + 1], S16),
+                                                svbq_funnel(ul[o + 3], ul[o + 2], S16), svbq_funnel(ul[o + 4], ul[o + 3], S16));
+                            } else {
+                                const int o = t >> 1;
+                                bh = make_uint4(uh[o], uh[o + 1], uh[o + 2], uh[o + 3]);
+                                bl = make_uint4(ul[o], ul[o + 1], ul[o + 2], ul[o + 3]);
+                            }
 #pragma unroll
-                        for (int d = 0; d < 5; ++d) { uh[d] = bhp[dw + d]; ul[d] = blp[dw + d]; }
-                        const uint4 bh = make_uint4(svbq_funnel(uh[1], uh[0], sh), svbq_funnel(uh[2], uh[1], sh),
-                                                    svbq_funnel(uh[3], uh[2], sh), svbq_funnel(uh[4], uh[3], sh));
-                        const uint4 bl = make_uint4(svbq_funnel(ul[1], ul[0], sh), svbq_funnel(ul[2], ul[1], sh),
-                                                    svbq_funnel(ul[3], ul[2], sh), svbq_funnel(ul[4], ul[3], sh));
-                        mma3(ah, al, bh, bl, acc[t]);
+                            for (int ia = 0; ia < AT; ++ia) mma3(ahf[ia], alf[ia], bh, bl, acc[ia][ib][t]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < TGW; ++t) {
+                        if (t < ntap) {
+                            const int bp = 8 * s + t * a.dil;
+                            const int dw = bp >> 1;
+                            const unsigned sh = (unsigned)(bp & 1) * 16u;
+                            unsigned uh[5], ul[5];
+#pragma unroll
+                            for (int d = 0; d < 5; ++d) { uh[d] = bhp[dw + d]; ul[d] = blp[dw + d]; }
+                            const uint4 bh = make_uint4(svbq_funnel(uh[1], uh[0], sh), svbq_funnel(uh[2], uh[1], sh),
+                                                        svbq_funnel(uh[3], uh[2], sh), svbq_funnel(uh[4], uh[3], sh));
+                            const uint4 bl = make_uint4(svbq_funnel(ul[1], ul[0], sh), svbq_funnel(ul[2], ul[1], sh),
+                                                        svbq_funnel(ul[3], ul[2], sh), svbq_funnel(ul[4], ul[3], sh));
+#pragma unroll
+                            for (int ia = 0; ia < AT; ++ia) mma3(ahf[ia], alf[ia], bh, bl, acc[ia][ib][t]);
+                        }
                     }
                 }
             }
@@ -987,21 +1020,25 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
 
     float* part = a.part + (size_t)blockIdx.y * a.CA * a.CB_g * a.k;
 #pragma unroll
-    for (int t = 0; t < TGW; ++t) {
-        if (t < ntap) {
+    for (int ia = 0; ia < AT; ++ia)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
-                const int al = a0 + wm * 32 + row;
-                const int bl = b0 + wn * 32 + l31;
-                if (al < a.CA_g && bl < a.CB_g)
-                    part[((size_t)(g * a.CA_g + al) * a.CB_g + bl) * a.k + (j0 + t * a.sx)] = acc[t][r];
+        for (int ib = 0; ib < BT; ++ib)
+#pragma unroll
+            for (int t = 0; t < TGW; ++t) {
+                if (t < ntap) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
+                        const int al = a0 + (wm + 2 * ia) * 32 + row;
+                        const int bl = b0 + (wn + 2 * ib) * 32 + l31;
+                        if (al < a.CA_g && bl < a.CB_g)
+                            part[((size_t)(g * a.CA_g + al) * a.CB_g + bl) * a.k + (j0 + t * a.sx)] = acc[ia][ib][t][r];
+                    }
+                }
             }
-        }
-    }
     if (do_bias) {        // row sums of this split's A tiles: the 32 lanes of a half-wave staged one row
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
+        for (int rr = 0; rr < RA; ++rr) {
             float v = bsum[rr];
 #pragma unroll
             for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -1045,6 +1082,19 @@ static int wgq_groups(int k, int sx, int pad, int dil, int* tgw_out, short* j0, 
     return n;
 }
 
+// Wave tile multiplicity: doubling ONE side (128x64 / 64x128 workgroup tiles) pays for the single-tap gradients of the 1x1
+// convs, whose 64x64 tile has only 12 MFMAs per wave and staged chunk; the staging registers of wider tiles, of gated
+// operands or of more taps do not fit 256 VGPRs (measured: spills), so those keep the 64x64 tile.  A side is doubled only
+// when that leaves no fully empty 64-row block.
+static void wgq_tile(int CA_g, int CB_g, int tgw, bool gated, int* at, int* bt) {
+    *at = *bt = 1;
+    if (tgw != 1 || gated || g_svbq_wg_narrow) return;
+    const bool a2 = CA_g >= 128 && (svb_cdiv(CA_g, 128) * 128 - CA_g) < 64;
+    const bool b2 = CB_g >= 128 && (svb_cdiv(CB_g, 128) * 128 - CB_g) < 64;
+    if (a2) *at = 2;
+    else if (b2) *bt = 2;
+}
+
 // 0 floats (and *nsplit = 0) when the shape is outside this kernel's envelope: the caller uses svb_conv1d_wgrad.
 extern "C" size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB, int groups, int TA, int k, int sx, int pad,
                                                            int dil, int* nsplit_out) {
@@ -1055,7 +1105,9 @@ extern "C" size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB
     const int n_tg = wgq_groups(k, sx, pad, dil, &tgw, nullptr, nullptr, nullptr, nullptr);
     if (n_tg <= 0) return 0;
     const int CA_g = CA / groups, CB_g = CB / groups;
-    const long tiles = (long)groups * svb_cdiv(CA_g, 64) * svb_cdiv(CB_g, 64) * n_tg;
+    int at = 1, bt = 1;
+    wgq_tile(CA_g, CB_g, tgw, false, &at, &bt);
+    const long tiles = (long)groups * svb_cdiv(CA_g, 64 * at) * svb_cdiv(CB_g, 64 * bt) * n_tg;
     const long chunks = (long)B * svb_cdiv(TA, SVBQ_WG_QC);
     const long slab = (long)CA * CB_g * k;
     long ns_cap = 512 / tiles;                                   // one resident wave of blocks at 2 per CU
@@ -1068,27 +1120,36 @@ extern "C" size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB
     return (size_t)ns * slab;
 }
 
-template <int TGW, int DIL, bool GATED>
+template <int TGW, int DIL, bool GATED, int AT, int BT>
 static void wgq_launch_kernel(const SvbWgradQArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_wgrad_bf16x3_kernel<TGW, DIL, GATED>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_wgrad_bf16x3_kernel<TGW, DIL, GATED, AT, BT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((svb_conv1d_wgrad_bf16x3_kernel<TGW, DIL, GATED>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((svb_conv1d_wgrad_bf16x3_kernel<TGW, DIL, GATED, AT, BT>), grid, dim3(256), lds, st, a);
+}
+
+template <int TGW, int AT, int BT>
+static void wgq_launch_t(const SvbWgradQArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    const bool gated = a.a_gate || a.b_gate;
+    if (a.dil == 1) {
+        if (gated) wgq_launch_kernel<TGW, 1, true, AT, BT>(a, grid, lds, st);
+        else wgq_launch_kernel<TGW, 1, false, AT, BT>(a, grid, lds, st);
+    } else {
+        if (gated) wgq_launch_kernel<TGW, 0, true, AT, BT>(a, grid, lds, st);
+        else wgq_launch_kernel<TGW, 0, false, AT, BT>(a, grid, lds, st);
+    }
 }
 
 template <int TGW>
 static void wgq_launch(const SvbWgradQArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-    const bool gated = a.a_gate || a.b_gate;
-    if (a.dil == 1) {
-        if (gated) wgq_launch_kernel<TGW, 1, true>(a, grid, lds, st);
-        else wgq_launch_kernel<TGW, 1, false>(a, grid, lds, st);
-    } else {
-        if (gated) wgq_launch_kernel<TGW, 0, true>(a, grid, lds, st);
-        else wgq_launch_kernel<TGW, 0, false>(a, grid, lds, st);
+    if constexpr (TGW == 1) {
+        if (a.at == 2) { wgq_launch_kernel<1, 1, false, 2, 1>(a, grid, lds, st); return; }       // (dil is irrelevant for one tap)
+        if (a.bt == 2) { wgq_launch_kernel<1, 1, false, 1, 2>(a, grid, lds, st); return; }
     }
+    wgq_launch_t<TGW, 1, 1>(a, grid, lds, st);
 }
 
 extern "C" int svb_conv1d_wgrad_bf16x3(const float* a_t, const float* b_t, float* part, int B, int CA, int CB, int groups,
@@ -1105,7 +1166,8 @@ extern "C" int svb_conv1d_wgrad_bf16x3(const float* a_t, const float* b_t, float
     int tgw = 0;
     a.n_tg = wgq_groups(k, sx, pad, dil, &tgw, a.tg_j0, a.tg_ntap, a.tg_r, a.tg_o0);
     if (a.n_tg <= 0) return SVB_ERR_UNSUPPORTED;
-    a.a_tiles = svb_cdiv(a.CA_g, 64); a.b_tiles = svb_cdiv(a.CB_g, 64);
+    wgq_tile(a.CA_g, a.CB_g, tgw, a_gate || b_gate, &a.at, &a.bt);
+    a.a_tiles = svb_cdiv(a.CA_g, 64 * a.at); a.b_tiles = svb_cdiv(a.CB_g, 64 * a.bt);
     a.chunks_per_b = svb_cdiv(TA, SVBQ_WG_QC); a.total_chunks = B * a.chunks_per_b;
     if (nsplit > a.total_chunks) return SVB_ERR_ARG;
     a.nsplit = nsplit;
@@ -1113,7 +1175,7 @@ extern "C" int svb_conv1d_wgrad_bf16x3(const float* a_t, const float* b_t, float
     a.pb = 32 + ((tgw - 1) * dil + 1) / 2 + 6;
     a.pb += a.pb & 1;
     if (!((a.pb >> 1) & 1)) a.pb += 2;                       // 2 * odd
-    const size_t lds = (size_t)64 * (a.pa + a.pb) * 2 * sizeof(unsigned);
+    const size_t lds = (size_t)64 * (a.at * a.pa + a.bt * a.pb) * 2 * sizeof(unsigned);
     dim3 grid(groups * a.a_tiles * a.b_tiles * a.n_tg, nsplit);
     hipStream_t st = (hipStream_t)stream;
     switch (tgw) {

@@ -398,6 +398,9 @@ WGQ_CASES = [
     (1, 10, 6, 1, 130, 11, 25, 5),       # k11 d5 (hifigan.py:33-41)
     (2, 8, 12, 2, 77, 4, 2, 1),          # grouped, even taps
     (1, 6, 6, 1, 64, 2, 0, 1),
+    (2, 40, 200, 1, 70, 1, 0, 1),        # 1x1, Cout (A rows) >= 128: 128x64 workgroup tile, ragged second tile
+    (2, 130, 70, 1, 90, 1, 0, 1),        # 1x1, Cin (B rows) >= 128 only: 64x128 workgroup tile
+    (1, 256, 384, 1, 130, 1, 0, 1),      # both sides wide: the A side is doubled
 ]
 
 
