@@ -419,7 +419,9 @@ def main():
             torch.cuda.synchronize()
         t0 = time.perf_counter()
         run_steps(trainer, task, batch, args.steps, 1 + args.warmup)
+        t_host = time.perf_counter() - t0           # host side done issuing; the GPU may still be working
         torch.cuda.synchronize()
+        log(f"host finished issuing {args.steps} steps after {t_host / args.steps * 1e3:.2f} ms/step")
         if os.environ.get("SVB_BENCH_MARKERS"):
             torch.cuda._sleep(1000)
             torch.cuda.synchronize()

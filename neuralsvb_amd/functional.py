@@ -93,6 +93,8 @@ def _c(t):
     return None if t is None else t.contiguous()
 
 
+CAPTURING = False        # set by the Trainer while it captures a hipGraph (a cache hit there would record no pack kernel; asking
+                         # the driver on every call instead costs ~10 us x 140 calls per step on a host-bound step)
 PACK_CACHE = True        # reuse a weight's packed image while the weight is known to be unchanged
 PACK_REGISTRY = True     # bf16x3 + Trainer-managed step: trainable conv weights keep PERSISTENT packed images that are refilled
                          # by one multi-tensor launch per optimizer step (repack_registered) instead of one launch per conv call
@@ -209,7 +211,7 @@ def _pack(v, g, groups=1, want_a=True, want_b=True):
     if not PACK_CACHE or not v.is_leaf or (g is not None and not g.is_leaf):
         return make(want_a, want_b)
     trainable = v.requires_grad or v.grad is not None or (g is not None and (g.requires_grad or g.grad is not None))
-    if trainable and (PACK_EPOCH is None or (v.is_cuda and torch.cuda.is_current_stream_capturing())):
+    if trainable and (PACK_EPOCH is None or CAPTURING):
         return make(want_a, want_b)
     if trainable and PRECISION == "bf16x3" and PACK_REGISTRY:
         return _pack_registered(v, g, groups, want_a, want_b)

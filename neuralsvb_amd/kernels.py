@@ -30,22 +30,25 @@ _TUNED = {}
 
 def _tuned_cfg(sig, launch, ncfg=5):
     """launch(force_cfg) enqueues the kernel once.  Returns the cached/measured best force_cfg (1..ncfg) or 0 (heuristic)."""
-    if not AUTOTUNE or PROFILE is not None or torch.cuda.is_current_stream_capturing():
-        return _TUNED.get(sig, 0)        # (timing needs an event synchronise: never inside a hipGraph capture -> heuristic tile)
     best = _TUNED.get(sig)
-    if best is None:
-        times = []
-        for cfg in range(1, ncfg + 1):
-            launch(cfg)                                   # warm (also validates the configuration)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                launch(cfg)
-            e1.record()
-            e1.synchronize()
-            times.append(e0.elapsed_time(e1))
-        best = 1 + min(range(ncfg), key=lambda i: times[i])
-        _TUNED[sig] = best
+    if best is not None:
+        return best
+    # (timing needs an event synchronise: never inside a hipGraph capture -> heuristic tile.  The capture query is a driver
+    # call: it is only made on a cache miss -- the step is host-bound enough for 250 of them per step to cost 3 ms.)
+    if not AUTOTUNE or PROFILE is not None or torch.cuda.is_current_stream_capturing():
+        return 0
+    times = []
+    for cfg in range(1, ncfg + 1):
+        launch(cfg)                                   # warm (also validates the configuration)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            launch(cfg)
+        e1.record()
+        e1.synchronize()
+        times.append(e0.elapsed_time(e1))
+    best = 1 + min(range(ncfg), key=lambda i: times[i])
+    _TUNED[sig] = best
     return best
 
 

@@ -414,8 +414,13 @@ class Trainer:
             return out
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, pool=self._graph_pool, stream=self._graph_stream):
-            out = self._forward_backward(batch, batch_idx, opt_idx)
+        from .. import functional as SF
+        SF.CAPTURING = True
+        try:
+            with torch.cuda.graph(graph, pool=self._graph_pool, stream=self._graph_stream):
+                out = self._forward_backward(batch, batch_idx, opt_idx)
+        finally:
+            SF.CAPTURING = False
         if self._graph_pool is None:
             self._graph_pool = graph.pool()
         ent["graph"], ent["out"] = graph, out
