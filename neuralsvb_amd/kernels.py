@@ -72,6 +72,11 @@ class _ConvProbe:
             PROFILE.append((self.name, self.flops, self.e0, self.e1, self.tag))
 
 
+def _raw_stream(dev):
+    """hipStream_t of torch's current stream on `dev` (the raw-handle accessor: no Stream object per kernel call)."""
+    return torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -94,7 +99,7 @@ def _prep(*tensors):
     if dev.type == "cuda":
         if L.lib_is_emulator():
             raise RuntimeError("CPU emulator library is loaded but tensors are on the GPU")
-        return lib, torch.cuda.current_stream(dev).cuda_stream
+        return lib, _raw_stream(dev)
     if not L.lib_is_emulator():
         raise RuntimeError("neuralsvb_amd kernels run on the MI355X only (got CPU tensors); there is no CPU fallback")
     return lib, None
@@ -592,7 +597,7 @@ def _prep_strided(*tensors):
     lib = L.get_lib()
     dev = next(t.device for t in tensors if t is not None)
     if dev.type == "cuda":
-        return lib, torch.cuda.current_stream(dev).cuda_stream
+        return lib, _raw_stream(dev)
     if not L.lib_is_emulator():
         raise RuntimeError("neuralsvb_amd kernels run on the MI355X only (got CPU tensors); there is no CPU fallback")
     return lib, None
