@@ -78,9 +78,9 @@ def main():
         cal[counter] = {"raw_bytes": raw, "known_bytes": known, "factor": known / raw}
         print("calibration", counter, cal[counter], flush=True)
     out = {"kernel": dom, "cfg": cfg, "calibration": cal, "method": __doc__.split("\n\n")[1], "shapes": {}}
-    for tag, cnt in tags[:8]:
+    for tag, cnt in tags[:16]:
         op, B, ca, cb_, G, T, k, s, dil = tag
-        if G != 1 or s != 1 or dil != 1:
+        if G != 1 or s != 1 or dil != 1 or op == "taps":
             continue
         what = "fwd" if op == "fwd" else "dgrad"
         cin, cout = (ca, cb_) if op == "fwd" else (cb_, ca)      # pmc_conv dgrad: dy [B,Cout,T] -> dx [B,Cin,T]
