@@ -41,12 +41,14 @@ struct SvbConvQArgs {
     int sx, out_stride;
     int w_tap_slabs, w_g_slabs, w_slab_rows, w_goff_m, kchunks;
     int tg, kch, xrows, fast_x, xit;   // xit: 128-position groups per chunk on the register-staged path (1..3)
+    int fast;                          // direct-A tiles, every K phase has exactly SLB slabs: straight-line pipelined loop
     int w_floats16, x_floats16;   // LDS carve sizes in 16-byte units (one of hi/lo each)
     int force_cfg;
     unsigned long long* dbg;      // optional per-phase cycle stamps (svb_debug_set_timing_buffer; tools/stage_timing.py)
 };
 
 static unsigned long long* g_svbq_dbg = nullptr;
+static const bool g_svbq_nofast = getenv("SVB_NO_FASTLOOP") != nullptr;     // A/B switch for benchmarking
 static const bool g_svbq_wg_narrow = getenv("SVB_WGRAD_NARROW") != nullptr;     // A/B switch: 64x64 weight-gradient tiles only
 extern "C" void svb_debug_set_timing_buffer(void* p) { g_svbq_dbg = (unsigned long long*)p; }
 #define SVBQ_DBG_BLOCKS 64
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     // x staging roles: threads 0..127 own channel half 0, 128..255 half 1; position = (tid & 127) + 128 * it
     const int xh = tid >> 7, xp0 = tid & 127;
 
+    int xw = 0;                                            // x-tile buffer the staging lambdas write (16-byte units)
     uint4 wr[WU];
     float xr[SVBQ_XUNITS][8];
     int u_c[SVBQ_XUNITS], u_it[SVBQ_XUNITS];               // unit u -> (chunk u / xit, 128-position group u % xit)
@@ -217,8 +220,8 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
                 svbq_split8(xr[u], hi, lo);
                 if (!x_ok[u]) { hi = make_uint4(0u, 0u, 0u, 0u); lo = hi; }
                 const int d = (c * a.xrows + i) * 3 + xh;
-                x_hi[d] = hi;
-                x_lo[d] = lo;
+                x_hi[xw + d] = hi;
+                x_lo[xw + d] = lo;
             }
         }
     };
@@ -242,8 +245,8 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
                 uint4 hi, lo;
                 svbq_split8(vv, hi, lo);
                 const int d = (c * a.xrows + i) * 3 + xh;
-                x_hi[d] = hi;
-                x_lo[d] = lo;
+                x_hi[xw + d] = hi;
+                x_lo[xw + d] = lo;
             }
         }
     };
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
         const int kch_here = min(a.kch, a.kchunks - kc0);
 #pragma unroll
         for (int u = 0; u < (QIN ? SVBQ_QUNITS : 0); ++u)
-            if (q_c[u] < kch_here) x_hi[q_dst[u]] = q_ok[u] ? qr[u] : make_uint4(0u, 0u, 0u, 0u);
+            if (q_c[u] < kch_here) x_hi[xw + q_dst[u]] = q_ok[u] ? qr[u] : make_uint4(0u, 0u, 0u, 0u);
     };
     // ---- WN == 1 tiles ("direct-A"): every wave owns 32 weight rows and all BN columns, so its MFMA A operands
     // (row l31, 16-byte half kb of each (tap, chunk) slab) are exactly one coalesced 1-KiB global read per slab -- no LDS
@@ -353,7 +356,86 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
 
     int kc0 = 0, tg0 = 0;
     int dbg_stage = 0;
-    if (DIRECT_A) {
+    if (DIRECT_A && a.fast) {
+        // ---- every K phase has exactly SLB slabs (tg * kch == SLB, tg | ntap, kch | kchunks): the phase body is ONE basic
+        // block.  The per-slab tap offsets are fetched before the first LDS read (a scalar load in the slab loop drains the
+        // whole LDS queue: lgkmcnt is shared), the B fragments of slab i+1 are requested before the MFMAs of slab i, the three
+        // products walk the NT accumulators round-robin, the weight fragments of the next phase are requested branch-free
+        // right after their slab's last MFMA, and the next x tile goes into the second LDS buffer (one barrier per tile).
+        const int xbuf = 2 * a.x_floats16;
+        SVBQ_STAMP(6)
+        int sl_t[SLB], sl_c[SLB];
+#pragma unroll
+        for (int i = 0; i < SLB; ++i) { sl_t[i] = i / a.kch; sl_c[i] = i - sl_t[i] * a.kch; }
+        auto load_wf_full = [&](int i, int kcn, int tgn) {
+            const size_t base16 = (w_off0 + ((size_t)(tgn + sl_t[i]) * tap_step * a.w_tap_slabs + (size_t)(kcn + sl_c[i])) * slab_elems) / 8;
+            wfh[i] = (reinterpret_cast<const uint4*>(a.wq_hi) + base16)[wf_lane16];
+            wfl[i] = (reinterpret_cast<const uint4*>(a.wq_lo) + base16)[wf_lane16];
+        };
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SLB; ++i) load_wf_full(i, 0, 0);
+        if (QIN) { load_xq(0); store_xq(0); }
+        else if (phase_fast(0)) { load_x(0); store_x(0); } else { stage_x_slow(0); }
+        __syncthreads();
+        SVBQ_STAMP(7)
+        int cur = 0;
+        while (true) {
+            int ntg = tg0 + a.tg, nkc = kc0;
+            if (ntg >= ntap) { ntg = 0; nkc = kc0 + a.kch; }
+            const bool has_next = nkc < a.kchunks;
+            const bool new_x = has_next && ntg == 0;
+            const bool fastn = new_x && (QIN || phase_fast(nkc));
+            const int lkc = has_next ? nkc : kc0, ltg = has_next ? ntg : tg0;      // (last phase: harmless re-request)
+            int xoff[SLB];
+#pragma unroll
+            for (int i = 0; i < SLB; ++i) xoff[i] = cur + (sl_c[i] * a.xrows + p.tap_off[t0 + tg0 + sl_t[i]] - min_off) * 3;
+            SVBQ_STAMP(0)
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // this phase's weight fragments (requested a phase ago)
+            if (fastn) { if (QIN) load_xq(nkc); else load_x(nkc); }
+            SVBQ_STAMP(1)
+            uint4 bh_u[2][NT], bl_u[2][NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) { bh_u[0][n] = x_hi[xbase[n] + xoff[0]]; bl_u[0][n] = x_lo[xbase[n] + xoff[0]]; }
+#pragma unroll
+            for (int i = 0; i < SLB; ++i) {
+                if (i + 1 < SLB) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        bh_u[(i + 1) & 1][n] = x_hi[xbase[n] + xoff[i + 1]];
+                        bl_u[(i + 1) & 1][n] = x_lo[xbase[n] + xoff[i + 1]];
+                    }
+                }
+                // pin the order: left alone, the scheduler sinks every LDS read to just before its MFMA (to save registers) and
+                // waits lgkmcnt(0) between consecutive MFMAs -- the LDS latency of each read is then exposed
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&wfh[i]), al = *reinterpret_cast<const bf16x8*>(&wfl[i]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, *reinterpret_cast<const bf16x8*>(&bh_u[i & 1][n]), acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, *reinterpret_cast<const bf16x8*>(&bl_u[i & 1][n]), acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, *reinterpret_cast<const bf16x8*>(&bh_u[i & 1][n]), acc[n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_wf_full(i, lkc, ltg);
+            }
+            SVBQ_STAMP(2)
+            if (!has_next) break;
+            if (new_x) {
+                xw = xbuf - cur;
+                if (QIN) store_xq(nkc); else if (fastn) store_x(nkc); else stage_x_slow(nkc);
+                SVBQ_STAMP(4)
+                __syncthreads();
+                SVBQ_STAMP(5)
+                cur = xw;
+            }
+            kc0 = nkc; tg0 = ntg;
+            ++dbg_stage;
+        }
+    } else if (DIRECT_A) {
         if (ntap > 0) {
             __syncthreads();
 #pragma unroll
@@ -423,6 +505,8 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     }
 
     const int out_base = p.phase_out_base[ph];
+    dbg_stage = SVBQ_DBG_STAGES - 1;
+    SVBQ_STAMP(6)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int ql = q0 + (wn * NT + n) * 32 + l31;
@@ -444,6 +528,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
             }
         }
     }
+    SVBQ_STAMP(7)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -553,9 +638,25 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     if (kch > kch_cap) kch = kch_cap;
     if (kch > a.kchunks) kch = a.kchunks;
     if (kch < 1) kch = 1;
+    // direct-A tiles: when all output phases have the same tap count and (tap group) x (chunk group) can be made exactly SLB
+    // slabs with whole phases, the straight-line pipelined loop runs
+    a.fast = 0;
+    if (WN == 1 && !g_svbq_nofast && ntap_max >= 1) {
+        bool same = true;
+        for (int ph = 0; ph < p.n_phase; ++ph) same = same && (p.phase_start[ph + 1] - p.phase_start[ph] == ntap_max);
+        for (int tg = SLB; same && tg >= 1 && !a.fast; --tg) {
+            if (ntap_max % tg || SLB % tg) continue;
+            const int kc = SLB / tg;
+            if (kc > kch_cap || a.kchunks % kc) continue;
+            if ((size_t)4 * kc * span_max * 48 + SVB_MAX_TAPS * 4 > 78 * 1024) continue;
+            a.fast = 1; a.tg = tg; kch = kc;
+        }
+    }
     // (WN == 1 tiles read their weight fragments straight from global memory: no weight tile in LDS)
-    auto lds_bytes = [&](int kc) { return (size_t)2 * ((WN == 1 ? 0 : a.tg * kc * BM) + kc * a.xrows) * 48 + SVB_MAX_TAPS * 4; };
-    while (kch > 1 && lds_bytes(kch) > 78 * 1024) --kch;
+    auto lds_bytes = [&](int kc) {
+        return (size_t)2 * ((WN == 1 ? 0 : a.tg * kc * BM) + (a.fast ? 2 : 1) * kc * a.xrows) * 48 + SVB_MAX_TAPS * 4;
+    };
+    while (!a.fast && kch > 1 && lds_bytes(kch) > 78 * 1024) --kch;
     if (lds_bytes(kch) > 150 * 1024) return SVB_ERR_UNSUPPORTED;
     a.kch = kch;
     a.w_floats16 = WN == 1 ? 0 : a.tg * a.kch * BM * 3;

@@ -45,5 +45,12 @@ print(f"shape B{B} {Cin}->{Cout} k{k} T{T} cfg {cfg}: {len(rows)} (block, stage)
 for i, n in enumerate(names):
     print(f"  {n:22s} {rows[:, i].mean():9.0f} {np.median(rows[:, i]):9.0f}")
 print(f"  {'stage total':22s} {rows.sum(1).mean():9.0f}")
-pro = [(t[b, 0, 7] - t[b, 0, 6]) for b in range(64) if t[b, 0, 7]]
-print(f"  prologue (first tiles)  {np.mean(pro):9.0f}")
+pro = [(t[b, 0, 7] - t[b, 0, 6]) for b in range(64) if t[b, 0, 7] and t[b, 0, 6]]
+if pro:
+    print(f"  prologue (first tiles)  {np.median(pro):9.0f}")
+epi = [(t[b, 31, 7] - t[b, 31, 6]) for b in range(64) if t[b, 31, 7] and t[b, 31, 6]]
+if epi:
+    print(f"  epilogue (stores)       {np.median(epi):9.0f}")
+tot = [(t[b, 31, 7] - t[b, 0, 6]) for b in range(64) if t[b, 31, 7] and t[b, 0, 6]]
+if tot:
+    print(f"  workgroup total         {np.median(tot):9.0f}")
