@@ -203,6 +203,30 @@ int svb_col2im(const float* dcols, float* dx, int B, int C, int H, int W, int KH
 int svb_s2d_pad(const float* x, float* out, int N, int C, int H, int W, long sn, long sc, long sh, long sw, void* stream);
 int svb_s2d_pad_bwd(const float* dout, float* dx, int N, int C, int H, int W, void* stream);
 
+/* ---- the rest of a critic block around that conv (reference multi_window_disc.py:14-31, :62-64), batch-stacked planes.
+ * svb_s2_weight:      w [Cout][C][3][3] -> w4 [Cout][4C][4], the 2x2 stride-1 kernel over the space-to-depth planes
+ *                     (channel (ph*2+pw)*C + c, tap (di+1)*2 + (dj+1); kernel row kh <-> (di,ph): 0:(-1,1) 1:(0,0) 2:(0,1)).
+ * svb_s2_weight_bwd:  the inverse gather of the weight gradient; dwa / dwb = its tap pairs {0,1} / {2,3}, each [Cout][4C][2];
+ *                     accumulate != 0 adds into dw (a parameter's .grad).
+ * svb_crop_drop_inorm_fwd: y4 [C][N][Ho+1][Wo+1] (conv output, row 0 / column 0 junk) -> out [C][N][Ho][Wo]:
+ *                     u = y4 * keep[n][c] (Dropout2d factor, keep may be null); gamma ? InstanceNorm2d(u) * gamma + beta : u
+ *                     (biased variance per plane, eps inside the root); stats [C][N][2] = mean, rstd (gamma only).
+ * svb_crop_drop_inorm_bwd: dout [N][C][Ho][Wo] by element strides -> dy4 (padded layout, zero border) and the per-plane
+ *                     sums dgb [2][N][C] = (sum dout * xhat, sum dout) whose sums over N are dgamma / dbeta.
+ * svb_plane_score_fwd/bwd: score[n] = bias + sum_{c,e} h[n][c][e] * w[c*HW+e] over contiguous (h,w) planes with element
+ *                     strides sn / sc; backward writes dh with the same strides, dw [C*HW], db [1] (each optional).      */
+int svb_s2_weight(const float* w, float* w4, int cout, int c, void* stream);
+int svb_s2_weight_bwd(const float* dwa, const float* dwb, float* dw, int cout, int c, int accumulate, void* stream);
+int svb_crop_drop_inorm_fwd(const float* y4, const float* keep, const float* gamma, const float* beta, float eps, float* out,
+                            float* stats, int N, int C, int Ho, int Wo, void* stream);
+int svb_crop_drop_inorm_bwd(const float* dout, long sn, long sc, long sh, long sw, const float* y4, const float* keep,
+                            const float* gamma, const float* stats, float* dy4, float* dgb, int N, int C, int Ho, int Wo,
+                            void* stream);
+int svb_plane_score_fwd(const float* h, long sn, long sc, const float* w, const float* bias, float* score, int N, int C, int HW,
+                        void* stream);
+int svb_plane_score_bwd(const float* ds, const float* h, long sn, long sc, const float* w, float* dh, float* dw, float* db, int N,
+                        int C, int HW, void* stream);
+
 /* ---- SSIM map of two [B, T, F] mel images (+bias), 11x11 gaussian sigma 1.5, zero padding, C1=1e-4, C2=9e-4
  * (reference modules/commons/ssim.py:331-351 via tasks/tts/fs2.py:166-175).  Inputs are addressed with element
  * strides (batch, time, bin) so the decoder's [B,F,T] output is read in place.  out_map/dmap/dpred: contiguous

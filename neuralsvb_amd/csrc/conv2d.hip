@@ -145,3 +145,217 @@ extern "C" int svb_s2d_pad_bwd(const float* dout, float* dx, int N, int C, int H
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight re-layout for the space-to-depth conv: w [Cout][C][3][3] -> w4 [Cout][4C][4]
+//   channel (ph*2+pw)*C + c, tap (di+1)*2 + (dj+1);  kernel row kh <-> (di, ph): 0 <-> (-1,1), 1 <-> (0,0), 2 <-> (0,1);
+//   the 7 (block, tap) slots without a kernel entry are zero.  The inverse gathers the weight gradient back (its two tap
+//   pairs come from two dilation-1 weight-gradient calls: dwa = taps {0,1}, dwb = taps {2,3}, each [Cout][4C][2]).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int svb_s2_k(int d, int ph) { return d == 0 ? (ph ? 0 : -1) : (ph ? 2 : 1); }
+
+__global__ __launch_bounds__(256) void svb_s2_weight_kernel(const float* w, float* w4, int cout, int c) {
+    const long total = (long)cout * c * 16;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int tap = (int)(i & 3);
+        long r = i >> 2;
+        const int ch = (int)(r % (4 * c));
+        const int co = (int)(r / (4 * c));
+        const int blk = ch / c, ci = ch - blk * c;
+        const int kh = svb_s2_k(tap >> 1, blk >> 1), kw = svb_s2_k(tap & 1, blk & 1);
+        w4[i] = (kh >= 0 && kw >= 0) ? w[((long)co * c + ci) * 9 + kh * 3 + kw] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void svb_s2_weight_bwd_kernel(const float* dwa, const float* dwb, float* dw, int cout, int c,
+                                                                int accumulate) {
+    const long total = (long)cout * c * 9;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int kk = (int)(i % 9);
+        const long r = i / 9;
+        const int ci = (int)(r % c);
+        const int co = (int)(r / c);
+        const int kh = kk / 3, kw = kk - kh * 3;
+        const int di = kh == 0 ? 0 : 1, ph = kh == 1 ? 0 : 1;          // (tap row index, row phase)
+        const int dj = kw == 0 ? 0 : 1, pw = kw == 1 ? 0 : 1;
+        const long ch = (long)co * 4 * c + (ph * 2 + pw) * c + ci;
+        const float v = (di ? dwb : dwa)[ch * 2 + dj];
+        dw[i] = accumulate ? dw[i] + v : v;
+    }
+}
+
+extern "C" int svb_s2_weight(const float* w, float* w4, int cout, int c, void* stream) {
+    if (!w || !w4 || cout <= 0 || c <= 0) return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_s2_weight_kernel, dim3(g1d((long)cout * c * 16)), dim3(256), 0, (hipStream_t)stream, w, w4, cout, c);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_s2_weight_bwd(const float* dwa, const float* dwb, float* dw, int cout, int c, int accumulate, void* stream) {
+    if (!dwa || !dwb || !dw || cout <= 0 || c <= 0) return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_s2_weight_bwd_kernel, dim3(g1d((long)cout * c * 9)), dim3(256), 0, (hipStream_t)stream, dwa, dwb, dw,
+                       cout, c, accumulate);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Crop + Dropout2d scale + InstanceNorm2d(affine) behind the space-to-depth conv (reference multi_window_disc.py:20-27:
+// Conv2d -> LeakyReLU -> Dropout2d(0.25) -> InstanceNorm2d; the LeakyReLU is the conv kernel's epilogue).
+//   y4   [C][N][Ho+1][Wo+1]  conv output, row 0 / column 0 of every plane are junk
+//   keep [N][C] or null      Dropout2d factor of the plane (0 or 1/(1-p))
+//   out  [C][N][Ho][Wo]      u = y4 * keep;  gamma ? (u - mean) * rstd * gamma[c] + beta[c] : u   (biased variance per plane)
+//   stats[C][N][2]           mean, rstd (written when gamma)
+// One workgroup per plane: three cache-hot passes (mean, centred second moment -- the two-pass form torch's statistics
+// agree with to fp32 rounding -- and the write).
+// Backward: dy4 in the padded layout (zero border), the per-plane sums for dgamma / dbeta into dgb [2][N][C].
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void svb_crop_drop_inorm_fwd_kernel(const float* y4, const float* keep, const float* gamma,
+                                                                      const float* beta, float eps, float* out, float* stats,
+                                                                      int N, int C, int Ho, int Wo) {
+    __shared__ float red[4];
+    const int c = blockIdx.x / N, n = blockIdx.x - c * N;
+    const int P = Wo + 1, HW = Ho * Wo;
+    const float* src = y4 + ((long)blockIdx.x * (Ho + 1) + 1) * P + 1;
+    float* dst = out + (long)blockIdx.x * HW;
+    const float s = keep ? keep[(long)n * C + c] : 1.f;
+    if (!gamma) {
+        for (int e = threadIdx.x; e < HW; e += 256) dst[e] = src[(e / Wo) * P + e % Wo] * s;
+        return;
+    }
+    float sum = 0.f;
+    for (int e = threadIdx.x; e < HW; e += 256) sum += src[(e / Wo) * P + e % Wo] * s;
+    const float mean = svb_block_sum<256>(sum, red) / (float)HW;
+    float sq = 0.f;
+    for (int e = threadIdx.x; e < HW; e += 256) {
+        const float d = src[(e / Wo) * P + e % Wo] * s - mean;
+        sq += d * d;
+    }
+    const float var = svb_block_sum<256>(sq, red) / (float)HW;
+    const float rstd = 1.f / sqrtf(var + eps);
+    const float g = gamma[c], b = beta ? beta[c] : 0.f;
+    for (int e = threadIdx.x; e < HW; e += 256) dst[e] = (src[(e / Wo) * P + e % Wo] * s - mean) * rstd * g + b;
+    if (threadIdx.x == 0) {
+        stats[2L * blockIdx.x] = mean;
+        stats[2L * blockIdx.x + 1] = rstd;
+    }
+}
+
+__global__ __launch_bounds__(256) void svb_crop_drop_inorm_bwd_kernel(const float* dout, long sn, long sc, long sh, long sw,
+                                                                      const float* y4, const float* keep, const float* gamma,
+                                                                      const float* stats, float* dy4, float* dgb, int N, int C,
+                                                                      int Ho, int Wo) {
+    __shared__ float red[4];
+    const int c = blockIdx.x / N, n = blockIdx.x - c * N;
+    const int P = Wo + 1, HW = Ho * Wo;
+    const long plane = (long)blockIdx.x * (Ho + 1) * P;
+    const float* src = y4 + plane + P + 1;
+    float* dst = dy4 + plane + P + 1;
+    const float* dob = dout + (long)n * sn + (long)c * sc;
+    const float s = keep ? keep[(long)n * C + c] : 1.f;
+    for (int e = threadIdx.x; e < P + Ho; e += 256) dy4[plane + (e < P ? e : (long)(e - P + 1) * P)] = 0.f;      // border
+    if (!gamma) {
+        for (int e = threadIdx.x; e < HW; e += 256) {
+            const int i = e / Wo, j = e - i * Wo;
+            dst[i * P + j] = dob[(long)i * sh + (long)j * sw] * s;
+        }
+        return;
+    }
+    const float mean = stats[2L * blockIdx.x], rstd = stats[2L * blockIdx.x + 1], g = gamma[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = threadIdx.x; e < HW; e += 256) {
+        const int i = e / Wo, j = e - i * Wo;
+        const float d = dob[(long)i * sh + (long)j * sw];
+        s1 += d;
+        s2 += d * ((src[i * P + j] * s - mean) * rstd);
+    }
+    s1 = svb_block_sum<256>(s1, red);
+    s2 = svb_block_sum<256>(s2, red);
+    const float m1 = s1 * g / (float)HW, m2 = s2 * g / (float)HW;
+    for (int e = threadIdx.x; e < HW; e += 256) {
+        const int i = e / Wo, j = e - i * Wo;
+        const float xh = (src[i * P + j] * s - mean) * rstd;
+        dst[i * P + j] = rstd * (dob[(long)i * sh + (long)j * sw] * g - m1 - xh * m2) * s;
+    }
+    if (threadIdx.x == 0) {
+        dgb[(long)n * C + c] = s2;
+        dgb[(long)N * C + (long)n * C + c] = s1;
+    }
+}
+
+extern "C" int svb_crop_drop_inorm_fwd(const float* y4, const float* keep, const float* gamma, const float* beta, float eps,
+                                       float* out, float* stats, int N, int C, int Ho, int Wo, void* stream) {
+    if (!y4 || !out || N <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || (gamma && !stats)) return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_crop_drop_inorm_fwd_kernel, dim3(N * C), dim3(256), 0, (hipStream_t)stream, y4, keep, gamma, beta, eps,
+                       out, stats, N, C, Ho, Wo);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_crop_drop_inorm_bwd(const float* dout, long sn, long sc, long sh, long sw, const float* y4, const float* keep,
+                                       const float* gamma, const float* stats, float* dy4, float* dgb, int N, int C, int Ho, int Wo,
+                                       void* stream) {
+    if (!dout || !y4 || !dy4 || N <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || (gamma && (!stats || !dgb))) return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_crop_drop_inorm_bwd_kernel, dim3(N * C), dim3(256), 0, (hipStream_t)stream, dout, sn, sc, sh, sw, y4,
+                       keep, gamma, stats, dy4, dgb, N, C, Ho, Wo);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Critic score: tower.adv_layer(h.flatten(1)) (reference multi_window_disc.py:62-64, nn.Linear(C*H*W, 1)) on feature maps
+// whose (h, w) planes are contiguous (element strides sn, sc between clips / channels):
+//   score[n] = bias + sum_{c,e} h[n][c][e] * w[c*HW + e]
+// Backward in one pass: dh[n][c][e] = ds[n] * w[c*HW+e] (written with the strides of h), dw[k] = sum_n ds[n] * h[n][k],
+// db = sum_n ds[n].
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void svb_plane_score_fwd_kernel(const float* h, long sn, long sc, const float* w, const float* bias,
+                                                                  float* score, int C, int HW) {
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < C * HW; k += 256) {
+        const int c = k / HW, e = k - c * HW;
+        acc += h[(long)n * sn + (long)c * sc + e] * w[k];
+    }
+    acc = svb_block_sum<256>(acc, red);
+    if (threadIdx.x == 0) score[n] = acc + (bias ? bias[0] : 0.f);
+}
+
+__global__ __launch_bounds__(256) void svb_plane_score_bwd_kernel(const float* ds, const float* h, long sn, long sc, const float* w,
+                                                                  float* dh, float* dw, float* db, int N, int C, int HW) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k == 0 && db) {
+        float t = 0.f;
+        for (int n = 0; n < N; ++n) t += ds[n];
+        db[0] = t;
+    }
+    if (k >= C * HW) return;
+    const int c = k / HW, e = k - c * HW;
+    const float wk = w[k];
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const long o = (long)n * sn + (long)c * sc + e;
+        const float d = ds[n];
+        if (dw) acc += d * h[o];
+        if (dh) dh[o] = d * wk;
+    }
+    if (dw) dw[k] = acc;
+}
+
+extern "C" int svb_plane_score_fwd(const float* h, long sn, long sc, const float* w, const float* bias, float* score, int N, int C,
+                                   int HW, void* stream) {
+    if (!h || !w || !score || N <= 0 || C <= 0 || HW <= 0) return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_plane_score_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, h, sn, sc, w, bias, score, C, HW);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_plane_score_bwd(const float* ds, const float* h, long sn, long sc, const float* w, float* dh, float* dw, float* db,
+                                   int N, int C, int HW, void* stream) {
+    if (!ds || !h || !w || N <= 0 || C <= 0 || HW <= 0) return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_plane_score_bwd_kernel, dim3(svb_cdiv(C * HW, 256)), dim3(256), 0, (hipStream_t)stream, ds, h, sn, sc, w,
+                       dh, dw, db, N, C, HW);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}

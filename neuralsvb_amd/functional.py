@@ -126,11 +126,16 @@ def note_weights_updated(params=None):
     if params is None:
         for e in _REG.values():
             e.dirty = True
+        for ent in _S2W.values():
+            ent[3] = True
     else:
         ids = {id(p) for p in params}
         for e in _REG.values():
             if e.vid in ids or e.gid in ids:
                 e.dirty = True
+        for k, ent in _S2W.items():
+            if k in ids:
+                ent[3] = True
 
 
 class _PackEntry:
@@ -604,85 +609,142 @@ class _Conv2dFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
-class _S2DPadFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        ctx.shape = tuple(x.shape)
-        return K.s2d_pad(x)
+CONV2D_S2D = True        # 3x3 stride-2 pad-1 Conv2d via space-to-depth + the tap-table conv (no 9x im2col expansion)
+_S2W = {}                # id(weight) -> [weakref(weight), (version, data_ptr), w4, dirty]: the re-laid-out kernel, refreshed in place
+
+
+def _s2_image(weight):
+    """Persistent [Cout,4C,4] image of a 3x3 stride-2 kernel (one gather launch whenever the weight has changed; the
+    generator pass and the critic pass of a step share it).  Not tracked by autograd: _Conv2dS2Fn maps the gradient back.
+    Same validity rule as the packed images (_pack): a trainable weight's image is only reused inside a Trainer-managed
+    step, where every in-place update is announced by note_weights_updated() -- a fused optimizer step does not move the
+    tensor's version counter -- and never while a hipGraph is being captured."""
+    ver = (weight._version, weight.data_ptr())
+    ent = _S2W.get(id(weight))
+    if ent is None or ent[0]() is not weight:
+        ent = _S2W[id(weight)] = [weakref.ref(weight), None, None, True]
+    trainable = weight.requires_grad or weight.grad is not None
+    if ent[3] or ent[1] != ver or (trainable and (PACK_EPOCH is None or CAPTURING)):
+        if ent[2] is None:
+            ent[2] = K.s2_weight(weight)
+        else:
+            K.s2_weight(weight, out=ent[2])
+            torch.autograd.graph.increment_version(ent[2])          # the packed-image cache keys on it
+        ent[1], ent[3] = ver, False
+    return ent[2]
+
+
+class _Conv2dS2Fn(torch.autograd.Function):
+    """3x3 stride-2 pad-1 Conv2d + LeakyReLU (reference multi_window_disc.py:14-22) over batch-stacked planes.
+    x [N,C,H,W] (any strides; H, W even) -> y4 [1, Cout, N*(H/2+1)*(W/2+1)]: the conv output in the padded plane layout
+    [Cout][N][Ho+1][Wo+1] whose row 0 / column 0 are junk (crop_drop_norm removes them)."""
 
     @staticmethod
-    def backward(ctx, dout):
-        return K.s2d_pad_bwd(dout.contiguous(), *ctx.shape)
-
-
-class _ConvTapsFn(torch.autograd.Function):
-    """Stride-1 conv with an arbitrary tap table (+ fused LeakyReLU): x [B,Cin,T], w [Cout,Cin,ntaps], y [B,Cout,T]."""
-
-    @staticmethod
-    def forward(ctx, x, w, bias, cfg):
-        offsets, slope = cfg
-        x, w = x.contiguous(), w.contiguous()
-        cout = w.shape[0]
-        pa, pb = _pack(w, None, 1, want_a=True, want_b=ctx.needs_input_grad[0])
-        y = K.conv1d_taps(x, pa, cout, offsets, bias=bias, out_act=ACT_LRELU if slope is not None else ACT_NONE,
-                          out_slope=slope if slope is not None else 0.0)
-        ctx.cfg, ctx.pb, ctx.has_bias = cfg, pb, bias is not None
-        ctx.save_for_backward(x if ctx.needs_input_grad[1] else None, y if slope is not None else None)
-        ctx.cin = x.shape[1]
-        return y
+    def forward(ctx, x, weight, bias, slope):
+        N, C, H, W = x.shape
+        Ho, Wo = H // 2, W // 2
+        P = Wo + 1
+        cout = weight.shape[0]
+        weight = weight.contiguous()
+        offsets = (-P - 1, -P, -1, 0)
+        x4 = K.s2d_pad(x).view(1, 4 * C, N * (Ho + 1) * P)
+        pa, pb = _pack(_s2_image(weight), None, 1, want_a=True, want_b=ctx.needs_input_grad[0])
+        y4 = K.conv1d_taps(x4, pa, cout, offsets, bias=_c(bias), out_act=ACT_LRELU if slope is not None else ACT_NONE,
+                           out_slope=slope if slope is not None else 0.0)
+        ctx.dims, ctx.slope, ctx.pb, ctx.has_bias, ctx.offsets = (N, C, H, W, cout), slope, pb, bias is not None, offsets
+        ctx.save_for_backward(x4 if ctx.needs_input_grad[1] else None, y4 if slope is not None else None, weight)
+        return y4
 
     @staticmethod
-    def backward(ctx, dy):
-        offsets, slope = ctx.cfg
-        x, yact = ctx.saved_tensors
-        dy = dy.contiguous()
-        a_slope = slope if slope is not None else 0.0
+    def backward(ctx, dy4):
+        N, C, H, W, cout = ctx.dims
+        x4, yact, weight = ctx.saved_tensors
+        dy4 = dy4.contiguous()
+        a_slope = ctx.slope if ctx.slope is not None else 0.0
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = K.conv1d_taps(dy, ctx.pb, ctx.cin, [-o for o in offsets], in_gate=yact, in_slope=a_slope)
+            dx4 = K.conv1d_taps(dy4, ctx.pb, 4 * C, [-o for o in ctx.offsets], in_gate=yact, in_slope=a_slope)
+            dx = K.s2d_pad_bwd(dx4, N, C, H, W)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            parts, i = [], 0
-            while i < len(offsets):                      # runs of consecutive offsets = one dilation-1 weight-gradient call
-                n = 1
-                while i + n < len(offsets) and offsets[i + n] == offsets[i + n - 1] + 1:
-                    n += 1
-                r = K.conv1d_wgrad(dy, x, n, 1, -offsets[i], 1, 1, a_gate=yact, a_slope=a_slope, want_bias=want_b and i == 0)
-                if want_b and i == 0:
-                    r, db = r
-                parts.append(r)
-                i += n
-            dw = torch.cat(parts, 2) if len(parts) > 1 else parts[0]
+            ra = K.conv1d_wgrad(dy4, x4, 2, 1, -ctx.offsets[0], 1, 1, a_gate=yact, a_slope=a_slope, want_bias=want_b)
+            if want_b:
+                ra, db = ra
+            rb = K.conv1d_wgrad(dy4, x4, 2, 1, -ctx.offsets[2], 1, 1, a_gate=yact, a_slope=a_slope)
+            sink = _gbuf(weight)
+            dw = K.s2_weight_bwd(ra, rb, cout, C, into=sink)
+            _notify((sink,), (weight,), (dw,))
         elif want_b:
-            db = K.bias_grad(dy, yact, a_slope)
+            db = K.bias_grad(dy4, yact, a_slope)
         return dx, dw, db, None
 
 
-_S2_MAP = {}
+class _CropDropNormFn(torch.autograd.Function):
+    """Crop of the padded conv output + Dropout2d factor + InstanceNorm2d(affine) (reference multi_window_disc.py:23-27) in
+    one pass per direction.  y4: [1,C,N*(Ho+1)*(Wo+1)]; keep: [N,C] or None; gamma/beta: [C] or None (no norm).
+    Returns the [N,C,Ho,Wo] view of channel-major memory."""
+
+    @staticmethod
+    def forward(ctx, y4, keep, gamma, beta, dims):
+        N, C, Ho, Wo, eps = dims
+        out, stats = K.crop_drop_inorm(y4, keep, _c(gamma), _c(beta), N, C, Ho, Wo, eps)
+        ctx.dims = dims
+        ctx.save_for_backward(y4, keep, gamma, stats)
+        return out.permute(1, 0, 2, 3)
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, C, Ho, Wo, eps = ctx.dims
+        y4, keep, gamma, stats = ctx.saved_tensors
+        dy4, dgb = K.crop_drop_inorm_bwd(dout, y4, keep, _c(gamma), stats, N, C, Ho, Wo)
+        dg = db = None
+        if dgb is not None:
+            dg, db = dgb.sum(1).unbind(0)
+        return dy4.view(y4.shape), None, dg, db, None
 
 
-def _s2_weight(weight):
-    """[Cout,C,3,3] stride-2 kernel -> [Cout,4C,4]: the equivalent 2x2 stride-1 kernel over the space-to-depth planes
-    (channel block ph*2+pw, tap (di+1)*2+(dj+1) with kernel row kh -> (di, ph) = 0:(-1,1) 1:(0,0) 2:(0,1); 7 of the 16
-    (block, tap) slots have no kernel entry and stay zero)."""
-    dev = weight.device
-    m = _S2_MAP.get(dev)
-    if m is None:
-        idx = torch.zeros(4, 4, dtype=torch.long)
-        msk = torch.zeros(4, 4)
-        dp = {0: (-1, 1), 1: (0, 0), 2: (0, 1)}
-        for kh in range(3):
-            for kw in range(3):
-                (di, ph), (dj, pw) = dp[kh], dp[kw]
-                idx[ph * 2 + pw, (di + 1) * 2 + (dj + 1)] = kh * 3 + kw
-                msk[ph * 2 + pw, (di + 1) * 2 + (dj + 1)] = 1.0
-        m = _S2_MAP[dev] = (idx.flatten().to(dev), msk.flatten().to(dev))
-    cout, c = weight.shape[:2]
-    w16 = weight.reshape(cout, c, 9).index_select(2, m[0]) * m[1]               # [Cout, C, 16] (block, tap)
-    return w16.view(cout, c, 4, 4).permute(0, 2, 1, 3).reshape(cout, 4 * c, 4)
+class _PlaneScoreFn(torch.autograd.Function):
+    """nn.Linear(C*H*W, 1) on feature maps with contiguous (H,W) planes (reference multi_window_disc.py:62-64)."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias):
+        w = weight.contiguous().view(-1)
+        ctx.save_for_backward(h, w)
+        ctx.wshape, ctx.has_bias = weight.shape, bias is not None
+        return K.plane_score(h, w, _c(bias))
+
+    @staticmethod
+    def backward(ctx, ds):
+        h, w = ctx.saved_tensors
+        dh, dw, db = K.plane_score_bwd(ds.contiguous().view(-1), h, w, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                       ctx.has_bias and ctx.needs_input_grad[2])
+        return dh, (dw.view(ctx.wshape) if dw is not None else None), db
 
 
-CONV2D_S2D = True        # 3x3 stride-2 pad-1 Conv2d via space-to-depth + the tap-table conv (no 9x im2col expansion)
+def dropout2d_keep(n, c, p, device):
+    """Dropout2d's per-(clip, channel) factor: 0 with probability p, else 1/(1-p) (F.dropout2d draws the same Bernoulli
+    field, shape [N,C,1,1]).  One function so that a test can replay recorded masks."""
+    return torch.empty((n, c), device=device, dtype=torch.float32).bernoulli_(1.0 - p).div_(1.0 - p)
+
+
+def critic_block(x, weight, bias, lrelu_slope, drop_p, gamma, beta, eps=1e-5):
+    """One block of the mel critic: Conv2d(3x3, s2, p1) -> LeakyReLU -> Dropout2d(drop_p; 0/None = off) -> InstanceNorm2d
+    (gamma None = none).  x [N,C,H,W], H and W even.  Four launches forward (space-to-depth, conv, crop/norm, + the
+    Bernoulli draw)."""
+    N, C, H, W = x.shape
+    if not (CONV2D_S2D and tuple(weight.shape[2:]) == (3, 3) and H % 2 == 0 and W % 2 == 0):
+        raise ValueError("critic_block: 3x3 stride-2 kernels on even planes only")
+    cout = weight.shape[0]
+    y4 = _Conv2dS2Fn.apply(x, weight, bias, lrelu_slope)
+    keep = dropout2d_keep(N, cout, drop_p, x.device) if drop_p else None
+    return _CropDropNormFn.apply(y4, keep, gamma, beta, (N, cout, H // 2, W // 2, eps))
+
+
+def plane_score(h, weight, bias):
+    N, C, H, W = h.shape
+    if h.stride(3) != 1 or h.stride(2) != W:
+        h = h.contiguous()
+    return _PlaneScoreFn.apply(h, weight, bias)
 
 
 def conv2d_lrelu(x, weight, bias, stride, padding, lrelu_slope=None):
@@ -691,9 +753,6 @@ def conv2d_lrelu(x, weight, bias, stride, padding, lrelu_slope=None):
     N, C, H, W = x.shape
     if (CONV2D_S2D and tuple(weight.shape[2:]) == (3, 3) and int(stride) == 2 and int(padding) == 1 and H % 2 == 0
             and W % 2 == 0):
-        Ho, Wo = H // 2, W // 2
-        P = Wo + 1
-        x4 = _S2DPadFn.apply(x).view(1, 4 * C, N * (Ho + 1) * P)              # clips folded into one long position axis
-        y4 = _ConvTapsFn.apply(x4, _s2_weight(weight), bias, ((-P - 1, -P, -1, 0), lrelu_slope))
-        return y4.view(weight.shape[0], N, Ho + 1, P)[:, :, 1:, 1:].permute(1, 0, 2, 3)
+        y4 = _Conv2dS2Fn.apply(x, weight, bias, lrelu_slope)
+        return _CropDropNormFn.apply(y4, None, None, None, (N, weight.shape[0], H // 2, W // 2, 1e-5))
     return _Conv2dFn.apply(x, weight, bias, (int(stride), int(padding), lrelu_slope))

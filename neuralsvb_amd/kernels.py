@@ -592,6 +592,73 @@ def s2d_pad_bwd(dout, N, Cc, H, W):
     return dx
 
 
+def s2_weight(w, out=None):
+    """[Cout,C,3,3] stride-2 kernel -> [Cout,4C,4], the equivalent 2x2 stride-1 kernel over the space-to-depth planes."""
+    _f32(w)
+    lib, st = _prep(w)
+    cout, c = w.shape[:2]
+    if out is None:
+        out = torch.empty((cout, 4 * c, 4), device=w.device, dtype=torch.float32)
+    L.check(lib.svb_s2_weight(_ptr(w), _ptr(out), cout, c, st), "svb_s2_weight")
+    return out
+
+
+def s2_weight_bwd(dwa, dwb, cout, c, into=None):
+    """The weight gradient back in [Cout,C,3,3]; dwa / dwb = its tap pairs {0,1} / {2,3}, each [Cout,4C,2].  `into`: a
+    gradient buffer to accumulate into (returns None then)."""
+    _f32(dwa, dwb)
+    lib, st = _prep(dwa, dwb)
+    dw = into if into is not None else torch.empty((cout, c, 3, 3), device=dwa.device, dtype=torch.float32)
+    L.check(lib.svb_s2_weight_bwd(_ptr(dwa), _ptr(dwb), _ptr(dw), cout, c, int(into is not None), st), "svb_s2_weight_bwd")
+    return None if into is not None else dw
+
+
+def crop_drop_inorm(y4, keep, gamma, beta, N, Cc, Ho, Wo, eps=1e-5):
+    """y4: conv output in the padded plane layout [C][N][Ho+1][Wo+1] (any shape with that memory).  Returns (out [C,N,Ho,Wo],
+    stats [C,N,2] or None)."""
+    _f32(y4, keep, gamma, beta)
+    lib, st = _prep(y4, keep, gamma, beta)
+    out = torch.empty((Cc, N, Ho, Wo), device=y4.device, dtype=torch.float32)
+    stats = torch.empty((Cc, N, 2), device=y4.device, dtype=torch.float32) if gamma is not None else None
+    L.check(lib.svb_crop_drop_inorm_fwd(_ptr(y4), _ptr(keep), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), _ptr(stats), N, Cc,
+                                        Ho, Wo, st), "svb_crop_drop_inorm_fwd")
+    return out, stats
+
+
+def crop_drop_inorm_bwd(dout, y4, keep, gamma, stats, N, Cc, Ho, Wo):
+    """dout [N,C,Ho,Wo] (any strides).  Returns (dy4 [C,N,Ho+1,Wo+1] with a zero border, dgb [2,N,C] or None)."""
+    _f32(dout, y4, keep, gamma, stats)
+    lib, st = _prep_strided(dout, y4)
+    dy4 = torch.empty((Cc, N, Ho + 1, Wo + 1), device=y4.device, dtype=torch.float32)
+    dgb = torch.empty((2, N, Cc), device=y4.device, dtype=torch.float32) if gamma is not None else None
+    L.check(lib.svb_crop_drop_inorm_bwd(_ptr(dout), *dout.stride(), _ptr(y4), _ptr(keep), _ptr(gamma), _ptr(stats), _ptr(dy4),
+                                        _ptr(dgb), N, Cc, Ho, Wo, st), "svb_crop_drop_inorm_bwd")
+    return dy4, dgb
+
+
+def plane_score(h, w, bias):
+    """h [N,C,H,W] with contiguous (H,W) planes, w [C*H*W], bias [1] -> [N,1]."""
+    _f32(h, w, bias)
+    lib, st = _prep_strided(h, w)
+    N, Cc, H, W = h.shape
+    score = torch.empty((N, 1), device=h.device, dtype=torch.float32)
+    L.check(lib.svb_plane_score_fwd(_ptr(h), h.stride(0), h.stride(1), _ptr(w), _ptr(bias), _ptr(score), N, Cc, H * W, st),
+            "svb_plane_score_fwd")
+    return score
+
+
+def plane_score_bwd(ds, h, w, want_dh, want_dw, want_db):
+    _f32(ds, h, w)
+    lib, st = _prep_strided(h, ds)
+    N, Cc, H, W = h.shape
+    dh = torch.empty_strided(h.shape, h.stride(), device=h.device, dtype=torch.float32) if want_dh else None
+    dw = torch.empty((Cc * H * W,), device=h.device, dtype=torch.float32) if want_dw else None
+    db = torch.empty((1,), device=h.device, dtype=torch.float32) if want_db else None
+    L.check(lib.svb_plane_score_bwd(_ptr(ds), _ptr(h), h.stride(0), h.stride(1), _ptr(w), _ptr(dh), _ptr(dw), _ptr(db), N, Cc,
+                                    H * W, st), "svb_plane_score_bwd")
+    return dh, dw, db
+
+
 def _prep_strided(*tensors):
     """like _prep but allows non-contiguous tensors (kernels that take element strides)."""
     lib = L.get_lib()

@@ -7,24 +7,32 @@ Semantics kept: one np.random window start per window length shared by the whole
 non-zero frames (:190), Dropout2d(0.25) on whole channels in train mode (:23), `y=None` when a clip is shorter
 than a window (:140-142).
 
-The 3x3 stride-2 Conv2d + LeakyReLU blocks run on the HIP kernels (im2col -> implicit-GEMM conv kernel with the
-LeakyReLU fused in its epilogue, col2im / split-K wgrad for the backward); Dropout2d and InstanceNorm2d are
-elementwise/statistics passes left on torch-ROCm ops.
+Every block runs on the HIP kernels: space-to-depth planes -> tap-table implicit-GEMM conv with the LeakyReLU in its
+epilogue -> one crop + Dropout2d-factor + InstanceNorm2d pass (SF.critic_block); the score layer is one reduction kernel
+(SF.plane_score).  Only the 'bn' norm variant (not used by vae_global_mle_eng) keeps torch's BatchNorm2d.
 """
 import numpy as np
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from .. import functional as SF
 
 
 def _adv_score(adv_layer, h):
-    """tower.adv_layer(h.flatten(1)) -- nn.Linear(C*H*W, 1), multi_window_disc.py:62-64 -- as a broadcast multiply + row sum:
-    the [B, 20480] x [20480, 1] product is a GEMV per clip, for which rocBLAS picks a 120 us tile GEMM (0.7 ms per step over
-    the six critic passes); the elementwise form moves the same 5 MB in two ~5 us passes and its autograd is as cheap."""
-    hf = h.flatten(1)
-    return (hf * adv_layer.weight).sum(1, keepdim=True) + adv_layer.bias
+    """tower.adv_layer(h.flatten(1)) -- nn.Linear(C*H*W, 1), multi_window_disc.py:62-64 -- as one row-reduction kernel
+    over the channel-major feature maps (rocBLAS picks a 120 us tile GEMM for this GEMV)."""
+    return SF.plane_score(h, adv_layer.weight, adv_layer.bias)
+
+
+def _block(blk, h):
+    """Conv2d 3x3 s2 p1 -> LeakyReLU(0.2) -> Dropout2d [-> InstanceNorm2d | BatchNorm2d] (multi_window_disc.py:14-31)."""
+    conv, drop = blk[0], blk[2]
+    norm = blk[3] if len(blk) > 3 else None
+    p = drop.p if drop.training else 0.0
+    if isinstance(norm, nn.InstanceNorm2d):
+        return SF.critic_block(h, conv.weight, conv.bias, 0.2, p, norm.weight, norm.bias, norm.eps)
+    h = SF.critic_block(h, conv.weight, conv.bias, 0.2, p, None, None)
+    return norm(h) if norm is not None else h
 
 
 def _critic_tower(time_length, freq_length, kernel, c_in, hidden, norm_type, reduction):
@@ -83,10 +91,7 @@ class Discriminator(nn.Module):
                 s = starts[w][0]
                 h = x[:, :, s:s + wl]
             for blk in tower.model:
-                conv = blk[0]     # Conv2d 3x3 s2 p1 + LeakyReLU(0.2): im2col + HIP implicit-GEMM kernel, fused epilogue
-                h = SF.conv2d_lrelu(h, conv.weight, conv.bias, conv.stride[0], conv.padding[0], 0.2)
-                for m in list(blk)[2:]:                      # Dropout2d(0.25) [, InstanceNorm2d]
-                    h = m(h)
+                h = _block(blk, h)
                 fmaps.append(h)
             scores.append(_adv_score(tower.adv_layer, h))
         y = None
@@ -113,10 +118,7 @@ class Discriminator(nn.Module):
                     crops.append(x[:, :, s:s + wl])
             h = torch.cat(crops, 0)
             for blk in tower.model:
-                conv = blk[0]
-                h = SF.conv2d_lrelu(h, conv.weight, conv.bias, conv.stride[0], conv.padding[0], 0.2)
-                for m in list(blk)[2:]:
-                    h = m(h)
+                h = _block(blk, h)
                 fmaps.append(h)
             scores.append(_adv_score(tower.adv_layer, h))
         y = torch.stack(scores, -1) if self.reduction == "stack" else sum(scores)

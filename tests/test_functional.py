@@ -186,6 +186,111 @@ def test_conv2d_lrelu_autograd(dev):
             assert rel_err(a.grad, r.grad) < 3e-5
 
 
+def test_critic_block_autograd(dev):
+    """Whole critic block -- Conv2d(3x3,s2,p1) -> LeakyReLU(0.2) -> Dropout2d -> InstanceNorm2d(affine)
+    (multi_window_disc.py:14-31) -- as space-to-depth conv + one crop/drop/norm pass, against stock torch with the SAME
+    keep mask; with and without the norm, with and without dropout; gradients of input, kernel, bias, gamma, beta."""
+    g_ = torch.Generator().manual_seed(43)
+    for cin, H, W, norm, p in ((1, 32, 80, False, 0.25), (6, 16, 40, True, 0.25), (6, 8, 20, True, 0.0), (5, 4, 10, True, 0.5)):
+        N, cout = 3, 10
+        x = torch.randn(N, cin, H, W, generator=g_)
+        w = torch.randn(cout, cin, 3, 3, generator=g_) * 0.3
+        b = torch.randn(cout, generator=g_)
+        gm, bt = torch.rand(cout, generator=g_) + 0.5, torch.randn(cout, generator=g_)
+        keep = (torch.rand(N, cout, generator=g_) >= p).float() / (1.0 - p)
+        rl = [t.clone().requires_grad_(True) for t in (x, w, b, gm, bt)]
+        yr = F.leaky_relu(F.conv2d(rl[0], rl[1], rl[2], 2, 1), 0.2) * keep[:, :, None, None]
+        if norm:
+            yr = F.instance_norm(yr, weight=rl[3], bias=rl[4], eps=1e-5)
+        dy = torch.randn(yr.shape, generator=g_)
+        yr.backward(dy)
+        dl = [_leaf(t, dev) for t in (x, w, b, gm, bt)]
+        old = SF.dropout2d_keep
+        SF.dropout2d_keep = lambda n, c, pp, device: keep.to(device)
+        try:
+            y = SF.critic_block(dl[0], dl[1], dl[2], 0.2, p, dl[3] if norm else None, dl[4] if norm else None)
+        finally:
+            SF.dropout2d_keep = old
+        assert y.shape == yr.shape and rel_err(y, yr) < 3e-5
+        y.backward(dy.to(dev))
+        for a, r in list(zip(dl, rl))[:5 if norm else 3]:
+            assert rel_err(a.grad, r.grad) < 1e-4, (cin, H, W, norm, p)
+
+
+def test_critic_block_accumulates_into_grad_buffers(dev):
+    """A kernel that already owns a .grad buffer gets its gradient added there by the gather kernel (no autograd add)."""
+    g_ = torch.Generator().manual_seed(44)
+    x = torch.randn(2, 4, 8, 10, generator=g_)
+    w = torch.randn(6, 4, 3, 3, generator=g_) * 0.3
+    rl = [t.clone().requires_grad_(True) for t in (x, w)]
+    yr = F.leaky_relu(F.conv2d(rl[0], rl[1], None, 2, 1), 0.2)
+    dy = torch.randn(yr.shape, generator=g_)
+    yr.backward(dy)
+    xd, wd = _leaf(x, dev), _leaf(w, dev)
+    wd.grad = torch.full_like(wd, 0.5)
+    buf = wd.grad
+    SF.critic_block(xd, wd, None, 0.2, 0.0, None, None).backward(dy.to(dev))
+    assert wd.grad is buf and rel_err(wd.grad - 0.5, rl[1].grad) < 1e-4
+
+
+def test_critic_block_sees_fused_optimizer_updates(dev):
+    """A fused AdamW step changes the kernel without moving its version counter: inside a Trainer-managed weight epoch the
+    re-laid-out kernel image must follow note_weights_updated(); outside one it is rebuilt on every call."""
+    g_ = torch.Generator().manual_seed(46)
+    x = torch.randn(2, 3, 8, 10, generator=g_)
+    w = torch.randn(5, 3, 3, 3, generator=g_) * 0.3
+    xd, wd = x.to(dev), _leaf(w, dev)
+    opt = torch.optim.AdamW([wd], lr=0.05, fused=True)
+
+    def ref():
+        return F.leaky_relu(F.conv2d(x, wd.detach().cpu(), None, 2, 1), 0.2)
+
+    def run():
+        return SF.critic_block(xd, wd, None, 0.2, 0.0, None, None)
+    for managed in (True, False):
+        if managed:
+            SF.begin_weight_epoch()
+        try:
+            y = run()
+            assert rel_err(y, ref()) < 3e-5
+            y.sum().backward()
+            ver = wd._version
+            opt.step()
+            assert wd._version == ver                       # the premise of this test
+            if managed:
+                SF.note_weights_updated([wd])
+            assert rel_err(run(), ref()) < 3e-5
+        finally:
+            SF.end_weight_epoch()
+
+
+def test_dropout2d_keep_is_a_bernoulli_field(dev):
+    k = SF.dropout2d_keep(64, 128, 0.25, dev)
+    vals = sorted(torch.unique(k).tolist())
+    assert k.shape == (64, 128) and len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1.0 / 0.75) < 1e-6
+    assert abs(float((k > 0).float().mean()) - 0.75) < 0.03
+
+
+def test_plane_score_autograd(dev):
+    """adv_layer (nn.Linear(C*H*W, 1), multi_window_disc.py:62-64) on channel-major feature maps."""
+    g_ = torch.Generator().manual_seed(45)
+    N, C, H, W = 5, 12, 4, 10
+    base = torch.randn(C, N, H, W, generator=g_)
+    wt, bs = torch.randn(1, C * H * W, generator=g_) * 0.1, torch.randn(1, generator=g_)
+    hr = base.permute(1, 0, 2, 3).clone().requires_grad_(True)
+    rl = [hr, wt.clone().requires_grad_(True), bs.clone().requires_grad_(True)]
+    yr = F.linear(hr.flatten(1), rl[1], rl[2])
+    dy = torch.randn(yr.shape, generator=g_)
+    yr.backward(dy)
+    hb = base.to(dev).requires_grad_(True)
+    wd, bd = _leaf(wt, dev), _leaf(bs, dev)
+    y = SF.plane_score(hb.permute(1, 0, 2, 3), wd, bd)
+    assert y.shape == yr.shape and rel_err(y, yr) < 2e-5
+    y.backward(dy.to(dev))
+    assert rel_err(hb.grad.permute(1, 0, 2, 3), hr.grad) < 2e-5
+    assert rel_err(wd.grad, rl[1].grad) < 2e-5 and rel_err(bd.grad, rl[2].grad) < 2e-5
+
+
 def test_wn_stack_bf16x3_mode(dev):
     """WN stack with forward + data-gradient convs in bf16x3 mode (weight gradients stay fp32): 2e-4 relative."""
     g_ = torch.Generator().manual_seed(33)
