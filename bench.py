@@ -93,14 +93,14 @@ def conv_roofline(trainer, task, batch, steps, start_step, precision="fp32"):
             d[0] += flops
             d[1] += sec
             d[2] += 1
-        d = by_shape.setdefault(tag, [0.0, 0.0, 0])
+        d = by_shape.setdefault((tag, name.split("<")[-1].split(">")[0] if "<" in name else ""), [0.0, 0.0, 0])
         d[0] += flops
         d[1] += sec
         d[2] += 1
     if os.environ.get("SVB_BENCH_SHAPES"):
         log("per-shape conv time (op, B, C_a, C_b, groups, T, k, stride, dil): calls/step, ms/step, TFLOP/s")
         for tag, (fl, sec, cnt) in sorted(by_shape.items(), key=lambda kv: -kv[1][1]):
-            log(f"  {str(tag):56s} {cnt / steps:6.1f} {sec / steps * 1e3:8.3f} {fl / sec / 1e12:8.1f}")
+            log(f"  {str(tag[0]):56s} {tag[1]:14s} {cnt / steps:6.1f} {sec / steps * 1e3:8.3f} {sec / cnt * 1e6:8.1f} us {fl / sec / 1e12:8.1f}")
     if not by_cfg:
         return None
     name, (fl, sec, cnt) = max(by_cfg.items(), key=lambda kv: kv[1][1])

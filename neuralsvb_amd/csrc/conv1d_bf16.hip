@@ -45,17 +45,19 @@ struct SvbConvQArgs {
     int w_floats16, x_floats16;   // LDS carve sizes in 16-byte units (one of hi/lo each)
     int force_cfg;
     unsigned long long* dbg;      // optional per-phase cycle stamps (svb_debug_set_timing_buffer; tools/stage_timing.py)
+    int dbg_block0;               // first launch-order workgroup id that is stamped (env SVB_DBG_BLOCK0)
 };
 
 static unsigned long long* g_svbq_dbg = nullptr;
 static const bool g_svbq_nofast = getenv("SVB_NO_FASTLOOP") != nullptr;     // A/B switch for benchmarking
 static const bool g_svbq_wg_narrow = getenv("SVB_WGRAD_NARROW") != nullptr;     // A/B switch: 64x64 weight-gradient tiles only
 extern "C" void svb_debug_set_timing_buffer(void* p) { g_svbq_dbg = (unsigned long long*)p; }
+static const int g_svbq_dbg_block0 = getenv("SVB_DBG_BLOCK0") ? atoi(getenv("SVB_DBG_BLOCK0")) : 0;   // first sampled workgroup
 #define SVBQ_DBG_BLOCKS 64
 #define SVBQ_DBG_STAGES 32
 #define SVBQ_STAMP(slot)                                                                                            \
-    if (a.dbg && tid == 0 && wgid < SVBQ_DBG_BLOCKS && dbg_stage < SVBQ_DBG_STAGES)                                  \
-        a.dbg[((size_t)wgid * SVBQ_DBG_STAGES + dbg_stage) * 8 + (slot)] = __builtin_readcyclecounter();
+    if (a.dbg && tid == 0 && dbg_id >= 0 && dbg_id < SVBQ_DBG_BLOCKS && dbg_stage < SVBQ_DBG_STAGES)                 \
+        a.dbg[((size_t)dbg_id * SVBQ_DBG_STAGES + dbg_stage) * 8 + (slot)] = __builtin_readcyclecounter();
 
 // load base[byte_off]: `base` wave-uniform, byte_off a 32-bit per-lane offset (scalar-base + vector-offset addressing)
 __device__ __forceinline__ float svbq_ld(const float* base, unsigned byte_off) {
@@ -84,8 +86,11 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     constexpr int BM = 32 * WM, BN = 32 * WN * NT;
     constexpr int WTASKS = SLB * BM * 2;                 // 16-byte units per (hi|lo) weight tile
     constexpr int WU = (2 * WTASKS + 255) / 256;         // per-thread units, hi and lo together
+    // "direct-A" instantiations (SLB <= 5): every wave reads the MFMA A operands of its 32 weight rows straight from global
+    // memory (waves that share rows -- WN > 1 -- repeat the read: 1 KiB per slab, an L1/L2 hit); SLB = 8 stages weights in LDS
+    constexpr bool DIRECT_A = SLB <= 5;
     static_assert(WM * WN == 4, "256 threads = 4 waves");
-    static_assert(WTASKS % 256 == 0, "a staging unit index u addresses either the hi or the lo weight array");
+    static_assert(DIRECT_A || WTASKS % 256 == 0, "a staging unit index u addresses either the hi or the lo weight array");
     HIP_DYNAMIC_SHARED(uint4, dyn_smem)
     uint4* w_hi = dyn_smem;
     uint4* w_lo = w_hi + a.w_floats16;
@@ -102,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     const int qd = nwg >> 3, rd = nwg & 7, xcd = orig & 7;
     const int wgid = (xcd < rd ? xcd * (qd + 1) : rd * (qd + 1) + (xcd - rd) * qd) + (orig >> 3);
     const int mt = wgid % gridDim.x, qt = wgid / gridDim.x;
+    const int dbg_id = a.dbg ? (int)blockIdx.z * nwg + orig - a.dbg_block0 : -1;      // launch order, for the stage stamps
     const int m_tiles_g = gridDim.x / a.G;
     const int g = mt / m_tiles_g, mtile = mt % m_tiles_g;
     const int b = blockIdx.z / p.n_phase, ph = blockIdx.z % p.n_phase;
@@ -285,11 +291,10 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
         for (int u = 0; u < (QIN ? SVBQ_QUNITS : 0); ++u)
             if (q_c[u] < kch_here) x_hi[xw + q_dst[u]] = q_ok[u] ? qr[u] : make_uint4(0u, 0u, 0u, 0u);
     };
-    // ---- WN == 1 tiles ("direct-A"): every wave owns 32 weight rows and all BN columns, so its MFMA A operands
+    // ---- direct-A tiles: every wave owns 32 weight rows (and all or half of the BN columns), so its MFMA A operands
     // (row l31, 16-byte half kb of each (tap, chunk) slab) are exactly one coalesced 1-KiB global read per slab -- no LDS
     // staging, no ds_write, no LDS read for the weights.  The fragments of phase s+1 are loaded into the registers of
     // phase s right after their last use (rolling prefetch), so they have a whole phase to arrive.
-    constexpr bool DIRECT_A = WN == 1;
     uint4 wfh[SLB], wfl[SLB];
     const int wf_row = wm * 32 + l31;
     const int wf_lane16 = (wf_row < m_valid ? wf_row : 0) * 2 + kb;                 // 16-byte units inside a slab
@@ -504,27 +509,64 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
         }
     }
 
+    // ---- epilogue.  Everything that does not depend on the accumulator element is hoisted: per accumulator row r the channel's
+    // 32-bit offset and bias, per column block n the position; the store is `uniform base + 32-bit lane offset`.  (Written
+    // naively -- 64-bit index products and the activation switch per element -- this block cost ~45 VALU instructions per
+    // element, a fifth of the workgroup's time.)  The feature switches are kernel arguments, i.e. scalar branches.
     const int out_base = p.phase_out_base[ph];
     dbg_stage = SVBQ_DBG_STAGES - 1;
     SVBQ_STAMP(6)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int ql = q0 + (wn * NT + n) * 32 + l31;
+    {
+        const size_t yb_off = (size_t)b * a.Cout * a.Tout;
+        float* yb = a.y + yb_off;
+        int rowoff[16];
+        float bv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
-            const int ml = m_base + wm * 32 + row;
-            if (ml < a.Cout_g && ql < nq) {
-                const int co = g * a.Cout_g + ml;
+            const int ml = m_base + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+            const int co = g * a.Cout_g + ml;
+            const bool ok = ml < a.Cout_g;
+            rowoff[r] = ok ? co * a.Tout : -1;
+            bv[r] = (a.bias && ok) ? a.bias[co] : 0.f;
+        }
+        const bool plain = !a.out_gate && !a.residual && !a.mask;
+        const int act = a.out_act;
+        const float slope = a.out_slope;
+        if (plain && act != SVB_ACT_TANH) {
+            const float neg = act == SVB_ACT_RELU ? 0.f : (act == SVB_ACT_LRELU ? slope : 1.f);      // v > 0 ? v : v * neg
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int ql = q0 + (wn * NT + n) * 32 + l31;
                 const int pos = ql * a.out_stride + out_base;
-                float v = acc[n][r];
-                if (a.bias) v += a.bias[co];
-                v = svb_apply_act(v, a.out_act, a.out_slope);
-                const size_t oi = ((size_t)b * a.Cout + co) * a.Tout + pos;
-                if (a.out_gate) v *= svb_gate(a.out_gate[oi], a.out_gate_slope);
-                if (a.residual) v += a.residual[oi];
-                if (a.mask) v *= a.mask[(size_t)b * a.Tout + pos];
-                a.y[oi] = v;
+                if (ql < nq) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[n][r] + bv[r];
+                        if (rowoff[r] >= 0) yb[rowoff[r] + pos] = v > 0.f ? v : v * neg;
+                    }
+                }
+            }
+        } else {
+            const float* gateb = a.out_gate ? a.out_gate + yb_off : nullptr;
+            const float* resb = a.residual ? a.residual + yb_off : nullptr;
+            const float* maskb = a.mask ? a.mask + (size_t)b * a.Tout : nullptr;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int ql = q0 + (wn * NT + n) * 32 + l31;
+                const int pos = ql * a.out_stride + out_base;
+                if (ql < nq) {
+                    const float mk = maskb ? maskb[pos] : 1.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (rowoff[r] >= 0) {
+                            const int oi = rowoff[r] + pos;
+                            float v = svb_apply_act(acc[n][r] + bv[r], act, slope);
+                            if (gateb) v *= svb_gate(gateb[oi], a.out_gate_slope);
+                            if (resb) v += resb[oi];
+                            yb[oi] = v * mk;
+                        }
+                    }
+                }
             }
         }
     }
@@ -591,8 +633,9 @@ __global__ __launch_bounds__(256) void svb_weight_pack_bf16x3_multi_kernel(const
 
 // ==================================================================================================================
 struct QCfg { int BM, BN; };
-#define SVBQ_NCFG 7
-static const QCfg kQCfgs[SVBQ_NCFG] = {{64, 128}, {128, 96}, {128, 128}, {64, 64}, {32, 128}, {64, 192}, {64, 256}};
+#define SVBQ_NCFG 10
+static const QCfg kQCfgs[SVBQ_NCFG] = {{64, 128}, {128, 96}, {128, 128}, {64, 64}, {32, 128}, {64, 192}, {64, 256},
+                                       {64, 128}, {64, 192}, {64, 256}};      // 7..9: the direct-A forms of 0, 5, 6
 
 static int q_pick(int cout_g, int nq_max, long nz) {
     long best_cost = -1;
@@ -621,7 +664,8 @@ static void q_launch_kernel(const SvbConvQArgs& a, const SvbConvPlan& p, dim3 gr
 }
 
 template <int WM, int WN, int NT, int SLB>
-static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_off_max, int ntap_max, hipStream_t stream) {
+static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_off_max, int ntap_max, hipStream_t stream,
+                    bool probe_fast = false) {
     constexpr int BM = 32 * WM, BN = 32 * WN * NT;
     const int span_max = (BN - 1) * a.sx + span_off_max + 1;
     a.xrows = span_max;
@@ -641,7 +685,7 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     // direct-A tiles: when all output phases have the same tap count and (tap group) x (chunk group) can be made exactly SLB
     // slabs with whole phases, the straight-line pipelined loop runs
     a.fast = 0;
-    if (WN == 1 && !g_svbq_nofast && ntap_max >= 1) {
+    if (SLB <= 5 && !g_svbq_nofast && ntap_max >= 1) {
         bool same = true;
         for (int ph = 0; ph < p.n_phase; ++ph) same = same && (p.phase_start[ph + 1] - p.phase_start[ph] == ntap_max);
         for (int tg = SLB; same && tg >= 1 && !a.fast; --tg) {
@@ -652,14 +696,15 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
             a.fast = 1; a.tg = tg; kch = kc;
         }
     }
-    // (WN == 1 tiles read their weight fragments straight from global memory: no weight tile in LDS)
+    // (direct-A tiles read their weight fragments straight from global memory: no weight tile in LDS)
+    if (probe_fast) return a.fast;
     auto lds_bytes = [&](int kc) {
-        return (size_t)2 * ((WN == 1 ? 0 : a.tg * kc * BM) + (a.fast ? 2 : 1) * kc * a.xrows) * 48 + SVB_MAX_TAPS * 4;
+        return (size_t)2 * ((SLB <= 5 ? 0 : a.tg * kc * BM) + (a.fast ? 2 : 1) * kc * a.xrows) * 48 + SVB_MAX_TAPS * 4;
     };
     while (!a.fast && kch > 1 && lds_bytes(kch) > 78 * 1024) --kch;
     if (lds_bytes(kch) > 150 * 1024) return SVB_ERR_UNSUPPORTED;
     a.kch = kch;
-    a.w_floats16 = WN == 1 ? 0 : a.tg * a.kch * BM * 3;
+    a.w_floats16 = SLB <= 5 ? 0 : a.tg * a.kch * BM * 3;
     a.x_floats16 = a.kch * a.xrows * 3;
     dim3 grid(a.G * svb_cdiv(a.Cout_g, BM), svb_cdiv(nq_max, BN), a.B * p.n_phase);
     if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, 1>(a, p, grid, lds_bytes(a.kch), stream);
@@ -668,6 +713,15 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
+
+// direct-A tile with 5-slab phases, or with 4-slab phases when only those divide the K extent into whole phases (the straight-
+// line pipelined loop needs that: e.g. 1x1 convs, whose 12 / 16 / 24 / 64 channel chunks are multiples of 4 but not of 5)
+#define SVBQ_DIRECT(WM_, WN_, NT_)                                                                                   \
+    if (!q_launch<WM_, WN_, NT_, 5>(a, p, nq_max, span_off_max, ntap_max, stream, true) &&                            \
+        q_launch<WM_, WN_, NT_, 4>(a, p, nq_max, span_off_max, ntap_max, stream, true))                               \
+        rc = q_launch<WM_, WN_, NT_, 4>(a, p, nq_max, span_off_max, ntap_max, stream);                                \
+    else                                                                                                             \
+        rc = q_launch<WM_, WN_, NT_, 5>(a, p, nq_max, span_off_max, ntap_max, stream);
 
 static int q_dispatch(SvbConvQArgs& a, const SvbConvPlan& p, hipStream_t stream) {
     int nq_max = 0, span_off_max = 0, ntap_max = 0;
@@ -679,18 +733,22 @@ static int q_dispatch(SvbConvQArgs& a, const SvbConvPlan& p, hipStream_t stream)
     }
     if (nq_max <= 0) return SVB_OK;
     if ((long)a.B * p.n_phase > 65535) return SVB_ERR_UNSUPPORTED;
+    if ((long)a.Cout * a.Tout > 0x7fffffffL) return SVB_ERR_UNSUPPORTED;      // the epilogue's per-clip offsets are 32-bit
     int cfg = q_pick(a.Cout_g, nq_max, (long)a.B * p.n_phase * a.G);
     if (a.force_cfg >= 0 && a.force_cfg < SVBQ_NCFG) cfg = a.force_cfg;
     for (int attempt = 0; attempt < 2; ++attempt) {
         int rc;
         switch (cfg) {
             case 0: rc = q_launch<2, 2, 2, 8>(a, p, nq_max, span_off_max, ntap_max, stream); break;
-            case 1: rc = q_launch<4, 1, 3, 5>(a, p, nq_max, span_off_max, ntap_max, stream); break;
-            case 2: rc = q_launch<4, 1, 4, 5>(a, p, nq_max, span_off_max, ntap_max, stream); break;
+            case 1: SVBQ_DIRECT(4, 1, 3) break;
+            case 2: SVBQ_DIRECT(4, 1, 4) break;
             case 3: rc = q_launch<2, 2, 1, 8>(a, p, nq_max, span_off_max, ntap_max, stream); break;
             case 4: rc = q_launch<1, 4, 1, 8>(a, p, nq_max, span_off_max, ntap_max, stream); break;
             case 5: rc = q_launch<2, 2, 3, 8>(a, p, nq_max, span_off_max, ntap_max, stream); break;
-            default: rc = q_launch<2, 2, 4, 8>(a, p, nq_max, span_off_max, ntap_max, stream); break;
+            case 6: rc = q_launch<2, 2, 4, 8>(a, p, nq_max, span_off_max, ntap_max, stream); break;
+            case 7: SVBQ_DIRECT(2, 2, 2) break;
+            case 8: SVBQ_DIRECT(2, 2, 3) break;
+            default: SVBQ_DIRECT(2, 2, 4) break;
         }
         if (rc != SVB_ERR_UNSUPPORTED || cfg == 3) return rc;
         cfg = 3;        // strided convs with very wide input spans: the narrowest tile has the smallest LDS footprint
@@ -711,6 +769,7 @@ static void q_fill(SvbConvQArgs& a, const SvbConvEpilogue* e) {
     a.force_cfg = e ? e->force_cfg - 1 : -1;
     a.xq = e ? e->x_q : nullptr;
     a.dbg = g_svbq_dbg;
+    a.dbg_block0 = g_svbq_dbg_block0;
 }
 
 extern "C" int svb_weight_pack_bf16x3(const float* v, const float* g, unsigned short* qa_hi, unsigned short* qa_lo,

@@ -18,8 +18,9 @@ PROFILE = None
 _CFG_NAMES = ["svb_conv1d_mfma_kernel<2,2,2,*,80> (64x128)", "svb_conv1d_mfma_kernel<4,1,3,*,80> (128x96)",
               "svb_conv1d_mfma_kernel<4,1,4,*,80> (128x128)", "svb_conv1d_mfma_kernel<2,2,1,*,80> (64x64)",
               "svb_conv1d_mfma_kernel<1,4,1,*,80> (32x128)", "svb_conv1d_mfma_kernel<2,2,3,*,80> (64x192)",
-              "svb_conv1d_mfma_kernel<2,2,4,*,80> (64x256)"]
-_NCFG_Q = 7      # tile configurations of the bf16x3 kernel (the fp32 kernel has the first 5)
+              "svb_conv1d_mfma_kernel<2,2,4,*,80> (64x256)", "svb_conv1d_mfma_kernel<2,2,2,direct> (64x128)",
+              "svb_conv1d_mfma_kernel<2,2,3,direct> (64x192)", "svb_conv1d_mfma_kernel<2,2,4,direct> (64x256)"]
+_NCFG_Q = 10     # tile configurations of the bf16x3 kernel (the fp32 kernel has the first 5)
 
 
 # ---- per-shape tile autotuning ("measure, don't guess"): the first time a conv signature is seen on the GPU all five

@@ -346,7 +346,7 @@ def test_conv1d_bf16x3_forward_dgrad(dev, case):
     assert rel_err(dx, xr.grad) < 6e-5
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_conv1d_bf16x3_tile_configs_and_convt(dev, cfg):
     g = torch.Generator().manual_seed(cfg)
     B, Cin, Cout, T, k, s, pad = 2, 40, 72, 37, 8, 4, 2
@@ -438,7 +438,33 @@ def test_conv1d_wgrad_bf16x3_gates_and_weight_norm(dev):
     assert rel_err(db, (dy * (y > 0)).sum((0, 2))) < 1e-5
 
 
-@pytest.mark.parametrize("cfg", [6, 7])
+@pytest.mark.parametrize("cfg", [2, 3, 8, 9, 10])
+@pytest.mark.parametrize("shape", [(64, 1), (128, 1), (80, 5), (160, 5), (48, 3), (64, 3)])
+def test_conv1d_bf16x3_direct_tiles_whole_phase_loops(dev, cfg, shape):
+    """Direct-A tiles (weight fragments straight from global memory) on K extents that divide into whole 5-slab phases
+    (k5: 5 taps x 1 chunk; 80 / 160 channels x 1 tap), whole 4-slab phases (1x1 and k3 convs over 4 / 8 / 4 chunks) or
+    neither (48 channels x 3 taps: the generic loop) -- with bias + LeakyReLU in the hoisted epilogue, and the transposed
+    form with residual + mask through the general epilogue."""
+    Cin, k = shape
+    g = torch.Generator().manual_seed(cfg * 100 + Cin + k)
+    B, Cout, T = 2, 72, 150
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) * 0.2
+    bias = torch.randn(Cout, generator=g)
+    ref = F.leaky_relu(oops.conv1d(x, w, bias, 1, k // 2), 0.2)
+    qa, qb = K.weight_pack_q(w.to(dev), None, 1)
+    y = K.conv1d_forward(x.to(dev), qa, Cout, k, 1, k // 2, 1, 1, bias=bias.to(dev), out_act=K.ACT_LRELU, out_slope=0.2,
+                         force_cfg=cfg)
+    assert rel_err(y, ref) < 6e-5
+    dy = torch.randn(ref.shape, generator=g)
+    res = torch.randn(B, Cin, T, generator=g)
+    mask = (torch.rand(B, T, generator=g) > 0.2).float()
+    dref = (torch.autograd.grad(oops.conv1d(x.requires_grad_(True), w, None, 1, k // 2), x, dy)[0] + res) * mask[:, None]
+    dx = K.conv1d_transposed(dy.to(dev), qb, Cin, T, k, 1, k // 2, 1, 1, residual=res.to(dev), mask=mask.to(dev), force_cfg=cfg)
+    assert rel_err(dx, dref) < 6e-5
+
+
+@pytest.mark.parametrize("cfg", [6, 7, 9, 10])
 def test_conv1d_bf16x3_wide_tiles_three_position_groups(dev, cfg):
     """64x192 / 64x256 tiles on a long sequence: the register-staged x path with up to 3 groups of 128 positions."""
     g = torch.Generator().manual_seed(cfg)

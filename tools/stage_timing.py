@@ -19,6 +19,13 @@ pad = (k - 1) // 2
 xq = K.split_q(x) if USEQ else None
 for _ in range(3):
     K.conv1d_forward(x, qa, Cout, k, 1, pad, 1, 1, force_cfg=cfg, x_q=xq)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    K.conv1d_forward(x, qa, Cout, k, 1, pad, 1, 1, force_cfg=cfg, x_q=xq)
+e1.record()
+torch.cuda.synchronize()
+KERNEL_US = e0.elapsed_time(e1) * 1e3 / 20
 buf = torch.zeros(64 * 32 * 8, dtype=torch.int64, device=dev)
 lib = L.get_lib()
 lib.svb_debug_set_timing_buffer(buf.data_ptr())
@@ -54,3 +61,6 @@ if epi:
 tot = [(t[b, 31, 7] - t[b, 0, 6]) for b in range(64) if t[b, 31, 7] and t[b, 0, 6]]
 if tot:
     print(f"  workgroup total         {np.median(tot):9.0f}")
+    span = max(t[b, 31, 7] for b in range(64) if t[b, 31, 7]) - min(t[b, 0, 6] for b in range(64) if t[b, 0, 6])
+    print(f"  first start .. last end of the sampled workgroups {span}; kernel {KERNEL_US:.1f} us "
+          f"({2.0 * B * Cout * T * Cin * k / KERNEL_US / 1e6:.1f} TFLOP/s)")
