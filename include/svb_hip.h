@@ -213,15 +213,18 @@ int svb_s2d_pad_bwd(const float* dout, float* dx, int N, int C, int H, int W, vo
  *                     (biased variance per plane, eps inside the root); stats [C][N][2] = mean, rstd (gamma only).
  * svb_crop_drop_inorm_bwd: dout [N][C][Ho][Wo] by element strides -> dy4 (padded layout, zero border) and the per-plane
  *                     sums dgb [2][N][C] = (sum dout * xhat, sum dout) whose sums over N are dgamma / dbeta.
+ *                     s2d != 0 (Ho, Wo even): `out` / `dout` are the NEXT block's conv input / input gradient in its
+ *                     space-to-depth layout [4C][N][Ho/2+1][Wo/2+1] (svb_s2d_pad's), so no separate re-layout pass runs
+ *                     between two blocks (the strides of dout are ignored then).
  * svb_plane_score_fwd/bwd: score[n] = bias + sum_{c,e} h[n][c][e] * w[c*HW+e] over contiguous (h,w) planes with element
  *                     strides sn / sc; backward writes dh with the same strides, dw [C*HW], db [1] (each optional).      */
 int svb_s2_weight(const float* w, float* w4, int cout, int c, void* stream);
 int svb_s2_weight_bwd(const float* dwa, const float* dwb, float* dw, int cout, int c, int accumulate, void* stream);
 int svb_crop_drop_inorm_fwd(const float* y4, const float* keep, const float* gamma, const float* beta, float eps, float* out,
-                            float* stats, int N, int C, int Ho, int Wo, void* stream);
+                            float* stats, int N, int C, int Ho, int Wo, int s2d, void* stream);
 int svb_crop_drop_inorm_bwd(const float* dout, long sn, long sc, long sh, long sw, const float* y4, const float* keep,
                             const float* gamma, const float* stats, float* dy4, float* dgb, int N, int C, int Ho, int Wo,
-                            void* stream);
+                            int s2d, void* stream);
 int svb_plane_score_fwd(const float* h, long sn, long sc, const float* w, const float* bias, float* score, int N, int C, int HW,
                         void* stream);
 int svb_plane_score_bwd(const float* ds, const float* h, long sn, long sc, const float* w, float* dh, float* dw, float* db, int N,
@@ -258,6 +261,14 @@ int svb_nsf_source(const float* f0, const float* rand_ini, const float* noise, c
  * (f64 input, rint half-to-even) ; mode 1: torch semantics (f32 input, (x+0.5) truncation).                     */
 int svb_f0_to_coarse_f64(const double* f0, int64_t* out, int64_t n, void* stream);
 int svb_f0_to_coarse_f32(const float* f0, int64_t* out, int64_t n, void* stream);
+
+/* ---- pitch-bin embedding in the conv layout (reference modules/voice_conversion/svb_vae.py:66, nn.Embedding(300, H,
+ * padding_idx=0) + transpose): out [B][H][T] = w[idx[b][t]][h]; _bwd: dw [V][H] = sum of dy [B][H][T] over the positions
+ * that hold each row (row padding_idx stays zero; accumulate != 0 adds into dw), deterministic summation order;
+ * part: workspace of B*V*H floats (per-clip partial sums).                                                              */
+int svb_embed_nct_fwd(const int64_t* idx, const float* w, float* out, int B, int H, int T, int V, void* stream);
+int svb_embed_nct_bwd(const int64_t* idx, const float* dy, float* part, float* dw, int B, int H, int T, int V, int padding_idx,
+                      int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

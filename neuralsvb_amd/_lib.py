@@ -65,8 +65,8 @@ SIGNATURES = {
     "svb_s2d_pad_bwd": (I, [P, P, I, I, I, I, P]),
     "svb_s2_weight": (I, [P, P, I, I, P]),
     "svb_s2_weight_bwd": (I, [P, P, P, I, I, I, P]),
-    "svb_crop_drop_inorm_fwd": (I, [P, P, P, P, C.c_float, P, P, I, I, I, I, P]),
-    "svb_crop_drop_inorm_bwd": (I, [P, C.c_long, C.c_long, C.c_long, C.c_long, P, P, P, P, P, P, I, I, I, I, P]),
+    "svb_crop_drop_inorm_fwd": (I, [P, P, P, P, C.c_float, P, P, I, I, I, I, I, P]),
+    "svb_crop_drop_inorm_bwd": (I, [P, C.c_long, C.c_long, C.c_long, C.c_long, P, P, P, P, P, P, I, I, I, I, I, P]),
     "svb_plane_score_fwd": (I, [P, C.c_long, C.c_long, P, P, P, I, I, I, P]),
     "svb_plane_score_bwd": (I, [P, P, C.c_long, C.c_long, P, P, P, P, I, I, I, P]),
     "svb_ssim_fwd": (I, [P, C.c_long, C.c_long, C.c_long, P, C.c_long, C.c_long, C.c_long, P, I, I, I, F, P]),
@@ -75,6 +75,8 @@ SIGNATURES = {
     "svb_nsf_source": (I, [P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, P]),
     "svb_f0_to_coarse_f64": (I, [P, P, I64, P]),
     "svb_f0_to_coarse_f32": (I, [P, P, I64, P]),
+    "svb_embed_nct_fwd": (I, [P, P, P, I, I, I, I, P]),
+    "svb_embed_nct_bwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
 }
 
 _LIB = None

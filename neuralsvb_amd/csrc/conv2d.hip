@@ -210,41 +210,62 @@ extern "C" int svb_s2_weight_bwd(const float* dwa, const float* dwb, float* dw, 
 // agree with to fp32 rounding -- and the write).
 // Backward: dy4 in the padded layout (zero border), the per-plane sums for dgamma / dbeta into dgb [2][N][C].
 // ------------------------------------------------------------------------------------------------------------------
+// s2d != 0: `out` is the NEXT block's conv input, written directly in its space-to-depth layout [4C][N][Ho/2+1][Wo/2+1]
+// (zero top row / left column; Ho, Wo even) -- the stand-alone svb_s2d_pad pass between two blocks disappears.
+__device__ __forceinline__ long svb_s2d_index(int c, int n, int i, int j, int N, int C, int Ho, int Wo) {
+    const int R2 = Ho / 2 + 1, P2 = Wo / 2 + 1;
+    return ((((long)((i & 1) * 2 + (j & 1)) * C + c) * N + n) * R2 + (i >> 1) + 1) * P2 + (j >> 1) + 1;
+}
+
 __global__ __launch_bounds__(256) void svb_crop_drop_inorm_fwd_kernel(const float* y4, const float* keep, const float* gamma,
                                                                       const float* beta, float eps, float* out, float* stats,
-                                                                      int N, int C, int Ho, int Wo) {
+                                                                      int N, int C, int Ho, int Wo, int s2d) {
     __shared__ float red[4];
     const int c = blockIdx.x / N, n = blockIdx.x - c * N;
     const int P = Wo + 1, HW = Ho * Wo;
     const float* src = y4 + ((long)blockIdx.x * (Ho + 1) + 1) * P + 1;
     float* dst = out + (long)blockIdx.x * HW;
     const float s = keep ? keep[(long)n * C + c] : 1.f;
-    if (!gamma) {
-        for (int e = threadIdx.x; e < HW; e += 256) dst[e] = src[(e / Wo) * P + e % Wo] * s;
-        return;
+    if (s2d) {          // zero borders of this (channel, clip)'s four sub-planes
+        const int R2 = Ho / 2 + 1, P2 = Wo / 2 + 1;
+        for (int e = threadIdx.x; e < 4 * (P2 + R2 - 1); e += 256) {
+            const int blk = e / (P2 + R2 - 1), q = e - blk * (P2 + R2 - 1);
+            const long plane = (((long)blk * C + c) * N + n) * R2 * P2;
+            out[plane + (q < P2 ? q : (long)(q - P2 + 1) * P2)] = 0.f;
+        }
     }
-    float sum = 0.f;
-    for (int e = threadIdx.x; e < HW; e += 256) sum += src[(e / Wo) * P + e % Wo] * s;
-    const float mean = svb_block_sum<256>(sum, red) / (float)HW;
-    float sq = 0.f;
+    float mean = 0.f, mul = s, add = 0.f;           // out = u * mul' + add with u = y4 * s
+    if (gamma) {
+        float sum = 0.f;
+        for (int e = threadIdx.x; e < HW; e += 256) sum += src[(e / Wo) * P + e % Wo] * s;
+        mean = svb_block_sum<256>(sum, red) / (float)HW;
+        float sq = 0.f;
+        for (int e = threadIdx.x; e < HW; e += 256) {
+            const float d = src[(e / Wo) * P + e % Wo] * s - mean;
+            sq += d * d;
+        }
+        const float var = svb_block_sum<256>(sq, red) / (float)HW;
+        const float rstd = 1.f / sqrtf(var + eps);
+        mul = rstd * gamma[c];
+        add = beta ? beta[c] : 0.f;
+        if (threadIdx.x == 0) {
+            stats[2L * blockIdx.x] = mean;
+            stats[2L * blockIdx.x + 1] = rstd;
+        }
+    }
     for (int e = threadIdx.x; e < HW; e += 256) {
-        const float d = src[(e / Wo) * P + e % Wo] * s - mean;
-        sq += d * d;
-    }
-    const float var = svb_block_sum<256>(sq, red) / (float)HW;
-    const float rstd = 1.f / sqrtf(var + eps);
-    const float g = gamma[c], b = beta ? beta[c] : 0.f;
-    for (int e = threadIdx.x; e < HW; e += 256) dst[e] = (src[(e / Wo) * P + e % Wo] * s - mean) * rstd * g + b;
-    if (threadIdx.x == 0) {
-        stats[2L * blockIdx.x] = mean;
-        stats[2L * blockIdx.x + 1] = rstd;
+        const int i = e / Wo, j = e - i * Wo;
+        const float u = src[i * P + j] * s;
+        const float v = gamma ? (u - mean) * mul + add : u;
+        if (s2d) out[svb_s2d_index(c, n, i, j, N, C, Ho, Wo)] = v;
+        else dst[e] = v;
     }
 }
 
 __global__ __launch_bounds__(256) void svb_crop_drop_inorm_bwd_kernel(const float* dout, long sn, long sc, long sh, long sw,
                                                                       const float* y4, const float* keep, const float* gamma,
                                                                       const float* stats, float* dy4, float* dgb, int N, int C,
-                                                                      int Ho, int Wo) {
+                                                                      int Ho, int Wo, int s2d) {
     __shared__ float red[4];
     const int c = blockIdx.x / N, n = blockIdx.x - c * N;
     const int P = Wo + 1, HW = Ho * Wo;
@@ -253,11 +274,15 @@ __global__ __launch_bounds__(256) void svb_crop_drop_inorm_bwd_kernel(const floa
     float* dst = dy4 + plane + P + 1;
     const float* dob = dout + (long)n * sn + (long)c * sc;
     const float s = keep ? keep[(long)n * C + c] : 1.f;
+    // dout element (i, j) of this plane: plain strides, or (s2d) the next block's input gradient in its space-to-depth layout
+    auto dval = [&](int i, int j) {
+        return s2d ? dout[svb_s2d_index(c, n, i, j, N, C, Ho, Wo)] : dob[(long)i * sh + (long)j * sw];
+    };
     for (int e = threadIdx.x; e < P + Ho; e += 256) dy4[plane + (e < P ? e : (long)(e - P + 1) * P)] = 0.f;      // border
     if (!gamma) {
         for (int e = threadIdx.x; e < HW; e += 256) {
             const int i = e / Wo, j = e - i * Wo;
-            dst[i * P + j] = dob[(long)i * sh + (long)j * sw] * s;
+            dst[i * P + j] = dval(i, j) * s;
         }
         return;
     }
@@ -265,7 +290,7 @@ __global__ __launch_bounds__(256) void svb_crop_drop_inorm_bwd_kernel(const floa
     float s1 = 0.f, s2 = 0.f;
     for (int e = threadIdx.x; e < HW; e += 256) {
         const int i = e / Wo, j = e - i * Wo;
-        const float d = dob[(long)i * sh + (long)j * sw];
+        const float d = dval(i, j);
         s1 += d;
         s2 += d * ((src[i * P + j] * s - mean) * rstd);
     }
@@ -275,7 +300,7 @@ __global__ __launch_bounds__(256) void svb_crop_drop_inorm_bwd_kernel(const floa
     for (int e = threadIdx.x; e < HW; e += 256) {
         const int i = e / Wo, j = e - i * Wo;
         const float xh = (src[i * P + j] * s - mean) * rstd;
-        dst[i * P + j] = rstd * (dob[(long)i * sh + (long)j * sw] * g - m1 - xh * m2) * s;
+        dst[i * P + j] = rstd * (dval(i, j) * g - m1 - xh * m2) * s;
     }
     if (threadIdx.x == 0) {
         dgb[(long)n * C + c] = s2;
@@ -284,20 +309,21 @@ __global__ __launch_bounds__(256) void svb_crop_drop_inorm_bwd_kernel(const floa
 }
 
 extern "C" int svb_crop_drop_inorm_fwd(const float* y4, const float* keep, const float* gamma, const float* beta, float eps,
-                                       float* out, float* stats, int N, int C, int Ho, int Wo, void* stream) {
-    if (!y4 || !out || N <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || (gamma && !stats)) return SVB_ERR_ARG;
+                                       float* out, float* stats, int N, int C, int Ho, int Wo, int s2d, void* stream) {
+    if (!y4 || !out || N <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || (gamma && !stats) || (s2d && ((Ho | Wo) & 1))) return SVB_ERR_ARG;
     hipLaunchKernelGGL(svb_crop_drop_inorm_fwd_kernel, dim3(N * C), dim3(256), 0, (hipStream_t)stream, y4, keep, gamma, beta, eps,
-                       out, stats, N, C, Ho, Wo);
+                       out, stats, N, C, Ho, Wo, s2d);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
 
 extern "C" int svb_crop_drop_inorm_bwd(const float* dout, long sn, long sc, long sh, long sw, const float* y4, const float* keep,
                                        const float* gamma, const float* stats, float* dy4, float* dgb, int N, int C, int Ho, int Wo,
-                                       void* stream) {
-    if (!dout || !y4 || !dy4 || N <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || (gamma && (!stats || !dgb))) return SVB_ERR_ARG;
+                                       int s2d, void* stream) {
+    if (!dout || !y4 || !dy4 || N <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || (gamma && (!stats || !dgb)) || (s2d && ((Ho | Wo) & 1)))
+        return SVB_ERR_ARG;
     hipLaunchKernelGGL(svb_crop_drop_inorm_bwd_kernel, dim3(N * C), dim3(256), 0, (hipStream_t)stream, dout, sn, sc, sh, sw, y4,
-                       keep, gamma, stats, dy4, dgb, N, C, Ho, Wo);
+                       keep, gamma, stats, dy4, dgb, N, C, Ho, Wo, s2d);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }

@@ -278,3 +278,90 @@ extern "C" int svb_f0_to_coarse_f32(const float* f0, int64_t* out, int64_t n, vo
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Pitch-bin embedding in the conv layout (reference modules/voice_conversion/svb_vae.py:66 `self.pitch_embed(pitch)`,
+// nn.Embedding(300, H, padding_idx=0), followed there by a transpose for the Conv1d stack):
+//   out[b][h][t] = W[idx[b][t]][h]                         one gather that writes [B,H,T] directly (lanes along t)
+//   dW[v][h]     = sum over (b,t) with idx[b][t] == v of dy[b][h][t], v != padding_idx (row padding_idx stays 0)
+// The gradient is DETERMINISTIC (torch sorts the indices for that; an atomic scatter would not be): one workgroup per
+// (vocabulary row, clip) scans the clip's indices in t order -- a coalesced 64-index read + ballot per wave step -- and thread h
+// adds dy[b][h][t] of every match to its register; a second kernel adds the per-clip partial sums [B][V][H] in clip order.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void svb_embed_nct_fwd_kernel(const int64_t* idx, const float* w, float* out, int B, int H, int T,
+                                                                int V) {
+    const long total = (long)B * H * T;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int t = (int)(i % T);
+        const long r = i / T;
+        const int h = (int)(r % H);
+        const int b = (int)(r / H);
+        const int64_t v = idx[(long)b * T + t];
+        out[i] = (v >= 0 && v < V) ? w[v * H + h] : 0.f;
+    }
+}
+
+// part[b][v][h] = sum over t with idx[b][t] == v of dy[b][h][t], in t order.  grid (V, B): a (row, clip) pair without a match
+// costs one scan of the clip's indices.  The loads of up to four matches are in flight together (the loop is latency-bound:
+// every match is one scattered 4-byte read per thread); they are added in t order, so the result does not depend on timing.
+__global__ __launch_bounds__(256) void svb_embed_nct_bwd_part_kernel(const int64_t* idx, const float* dy, float* part, int H, int T,
+                                                                     int V, int padding_idx) {
+    const int v = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int64_t* ib = idx + (long)b * T;
+    for (int h0 = 0; h0 < H; h0 += 256) {
+        const int h = h0 + threadIdx.x;
+        const float* dyb = dy + ((long)b * H + (h < H ? h : 0)) * T;
+        float acc = 0.f;
+        if (v != padding_idx) {
+            for (int t0 = 0; t0 < T; t0 += 64) {
+                const int t = t0 + lane;
+                unsigned long long m = __ballot(t < T && ib[t] == (int64_t)v);
+                while (m) {
+                    float x[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int j = m ? __ffsll((long long)m) - 1 : -1;
+                        m = m ? (m & (m - 1)) : 0ull;
+                        x[q] = j >= 0 ? dyb[t0 + j] : 0.f;
+                    }
+                    acc += x[0];
+                    acc += x[1];
+                    acc += x[2];
+                    acc += x[3];
+                }
+            }
+        }
+        if (h < H) part[((long)b * V + v) * H + h] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void svb_embed_nct_bwd_sum_kernel(const float* part, float* dw, int B, long VH, int accumulate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= VH) return;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += part[(long)b * VH + i];
+    dw[i] = accumulate ? dw[i] + acc : acc;
+}
+
+extern "C" int svb_embed_nct_fwd(const int64_t* idx, const float* w, float* out, int B, int H, int T, int V, void* stream) {
+    if (!idx || !w || !out || B <= 0 || H <= 0 || T <= 0 || V <= 0) return SVB_ERR_ARG;
+    const long total = (long)B * H * T;
+    const int grid = (int)((total + 255) / 256 > 65535 * 8 ? 65535 * 8 : (total + 255) / 256);
+    hipLaunchKernelGGL(svb_embed_nct_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, w, out, B, H, T, V);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_embed_nct_bwd(const int64_t* idx, const float* dy, float* part, float* dw, int B, int H, int T, int V,
+                                 int padding_idx, int accumulate, void* stream) {
+    if (!idx || !dy || !part || !dw || B <= 0 || B > 65535 || H <= 0 || T <= 0 || V <= 0) return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_embed_nct_bwd_part_kernel, dim3(V, B), dim3(256), 0, (hipStream_t)stream, idx, dy, part, H, T, V,
+                       padding_idx);
+    SVB_CHECK_LAUNCH();
+    const long VH = (long)V * H;
+    hipLaunchKernelGGL(svb_embed_nct_bwd_sum_kernel, dim3((unsigned)((VH + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
+                       dw, B, VH, accumulate);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}

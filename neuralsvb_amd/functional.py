@@ -634,20 +634,35 @@ def _s2_image(weight):
     return ent[2]
 
 
-class _Conv2dS2Fn(torch.autograd.Function):
-    """3x3 stride-2 pad-1 Conv2d + LeakyReLU (reference multi_window_disc.py:14-22) over batch-stacked planes.
-    x [N,C,H,W] (any strides; H, W even) -> y4 [1, Cout, N*(H/2+1)*(W/2+1)]: the conv output in the padded plane layout
-    [Cout][N][Ho+1][Wo+1] whose row 0 / column 0 are junk (crop_drop_norm removes them)."""
+class _S2DPadFn(torch.autograd.Function):
+    """x [N,C,H,W] (any strides; H, W even) -> the space-to-depth planes [1, 4C, N*(H/2+1)*(W/2+1)] with zero borders."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, slope):
-        N, C, H, W = x.shape
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        N, C, H, W = ctx.shape
+        return K.s2d_pad(x).view(1, 4 * C, N * (H // 2 + 1) * (W // 2 + 1))
+
+    @staticmethod
+    def backward(ctx, dx4):
+        return K.s2d_pad_bwd(dx4.contiguous(), *ctx.shape)
+
+
+class _Conv2dS2Fn(torch.autograd.Function):
+    """3x3 stride-2 pad-1 Conv2d + LeakyReLU (reference multi_window_disc.py:14-22) over batch-stacked planes.
+    x4 [1, 4C, N*(H/2+1)*(W/2+1)]: the input's space-to-depth planes (_S2DPadFn, or written directly by the previous block)
+    -> y4 [1, Cout, N*(H/2+1)*(W/2+1)]: the conv output in the padded plane layout [Cout][N][Ho+1][Wo+1] whose row 0 /
+    column 0 are junk (_CropDropNormFn removes them)."""
+
+    @staticmethod
+    def forward(ctx, x4, weight, bias, cfg):
+        N, C, H, W, slope = cfg
         Ho, Wo = H // 2, W // 2
         P = Wo + 1
         cout = weight.shape[0]
         weight = weight.contiguous()
         offsets = (-P - 1, -P, -1, 0)
-        x4 = K.s2d_pad(x).view(1, 4 * C, N * (Ho + 1) * P)
+        x4 = x4.contiguous().view(1, 4 * C, N * (Ho + 1) * P)
         pa, pb = _pack(_s2_image(weight), None, 1, want_a=True, want_b=ctx.needs_input_grad[0])
         y4 = K.conv1d_taps(x4, pa, cout, offsets, bias=_c(bias), out_act=ACT_LRELU if slope is not None else ACT_NONE,
                            out_slope=slope if slope is not None else 0.0)
@@ -661,10 +676,9 @@ class _Conv2dS2Fn(torch.autograd.Function):
         x4, yact, weight = ctx.saved_tensors
         dy4 = dy4.contiguous()
         a_slope = ctx.slope if ctx.slope is not None else 0.0
-        dx = dw = db = None
+        dx4 = dw = db = None
         if ctx.needs_input_grad[0]:
             dx4 = K.conv1d_taps(dy4, ctx.pb, 4 * C, [-o for o in ctx.offsets], in_gate=yact, in_slope=a_slope)
-            dx = K.s2d_pad_bwd(dx4, N, C, H, W)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             ra = K.conv1d_wgrad(dy4, x4, 2, 1, -ctx.offsets[0], 1, 1, a_gate=yact, a_slope=a_slope, want_bias=want_b)
@@ -676,27 +690,28 @@ class _Conv2dS2Fn(torch.autograd.Function):
             _notify((sink,), (weight,), (dw,))
         elif want_b:
             db = K.bias_grad(dy4, yact, a_slope)
-        return dx, dw, db, None
+        return dx4, dw, db, None
 
 
 class _CropDropNormFn(torch.autograd.Function):
     """Crop of the padded conv output + Dropout2d factor + InstanceNorm2d(affine) (reference multi_window_disc.py:23-27) in
     one pass per direction.  y4: [1,C,N*(Ho+1)*(Wo+1)]; keep: [N,C] or None; gamma/beta: [C] or None (no norm).
-    Returns the [N,C,Ho,Wo] view of channel-major memory."""
+    Returns the [N,C,Ho,Wo] view of channel-major memory, or (s2d) the next block's space-to-depth input
+    [1, 4C, N*(Ho/2+1)*(Wo/2+1)] -- same values, written straight in the layout the next conv reads."""
 
     @staticmethod
     def forward(ctx, y4, keep, gamma, beta, dims):
-        N, C, Ho, Wo, eps = dims
-        out, stats = K.crop_drop_inorm(y4, keep, _c(gamma), _c(beta), N, C, Ho, Wo, eps)
+        N, C, Ho, Wo, eps, s2d = dims
+        out, stats = K.crop_drop_inorm(y4, keep, _c(gamma), _c(beta), N, C, Ho, Wo, eps, s2d)
         ctx.dims = dims
         ctx.save_for_backward(y4, keep, gamma, stats)
-        return out.permute(1, 0, 2, 3)
+        return out.view(1, 4 * C, -1) if s2d else out.permute(1, 0, 2, 3)
 
     @staticmethod
     def backward(ctx, dout):
-        N, C, Ho, Wo, eps = ctx.dims
+        N, C, Ho, Wo, eps, s2d = ctx.dims
         y4, keep, gamma, stats = ctx.saved_tensors
-        dy4, dgb = K.crop_drop_inorm_bwd(dout, y4, keep, _c(gamma), stats, N, C, Ho, Wo)
+        dy4, dgb = K.crop_drop_inorm_bwd(dout.contiguous() if s2d else dout, y4, keep, _c(gamma), stats, N, C, Ho, Wo, s2d)
         dg = db = None
         if dgb is not None:
             dg, db = dgb.sum(1).unbind(0)
@@ -721,23 +736,50 @@ class _PlaneScoreFn(torch.autograd.Function):
         return dh, (dw.view(ctx.wshape) if dw is not None else None), db
 
 
+class _EmbedNCTFn(torch.autograd.Function):
+    """nn.Embedding lookup returned in the conv layout [B,H,T]; deterministic weight gradient (reference svb_vae.py:66)."""
+
+    @staticmethod
+    def forward(ctx, idx, weight, padding_idx):
+        idx, weight = idx.contiguous(), weight.contiguous()
+        ctx.save_for_backward(idx, weight)
+        ctx.padding_idx = -1 if padding_idx is None else int(padding_idx)
+        return K.embed_nct(idx, weight)
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx, weight = ctx.saved_tensors
+        sink = _gbuf(weight)
+        dw = K.embed_nct_bwd(idx, dy.contiguous(), weight.shape[0], ctx.padding_idx, into=sink)
+        _notify((sink,), (weight,), (dw,))
+        return None, dw, None
+
+
+def embedding_nct(idx, weight, padding_idx=None):
+    """embedding(idx).transpose(1, 2) as one kernel: idx int64 [B,T], weight [V,H] -> [B,H,T]."""
+    return _EmbedNCTFn.apply(idx, weight, padding_idx)
+
+
 def dropout2d_keep(n, c, p, device):
     """Dropout2d's per-(clip, channel) factor: 0 with probability p, else 1/(1-p) (F.dropout2d draws the same Bernoulli
     field, shape [N,C,1,1]).  One function so that a test can replay recorded masks."""
     return torch.empty((n, c), device=device, dtype=torch.float32).bernoulli_(1.0 - p).div_(1.0 - p)
 
 
-def critic_block(x, weight, bias, lrelu_slope, drop_p, gamma, beta, eps=1e-5):
+def critic_block(x, weight, bias, lrelu_slope, drop_p, gamma, beta, eps=1e-5, planes=None, s2d_out=False):
     """One block of the mel critic: Conv2d(3x3, s2, p1) -> LeakyReLU -> Dropout2d(drop_p; 0/None = off) -> InstanceNorm2d
-    (gamma None = none).  x [N,C,H,W], H and W even.  Four launches forward (space-to-depth, conv, crop/norm, + the
-    Bernoulli draw)."""
-    N, C, H, W = x.shape
+    (gamma None = none).  x [N,C,H,W], H and W even -- or, with planes=(N,C,H,W), the space-to-depth tensor a previous
+    block wrote with s2d_out=True (then no re-layout pass runs between the two blocks).  Returns the [N,Cout,H/2,W/2] feature
+    map, or with s2d_out (H/2, W/2 even) (x4_next, planes_next) for the next block."""
+    N, C, H, W = planes if planes is not None else x.shape
     if not (CONV2D_S2D and tuple(weight.shape[2:]) == (3, 3) and H % 2 == 0 and W % 2 == 0):
         raise ValueError("critic_block: 3x3 stride-2 kernels on even planes only")
     cout = weight.shape[0]
-    y4 = _Conv2dS2Fn.apply(x, weight, bias, lrelu_slope)
-    keep = dropout2d_keep(N, cout, drop_p, x.device) if drop_p else None
-    return _CropDropNormFn.apply(y4, keep, gamma, beta, (N, cout, H // 2, W // 2, eps))
+    x4 = x if planes is not None else _S2DPadFn.apply(x)
+    y4 = _Conv2dS2Fn.apply(x4, weight, bias, (N, C, H, W, lrelu_slope))
+    keep = dropout2d_keep(N, cout, drop_p, y4.device) if drop_p else None
+    h = _CropDropNormFn.apply(y4, keep, gamma, beta, (N, cout, H // 2, W // 2, eps, bool(s2d_out)))
+    return (h, (N, cout, H // 2, W // 2)) if s2d_out else h
 
 
 def plane_score(h, weight, bias):
@@ -753,6 +795,6 @@ def conv2d_lrelu(x, weight, bias, stride, padding, lrelu_slope=None):
     N, C, H, W = x.shape
     if (CONV2D_S2D and tuple(weight.shape[2:]) == (3, 3) and int(stride) == 2 and int(padding) == 1 and H % 2 == 0
             and W % 2 == 0):
-        y4 = _Conv2dS2Fn.apply(x, weight, bias, lrelu_slope)
-        return _CropDropNormFn.apply(y4, None, None, None, (N, weight.shape[0], H // 2, W // 2, 1e-5))
+        y4 = _Conv2dS2Fn.apply(_S2DPadFn.apply(x), weight, bias, (N, C, H, W, lrelu_slope))
+        return _CropDropNormFn.apply(y4, None, None, None, (N, weight.shape[0], H // 2, W // 2, 1e-5, False))
     return _Conv2dFn.apply(x, weight, bias, (int(stride), int(padding), lrelu_slope))

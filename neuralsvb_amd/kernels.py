@@ -614,26 +614,33 @@ def s2_weight_bwd(dwa, dwb, cout, c, into=None):
     return None if into is not None else dw
 
 
-def crop_drop_inorm(y4, keep, gamma, beta, N, Cc, Ho, Wo, eps=1e-5):
-    """y4: conv output in the padded plane layout [C][N][Ho+1][Wo+1] (any shape with that memory).  Returns (out [C,N,Ho,Wo],
-    stats [C,N,2] or None)."""
+def crop_drop_inorm(y4, keep, gamma, beta, N, Cc, Ho, Wo, eps=1e-5, s2d=False):
+    """y4: conv output in the padded plane layout [C][N][Ho+1][Wo+1] (any shape with that memory).  Returns (out, stats [C,N,2]
+    or None); out is [C,N,Ho,Wo], or with s2d the next block's space-to-depth input [4C, N, Ho/2+1, Wo/2+1]."""
     _f32(y4, keep, gamma, beta)
     lib, st = _prep(y4, keep, gamma, beta)
-    out = torch.empty((Cc, N, Ho, Wo), device=y4.device, dtype=torch.float32)
+    shape = (4 * Cc, N, Ho // 2 + 1, Wo // 2 + 1) if s2d else (Cc, N, Ho, Wo)
+    out = torch.empty(shape, device=y4.device, dtype=torch.float32)
     stats = torch.empty((Cc, N, 2), device=y4.device, dtype=torch.float32) if gamma is not None else None
     L.check(lib.svb_crop_drop_inorm_fwd(_ptr(y4), _ptr(keep), _ptr(gamma), _ptr(beta), float(eps), _ptr(out), _ptr(stats), N, Cc,
-                                        Ho, Wo, st), "svb_crop_drop_inorm_fwd")
+                                        Ho, Wo, int(s2d), st), "svb_crop_drop_inorm_fwd")
     return out, stats
 
 
-def crop_drop_inorm_bwd(dout, y4, keep, gamma, stats, N, Cc, Ho, Wo):
-    """dout [N,C,Ho,Wo] (any strides).  Returns (dy4 [C,N,Ho+1,Wo+1] with a zero border, dgb [2,N,C] or None)."""
+def crop_drop_inorm_bwd(dout, y4, keep, gamma, stats, N, Cc, Ho, Wo, s2d=False):
+    """dout [N,C,Ho,Wo] (any strides), or with s2d the contiguous gradient of the space-to-depth tensor the forward wrote.
+    Returns (dy4 [C,N,Ho+1,Wo+1] with a zero border, dgb [2,N,C] or None)."""
     _f32(dout, y4, keep, gamma, stats)
-    lib, st = _prep_strided(dout, y4)
+    if s2d:
+        lib, st = _prep(dout, y4)
+        strides = (0, 0, 0, 0)
+    else:
+        lib, st = _prep_strided(dout, y4)
+        strides = dout.stride()
     dy4 = torch.empty((Cc, N, Ho + 1, Wo + 1), device=y4.device, dtype=torch.float32)
     dgb = torch.empty((2, N, Cc), device=y4.device, dtype=torch.float32) if gamma is not None else None
-    L.check(lib.svb_crop_drop_inorm_bwd(_ptr(dout), *dout.stride(), _ptr(y4), _ptr(keep), _ptr(gamma), _ptr(stats), _ptr(dy4),
-                                        _ptr(dgb), N, Cc, Ho, Wo, st), "svb_crop_drop_inorm_bwd")
+    L.check(lib.svb_crop_drop_inorm_bwd(_ptr(dout), *strides, _ptr(y4), _ptr(keep), _ptr(gamma), _ptr(stats), _ptr(dy4),
+                                        _ptr(dgb), N, Cc, Ho, Wo, int(s2d), st), "svb_crop_drop_inorm_bwd")
     return dy4, dgb
 
 
@@ -726,6 +733,29 @@ def nsf_source(f0, rand_ini, noise, lin_w, lin_b, upp, sample_rate, sine_amp=0.1
                                _ptr(uv), B, frames, upp, H, float(sample_rate), float(sine_amp), float(noise_std), st),
             "svb_nsf_source")
     return merged, sw, uv
+
+
+def embed_nct(idx, w):
+    """idx int64 [B,T], w [V,H] -> [B,H,T] = w[idx].transpose(1,2), one gather."""
+    _f32(w)
+    lib, st = _prep(idx, w)
+    B, T = idx.shape
+    V, H = w.shape
+    out = torch.empty((B, H, T), device=w.device, dtype=torch.float32)
+    L.check(lib.svb_embed_nct_fwd(_ptr(idx), _ptr(w), _ptr(out), B, H, T, V, st), "svb_embed_nct_fwd")
+    return out
+
+
+def embed_nct_bwd(idx, dy, V, padding_idx=-1, into=None):
+    """dw [V,H] of embed_nct (row padding_idx zero), deterministic.  `into`: gradient buffer to accumulate into (-> None)."""
+    _f32(dy)
+    lib, st = _prep(idx, dy)
+    B, H, T = dy.shape
+    dw = into if into is not None else torch.empty((V, H), device=dy.device, dtype=torch.float32)
+    part = torch.empty((B, V, H), device=dy.device, dtype=torch.float32)
+    L.check(lib.svb_embed_nct_bwd(_ptr(idx), _ptr(dy), _ptr(part), _ptr(dw), B, H, T, V, int(padding_idx), int(into is not None),
+                                  st), "svb_embed_nct_bwd")
+    return None if into is not None else dw
 
 
 def f0_to_coarse(f0):

@@ -24,15 +24,36 @@ def _adv_score(adv_layer, h):
     return SF.plane_score(h, adv_layer.weight, adv_layer.bias)
 
 
-def _block(blk, h):
-    """Conv2d 3x3 s2 p1 -> LeakyReLU(0.2) -> Dropout2d [-> InstanceNorm2d | BatchNorm2d] (multi_window_disc.py:14-31)."""
+def _block(blk, h, planes=None, s2d_out=False):
+    """Conv2d 3x3 s2 p1 -> LeakyReLU(0.2) -> Dropout2d [-> InstanceNorm2d | BatchNorm2d] (multi_window_disc.py:14-31).
+    planes / s2d_out: the block reads / writes the space-to-depth layout of the conv directly (SF.critic_block)."""
     conv, drop = blk[0], blk[2]
     norm = blk[3] if len(blk) > 3 else None
     p = drop.p if drop.training else 0.0
-    if isinstance(norm, nn.InstanceNorm2d):
-        return SF.critic_block(h, conv.weight, conv.bias, 0.2, p, norm.weight, norm.bias, norm.eps)
-    h = SF.critic_block(h, conv.weight, conv.bias, 0.2, p, None, None)
-    return norm(h) if norm is not None else h
+    if norm is None or isinstance(norm, nn.InstanceNorm2d):
+        gamma, beta, eps = (norm.weight, norm.bias, norm.eps) if norm is not None else (None, None, 1e-5)
+        return SF.critic_block(h, conv.weight, conv.bias, 0.2, p, gamma, beta, eps, planes=planes, s2d_out=s2d_out)
+    assert planes is None and not s2d_out
+    return norm(SF.critic_block(h, conv.weight, conv.bias, 0.2, p, None, None))
+
+
+def _tower(tower, h, want_fmaps, fmaps):
+    """The three blocks of one window's tower.  Without feature maps (and without BatchNorm2d) the blocks hand each other the
+    conv's space-to-depth layout directly; the last block returns the plain feature map for the score layer."""
+    blocks = list(tower.model)
+    chain = not want_fmaps and all(len(b) <= 3 or isinstance(b[3], nn.InstanceNorm2d) for b in blocks)
+    planes = None
+    for i, blk in enumerate(blocks):
+        if chain and i + 1 < len(blocks):
+            N, C, H, W = planes if planes is not None else h.shape
+            if (H // 2) % 2 == 0 and (W // 2) % 2 == 0:
+                h, planes = _block(blk, h, planes, s2d_out=True)
+                continue
+        h = _block(blk, h, planes)
+        planes = None
+        if want_fmaps:
+            fmaps.append(h)
+    return h
 
 
 def _critic_tower(time_length, freq_length, kernel, c_in, hidden, norm_type, reduction):
@@ -66,14 +87,16 @@ class Discriminator(nn.Module):
         self.discriminator.conv_layers = nn.ModuleList(
             [_critic_tower(tl, freq_length, kernel, c_in, hidden_size, norm_type, reduction) for tl in self.time_lengths])
 
-    def forward(self, x, cond=None, start_frames_wins=None, starts_dev=None, longest=None):
+    def forward(self, x, cond=None, start_frames_wins=None, starts_dev=None, longest=None, want_fmaps=True):
         """x [B,T,n_mels] (or [B,1,T,n_mels]).  Returns {'y': [B,1,W] or None, 'y_c': None, 'h': fmaps,
         'start_frames_wins': [[s]*B per window]}.
 
         `longest` (max number of non-zero frames over the batch) and `start_frames_wins` may be supplied by a caller
         that already knows them on the host (the task draws the step's window starts up front, in the reference's
         order), which removes the device->host sync of :190.  `starts_dev` (int64 [n_windows], device) makes the window
-        crop a device-side gather so that the call can be replayed from a captured hipGraph with fresh starts."""
+        crop a device-side gather so that the call can be replayed from a captured hipGraph with fresh starts.
+        `want_fmaps=False` (the training task: it only reads 'y') returns 'h': [] and lets the blocks of a tower hand each
+        other the conv's own input layout."""
         if x.dim() == 3:
             x = x[:, None]
         if longest is None:
@@ -90,16 +113,14 @@ class Discriminator(nn.Module):
             else:
                 s = starts[w][0]
                 h = x[:, :, s:s + wl]
-            for blk in tower.model:
-                h = _block(blk, h)
-                fmaps.append(h)
+            h = _tower(tower, h, want_fmaps, fmaps)
             scores.append(_adv_score(tower.adv_layer, h))
         y = None
         if len(scores) == len(self.time_lengths):
             y = torch.stack(scores, -1) if self.reduction == "stack" else sum(scores)
         return {"y": y, "y_c": None, "h": fmaps, "start_frames_wins": starts}
 
-    def forward_many(self, calls):
+    def forward_many(self, calls, want_fmaps=True):
         """Several independent critic calls -- [(x, start_frames_wins, starts_dev, longest), ...] with equal shapes and all
         windows present -- as ONE pass per tower over the stacked crops [n*B,1,wl,80].  Every layer of the tower is
         per-clip (Conv2d, LeakyReLU, Dropout2d, InstanceNorm2d), so each call's scores equal those of a separate
@@ -117,9 +138,7 @@ class Discriminator(nn.Module):
                     s = starts[w][0]
                     crops.append(x[:, :, s:s + wl])
             h = torch.cat(crops, 0)
-            for blk in tower.model:
-                h = _block(blk, h)
-                fmaps.append(h)
+            h = _tower(tower, h, want_fmaps, fmaps)
             scores.append(_adv_score(tower.adv_layer, h))
         y = torch.stack(scores, -1) if self.reduction == "stack" else sum(scores)
         return [{"y": y[i * B:(i + 1) * B], "y_c": None, "h": fmaps, "start_frames_wins": list(c[1])}

@@ -85,7 +85,8 @@ class MleSVBVAE(nn.Module):
     # ---- conditioning (svb_vae.py:60-86); all tensors NCT --------------------------------------------------------
     def prepare_condition(self, mels_content, pitch, spk_ids, groups=1):
         T = pitch.shape[1]
-        h_pitch = self.pitch_encoder(self.pitch_embed(pitch).transpose(1, 2).contiguous())
+        pe = self.pitch_embed          # nn.Embedding(300, H, padding_idx=0) + transpose, as one gather into [B,H,T]
+        h_pitch = self.pitch_encoder(SF.embedding_nct(pitch, pe.weight, pe.padding_idx))
         h = self.vc_asr(mels_content)["h_content"].detach()
         for m in self.upsample_layer:
             if isinstance(m, nn.Sequential):

@@ -194,17 +194,17 @@ class SVBVAEMleTask(BaseTask):
                 dev = self._rand_dev["starts"][r["cursor"]] if r.get("dev") else None
                 r["cursor"] += 1
                 calls.append((x, d["starts"], dev, d["longest"]))
-            return [o["y"] for o in self.mel_disc.forward_many(calls)]
+            return [o["y"] for o in self.mel_disc.forward_many(calls, want_fmaps=False)]
         return [self._critic(x)["y"] for x in xs]
 
     def _critic(self, x):
         r = self._step_rand
         if r is None or r["cursor"] >= len(r["disc"]):
-            return self.mel_disc(x, None)
+            return self.mel_disc(x, None, want_fmaps=False)
         d = r["disc"][r["cursor"]]
         dev = self._rand_dev["starts"][r["cursor"]] if r.get("dev") else None
         r["cursor"] += 1
-        return self.mel_disc(x, None, start_frames_wins=d["starts"], starts_dev=dev, longest=d["longest"])
+        return self.mel_disc(x, None, start_frames_wins=d["starts"], starts_dev=dev, longest=d["longest"], want_fmaps=False)
 
     # ------------------------------------------------------------------ model run (svb_vae_task.py:120-165)
     def run_model(self, model, sample, concurrent_ways, return_output=False, infer=False, disable_map=False, **inject):

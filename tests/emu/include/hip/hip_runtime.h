@@ -10,7 +10,7 @@
 //        D reg r of lane l -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31; k-ordered fmaf chain.
 //   __builtin_amdgcn_mfma_f32_16x16x4f32 : A[l&15][k=l>>4], B[k=l>>4][l&15],
 //        D reg r of lane l -> row (l>>4)*4+r, col l&15.
-//   __shfl / __shfl_xor / __shfl_down / __shfl_up over 64-lane waves.
+//   __shfl / __shfl_xor / __shfl_down / __shfl_up / __ballot over 64-lane waves.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -179,6 +179,20 @@ template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64)
     const int s = l - (int)d;
     return emu_shfl_from(v, (s >= 0 && (s & ~(width - 1)) == (l & ~(width - 1))) ? s : l);
 }
+// __ballot: bit l of the result = predicate of lane l (all 64 lanes take part in the exchange)
+static inline unsigned long long __ballot(int pred) {
+    int p = pred ? 1 : 0;
+    emu_wave_exchange_begin(&p, sizeof(int));
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) {
+        int q;
+        memcpy(&q, emu_wave_slot(l), sizeof(int));
+        if (q) m |= 1ull << l;
+    }
+    emu_wave_exchange_end();
+    return m;
+}
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline float __builtin_amdgcn_readfirstlane_f(float v) { return emu_shfl_from(v, 0); }
 static inline int __builtin_amdgcn_readfirstlane_emu(int v) { return emu_shfl_from(v, 0); }
 #define __builtin_amdgcn_readfirstlane(v) __builtin_amdgcn_readfirstlane_emu(v)

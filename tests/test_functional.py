@@ -217,6 +217,38 @@ def test_critic_block_autograd(dev):
             assert rel_err(a.grad, r.grad) < 1e-4, (cin, H, W, norm, p)
 
 
+def test_critic_blocks_chained_through_the_conv_layout(dev):
+    """Two blocks where the first writes the second's space-to-depth conv input directly (s2d_out / planes): outputs and all
+    gradients equal the plain composition's (stock torch)."""
+    g_ = torch.Generator().manual_seed(47)
+    N, c0, c1, c2, H, W, p = 3, 1, 6, 5, 16, 40, 0.25
+    x = torch.randn(N, c0, H, W, generator=g_)
+    w1, b1 = torch.randn(c1, c0, 3, 3, generator=g_) * 0.4, torch.randn(c1, generator=g_)
+    w2, b2 = torch.randn(c2, c1, 3, 3, generator=g_) * 0.3, torch.randn(c2, generator=g_)
+    gm, bt = torch.rand(c2, generator=g_) + 0.5, torch.randn(c2, generator=g_)
+    keeps = [(torch.rand(N, c, generator=g_) >= p).float() / (1.0 - p) for c in (c1, c2)]
+    rl = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2, gm, bt)]
+    h1 = F.leaky_relu(F.conv2d(rl[0], rl[1], rl[2], 2, 1), 0.2) * keeps[0][:, :, None, None]
+    yr = F.instance_norm(F.leaky_relu(F.conv2d(h1, rl[3], rl[4], 2, 1), 0.2) * keeps[1][:, :, None, None], weight=rl[5],
+                         bias=rl[6], eps=1e-5)
+    dy = torch.randn(yr.shape, generator=g_)
+    yr.backward(dy)
+    dl = [_leaf(t, dev) for t in (x, w1, b1, w2, b2, gm, bt)]
+    it = iter(keeps)
+    old = SF.dropout2d_keep
+    SF.dropout2d_keep = lambda n, c, pp, device: next(it).to(device)
+    try:
+        x4, planes = SF.critic_block(dl[0], dl[1], dl[2], 0.2, p, None, None, s2d_out=True)
+        assert planes == (N, c1, H // 2, W // 2)
+        y = SF.critic_block(x4, dl[3], dl[4], 0.2, p, dl[5], dl[6], planes=planes)
+    finally:
+        SF.dropout2d_keep = old
+    assert y.shape == yr.shape and rel_err(y, yr) < 3e-5
+    y.backward(dy.to(dev))
+    for a, r in zip(dl, rl):
+        assert rel_err(a.grad, r.grad) < 1e-4
+
+
 def test_critic_block_accumulates_into_grad_buffers(dev):
     """A kernel that already owns a .grad buffer gets its gradient added there by the gather kernel (no autograd add)."""
     g_ = torch.Generator().manual_seed(44)
@@ -262,6 +294,30 @@ def test_critic_block_sees_fused_optimizer_updates(dev):
             assert rel_err(run(), ref()) < 3e-5
         finally:
             SF.end_weight_epoch()
+
+
+def test_embedding_nct_autograd(dev):
+    """pitch_embed(pitch).transpose(1, 2) (svb_vae.py:66; nn.Embedding(300, H, padding_idx=0)) as one gather, with the
+    deterministic weight gradient: padding row zero, repeated bins summed, two runs bit-identical."""
+    g_ = torch.Generator().manual_seed(48)
+    B, T, V, H = 3, 150, 300, 20
+    idx = torch.randint(0, 12, (B, T), generator=g_)
+    idx[0, 100:] = 0                                   # padding frames
+    idx[1, :5] = 299
+    w = torch.randn(V, H, generator=g_)
+    wr = w.clone().requires_grad_(True)
+    yr = F.embedding(idx, wr, padding_idx=0).transpose(1, 2)
+    dy = torch.randn(yr.shape, generator=g_)
+    yr.backward(dy)
+    grads = []
+    for _ in range(2):
+        wd = _leaf(w, dev)
+        y = SF.embedding_nct(idx.to(dev), wd, 0)
+        assert torch.equal(y.cpu(), yr.detach())
+        y.backward(dy.to(dev))
+        grads.append(wd.grad.cpu())
+    assert torch.equal(grads[0], grads[1])
+    assert rel_err(grads[0], wr.grad) < 1e-5 and float(grads[0][0].abs().max()) == 0.0
 
 
 def test_dropout2d_keep_is_a_bernoulli_field(dev):

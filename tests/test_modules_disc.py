@@ -45,7 +45,8 @@ def test_stacked_critic_calls_equal_separate_calls(dev):
     sep = [disc(x, None, start_frames_wins=[list(s) for s in st], longest=90)["y"] for x, st in zip(xs, starts)]
     loss_sep = sum(((y - 1) ** 2).mean() * (i + 1) for i, y in enumerate(sep))
     grads_sep = torch.autograd.grad(loss_sep, xs + list(disc.parameters()))
-    many = disc.forward_many([(x, [list(s) for s in st], None, 90) for x, st in zip(xs, starts)])
+    many = disc.forward_many([(x, [list(s) for s in st], None, 90) for x, st in zip(xs, starts)], want_fmaps=False)
+    assert many[0]["h"] == []                  # the towers' blocks handed each other the conv layout: no feature maps
     loss_many = sum(((o["y"] - 1) ** 2).mean() * (i + 1) for i, o in enumerate(many))
     grads_many = torch.autograd.grad(loss_many, xs + list(disc.parameters()))
     for a, b in zip(sep, many):

@@ -33,25 +33,26 @@ K.conv1d_forward(x, qa, Cout, k, 1, pad, 1, 1, force_cfg=cfg, x_q=xq)
 torch.cuda.synchronize()
 lib.svb_debug_set_timing_buffer(None)
 t = buf.cpu().numpy().reshape(64, 32, 8).astype(np.int64)
-fast = bool((t[:, :, 3] > t[:, :, 0]).any() and (t[:, :, 3] < t[:, :, 1]).any())      # the pipelined loop stamps 0 3 1 2 4 5
+SVBQ_LAST = 31
+fast = bool((t[:, :SVBQ_LAST, 3] <= t[:, :SVBQ_LAST, 1]).all())      # straight-line loop: stamps 0 3 1 2 (4 5)
 if fast:
     names = ["wait weight frags", "issue x loads", "compute (MFMA loop)", "store next tile", "barrier"]
 else:
     names = ["issue loads", "compute (MFMA loop)", "barrier 1", "stage to LDS", "barrier 2"]
 rows = []
 for blk in range(64):
-    for st in range(32):
+    for st in range(SVBQ_LAST):
         s = t[blk, st]
-        if s[0] and s[5]:
-            if fast:
-                rows.append([s[3] - s[0], s[1] - s[3], s[2] - s[1], s[4] - s[2], s[5] - s[4]])
-            else:
-                rows.append([s[1] - s[0], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[5] - s[4]])
+        if fast and s[0] and s[2]:
+            rows.append([s[3] - s[0], s[1] - s[3], s[2] - s[1], (s[4] - s[2]) if s[4] else 0, (s[5] - s[4]) if s[5] else 0])
+        elif not fast and s[0] and s[5]:
+            rows.append([s[1] - s[0], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[5] - s[4]])
 rows = np.array(rows)
-print(f"shape B{B} {Cin}->{Cout} k{k} T{T} cfg {cfg}: {len(rows)} (block, stage) samples; cycles mean / median")
+print(f"shape B{B} {Cin}->{Cout} k{k} T{T} cfg {cfg} ({'straight-line' if fast else 'generic'} loop): {len(rows)} (block, stage) samples; "
+      f"cycles mean / median")
 for i, n in enumerate(names):
-    print(f"  {n:22s} {rows[:, i].mean():9.0f} {np.median(rows[:, i]):9.0f}")
-print(f"  {'stage total':22s} {rows.sum(1).mean():9.0f}")
+    print(f"  {n:36s} {rows[:, i].mean():9.0f} {np.median(rows[:, i]):9.0f}")
+print(f"  {'stage total':36s} {rows.sum(1).mean():9.0f}")
 pro = [(t[b, 0, 7] - t[b, 0, 6]) for b in range(64) if t[b, 0, 7] and t[b, 0, 6]]
 if pro:
     print(f"  prologue (first tiles)  {np.median(pro):9.0f}")
