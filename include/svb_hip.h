@@ -177,6 +177,15 @@ int svb_layernorm_bwd(const float* x, const float* gamma, const float* dy, const
 int svb_relpos_softmax(const float* ac, const float* bd, const float* keep, float* attn, int B, int H, int T, float scale,
                        void* stream);
 
+/* ---- the same attention fused end to end (forward only; the PPG encoder is frozen): content scores (q + pos_u) . k, the
+ * rel-shifted position scores read from `bd` (UNSHIFTED (q + pos_v) . linear_pos(pos_emb), element strides batch / head /
+ * row), 1/sqrt(dk) scale, key mask, softmax and the product with v in one kernel -- no [B,h,T,T] score or attention
+ * tensor is written.  q, k, v, out: [B][H*dk][T] (conv layout); pos_u [H][dk]; keep [B][T]; dk must be 64.
+ * Split-bf16 MFMA arithmetic (fp32-class), online softmax in fp32.                                                       */
+int svb_relpos_attn_fwd(const float* q, const float* k, const float* v, const float* pos_u, const float* bd, long bd_sb,
+                        long bd_sh, long bd_sr, const float* keep, float* out, int B, int H, int dk, int T, float scale,
+                        void* stream);
+
 /* ---- Conformer convolution module between its pointwise convs, eval mode (reference
  * modules/fastspeech/conformer/layers.py:47-63): out = Swish(BatchNorm_eval(depthwise_conv1d(GLU(y)))).  y [B, 2C, T],
  * w [C][K] (K odd <= 63, padding (K-1)/2), bias [C] or NULL, BatchNorm weight / bias (NULL = 1 / 0), running mean / var,

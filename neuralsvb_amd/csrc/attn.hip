@@ -128,3 +128,229 @@ extern "C" int svb_glu_dwconv_bn_swish(const float* y, const float* w, const flo
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused relative-position self-attention (forward; the PPG encoder is frozen): the content scores, the rel-shifted
+// position scores, scale, key mask, softmax and the value product of espnet_transformer_attn.py:150-186 in ONE pass --
+// the [B,h,T,T] `ac` and `attn` tensors never exist.
+//
+//   q, k, v, out : [B][H*dk][T] (the conv layout; head hh = channels hh*dk ..), dk = 64
+//   pos_u        : [H][dk]  (pos_bias_u, added to q for the content term)
+//   bd           : position scores (q + pos_bias_v) . linear_pos(pos_emb), UNSHIFTED, element strides (batch, head, row);
+//                  the legacy rel_shift (:125-148) is applied while reading (see the header of this file)
+//   keep         : [B][T] float, 0 = padded key
+//
+// One 64-lane wave owns 32 queries and walks the keys in blocks of 32 with an online softmax; waves do not cooperate
+// (no LDS, no barrier): K and V tiles are read straight from global memory (a (batch, head)'s K/V are 2 x 144 KB, shared
+// by its 18 query tiles through L2).  Every product is an MFMA 32x32x16 in split-bf16 arithmetic (hi*hi + hi*lo + lo*hi,
+// fp32 accumulate), computed TRANSPOSED so that nothing has to change lanes between the two products:
+//   S^T[j][i] = sum_d K[j][d] * Qu[i][d]     A = K rows j (8 strided loads per lane, coalesced along j), B = Qu (registers)
+//   acc[r] of lane (i = lane & 31, kb = lane >> 5) is key j = j0 + 8*(r>>2) + 4*kb + (r&3): consecutive registers 8s'..8s'+7
+//   are exactly the 8 k-slots of that lane in the B operand of
+//   O^T[d][i] = sum_j V[d][j] * P[i][j]      A = V rows d: slot e of k-step s' is key j0 + 16*s' + 8*(e>>2) + 4*kb + (e&3),
+//                                            i.e. two 16-byte loads along the contiguous T axis.
+// bd and V are read with lanes across rows (16-byte pieces of 32..64 different rows per load instruction); measured, the kernel
+// is bound by those requests, not by the MFMAs (200 us for B32 H4 T562 = 51 TFLOP/s; staging bd row-wise through LDS was
+// slower).  HBM traffic: 4 B per score element + the K/V/Q/out tiles, a third of the unfused sequence's.
+// ------------------------------------------------------------------------------------------------------------------
+#include "svb_q.h"
+#include <type_traits>
+typedef __bf16 svba_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float svba_f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ void svba_split8(const float* v, svba_bf16x8& hi, svba_bf16x8& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) svbq_split2(v[2 * e], v[2 * e + 1], h[e], l[e]);
+    __builtin_memcpy(&hi, h, 16);
+    __builtin_memcpy(&lo, l, 16);
+}
+
+#define SVB_ATTN_DK 64
+__global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float* q, const float* k, const float* v, const float* pos_u,
+                                                                  const float* bd, long bd_sb, long bd_sh, long bd_sr,
+                                                                  const float* keep, float* out, int B, int H, int T,
+                                                                  float scale) {
+    constexpr int DK = SVB_ATTN_DK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, kb = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, hh = bh - b * H;
+    const int i0 = (blockIdx.x * 2 + wave) * 32;
+    if (i0 >= T) return;                                            // (waves are independent: no barrier below)
+    const int i = i0 + l31;
+    const bool iv = i < T;
+    const int ic = iv ? i : T - 1;
+    const size_t head = ((size_t)b * H + hh) * DK * T;
+    const float* qh = q + head;
+    const float* kh = k + head;
+    const float* vh = v + head;
+    const float* bdh = bd + (size_t)b * bd_sb + (size_t)hh * bd_sh;
+    const float* keepb = keep + (size_t)b * T;
+
+    // ---- B operand of the score product: Qu[i][d], d = 16s + 8kb + e.  The 8 fragments are this lane's alone; they live in a
+    // private LDS slot (conflict-free 16-byte rows, no barrier) rather than in 32 registers: the kernel is bound by memory
+    // latency, i.e. by how many waves fit on a SIMD.
+    __shared__ uint4 q_frag[2][8][64];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int d = 16 * s + 8 * kb + e;
+            t[e] = qh[(size_t)d * T + ic] + pos_u[hh * DK + d];
+        }
+        svba_bf16x8 fh, fl;
+        svba_split8(t, fh, fl);
+        __builtin_memcpy(&q_frag[wave][2 * s][lane], &fh, 16);
+        __builtin_memcpy(&q_frag[wave][2 * s + 1][lane], &fl, 16);
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const float* bd_i = bdh + (size_t)ic * bd_sr;                    // bd[i][.]
+    const float* bd_i1 = bdh + (size_t)(ic + 1 < T ? ic + 1 : ic) * bd_sr;      // bd[i+1][.] (never used for i = T-1)
+
+    // One key block.  CLS (wave-uniform): 0 = the whole 32x32 block lies on or below the diagonal (every position score comes
+    // from bd[i][T-1-i+j]: one 16-byte read per 4 keys), 1 = the whole block lies beyond the zero diagonal (bd[i+1][j-i-2]),
+    // 2 = the block straddles the diagonal or the end of the sequence (per-element reads).  FULL: all 32 keys exist.  The two
+    // common bodies are branch-free, so all of a block's loads are in flight together.
+    auto key_block = [&](int j0, auto cls_c, auto full_c) {
+        constexpr int CLS = decltype(cls_c)::value;
+        constexpr bool FULL = decltype(full_c)::value;
+        // ---- S^T block: rows j0 .. j0+31, columns i0 .. i0+31
+        f32x16 s_acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_acc[r] = 0.f;
+        const int jr = (FULL || j0 + l31 < T) ? j0 + l31 : T - 1;   // this lane's A row (clamped: masked below)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = kh[(size_t)(16 * s + 8 * kb + e) * T + jr];
+            svba_bf16x8 ah, al, quh, qul;
+            svba_split8(t, ah, al);
+            __builtin_memcpy(&quh, &q_frag[wave][2 * s][lane], 16);
+            __builtin_memcpy(&qul, &q_frag[wave][2 * s + 1][lane], 16);
+            s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, quh, s_acc, 0, 0, 0);
+            s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qul, s_acc, 0, 0, 0);
+            s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, quh, s_acc, 0, 0, 0);
+        }
+        // ---- + shifted position scores, scale, key mask; block maximum per query
+        float p[16];
+        unsigned okm = 0u;                                          // bit r: key of register r is a real, unpadded key
+        float mb = -INFINITY;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int jb = j0 + 8 * g4 + 4 * kb;                    // 4 consecutive keys jb .. jb+3
+            float sh[4], kp[4];
+            if (FULL) {
+                const svba_f4u t = *reinterpret_cast<const svba_f4u*>(keepb + jb);
+                kp[0] = t.x; kp[1] = t.y; kp[2] = t.z; kp[3] = t.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kp[e] = jb + e < T ? keepb[jb + e] : 0.f;
+            }
+            if (CLS == 0) {
+                const svba_f4u t = *reinterpret_cast<const svba_f4u*>(bd_i + (T - 1 - ic + jb));
+                sh[0] = t.x; sh[1] = t.y; sh[2] = t.z; sh[3] = t.w;
+            } else if (CLS == 1) {
+                const svba_f4u t = *reinterpret_cast<const svba_f4u*>(bd_i1 + (jb - ic - 2));
+                sh[0] = t.x; sh[1] = t.y; sh[2] = t.z; sh[3] = t.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = jb + e;
+                    sh[e] = (j >= T || j == ic + 1) ? 0.f : (j <= ic ? bd_i[T - 1 - ic + j] : bd_i1[j - ic - 2]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g4 + e;
+                p[r] = (s_acc[r] + sh[e]) * scale;
+                if (kp[e] != 0.f) {
+                    okm |= 1u << r;
+                    mb = fmaxf(mb, p[r]);
+                }
+            }
+        }
+        mb = fmaxf(mb, __shfl_xor(mb, 32, 64));                     // the two lane halves hold the same query
+        const float m_new = fmaxf(m_run, mb);
+        // (no branch here: the MFMAs and shuffles below need the whole wave.  While a query has seen nothing but padded keys
+        //  m_new is -inf, every p is 0 and o, l are still 0 -- alpha only must not be NaN)
+        const float alpha = m_new == -INFINITY ? 1.f : __expf(m_run - m_new);       // (m_run = -inf, m_new finite -> 0)
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = (okm >> r) & 1u ? __expf(p[r] - m_new) : 0.f;
+            psum += p[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        // ---- O^T += V . P^T
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            svba_bf16x8 ph, pl;
+            svba_split8(p + 8 * s2, ph, pl);
+            const int ja = j0 + 16 * s2 + 4 * kb;                   // slots 0-3: ja .. ja+3, slots 4-7: ja+8 .. ja+11
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const float* vr = vh + (size_t)(db * 32 + l31) * T;
+                float t[8];
+                if (FULL) {
+                    const svba_f4u t0 = *reinterpret_cast<const svba_f4u*>(vr + ja);
+                    const svba_f4u t1 = *reinterpret_cast<const svba_f4u*>(vr + ja + 8);
+                    t[0] = t0.x; t[1] = t0.y; t[2] = t0.z; t[3] = t0.w;
+                    t[4] = t1.x; t[5] = t1.y; t[6] = t1.z; t[7] = t1.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int j = ja + 8 * (e >> 2) + (e & 3);
+                        t[e] = j < T ? vr[j] : 0.f;
+                    }
+                }
+                svba_bf16x8 ah, al;
+                svba_split8(t, ah, al);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ph, o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pl, o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph, o[db], 0, 0, 0);
+            }
+        }
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    const int i_hi = min(i0 + 31, T - 1);                            // largest query of this wave
+    for (int j0 = 0; j0 < T; j0 += 32) {
+        const bool full = j0 + 32 <= T;
+        if (full && j0 + 31 <= i0) key_block(j0, C0{}, std::true_type{});
+        else if (full && j0 > i_hi + 1) key_block(j0, C1{}, std::true_type{});
+        else if (full) key_block(j0, C2{}, std::true_type{});
+        else key_block(j0, C2{}, std::false_type{});
+    }
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;              // (a query whose keys are all padded gets zeros, as :183-186)
+    if (iv) {
+        float* oh = out + head;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = db * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+                oh[(size_t)d * T + i] = o[db][r] * inv;
+            }
+    }
+}
+
+extern "C" int svb_relpos_attn_fwd(const float* q, const float* k, const float* v, const float* pos_u, const float* bd, long bd_sb,
+                                   long bd_sh, long bd_sr, const float* keep, float* out, int B, int H, int dk, int T, float scale,
+                                   void* stream) {
+    if (!q || !k || !v || !pos_u || !bd || !keep || !out || B <= 0 || H <= 0 || T <= 0) return SVB_ERR_ARG;
+    if (dk != SVB_ATTN_DK || (long)B * H > 65535) return SVB_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(svb_relpos_attn_fwd_kernel, dim3((T + 63) / 64, B * H), dim3(128), 0, (hipStream_t)stream, q, k, v, pos_u, bd,
+                       bd_sb, bd_sh, bd_sr, keep, out, B, H, T, scale);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}

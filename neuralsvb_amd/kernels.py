@@ -500,6 +500,21 @@ def relpos_softmax(ac, bd, keep, scale):
     return out
 
 
+def relpos_attention(q, k, v, pos_u, bd, keep, scale, n_head):
+    """Fused rel-pos self-attention forward.  q, k, v [B, H*dk, T] (dk = 64); pos_u [H, dk]; bd [B, H, T, T] (any batch / head /
+    row strides, unit column stride): the unshifted position scores; keep [B, T] float.  -> [B, H*dk, T]."""
+    _f32(q, k, v, pos_u, bd, keep)
+    lib, st = _prep(q, k, v, pos_u, keep)
+    B, D, T = q.shape
+    dk = D // n_head
+    if bd.stride(3) != 1 or tuple(bd.shape) != (B, n_head, T, T):
+        raise ValueError("bd must be [B, H, T, T] with contiguous rows")
+    out = torch.empty_like(q)
+    L.check(lib.svb_relpos_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(pos_u), _ptr(bd), bd.stride(0), bd.stride(1), bd.stride(2),
+                                    _ptr(keep), _ptr(out), B, n_head, dk, T, float(scale), st), "svb_relpos_attn_fwd")
+    return out
+
+
 def glu_dwconv_bn_swish(y, w, bias, bn_w, bn_b, bn_mean, bn_var, eps):
     """Swish(BatchNorm_eval(depthwise_conv1d(GLU(y)))): y [B,2C,T], w [C,1,K] or [C,K] -> [B,C,T] (forward only)."""
     w = w.reshape(w.shape[0], -1).contiguous()

@@ -60,17 +60,22 @@ class RelPositionMultiHeadedAttention(nn.Module):
         """x [B,D,T]; pos_emb [1,D,T]; mask [B,T] bool (True = keep)  (espnet_transformer_attn.py:150-186)."""
         B, D, T = x.shape
         h, dk = self.h, self.d_k
-        q = self.linear_q(x).view(B, h, dk, T)
-        k = self.linear_k(x).view(B, h, dk, T)
-        v = self.linear_v(x).view(B, h, dk, T)
+        q, k, v = self.linear_q(x), self.linear_k(x), self.linear_v(x)              # [B, D, T]
         p = self.linear_pos(pos_emb).view(1, h, dk, T)
-        q_u = (q + self.pos_bias_u[None, :, :, None]).transpose(-1, -2)
-        q_v = (q + self.pos_bias_v[None, :, :, None]).transpose(-1, -2)
-        ac = torch.matmul(q_u, k)                                   # [B,h,T,T]
-        bd = torch.matmul(q_v, p)
-        # rel_shift (:125-148) + add + 1/sqrt(dk) + key mask + softmax + mask: one HIP kernel, one pass over [B,h,T,T]
-        attn = K.relpos_softmax(ac, bd.expand(B, h, T, T).contiguous(), mask.float().contiguous(), 1.0 / math.sqrt(dk))
-        o = torch.matmul(v, attn.transpose(-1, -2)).reshape(B, D, T)
+        q4 = q.view(B, h, dk, T)
+        q_v = (q4 + self.pos_bias_v[None, :, :, None]).transpose(-1, -2)
+        bd = torch.matmul(q_v, p)                                   # [B,h,T,T] position scores, unshifted
+        scale = 1.0 / math.sqrt(dk)
+        if dk == 64 and not (torch.is_grad_enabled() and (x.requires_grad or self.pos_bias_u.requires_grad)):
+            # frozen encoder (the hot path): content scores, rel_shift (:125-148), scale, key mask, softmax and the value
+            # product in ONE kernel -- neither `ac` nor `attn` ([B,h,T,T] each) is ever written
+            o = K.relpos_attention(q, k, v, self.pos_bias_u.contiguous(), bd, mask.float().contiguous(), scale, h)
+        else:
+            q_u = (q4 + self.pos_bias_u[None, :, :, None]).transpose(-1, -2)
+            ac = torch.matmul(q_u, k.view(B, h, dk, T))             # [B,h,T,T]
+            # rel_shift + add + scale + key mask + softmax + mask: one HIP kernel, one pass over [B,h,T,T]
+            attn = K.relpos_softmax(ac, bd.expand(B, h, T, T).contiguous(), mask.float().contiguous(), scale)
+            o = torch.matmul(v.view(B, h, dk, T), attn.transpose(-1, -2)).reshape(B, D, T)
         return self.linear_out(o)
 
 

@@ -202,6 +202,7 @@ static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 
 static inline float __fdividef(float a, float b) { return a / b; }
+#define __expf(x) expf(x)            /* (glibc declares but does not export __expf) */
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline void sincosf_emu(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }

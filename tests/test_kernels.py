@@ -481,6 +481,35 @@ def test_conv1d_bf16x3_wide_tiles_three_position_groups(dev, cfg):
     assert rel_err(dx, dref) < 6e-5
 
 
+@pytest.mark.parametrize("T", [37, 64, 130])
+def test_relpos_attention_fused_matches_espnet(dev, T):
+    """svb_relpos_attn_fwd (content scores + rel-shifted position scores + scale + key mask + softmax + value product in one
+    kernel) against the reference's op sequence (espnet_transformer_attn.py:125-186) in fp32: legacy rel_shift via
+    pad/view/slice, masked_fill(min), softmax, masked_fill(0), matmul with v.  One clip has padded keys, one is fully padded."""
+    g = torch.Generator().manual_seed(100 + T)
+    B, H, dk = 3, 2, 64
+    q = torch.randn(B, H, dk, T, generator=g)
+    k = torch.randn(B, H, dk, T, generator=g)
+    v = torch.randn(B, H, dk, T, generator=g)
+    pu, pv = torch.randn(H, dk, generator=g) * 0.5, torch.randn(H, dk, generator=g) * 0.5
+    pe = torch.randn(1, H, dk, T, generator=g)
+    keep = torch.ones(B, T)
+    keep[1, T - 7:] = 0
+    keep[2, :] = 0
+    ac = torch.matmul((q + pu[None, :, :, None]).transpose(-1, -2), k)
+    bd = torch.matmul((q + pv[None, :, :, None]).transpose(-1, -2), pe)             # [B,H,T,T], unshifted
+    x = F.pad(bd, (1, 0)).view(B, H, T + 1, T)[:, :, 1:].reshape(B, H, T, T)
+    scores = (ac + x) / (dk ** 0.5)
+    drop = ~(keep.bool())[:, None, None, :]
+    attn = torch.softmax(scores.masked_fill(drop, torch.finfo(torch.float32).min), -1).masked_fill(drop, 0.0)
+    ref = torch.matmul(v, attn.transpose(-1, -2)).reshape(B, H * dk, T)
+    out = K.relpos_attention(q.reshape(B, H * dk, T).to(dev), k.reshape(B, H * dk, T).to(dev), v.reshape(B, H * dk, T).to(dev),
+                             pu.to(dev), bd.to(dev), keep.to(dev), 1.0 / dk ** 0.5, H)
+    assert out.shape == ref.shape
+    assert float(out[2].abs().max()) == 0.0                      # fully padded clip: zeros, as the reference
+    assert rel_err(out, ref) < 5e-5
+
+
 @pytest.mark.parametrize("T", [37, 130])
 def test_relpos_softmax_matches_espnet_rel_shift(dev, T):
     """svb_relpos_softmax against the reference's op sequence (espnet_transformer_attn.py:125-186): legacy rel_shift via
