@@ -450,6 +450,29 @@ def main():
         torch.cuda.synchronize()
         ms_h2d = (time.perf_counter() - t1) / n_h2d * 1e3
         log(f"{ms_h2d:.2f} ms/step with the H2D copy of the batch inside the step")
+        # the data side of a step, rank 0 only: the same B clips from the binary dataset to a batch resident in HBM
+        # -- host collater + one H2D copy per field (the reference's way) against slicing into pinned staging buffers + the
+        # collate / norm_interp_f0 kernels (tasks/device_collate.py).  Not part of `value`.
+        data_side = None
+        if rank == 0 and world == 1:
+            from neuralsvb_amd.tasks.device_collate import DeviceCollater
+            ds = task.dataset_cls("train", False)
+            idx = list(range(min(args.batch, len(ds))))
+            dc = DeviceCollater(ds, device)
+
+            def clock(fn, n=5):
+                fn()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t) / n * 1e3
+            data_side = {"clips": len(idx),
+                         "host_collate_h2d_ms": clock(lambda: move_to_device(ds.collater([ds[i] for i in idx]), device)),
+                         "device_collate_ms": clock(lambda: dc([ds.raw_item(i) for i in idx]))}
+            log(f"batch assembly: host collater + H2D {data_side['host_collate_h2d_ms']:.2f} ms, device collate "
+                f"{data_side['device_collate_ms']:.2f} ms")
         comm = None
         if world > 1:
             st = [g.stats for g in trainer.grad_sync if g is not None]
@@ -482,7 +505,7 @@ def main():
                                        f"hop 128, T={T}, 80-bin mel", "global_batch": args.batch * world,
                            "parallelism": f"dp{world}", "random_init_weights": True},
                 "value_with_h2d": args.batch * args.seconds * world / (ms_h2d * 1e-3), "ms_per_step_with_h2d": ms_h2d,
-                "comm": comm, "roofline": roof, "cpu_baseline": cpu}))
+                "comm": comm, "data_side": data_side, "roofline": roof, "cpu_baseline": cpu}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -271,6 +271,22 @@ int svb_nsf_source(const float* f0, const float* rand_ini, const float* noise, c
 int svb_f0_to_coarse_f64(const double* f0, int64_t* out, int64_t n, void* stream);
 int svb_f0_to_coarse_f32(const float* f0, int64_t* out, int64_t n, void* stream);
 
+/* ---- the data side of a batch on the GPU (reference utils/__init__.py:118-161 collate_1d/2d,
+ * utils/pitch_utils.py:148-177 norm_interp_f0, tasks/tts/dataset_utils.py:133-205).  Ragged input = the rows of all clips
+ * concatenated ([sum_len][W]); off[b] / len[b] (int32, device) = first row / row count of clip b.
+ * svb_collate_pad_f32: out [B][Tmax][W] = rows of clip b, then `pad`.   svb_collate_pad_i64: the same for int64 scalars per
+ * frame, optionally clamped to clip_max[b] (the a2p alignment, svb_vae_task.py:31-33).   svb_mel_energy: energy [B][Tmax] =
+ * sqrt(sum_f exp(mel)^2) on real frames, 0 on padding.   svb_norm_interp_f0: f0 (Hz, fp64, 0 = unvoiced) -> normalised,
+ * gap-interpolated fp32 track + unvoiced flags, both zero-padded; mode 0 none / 1 log2(f0 + 1e-8) / 2 (f0 - mean) / std;
+ * fp64 arithmetic in numpy's order (np.interp's slope form, no fused multiply-add); Tmax <= 6144.                        */
+int svb_collate_pad_f32(const float* src, const int* off, const int* len, float* out, int B, int Tmax, int W, float pad,
+                        void* stream);
+int svb_collate_pad_i64(const int64_t* src, const int* off, const int* len, const int* clip_max, int64_t* out, int B, int Tmax,
+                        int64_t pad, void* stream);
+int svb_mel_energy(const float* mels, const int* len, float* energy, int B, int Tmax, int W, void* stream);
+int svb_norm_interp_f0(const double* src, const int* off, const int* len, float* f0_out, float* uv_out, int B, int Tmax, int mode,
+                       double mean, double stdv, int use_uv, void* stream);
+
 /* ---- pitch-bin embedding in the conv layout (reference modules/voice_conversion/svb_vae.py:66, nn.Embedding(300, H,
  * padding_idx=0) + transpose): out [B][H][T] = w[idx[b][t]][h]; _bwd: dw [V][H] = sum of dy [B][H][T] over the positions
  * that hold each row (row padding_idx stays zero; accumulate != 0 adds into dw), deterministic summation order;

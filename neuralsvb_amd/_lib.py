@@ -76,6 +76,10 @@ SIGNATURES = {
     "svb_nsf_source": (I, [P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, P]),
     "svb_f0_to_coarse_f64": (I, [P, P, I64, P]),
     "svb_f0_to_coarse_f32": (I, [P, P, I64, P]),
+    "svb_collate_pad_f32": (I, [P, P, P, P, I, I, I, F, P]),
+    "svb_collate_pad_i64": (I, [P, P, P, P, P, I, I, I64, P]),
+    "svb_mel_energy": (I, [P, P, P, I, I, I, P]),
+    "svb_norm_interp_f0": (I, [P, P, P, P, P, I, I, I, C.c_double, C.c_double, I, P]),
     "svb_embed_nct_fwd": (I, [P, P, P, I, I, I, I, P]),
     "svb_embed_nct_bwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
 }

@@ -750,6 +750,50 @@ def nsf_source(f0, rand_ini, noise, lin_w, lin_b, upp, sample_rate, sine_amp=0.1
     return merged, sw, uv
 
 
+def collate_pad(src, off, length, tmax, width=1, pad=0, clip_max=None):
+    """Ragged rows (all clips concatenated: [sum_len, width] float32, or [sum_len] int64) -> zero/pad-filled batch
+    [B, tmax(, width)].  off / length: int32 [B] on the device.  clip_max (int64 only): per-clip upper clamp."""
+    lib, st = _prep(src, off, length, clip_max)
+    B = off.shape[0]
+    if src.dtype == torch.float32:
+        out = torch.empty((B, tmax, width) if src.dim() == 2 else (B, tmax), device=src.device, dtype=torch.float32)
+        L.check(lib.svb_collate_pad_f32(_ptr(src), _ptr(off), _ptr(length), _ptr(out), B, tmax, width, float(pad), st),
+                "svb_collate_pad_f32")
+    elif src.dtype == torch.int64:
+        out = torch.empty((B, tmax), device=src.device, dtype=torch.int64)
+        L.check(lib.svb_collate_pad_i64(_ptr(src), _ptr(off), _ptr(length), _ptr(clip_max), _ptr(out), B, tmax, int(pad), st),
+                "svb_collate_pad_i64")
+    else:
+        raise TypeError(src.dtype)
+    return out
+
+
+def mel_energy(mels, length):
+    """mels [B,T,F] float32 (padded), length int32 [B] -> energy [B,T] = sqrt(sum_f exp(mel)^2), 0 on padding."""
+    _f32(mels)
+    lib, st = _prep(mels, length)
+    B, T, W = mels.shape
+    out = torch.empty((B, T), device=mels.device, dtype=torch.float32)
+    L.check(lib.svb_mel_energy(_ptr(mels), _ptr(length), _ptr(out), B, T, W, st), "svb_mel_energy")
+    return out
+
+
+def norm_interp_f0(src, off, length, tmax, pitch_norm="log", mean=0.0, std=1.0, use_uv=True):
+    """f0 tracks in Hz (float64, all clips concatenated; 0 = unvoiced) -> (f0 [B,tmax] float32 normalised with the unvoiced
+    gaps interpolated, uv [B,tmax] float32), zero-padded: reference utils/pitch_utils.py:160-177 per clip."""
+    if src.dtype != torch.float64:
+        raise TypeError("f0 staging buffer must be float64 (the reference normalises in numpy float64)")
+    lib, st = _prep(src, off, length)
+    B = off.shape[0]
+    f0 = torch.empty((B, tmax), device=src.device, dtype=torch.float32)
+    uv = torch.empty((B, tmax), device=src.device, dtype=torch.float32)
+    mode = {"log": 1, "standard": 2}.get(pitch_norm, 0)
+    L.check(lib.svb_norm_interp_f0(_ptr(src), _ptr(off), _ptr(length), _ptr(f0), _ptr(uv), B, tmax, mode,
+                                   float(mean if mean is not None else 0.0), float(std if std is not None else 1.0),
+                                   int(bool(use_uv)), st), "svb_norm_interp_f0")
+    return f0, uv
+
+
 def embed_nct(idx, w):
     """idx int64 [B,T], w [V,H] -> [B,H,T] = w[idx].transpose(1,2), one gather."""
     _f32(w)

@@ -132,6 +132,12 @@ class BaseTask(nn.Module):
         if world > 1:   # rank r takes every world-th item; batches not divisible by the world size are dropped
             rank = dist.get_rank()
             batches = [b[rank::world] for b in batches if len(b) % world == 0]
+        if hparams.get("device_collate", False) and hasattr(dataset, "raw_item") and torch.cuda.is_available():
+            # batches assembled on the GPU (tasks/device_collate.py): workers only decode items
+            from .device_collate import DeviceCollateLoader
+            dev = self.trainer.device if self.trainer is not None and getattr(self.trainer, "device", None) is not None \
+                else torch.device("cuda", torch.cuda.current_device())
+            return DeviceCollateLoader(dataset, batches, dev, num_workers=dataset.num_workers)
         return torch.utils.data.DataLoader(dataset, collate_fn=dataset.collater, batch_sampler=batches,
                                            num_workers=dataset.num_workers, pin_memory=torch.cuda.is_available())
 

@@ -66,6 +66,15 @@ class MultiSpkEmbDataset(torch.utils.data.Dataset):
             self.indexed_ds = IndexedDataset(f"{self.data_dir}/{self.prefix}")
         return self.indexed_ds[self.avail_idxs[index]]
 
+    def raw_item(self, index):
+        """The decoded item as stored (numpy arrays, untruncated) + its dataset id: input of tasks/device_collate.py."""
+        item = dict(self._get_item(index))
+        assert max(len(item["mel"]), len(item["prof_mel"])) == self.sizes[index], (len(item["mel"]), self.sizes[index])
+        if self.hparams.get("normalize_pitch", False):
+            raise NotImplementedError("normalize_pitch is false on this path (vc_ppg.yaml)")
+        item["id"] = index
+        return item
+
     def _voice(self, item, pre):
         """mel / f0 / uv / pitch of one voice, truncated to max_frames and a multiple of frames_multiple."""
         hp = self.hparams

@@ -202,6 +202,10 @@ static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 
 static inline float __fdividef(float a, float b) { return a / b; }
+static inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }   /* (volatile: no contraction) */
+static inline double __dsub_rn(double a, double b) { volatile double r = a - b; return r; }
+static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
+static inline double __ddiv_rn(double a, double b) { volatile double r = a / b; return r; }
 #define __expf(x) expf(x)            /* (glibc declares but does not export __expf) */
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
