@@ -287,6 +287,22 @@ int svb_mel_energy(const float* mels, const int* len, float* energy, int B, int 
 int svb_norm_interp_f0(const double* src, const int* off, const int* len, float* f0_out, float* uv_out, int B, int Tmax, int mode,
                        double mean, double stdv, int use_uv, void* stream);
 
+/* ---- offline F0 alignment of the binarizer (reference data_gen/singing/binarize_para.py:168-185 ->
+ * modules/voice_conversion/dtw/enhance_sadtw.py:18-113 -> modules/voice_conversion/dtw/align.py:8-37), batched over P pairs
+ * whose tracks are padded to L / La / Lb frames (len arrays: int32 on the device).
+ * svb_f0_shape_hist: f0 [P][L] (Hz, fp64) -> hist [P][L][48] fp32, the normalised slope-class histograms of cal_hist_of_f0
+ *                    (max_window 64; scale[p] = the track's scale_factor, 1 for the source, len_tgt/len_src for the target).
+ * svb_hist_cost:     cost [P][Lb][La] = chi-square distance of target frame t and source frame s (cal_hist_dist, transposed
+ *                    as align_from_distances receives it).
+ * svb_dtw_align:     time_warp + back-tracking: dtw [P][Lb][La] (optional) the accumulated costs (bit-exact fp32), dir
+ *                    [P][Lb][La] bytes (workspace: arg-min direction per cell), align [P][Lb] int64 = for every target
+ *                    frame the matched source frame (0 where the path never passes).  Lb <= 4096.                         */
+int svb_f0_shape_hist(const double* f0, const int* len, const double* scale, float* hist, int P, int L, void* stream);
+int svb_hist_cost(const float* ha, const int* len_a, const float* hb, const int* len_b, float* cost, int P, int La, int Lb,
+                  void* stream);
+int svb_dtw_align(const float* cost, const int* len_b, const int* len_a, float* dtw, unsigned char* dir, int64_t* align, int P,
+                  int La, int Lb, void* stream);
+
 /* ---- pitch-bin embedding in the conv layout (reference modules/voice_conversion/svb_vae.py:66, nn.Embedding(300, H,
  * padding_idx=0) + transpose): out [B][H][T] = w[idx[b][t]][h]; _bwd: dw [V][H] = sum of dy [B][H][T] over the positions
  * that hold each row (row padding_idx stays zero; accumulate != 0 adds into dw), deterministic summation order;

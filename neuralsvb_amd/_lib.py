@@ -80,6 +80,9 @@ SIGNATURES = {
     "svb_collate_pad_i64": (I, [P, P, P, P, P, I, I, I64, P]),
     "svb_mel_energy": (I, [P, P, P, I, I, I, P]),
     "svb_norm_interp_f0": (I, [P, P, P, P, P, I, I, I, C.c_double, C.c_double, I, P]),
+    "svb_f0_shape_hist": (I, [P, P, P, P, I, I, P]),
+    "svb_hist_cost": (I, [P, P, P, P, P, I, I, I, P]),
+    "svb_dtw_align": (I, [P, P, P, P, P, P, I, I, I, P]),
     "svb_embed_nct_fwd": (I, [P, P, P, I, I, I, I, P]),
     "svb_embed_nct_bwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
 }

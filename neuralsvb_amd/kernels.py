@@ -794,6 +794,40 @@ def norm_interp_f0(src, off, length, tmax, pitch_norm="log", mean=0.0, std=1.0, 
     return f0, uv
 
 
+def f0_shape_hist(f0, length, scale):
+    """f0 [P,L] float64 (Hz), length int32 [P], scale float64 [P] -> [P,L,48] float32 slope-class histograms
+    (reference enhance_sadtw.py:18-83, max_window 64, normalised)."""
+    lib, st = _prep(f0, length, scale)
+    P_, L_ = f0.shape
+    hist = torch.empty((P_, L_, 48), device=f0.device, dtype=torch.float32)
+    L.check(lib.svb_f0_shape_hist(_ptr(f0), _ptr(length), _ptr(scale), _ptr(hist), P_, L_, st), "svb_f0_shape_hist")
+    return hist
+
+
+def hist_cost(ha, len_a, hb, len_b):
+    """chi-square cost [P, Lb, La] between target frames (hb) and source frames (ha) (enhance_sadtw.py:86-100, transposed)."""
+    _f32(ha, hb)
+    lib, st = _prep(ha, hb, len_a, len_b)
+    P_, La = ha.shape[:2]
+    Lb = hb.shape[1]
+    cost = torch.empty((P_, Lb, La), device=ha.device, dtype=torch.float32)
+    L.check(lib.svb_hist_cost(_ptr(ha), _ptr(len_a), _ptr(hb), _ptr(len_b), _ptr(cost), P_, La, Lb, st), "svb_hist_cost")
+    return cost
+
+
+def dtw_align(cost, len_b, len_a, want_dtw=False):
+    """time_warp + align_from_distances (dtw/align.py:8-37) on cost [P, Lb, La].  -> align int64 [P, Lb] (, dtw [P,Lb,La])."""
+    _f32(cost)
+    lib, st = _prep(cost, len_a, len_b)
+    P_, Lb, La = cost.shape
+    dtw = torch.empty_like(cost) if want_dtw else None
+    dirs = torch.empty((P_, Lb, La), device=cost.device, dtype=torch.uint8)
+    align = torch.empty((P_, Lb), device=cost.device, dtype=torch.int64)
+    L.check(lib.svb_dtw_align(_ptr(cost), _ptr(len_b), _ptr(len_a), _ptr(dtw), _ptr(dirs), _ptr(align), P_, La, Lb, st),
+            "svb_dtw_align")
+    return (align, dtw) if want_dtw else align
+
+
 def embed_nct(idx, w):
     """idx int64 [B,T], w [V,H] -> [B,H,T] = w[idx].transpose(1,2), one gather."""
     _f32(w)

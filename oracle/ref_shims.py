@@ -103,7 +103,11 @@ def install(chdir_to_reference: bool = False):
     sys.modules["skimage.transform"].resize = _Anything()
     sys.modules["skimage"].transform = sys.modules["skimage.transform"]
     sys.modules["pycwt"].wavelet = sys.modules["pycwt.wavelet"]
-    sys.modules["numba"].jit = lambda *a, **k: (lambda f: f)
+    def _jit(*a, **k):               # both `@jit` and `@jit(...)` leave the function as plain Python
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+    sys.modules["numba"].jit = _jit
     sys.modules["h5py"].File = _Anything
     try:
         import torch.utils.tensorboard  # noqa: F401
