@@ -34,9 +34,9 @@ torch.cuda.synchronize()
 lib.svb_debug_set_timing_buffer(None)
 t = buf.cpu().numpy().reshape(64, 32, 8).astype(np.int64)
 SVBQ_LAST = 31
-fast = bool((t[:, :SVBQ_LAST, 3] <= t[:, :SVBQ_LAST, 1]).all())      # straight-line loop: stamps 0 3 1 2 (4 5)
+fast = not t[:, :SVBQ_LAST, 3].any()          # the straight-line loop stamps 0 1 2 (4 5): slot 3 stays empty
 if fast:
-    names = ["wait weight frags", "issue x loads", "compute (MFMA loop)", "store next tile", "barrier"]
+    names = ["wait weight frags + issue x loads", "compute (MFMA loop)", "store next tile", "barrier"]
 else:
     names = ["issue loads", "compute (MFMA loop)", "barrier 1", "stage to LDS", "barrier 2"]
 rows = []
@@ -44,7 +44,7 @@ for blk in range(64):
     for st in range(SVBQ_LAST):
         s = t[blk, st]
         if fast and s[0] and s[2]:
-            rows.append([s[3] - s[0], s[1] - s[3], s[2] - s[1], (s[4] - s[2]) if s[4] else 0, (s[5] - s[4]) if s[5] else 0])
+            rows.append([s[1] - s[0], s[2] - s[1], (s[4] - s[2]) if s[4] else 0, (s[5] - s[4]) if s[5] else 0])
         elif not fast and s[0] and s[5]:
             rows.append([s[1] - s[0], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[5] - s[4]])
 rows = np.array(rows)
