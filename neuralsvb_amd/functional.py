@@ -69,7 +69,10 @@ def _gbuf(p):
     if not DIRECT_GRADS or p is None or not p.is_leaf or p.grad is None or not p.requires_grad:
         return None      # (a frozen parameter may still own a flat-buffer `.grad` view: never accumulate into it)
     gb = p.grad
-    return gb if (gb.dtype == torch.float32 and gb.is_contiguous() and gb.shape == p.shape) else None
+    if gb.dtype == torch.float32 and gb.is_contiguous() and gb.shape == p.shape:
+        p._svb_sink = True       # (FlatGradSync keeps a buffer only for parameters whose gradient a kernel accumulates in place)
+        return gb
+    return None
 
 
 def _sinks(v, g, b):

@@ -74,9 +74,15 @@ class FlatGradSync:
     (optimizer, phase, critic plan): the graph is static under a key, so the recorded counts are exact; an announcement
     beyond the recorded count raises instead of silently reducing a half-accumulated bucket."""
 
-    def __init__(self, params, world_size, group=None, bucket_bytes=8 << 20, overlap=True):
+    def __init__(self, params, world_size, group=None, bucket_bytes=8 << 20, overlap=True, drop_autograd_grads=False):
         self.params = [p for p in params]
         self.world_size, self.group = world_size, group
+        # One process, eager launches: a parameter whose gradient only ever arrives through autograd (norm affines, biases of
+        # torch ops, ...) gets `.grad = None` instead of a zeroed view after each optimizer step, so autograd hands it the
+        # new gradient tensor as-is rather than launching `grad += new` (~50 launches per step).  Parameters whose gradient
+        # a kernel accumulates in place (functional._gbuf marks them) keep their slice of the flat buffer.
+        self.drop_autograd_grads = bool(drop_autograd_grads) and world_size == 1
+        self._zeroed = 0
         n = sum((p.numel() + 3) // 4 * 4 for p in self.params)        # every view starts 16-byte aligned (vector kernels)
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
@@ -101,6 +107,23 @@ class FlatGradSync:
 
     def zero(self):
         self.flat.zero_()
+        self._zeroed += 1
+        if self.drop_autograd_grads and self._zeroed >= 1:
+            for p in self.params:
+                if not getattr(p, "_svb_sink", False):
+                    p.grad = None
+
+    def pin_views(self):
+        """Back to one fixed gradient buffer per parameter (hipGraph capture needs stable addresses)."""
+        self.drop_autograd_grads = False
+        off = 0
+        for p in self.params:
+            v = self.flat[off:off + p.numel()].view_as(p)
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                p.grad = v
+            off += (p.numel() + 3) // 4 * 4
 
     # ---- overlapped exchange ----------------------------------------------------------------------------------
     def begin_pass(self, key):
@@ -278,7 +301,8 @@ class Trainer:
             self.first_epoch = True
             self.grad_sync = [FlatGradSync([p for g in o.param_groups for p in g["params"]], self.world_size,
                                            bucket_bytes=int(hparams.get("ddp_bucket_mb", 8) * (1 << 20)),
-                                           overlap=hparams.get("ddp_overlap", True))
+                                           overlap=hparams.get("ddp_overlap", True),
+                                           drop_autograd_grads=not self.hip_graph and hparams.get("drop_autograd_grads", True))
                               if o is not None else None for o in self.optimizers]
         if checkpoint is not None:
             self.restore_opt_state(checkpoint)
@@ -456,6 +480,10 @@ class Trainer:
     def _run_training_batch_body(self, batch_idx, batch):
         task = self.task
         graph_mode = self.hip_graph and self.on_gpu
+        if graph_mode:
+            for g in self.grad_sync:
+                if g is not None and g.drop_autograd_grads:
+                    g.pin_views()
         if hasattr(task, "begin_step"):
             task.begin_step(batch, self.global_step, stage_device=graph_mode)   # host randoms (batch still on the host)
         sig = None
