@@ -10,6 +10,9 @@ timeout 300 python bench.py --steps 20 --warmup 5 > gpurun_out/r02_final/bench_t
 timeout 300 python bench.py --steps 20 --warmup 5 --precision fp32 --no-cpu-baseline > gpurun_out/r02_final/bench_train_fp32.json 2> gpurun_out/r02_final/bench_train_fp32.err
 timeout 300 python bench.py --workload vocoder --steps 8 --warmup 3 > gpurun_out/r02_final/bench_vocoder.json 2> gpurun_out/r02_final/bench_vocoder.err
 timeout 300 python bench.py --workload infer --steps 12 --warmup 2 > gpurun_out/r02_final/bench_infer.json 2> gpurun_out/r02_final/bench_infer.err
+timeout 200 python bench.py --steps 10 --warmup 4 --graph --no-cpu-baseline --no-roofline > gpurun_out/r02_final/bench_train_graph.json 2> gpurun_out/r02_final/bench_train_graph.err
+(timeout 100 python tools/attnbench.py; timeout 100 python tools/dtwbench.py) > gpurun_out/r02_final/attn_dtw_bench.log 2>/dev/null
+SVB_BENCH_SHAPES=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> gpurun_out/r02_final/bench_shapes.err
 cd /tmp
 SVB_BENCH_MARKERS=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o r02 --output-format csv -- python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > /root/repo/gpurun_out/r02_final/bench_under_rocprof.json 2> /root/repo/gpurun_out/r02_final/bench_under_rocprof.err
 python /root/repo/tools/trace_summary.py /tmp/prof/r02_kernel_trace.csv 20 70 > /root/repo/gpurun_out/r02_final/kernel_summary.txt
