@@ -76,3 +76,26 @@ def test_norm_interp_f0_kernel_edge_cases(dev):
             assert int(_ulp_diff(got, torch.FloatTensor(rf)).max()) <= 1, (hp, b)
             assert torch.equal(uv[b, :len(t)].cpu(), torch.FloatTensor(ru)), (hp, b)
             assert float(f0[b, len(t):].abs().max()) == 0.0 and float(uv[b, len(t):].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_build_dataloader_with_device_collate(ds, gpu_only):
+    """hparams device_collate=true: BaseTask.build_dataloader hands out batches assembled on the GPU (workers only decode
+    items); same batches, in the same order, as the default host loader."""
+    from neuralsvb_amd.utils.hparams import hparams
+    from neuralsvb_amd.tasks.svb_vae_task import SVBVAEMleTask
+    from neuralsvb_amd.utils.trainer import move_to_device
+    task = SVBVAEMleTask()
+    host = list(task.build_dataloader(ds, False, hparams["max_tokens"], 4))
+    hparams["device_collate"] = True
+    try:
+        devl = list(task.build_dataloader(ds, False, hparams["max_tokens"], 4))
+    finally:
+        hparams["device_collate"] = False
+    assert len(devl) == len(host) == 2
+    for hb, db in zip(host, devl):
+        hb = move_to_device(hb, gpu_only)
+        assert db["item_name"] == hb["item_name"] and db["mels"].is_cuda
+        for k in ("mels", "prof_mels", "pitch", "prof_pitch", "a2p_f0_alignment", "uv", "prof_uv", "multi_spk_emb"):
+            assert torch.equal(db[k], hb[k]), k
+        assert int(_ulp_diff(db["f0"].cpu(), hb["f0"].cpu()).max()) <= 1
