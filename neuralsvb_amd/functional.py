@@ -637,6 +637,14 @@ def _s2_image(weight):
     return ent[2]
 
 
+class _NoSide:
+    def __enter__(self):
+        return False
+
+    def __exit__(self, *exc):
+        return False
+
+
 class _S2DPadFn(torch.autograd.Function):
     """x [N,C,H,W] (any strides; H, W even) -> the space-to-depth planes [1, 4C, N*(H/2+1)*(W/2+1)] with zero borders."""
 
@@ -670,6 +678,7 @@ class _Conv2dS2Fn(torch.autograd.Function):
         y4 = K.conv1d_taps(x4, pa, cout, offsets, bias=_c(bias), out_act=ACT_LRELU if slope is not None else ACT_NONE,
                            out_slope=slope if slope is not None else 0.0)
         ctx.dims, ctx.slope, ctx.pb, ctx.has_bias, ctx.offsets = (N, C, H, W, cout), slope, pb, bias is not None, offsets
+        ctx.bias_ref = weakref.ref(bias) if bias is not None else None
         ctx.save_for_backward(x4 if ctx.needs_input_grad[1] else None, y4 if slope is not None else None, weight)
         return y4
 
@@ -684,13 +693,19 @@ class _Conv2dS2Fn(torch.autograd.Function):
             dx4 = K.conv1d_taps(dy4, ctx.pb, 4 * C, [-o for o in ctx.offsets], in_gate=yact, in_slope=a_slope)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            ra = K.conv1d_wgrad(dy4, x4, 2, 1, -ctx.offsets[0], 1, 1, a_gate=yact, a_slope=a_slope, want_bias=want_b)
-            if want_b:
-                ra, db = ra
-            rb = K.conv1d_wgrad(dy4, x4, 2, 1, -ctx.offsets[2], 1, 1, a_gate=yact, a_slope=a_slope)
             sink = _gbuf(weight)
-            dw = K.s2_weight_bwd(ra, rb, cout, C, into=sink)
-            _notify((sink,), (weight,), (dw,))
+            bsink = _gbuf(ctx.bias_ref()) if want_b and ctx.bias_ref is not None else None
+            # (both results accumulate into gradient buffers: the three launches may run beside the data gradient above)
+            with K.side_work(dy4, x4, yact) if (sink is not None and (not want_b or bsink is not None)) else _NoSide():
+                ra = K.conv1d_wgrad(dy4, x4, 2, 1, -ctx.offsets[0], 1, 1, a_gate=yact, a_slope=a_slope, want_bias=want_b)
+                if want_b:
+                    ra, db = ra
+                    if bsink is not None:
+                        bsink.add_(db)
+                        db = None
+                rb = K.conv1d_wgrad(dy4, x4, 2, 1, -ctx.offsets[2], 1, 1, a_gate=yact, a_slope=a_slope)
+                dw = K.s2_weight_bwd(ra, rb, cout, C, into=sink)
+            _notify((sink, bsink), (weight, ctx.bias_ref() if ctx.bias_ref is not None else None), (dw, db))
         elif want_b:
             db = K.bias_grad(dy4, yact, a_slope)
         return dx4, dw, db, None

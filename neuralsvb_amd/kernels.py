@@ -333,8 +333,66 @@ def conv1d_transposed(x, pb, cout, tout, k, stride=1, pad=0, dil=1, groups=1, ou
 WGRAD_BF16X3 = False      # set by functional.set_precision: stride-1 weight gradients on the bf16x3 kernel
 
 
+WGRAD_STREAM = None      # torch.cuda.Stream or None.  Set by the Trainer (one process, eager launches): weight gradients whose
+                         # results go straight into `.grad` buffers are enqueued on this side stream, so that they run
+                         # beside the data-gradient chain of the layers below instead of in front of it (neither kernel
+                         # fills the chip alone: 1.1 - 2.3 rounds of workgroups, a ragged last round each).  The Trainer joins
+                         # the stream after backward.
+
+
+class side_work:
+    """`with K.side_work(t1, t2, ...) as on_side:` -- when WGRAD_STREAM is set, the block's launches go to the side stream after
+    it has caught up with the current one; the given input tensors are marked as in use there.  Only for work whose results
+    land in gradient buffers nobody reads before the Trainer joins the stream (on_side tells the block whether that holds)."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+        self.ctx = None
+
+    def __enter__(self):
+        side = WGRAD_STREAM
+        if side is None or PROFILE is not None or not self.tensors or not self.tensors[0].is_cuda:
+            return False
+        side.wait_stream(torch.cuda.current_stream(self.tensors[0].device))
+        for t in self.tensors:
+            t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return True
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0, b_gate=None, b_slope=0.0,
                  v=None, g=None, accumulate_into=None, bf16x3=None, want_bias=False, sinks=None):
+    """Weight gradient (see _conv1d_wgrad).  With WGRAD_STREAM set and every result going into a sink, the launches are
+    issued on the side stream: it first waits for everything enqueued on the current stream so far (the producers of a / b);
+    the inputs are marked as in use there (the caching allocator must not recycle them when autograd drops them)."""
+    side = WGRAD_STREAM
+    if side is not None and a.is_cuda and sinks is not None and accumulate_into is None and PROFILE is None:
+        sv, sg, sb = sinks
+        wn = g is not None
+        all_sunk = sv is not None and (not wn or sg is not None) and (not want_bias or sb is not None)
+        if all_sunk and wn:
+            rowlen = (b.shape[1] // groups) * k
+            all_sunk = rowlen % 4 == 0 and rowlen <= 4096 and sv.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
+        if all_sunk and (bf16x3 if bf16x3 is not None else WGRAD_BF16X3):
+            side.wait_stream(torch.cuda.current_stream(a.device))
+            for t in (a, b, a_gate, b_gate, v, g):
+                if t is not None:
+                    t.record_stream(side)
+            with torch.cuda.stream(side):
+                return _conv1d_wgrad(a, b, k, sx, pad, dil, groups, a_gate, a_slope, b_gate, b_slope, v, g, accumulate_into,
+                                     bf16x3, want_bias, sinks)
+    return _conv1d_wgrad(a, b, k, sx, pad, dil, groups, a_gate, a_slope, b_gate, b_slope, v, g, accumulate_into, bf16x3,
+                         want_bias, sinks)
+
+
+def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0, b_gate=None, b_slope=0.0,
+                  v=None, g=None, accumulate_into=None, bf16x3=None, want_bias=False, sinks=None):
     """dW[ca, cb/groups, k] = sum_{n,q} a[n,ca,q] * b[n,cb,q*sx + j*dil - pad].
 
     With (v, g) given returns (dv, dg) of the weight-normalised parametrisation instead of dW.  want_bias: also return

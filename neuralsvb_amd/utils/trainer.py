@@ -421,6 +421,9 @@ class Trainer:
             loss = loss / self.accumulate_grad_batches
             if loss.requires_grad:
                 loss.backward()
+                from .. import kernels as _K
+                if _K.WGRAD_STREAM is not None:          # weight gradients enqueued beside the data-gradient chain
+                    torch.cuda.current_stream().wait_stream(_K.WGRAD_STREAM)
         return out
 
     def _graphed_forward_backward(self, sig, batch, batch_idx, opt_idx):
@@ -480,6 +483,12 @@ class Trainer:
     def _run_training_batch_body(self, batch_idx, batch):
         task = self.task
         graph_mode = self.hip_graph and self.on_gpu
+        from .. import kernels as _K
+        want_side = (self.on_gpu and not graph_mode and self.world_size == 1 and hparams.get("wgrad_side_stream", True))
+        if want_side and _K.WGRAD_STREAM is None:
+            _K.WGRAD_STREAM = torch.cuda.Stream(self.device)
+        elif not want_side:
+            _K.WGRAD_STREAM = None
         if graph_mode:
             for g in self.grad_sync:
                 if g is not None and g.drop_autograd_grads:
