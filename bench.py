@@ -40,7 +40,8 @@ def build_task(args, rank, world, device, tmp, extra_hparams=""):
     set_hparams(config=cfg, exp_name="", print_hparams=False,
                 hparams_str=f"audio_sample_rate={args.sample_rate},fmax={args.sample_rate // 2},max_sentences={args.batch},"
                             f"max_tokens=100000,ds_workers=0,num_sanity_val_steps=0,endless_ds=False,"
-                            f"conv_precision={args.precision}" + extra_hparams)
+                            f"conv_precision={args.precision}" +
+                            (",wgrad_side_stream=False" if getattr(args, "no_side_stream", False) else "") + extra_hparams)
     hparams["binary_data_dir"], hparams["pretrain_asr_ckpt"], hparams["work_dir"] = data_dir, asr_dir, ""
     hparams["amp"] = False
     torch.manual_seed(1234 + rank)
@@ -373,6 +374,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = try 8/16/32 threads and report the fastest")
     ap.add_argument("--use-q", action="store_true", help="A/B switch: pre-split (Q image) activations inside the gated stacks")
+    ap.add_argument("--no-side-stream", action="store_true",
+                    help="A/B switch: weight gradients on the compute stream (also what a per-kernel rocprofv3 table should be "
+                         "taken with: concurrent kernels inflate each other's durations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true",

@@ -14,7 +14,7 @@ timeout 200 python bench.py --steps 10 --warmup 4 --graph --no-cpu-baseline --no
 (timeout 100 python tools/attnbench.py; timeout 100 python tools/dtwbench.py) > gpurun_out/r02_final/attn_dtw_bench.log 2>/dev/null
 SVB_BENCH_SHAPES=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> gpurun_out/r02_final/bench_shapes.err
 cd /tmp
-SVB_BENCH_MARKERS=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o r02 --output-format csv -- python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > /root/repo/gpurun_out/r02_final/bench_under_rocprof.json 2> /root/repo/gpurun_out/r02_final/bench_under_rocprof.err
+SVB_BENCH_MARKERS=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o r02 --output-format csv -- python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-side-stream > /root/repo/gpurun_out/r02_final/bench_under_rocprof.json 2> /root/repo/gpurun_out/r02_final/bench_under_rocprof.err
 python /root/repo/tools/trace_summary.py /tmp/prof/r02_kernel_trace.csv 20 70 > /root/repo/gpurun_out/r02_final/kernel_summary.txt
 cp /tmp/prof/r02_kernel_stats.csv /root/repo/gpurun_out/r02_final/kernel_stats.csv
 for c in "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
