@@ -384,15 +384,28 @@ def conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0
             for t in (a, b, a_gate, b_gate, v, g):
                 if t is not None:
                     t.record_stream(side)
-            with torch.cuda.stream(side):
-                return _conv1d_wgrad(a, b, k, sx, pad, dil, groups, a_gate, a_slope, b_gate, b_slope, v, g, accumulate_into,
-                                     bf16x3, want_bias, sinks)
+            # (no `with torch.cuda.stream(side)`: the launches take the side stream's handle directly and their workspace is a
+            #  persistent buffer of that stream -- the context switch cost ~10 us per call on a step the host barely keeps up with)
+            return _conv1d_wgrad(a, b, k, sx, pad, dil, groups, a_gate, a_slope, b_gate, b_slope, v, g, accumulate_into,
+                                 bf16x3, want_bias, sinks, _side=side)
     return _conv1d_wgrad(a, b, k, sx, pad, dil, groups, a_gate, a_slope, b_gate, b_slope, v, g, accumulate_into, bf16x3,
                          want_bias, sinks)
 
 
+_SIDE_WS = {}            # (device index, slot) -> grow-only fp32 workspace of the side stream (its launches are serialised)
+
+
+def _side_ws(side, dev, slot, n):
+    key = (dev.index, slot)
+    ws = _SIDE_WS.get(key)
+    if ws is None or ws.numel() < n:
+        with torch.cuda.stream(side):
+            ws = _SIDE_WS[key] = torch.empty((max(n, 1 << 20),), device=dev, dtype=torch.float32)
+    return ws[:n]
+
+
 def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0, b_gate=None, b_slope=0.0,
-                  v=None, g=None, accumulate_into=None, bf16x3=None, want_bias=False, sinks=None):
+                  v=None, g=None, accumulate_into=None, bf16x3=None, want_bias=False, sinks=None, _side=None):
     """dW[ca, cb/groups, k] = sum_{n,q} a[n,ca,q] * b[n,cb,q*sx + j*dil - pad].
 
     With (v, g) given returns (dv, dg) of the weight-normalised parametrisation instead of dW.  want_bias: also return
@@ -403,6 +416,8 @@ def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.
     went into a sink are returned as None (the caller hands None to autograd, which skips its own `grad += new`)."""
     _f32(a, b, a_gate, b_gate, v, g)
     lib, st = _prep(a, b, a_gate, b_gate, v, g, accumulate_into)
+    if _side is not None:
+        st = _side.cuda_stream
     B, ca, ta = a.shape
     _, cb, tb = b.shape
     ns = C.c_int(0)
@@ -411,10 +426,14 @@ def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.
         nfl = lib.svb_conv1d_wgrad_bf16x3_workspace_floats(B, ca, cb, groups, ta, k, sx, pad, dil, C.byref(ns))
     wflops = 2.0 * B * ca * ta * (cb // groups) * k
     if nfl:
-        part = torch.empty((nfl,), device=a.device, dtype=torch.float32)
+        if _side is not None:
+            part = _side_ws(_side, a.device, 0, nfl)
+            bias_part = _side_ws(_side, a.device, 1, ns.value * ca).view(ns.value, ca) if want_bias else None
+        else:
+            part = torch.empty((nfl,), device=a.device, dtype=torch.float32)
+            bias_part = torch.empty((ns.value, ca), device=a.device, dtype=torch.float32) if want_bias else None
         probe = _ConvProbe(lib, a, 0, 0, wflops, family="svb_conv1d_wgrad_bf16x3_kernel",
                            tag=("wgrad", B, ca, cb, groups, ta, k, sx, dil))
-        bias_part = torch.empty((ns.value, ca), device=a.device, dtype=torch.float32) if want_bias else None
         L.check(lib.svb_conv1d_wgrad_bf16x3(_ptr(a), _ptr(b), _ptr(part), B, ca, cb, groups, ta, tb, k, sx, pad, dil,
                                             _ptr(a_gate), float(a_slope), _ptr(b_gate), float(b_slope), ns.value,
                                             _ptr(bias_part), st), "svb_conv1d_wgrad_bf16x3")
