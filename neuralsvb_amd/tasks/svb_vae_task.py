@@ -188,9 +188,14 @@ class SVBVAEMleTask(BaseTask):
         r = self._step_rand
         return (phase, tuple(plan), tuple(r["structure"]) if r else None)
 
+    independent_critic_pass = 1     # optimizer index of the pass the Trainer may run on its own stream (see critic_barrier)
+    critic_barrier = None           # set by the Trainer: makes the current stream wait for a critic pass still in flight
+
     def _critic_many(self, xs):
         """The critic on several mel batches at once (one stacked pass per tower) when the step's window starts were drawn
         up front and every window fits; otherwise one call after the other.  -> list of y."""
+        if self.critic_barrier is not None:
+            self.critic_barrier()
         r = self._step_rand
         n = len(xs)
         # (stacking is only an identity for per-clip layers: with disc_norm 'bn' the BatchNorm2d statistics would mix the
@@ -209,6 +214,8 @@ class SVBVAEMleTask(BaseTask):
         return [self._critic(x)["y"] for x in xs]
 
     def _critic(self, x):
+        if self.critic_barrier is not None:
+            self.critic_barrier()
         r = self._step_rand
         if r is None or r["cursor"] >= len(r["disc"]):
             return self.mel_disc(x, None, want_fmaps=False)
@@ -279,6 +286,8 @@ class SVBVAEMleTask(BaseTask):
                     # hipGraph mode: the critic pass (possibly another graph) reads the generated mels from fixed buffers
                     if not hasattr(self, "_gen_mel_buf"):
                         self._gen_mel_buf = {}
+                    if self.critic_barrier is not None:      # the previous step's critic pass may still read these buffers
+                        self.critic_barrier()
                     gt = {}
                     for w, o in self.model_out.items():
                         # one buffer per (way, shape), never freed: a captured graph has the address baked in, and the
@@ -301,6 +310,11 @@ class SVBVAEMleTask(BaseTask):
                 if disc_start and self.global_step % hparams["disc_interval"] == 0:
                     xs = [x for way in ways for x in (self.get_corresponding_gtmel(way, sample),
                                                       self.model_out_gt[way]["mel_out"])]
+                    if self.critic_barrier is not None and xs[0].is_cuda:
+                        # (this pass may run on the Trainer's critic stream: its inputs were produced on the compute stream
+                        #  and are dropped there when the next step replaces them)
+                        for x in xs:
+                            x.record_stream(torch.cuda.current_stream(x.device))
                     ys = self._critic_many(xs)   # disc_judge_gen (svb_para.py:133-170): real, fake per way, one pass
                     for i, way in enumerate(ways):
                         p, p_ = ys[2 * i], ys[2 * i + 1]

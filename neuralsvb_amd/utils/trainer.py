@@ -220,6 +220,7 @@ class Trainer:
             raise NotImplementedError("amp is not supported by the MI355X kernels: use conv_precision=bf16x3 (fp32 storage, "
                                       "bf16 matrix cores with an fp32-class operand split) instead of autocast")
         self.task, self.optimizers, self.grad_sync = None, [], []
+        self._critic_stream, self._critic_busy = None, False
         self._param_cache = None
         # hipGraph replay of each optimizer pass's forward+backward (fixed-shape batches; see _graphed_forward_backward)
         self.hip_graph, self.hip_graph_warmup, self.hip_graph_max_shapes = bool(hip_graph), hip_graph_warmup, hip_graph_max_shapes
@@ -346,6 +347,7 @@ class Trainer:
             self.save_checkpoint(epoch=self.current_epoch, logs=res)
 
     def evaluate(self, task, test=False, tqdm_desc="Valid", max_batches=None):
+        self._join_critic_stream()
         if max_batches == -1:
             max_batches = None
         self._broadcast_module_state()
@@ -504,60 +506,92 @@ class Trainer:
             batch = move_to_device(batch, self.device)            # once per step
         pbar, tb = {}, {}
         multi = len(self.optimizers) > 1
+        # The critic's own optimizer pass depends on nothing the generator pass of the NEXT step does before it calls the
+        # critic (it reads the generated mels kept from this step's forward, the batch and the critic; it writes the critic):
+        # it runs on a second stream that starts once everything issued so far is done, and the compute stream only waits
+        # for it where the generator pass first touches critic state (task.critic_barrier).  One process, eager launches.
+        disc_idx = getattr(task, "independent_critic_pass", None)
+        overlap_disc = (disc_idx is not None and self.on_gpu and not graph_mode and self.world_size == 1
+                        and self.accumulate_grad_batches == 1 and hparams.get("overlap_critic_pass", True))
+        if overlap_disc and self._critic_stream is None:
+            self._critic_stream = torch.cuda.Stream(self.device)
+        task.critic_barrier = self._join_critic_stream if overlap_disc else None
         for opt_idx, optimizer in enumerate(self.optimizers):
             if optimizer is None:
                 continue
-            if multi:   # only this optimizer's parameters receive gradients in this pass (:280-285)
-                # (the parameter lists are cached: walking task.parameters() -- a recursive named_modules() generator --
-                # three times per step cost 2 ms of a host-bound 22 ms step)
-                if self._param_cache is None or self._param_cache[0] is not task:
-                    self._param_cache = (task, list(task.parameters()),
-                                         [[p for g in o.param_groups for p in g["params"]] if o is not None else []
-                                          for o in self.optimizers])
-                for p in self._param_cache[1]:
-                    p.requires_grad = False
-                for p in self._param_cache[2][opt_idx]:
-                    p.requires_grad = True
-            sync = self.grad_sync[opt_idx] if opt_idx < len(self.grad_sync) else None
-            final_micro = (self.global_step + 1) % self.accumulate_grad_batches == 0
-            if sync is not None and not graph_mode and final_micro:
-                # overlapped exchange: buckets are all-reduced as their gradients become final during backward (only on the
-                # micro-batch that is followed by the optimizer step: earlier ones just accumulate locally)
-                from .. import functional as SF
-                key = (opt_idx, task.graph_key(self.global_step) if hasattr(task, "graph_key") else None)
-                sync.begin_pass(key)
-                SF.GRAD_READY = sync.grad_ready if sync.overlap else None
-            try:
-                if graph_mode:
-                    out = self._graphed_forward_backward(sig, batch, batch_idx, opt_idx)
-                else:
-                    out = self._forward_backward(batch, batch_idx, opt_idx)
-            finally:
-                if sync is not None and not graph_mode and final_micro:
-                    SF.GRAD_READY = None
-            if out["loss"] is None:
-                if sync is not None:
-                    sync._counts = None          # nothing to exchange in this pass
+            if overlap_disc and opt_idx == disc_idx:
+                s2 = self._critic_stream
+                s2.wait_stream(torch.cuda.current_stream(self.device))
+                for v in batch.values():
+                    if isinstance(v, torch.Tensor) and v.is_cuda:
+                        v.record_stream(s2)
+                with torch.cuda.stream(s2):
+                    self._optimizer_pass(task, batch, batch_idx, opt_idx, optimizer, multi, graph_mode, sig, pbar, tb)
+                self._critic_busy = True
                 continue
-            pbar.update(out["progress_bar"])
-            tb.update(out["tb_log"])
-            if self.print_nan_grads:
-                bad = [n for n, p in task.named_parameters() if p.grad is not None and torch.isnan(p.grad).any()]
-                if bad:
-                    print("| NaN grads: ", bad)
-                    sys.exit(0)
-            if (self.global_step + 1) % self.accumulate_grad_batches == 0:
-                sync = self.grad_sync[opt_idx]
-                sync.finish()
-                task.on_before_optimization(opt_idx)
-                optimizer.step()
-                _note_weights_updated(self._param_cache[2][opt_idx] if self._param_cache is not None else
-                                      [p for g in optimizer.param_groups for p in g["params"]], repack=True)
-                sync.zero()
-                task.on_after_optimization(self.current_epoch, batch_idx, optimizer, opt_idx)
+            self._optimizer_pass(task, batch, batch_idx, opt_idx, optimizer, multi, graph_mode, sig, pbar, tb)
         if hasattr(task, "end_step"):
             task.end_step()
         return pbar, tb
+
+    def _join_critic_stream(self):
+        """The current stream waits for the critic pass that was enqueued on its own stream (no-op from that stream itself)."""
+        if self._critic_stream is not None and self._critic_busy:
+            cur = torch.cuda.current_stream(self.device)
+            if cur != self._critic_stream:
+                cur.wait_stream(self._critic_stream)
+                self._critic_busy = False
+
+    def _optimizer_pass(self, task, batch, batch_idx, opt_idx, optimizer, multi, graph_mode, sig, pbar, tb):
+        """One optimizer of the step: forward + backward of its pass, gradient exchange, clipping, update."""
+        if multi:   # only this optimizer's parameters receive gradients in this pass (:280-285)
+            # (the parameter lists are cached: walking task.parameters() -- a recursive named_modules() generator --
+            # three times per step cost 2 ms of a host-bound 22 ms step)
+            if self._param_cache is None or self._param_cache[0] is not task:
+                self._param_cache = (task, list(task.parameters()),
+                                     [[p for g in o.param_groups for p in g["params"]] if o is not None else []
+                                      for o in self.optimizers])
+            for p in self._param_cache[1]:
+                p.requires_grad = False
+            for p in self._param_cache[2][opt_idx]:
+                p.requires_grad = True
+        sync = self.grad_sync[opt_idx] if opt_idx < len(self.grad_sync) else None
+        final_micro = (self.global_step + 1) % self.accumulate_grad_batches == 0
+        if sync is not None and not graph_mode and final_micro:
+            # overlapped exchange: buckets are all-reduced as their gradients become final during backward (only on the
+            # micro-batch that is followed by the optimizer step: earlier ones just accumulate locally)
+            from .. import functional as SF
+            key = (opt_idx, task.graph_key(self.global_step) if hasattr(task, "graph_key") else None)
+            sync.begin_pass(key)
+            SF.GRAD_READY = sync.grad_ready if sync.overlap else None
+        try:
+            if graph_mode:
+                out = self._graphed_forward_backward(sig, batch, batch_idx, opt_idx)
+            else:
+                out = self._forward_backward(batch, batch_idx, opt_idx)
+        finally:
+            if sync is not None and not graph_mode and final_micro:
+                SF.GRAD_READY = None
+        if out["loss"] is None:
+            if sync is not None:
+                sync._counts = None          # nothing to exchange in this pass
+            return
+        pbar.update(out["progress_bar"])
+        tb.update(out["tb_log"])
+        if self.print_nan_grads:
+            bad = [n for n, p in task.named_parameters() if p.grad is not None and torch.isnan(p.grad).any()]
+            if bad:
+                print("| NaN grads: ", bad)
+                sys.exit(0)
+        if (self.global_step + 1) % self.accumulate_grad_batches == 0:
+            sync = self.grad_sync[opt_idx]
+            sync.finish()
+            task.on_before_optimization(opt_idx)
+            optimizer.step()
+            _note_weights_updated(self._param_cache[2][opt_idx] if self._param_cache is not None else
+                                  [p for g in optimizer.param_groups for p in g["params"]], repack=True)
+            sync.zero()
+            task.on_after_optimization(self.current_epoch, batch_idx, optimizer, opt_idx)
 
     # ------------------------------------------------------------------ checkpoints (reference :347-436)
     def restore_weights(self, checkpoint):
@@ -599,6 +633,7 @@ class Trainer:
         os.replace(tmp, filepath)
 
     def save_checkpoint(self, epoch, logs=None):
+        self._join_critic_stream()
         path = f"{self.work_dir}/model_ckpt_steps_{self.global_step}.ckpt"
         logging.info(f"Epoch {epoch:05d}@{self.global_step}: saving model to {path}")
         self._atomic_save(path)
@@ -612,6 +647,7 @@ class Trainer:
 
     # ------------------------------------------------------------------ logging
     def log_metrics_to_tb(self, metrics, step=None):
+        self._join_critic_stream()
         metrics = dict(metrics)
         metrics["epoch"] = self.current_epoch
         step = self.global_step if step is None else step
