@@ -226,7 +226,8 @@ class SVBVAEMleTask(BaseTask):
 
     # ------------------------------------------------------------------ model run (svb_vae_task.py:120-165)
     def run_model(self, model, sample, concurrent_ways, return_output=False, infer=False, disable_map=False, **inject):
-        model.vc_asr.eval()
+        if model.vc_asr.training:          # (pinned to eval by VCASR.train(); walking its ~120 submodules every step cost 0.3 ms)
+            model.vc_asr.eval()
         r = self._step_rand
         if infer:
             spk = sample["multi_spk_emb"][:, 0, :]
@@ -277,7 +278,8 @@ class SVBVAEMleTask(BaseTask):
         phase, ways = self.phase_of(self.global_step)
         if optimizer_idx == 0:
             if phase in (1, 2):
-                self.model.z_mapping_function.eval()
+                if self.model.z_mapping_function.training:
+                    self.model.z_mapping_function.eval()
                 log_outputs, model_out = self.run_model(self.model, sample, ways, return_output=True)
                 self.model_out = {w: {k: v.detach() for k, v in o.items() if isinstance(v, torch.Tensor)}
                                   for w, o in model_out.items()}
@@ -306,7 +308,8 @@ class SVBVAEMleTask(BaseTask):
                             loss_weights[f"{way}_a"] = hparams["lambda_mel_adv"]
         elif optimizer_idx == 1:
             if phase in (1, 2):
-                self.model.z_mapping_function.eval()
+                if self.model.z_mapping_function.training:
+                    self.model.z_mapping_function.eval()
                 if disc_start and self.global_step % hparams["disc_interval"] == 0:
                     xs = [x for way in ways for x in (self.get_corresponding_gtmel(way, sample),
                                                       self.model_out_gt[way]["mel_out"])]
