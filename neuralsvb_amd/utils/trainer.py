@@ -221,6 +221,7 @@ class Trainer:
                                       "bf16 matrix cores with an fp32-class operand split) instead of autocast")
         self.task, self.optimizers, self.grad_sync = None, [], []
         self._critic_stream, self._critic_busy = None, False
+        self._grad_enabled_for = None        # (task, optimizer index) whose parameters currently have requires_grad = True
         self._param_cache = None
         # hipGraph replay of each optimizer pass's forward+backward (fixed-shape batches; see _graphed_forward_backward)
         self.hip_graph, self.hip_graph_warmup, self.hip_graph_max_shapes = bool(hip_graph), hip_graph_warmup, hip_graph_max_shapes
@@ -551,10 +552,19 @@ class Trainer:
                 self._param_cache = (task, list(task.parameters()),
                                      [[p for g in o.param_groups for p in g["params"]] if o is not None else []
                                       for o in self.optimizers])
-            for p in self._param_cache[1]:
-                p.requires_grad = False
-            for p in self._param_cache[2][opt_idx]:
-                p.requires_grad = True
+            # (only what changes: the previous pass's parameters off, this pass's on -- not all ~400 twice per pass)
+            prev = self._grad_enabled_for
+            fresh = prev is None or prev[0] is not task
+            if fresh:
+                for p in self._param_cache[1]:
+                    p.requires_grad = False
+            elif prev[1] != opt_idx:
+                for p in self._param_cache[2][prev[1]]:
+                    p.requires_grad = False
+            if fresh or prev[1] != opt_idx:
+                for p in self._param_cache[2][opt_idx]:
+                    p.requires_grad = True
+                self._grad_enabled_for = (task, opt_idx)
         sync = self.grad_sync[opt_idx] if opt_idx < len(self.grad_sync) else None
         final_micro = (self.global_step + 1) % self.accumulate_grad_batches == 0
         if sync is not None and not graph_mode and final_micro:
