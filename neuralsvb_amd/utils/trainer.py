@@ -59,7 +59,9 @@ class FlatGradSync:
     """Gradients of one optimizer live in one contiguous fp32 buffer (param.grad are views of it): zeroing is a single
     memset and the data-parallel exchange works on contiguous BUCKETS of that buffer.
 
-    Difference from the reference's `optimizer.zero_grad()` (grads -> None): a parameter that receives no gradient in a pass
+    Difference from the reference's `optimizer.zero_grad()` (grads -> None): a parameter that owns a slice of the buffer (all
+    of them when several processes exchange gradients or a hipGraph needs fixed addresses; otherwise only those a kernel
+    accumulates into, see `drop_autograd_grads`) and receives no gradient in a pass
     keeps a ZERO gradient here, so AdamW still applies its step to it (stale momentum decays towards zero, weight decay
     acts).  Results are identical to the reference exactly when every parameter of an optimizer gets a gradient in each of
     its passes -- true for the three optimizers of SVBVAEMleTask in every phase -- or when weight_decay == 0 and the
