@@ -212,6 +212,18 @@ int svb_col2im(const float* dcols, float* dx, int B, int C, int H, int W, int KH
 int svb_s2d_pad(const float* x, float* out, int N, int C, int H, int W, long sn, long sc, long sh, long sw, void* stream);
 int svb_s2d_pad_bwd(const float* dout, float* dx, int N, int C, int H, int W, void* stream);
 
+/* Random-window crop of stacked critic calls straight into the first block's planes (reference multi_window_disc.py:131-152:
+ * x[:, :, s:s+wl] per window length; the calls of a pass -- real / generated mels of each way -- stacked along the batch):
+ * source k = xs[k], a [B][T][F] mel addressed with element strides strides[3k..3k+2] (batch, time, bin), window start
+ * starts[k]; out = svb_s2d_pad's layout [4][n_src*B][wl/2+1][F/2+1] with C = 1 and clip b of source k at n = k*B + b.
+ * xs / strides / starts (and dplanes / wls below) are HOST arrays.  n_src <= 8, wl and F even.
+ * _bwd, all window lengths at once: dx [n_src][B][T][F] (contiguous) = sum over windows w with starts[w*n_src+k] <= t <
+ * starts[..] + wls[w] of dplanes[w] at the matching plane element, 0 where no window covers t.  n_win <= 4.          */
+int svb_win_s2d(const float* const* xs, const long* strides, const int* starts, float* out, int n_src, int B, int wl, int F,
+                void* stream);
+int svb_win_s2d_bwd(const float* const* dplanes, const int* wls, const int* starts, float* dx, int n_win, int n_src, int B, int T,
+                    int F, void* stream);
+
 /* ---- the rest of a critic block around that conv (reference multi_window_disc.py:14-31, :62-64), batch-stacked planes.
  * svb_s2_weight:      w [Cout][C][3][3] -> w4 [Cout][4C][4], the 2x2 stride-1 kernel over the space-to-depth planes
  *                     (channel (ph*2+pw)*C + c, tap (di+1)*2 + (dj+1); kernel row kh <-> (di,ph): 0:(-1,1) 1:(0,0) 2:(0,1)).
@@ -247,6 +259,18 @@ int svb_ssim_fwd(const float* pred, long psb, long pst, long psf, const float* t
                  float* out_map, int B, int T, int F, float bias, void* stream);
 int svb_ssim_bwd(const float* pred, long psb, long pst, long psf, const float* tgt, long tsb, long tst, long tsf,
                  const float* dmap, float* dpred, float* workspace, int B, int T, int F, float bias, void* stream);
+
+/* ---- Fused mel loss of one way (reference tasks/tts/fs2.py:143-175 l1_loss / ssim_loss with weights_nonzero_speech):
+ * w[b,t] = any_f(tgt[b,t,f] != 0);  out[0] = sum|pred-tgt|w / sum w;  out[1] = sum(1-ssim(pred+bias,tgt+bias))w / sum w;
+ * out[2] = sum w (sums over all B*T*F pixels).  terms: bit 0 = L1, bit 1 = SSIM (an unselected term's out[] is 0).
+ * part: 3*B*ceil(T/16) floats of scratch (per-tile partial sums, reduced in fixed order: deterministic).
+ * Backward: gout [2+] = d/d out[0], d/d out[1] (device), sums = the forward's out; dpred contiguous [B,T,F];
+ * workspace: 3*B*T*F floats (only with the SSIM term).  Only `pred` receives a gradient.                      */
+int svb_mel_loss_fwd(const float* pred, long psb, long pst, long psf, const float* tgt, long tsb, long tst, long tsf,
+                     float* out, float* part, int B, int T, int F, float bias, int terms, void* stream);
+int svb_mel_loss_bwd(const float* pred, long psb, long pst, long psf, const float* tgt, long tsb, long tst, long tsf,
+                     const float* gout, const float* sums, float* dpred, float* workspace, int B, int T, int F, float bias,
+                     int terms, void* stream);
 
 /* ---- STFT magnitude + mel filterbank + log, one kernel (reference data_gen/tts/data_gen_utils.py:123-134 and
  * modules/hifigan/mel_utils.py:45-79).  wav: [B, N].  mode 0 = offline front-end: zero-pad n_fft/2 both sides

@@ -64,6 +64,8 @@ SIGNATURES = {
     "svb_col2im": (I, [P, P] + [I] * 12 + [C.c_long] * 2 + [P]),
     "svb_s2d_pad": (I, [P, P, I, I, I, I, C.c_long, C.c_long, C.c_long, C.c_long, P]),
     "svb_s2d_pad_bwd": (I, [P, P, I, I, I, I, P]),
+    "svb_win_s2d": (I, [P, P, P, P, I, I, I, I, P]),
+    "svb_win_s2d_bwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "svb_s2_weight": (I, [P, P, I, I, P]),
     "svb_s2_weight_bwd": (I, [P, P, P, I, I, I, P]),
     "svb_crop_drop_inorm_fwd": (I, [P, P, P, P, C.c_float, P, P, I, I, I, I, I, P]),
@@ -72,6 +74,8 @@ SIGNATURES = {
     "svb_plane_score_bwd": (I, [P, P, C.c_long, C.c_long, P, P, P, P, I, I, I, P]),
     "svb_ssim_fwd": (I, [P, C.c_long, C.c_long, C.c_long, P, C.c_long, C.c_long, C.c_long, P, I, I, I, F, P]),
     "svb_ssim_bwd": (I, [P, C.c_long, C.c_long, C.c_long, P, C.c_long, C.c_long, C.c_long, P, P, P, I, I, I, F, P]),
+    "svb_mel_loss_fwd": (I, [P, C.c_long, C.c_long, C.c_long, P, C.c_long, C.c_long, C.c_long, P, P, I, I, I, F, I, P]),
+    "svb_mel_loss_bwd": (I, [P, C.c_long, C.c_long, C.c_long, P, C.c_long, C.c_long, C.c_long, P, P, P, P, I, I, I, F, I, P]),
     "svb_stft_mel": (I, [P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "svb_nsf_source": (I, [P, P, P, P, P, P, P, P, I, I, I, I, F, F, F, P]),
     "svb_f0_to_coarse_f64": (I, [P, P, I64, P]),

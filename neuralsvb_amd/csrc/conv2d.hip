@@ -147,6 +147,95 @@ extern "C" int svb_s2d_pad_bwd(const float* dout, float* dx, int N, int C, int H
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Random-window crop of several mel batches straight into the first block's space-to-depth planes, and its gradient.
+// The critic (reference multi_window_disc.py:131-152) crops x[:, :, s : s+wl] per window length and call; stacked calls
+// (real / generated mels of each way) become one batch.  Forward, one launch per window length: source k's clip b is plane
+// n = k*B + b of out [4][n_src*B][wl/2+1][F/2+1] -- replaces slice + cat + svb_s2d_pad.  Backward, ONE launch for all
+// window lengths: dx[k][b][t][f] = sum over the windows that contain t of the plane gradient -- replaces, per window
+// and source, the zero-filled full-size gradient of the slice, and the adds that sum the windows' gradients.
+// ------------------------------------------------------------------------------------------------------------------
+#define SVB_WIN_MAX_SRC 8
+#define SVB_WIN_MAX_WIN 4
+struct SvbWinSrc { const float* x[SVB_WIN_MAX_SRC]; long sb[SVB_WIN_MAX_SRC], st[SVB_WIN_MAX_SRC], sf[SVB_WIN_MAX_SRC];
+                   int start[SVB_WIN_MAX_SRC]; };
+struct SvbWinGrad { const float* dplanes[SVB_WIN_MAX_WIN]; int wl[SVB_WIN_MAX_WIN];
+                    int start[SVB_WIN_MAX_WIN * SVB_WIN_MAX_SRC]; };
+
+__global__ __launch_bounds__(256) void svb_win_s2d_kernel(SvbWinSrc src, float* out, int n_src, int B, int wl, int F) {
+    const int P = F / 2 + 1, R = wl / 2 + 1, N = n_src * B;
+    const long total = 4L * N * R * P;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int jp = (int)(i % P);
+        long r = i / P;
+        const int ip = (int)(r % R); r /= R;
+        const int n = (int)(r % N);
+        const int blk = (int)(r / N);
+        float v = 0.f;
+        if (ip > 0 && jp > 0) {
+            const int k = n / B, b = n - k * B;
+            const int t = src.start[k] + 2 * (ip - 1) + (blk >> 1), f = 2 * (jp - 1) + (blk & 1);
+            v = src.x[k][(long)b * src.sb[k] + (long)t * src.st[k] + (long)f * src.sf[k]];
+        }
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void svb_win_s2d_bwd_kernel(SvbWinGrad g, float* dx, int n_win, int n_src, int B, int T, int F) {
+    const int P = F / 2 + 1, N = n_src * B;
+    const long total = (long)N * T * F;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int f = (int)(i % F);
+        long r = i / F;
+        const int t = (int)(r % T);
+        const int n = (int)(r / T);
+        const int k = n / B;
+        float v = 0.f;
+        for (int w = 0; w < n_win; ++w) {
+            const int h = t - g.start[w * SVB_WIN_MAX_SRC + k];
+            if (h >= 0 && h < g.wl[w]) {
+                const int R = g.wl[w] / 2 + 1;
+                v += g.dplanes[w][((((long)((h & 1) * 2 + (f & 1))) * N + n) * R + (h >> 1) + 1) * P + (f >> 1) + 1];
+            }
+        }
+        dx[i] = v;
+    }
+}
+
+extern "C" int svb_win_s2d(const float* const* xs, const long* strides, const int* starts, float* out, int n_src, int B, int wl,
+                           int F, void* stream) {
+    if (!xs || !strides || !starts || !out || n_src <= 0 || n_src > SVB_WIN_MAX_SRC || B <= 0 || wl <= 0 || F <= 0 || (wl & 1) ||
+        (F & 1))
+        return SVB_ERR_ARG;
+    SvbWinSrc src;
+    for (int k = 0; k < n_src; ++k) {
+        if (!xs[k] || starts[k] < 0) return SVB_ERR_ARG;
+        src.x[k] = xs[k]; src.sb[k] = strides[3 * k]; src.st[k] = strides[3 * k + 1]; src.sf[k] = strides[3 * k + 2];
+        src.start[k] = starts[k];
+    }
+    hipLaunchKernelGGL(svb_win_s2d_kernel, dim3(g1d(4L * n_src * B * (wl / 2 + 1) * (F / 2 + 1))), dim3(256), 0,
+                       (hipStream_t)stream, src, out, n_src, B, wl, F);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_win_s2d_bwd(const float* const* dplanes, const int* wls, const int* starts, float* dx, int n_win, int n_src,
+                               int B, int T, int F, void* stream) {
+    if (!dplanes || !wls || !starts || !dx || n_win <= 0 || n_win > SVB_WIN_MAX_WIN || n_src <= 0 || n_src > SVB_WIN_MAX_SRC ||
+        B <= 0 || T <= 0 || F <= 0 || (F & 1))
+        return SVB_ERR_ARG;
+    SvbWinGrad g;
+    for (int w = 0; w < n_win; ++w) {
+        if (!dplanes[w] || wls[w] <= 0 || (wls[w] & 1)) return SVB_ERR_ARG;
+        g.dplanes[w] = dplanes[w]; g.wl[w] = wls[w];
+        for (int k = 0; k < n_src; ++k) g.start[w * SVB_WIN_MAX_SRC + k] = starts[w * n_src + k];
+    }
+    hipLaunchKernelGGL(svb_win_s2d_bwd_kernel, dim3(g1d((long)n_src * B * T * F)), dim3(256), 0, (hipStream_t)stream, g, dx, n_win,
+                       n_src, B, T, F);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Weight re-layout for the space-to-depth conv: w [Cout][C][3][3] -> w4 [Cout][4C][4]
 //   channel (ph*2+pw)*C + c, tap (di+1)*2 + (dj+1);  kernel row kh <-> (di, ph): 0 <-> (-1,1), 1 <-> (0,0), 2 <-> (0,1);
 //   the 7 (block, tap) slots without a kernel entry are zero.  The inverse gathers the weight gradient back (its two tap

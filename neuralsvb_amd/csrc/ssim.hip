@@ -145,6 +145,168 @@ __global__ __launch_bounds__(256) void svb_ssim_bwd2_kernel(const float* pred, l
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fused mel loss of one way (reference tasks/tts/fs2.py:143-175: l1_loss, ssim_loss, weights_nonzero_speech): the masked
+// L1 term and the masked (1 - SSIM) term of (pred, target) in ONE pass, forward and backward.  Replaces, per way and
+// step, ~17 stock elementwise / reduction launches forward (abs, sum, ne, float, sub, abs, mul, sum, div, rsub, ...)
+// and ~12 backward, plus the [B,T,F] SSIM map, weight and dmap tensors.
+//   w[b,t]   = any_f(target[b,t,f] != 0)                      (== target.abs().sum(-1).ne(0): a sum of magnitudes)
+//   out[0]   = sum |pred - target| w / sum w ;  out[1] = sum (1 - ssim) w / sum w ;  out[2] = sum w  (over all pixels)
+// Workgroup = the SSIM kernels' tile (16 frames x all bins); per-tile partial sums are written to `part` and summed in
+// fixed order by a one-workgroup second launch (deterministic, no atomics).  terms: bit 0 = L1, bit 1 = SSIM.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mel_speech_rows(const float* tgt, long tsb, long tst, long tsf, int b, int t0, int T, int F,
+                                                float* wrow) {
+    if (threadIdx.x < SSIM_TT) wrow[threadIdx.x] = 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
+        const int r = i / F, c = i - r * F;
+        const int t = t0 + r;
+        if (t < T && tgt[(long)b * tsb + (long)t * tst + (long)c * tsf] != 0.f) wrow[r] = 1.f;   // (benign race: one value)
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void svb_mel_loss_fwd_kernel(const float* pred, long psb, long pst, long psf, const float* tgt,
+                                                               long tsb, long tst, long tsf, float* part, int B, int T, int F,
+                                                               float bias, int terms, SsimWin w) {
+    __shared__ float xs[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    __shared__ float ys[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    __shared__ float wrow[SSIM_TT];
+    __shared__ float red[4];
+    const int b = blockIdx.y, t0 = blockIdx.x * SSIM_TT;
+    const int ld = F + 2 * SSIM_R, rows = SSIM_TT + 2 * SSIM_R;
+    if (terms & 2) {
+        ssim_stage(pred, psb, pst, psf, b, T, F, t0 - SSIM_R, rows, bias, xs, ld);
+        ssim_stage(tgt, tsb, tst, tsf, b, T, F, t0 - SSIM_R, rows, bias, ys, ld);
+    }
+    mel_speech_rows(tgt, tsb, tst, tsf, b, t0, T, F, wrow);
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    float a_l1 = 0.f, a_ss = 0.f, a_w = 0.f;
+    for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
+        const int r = i / F, c = i - r * F;
+        const int t = t0 + r;
+        if (t >= T) continue;
+        const float wt = wrow[r];
+        a_w += wt;
+        if (terms & 1) {
+            const float p = pred[(long)b * psb + (long)t * pst + (long)c * psf];
+            const float y = tgt[(long)b * tsb + (long)t * tst + (long)c * tsf];
+            a_l1 += fabsf(p - y) * wt;
+        }
+        if (terms & 2) {
+            const SsimStats s = ssim_window(xs, ys, r, c, ld, w);
+            const float mu1_sq = s.mu1 * s.mu1, mu2_sq = s.mu2 * s.mu2, mu12 = s.mu1 * s.mu2;
+            const float s1 = s.e11 - mu1_sq, s2 = s.e22 - mu2_sq, s12 = s.e12 - mu12;
+            const float m = ((2.f * mu12 + C1) * (2.f * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2));
+            a_ss += (1.f - m) * wt;
+        }
+    }
+    a_l1 = svb_block_sum<256>(a_l1, red);
+    a_ss = svb_block_sum<256>(a_ss, red);
+    a_w = svb_block_sum<256>(a_w, red);
+    if (threadIdx.x == 0) {
+        float* pp = part + 3 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        pp[0] = a_l1; pp[1] = a_ss; pp[2] = a_w;
+    }
+}
+
+// out[k] = sum_j part[j][k] (k = 0..2) in a fixed order, then the two means
+__global__ __launch_bounds__(256) void svb_mel_loss_final_kernel(const float* part, int n, float* out) {
+    __shared__ float red[4];
+    float a[3] = {0.f, 0.f, 0.f};
+    for (int j = threadIdx.x; j < n; j += 256)
+        for (int k = 0; k < 3; ++k) a[k] += part[3 * (size_t)j + k];
+    for (int k = 0; k < 3; ++k) a[k] = svb_block_sum<256>(a[k], red);
+    if (threadIdx.x == 0) { out[0] = a[0] / a[2]; out[1] = a[1] / a[2]; out[2] = a[2]; }
+}
+
+// backward stage 1 with d(map) = -gout[1] * w / sum w computed in place of a dmap tensor
+__global__ __launch_bounds__(256) void svb_mel_loss_bwd1_kernel(const float* pred, long psb, long pst, long psf, const float* tgt,
+                                                                long tsb, long tst, long tsf, const float* gout,
+                                                                const float* sums, float* gws, int B, int T, int F, float bias,
+                                                                SsimWin w) {
+    __shared__ float xs[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    __shared__ float ys[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    __shared__ float wrow[SSIM_TT];
+    const int b = blockIdx.y, t0 = blockIdx.x * SSIM_TT;
+    const int ld = F + 2 * SSIM_R, rows = SSIM_TT + 2 * SSIM_R;
+    ssim_stage(pred, psb, pst, psf, b, T, F, t0 - SSIM_R, rows, bias, xs, ld);
+    ssim_stage(tgt, tsb, tst, tsf, b, T, F, t0 - SSIM_R, rows, bias, ys, ld);
+    mel_speech_rows(tgt, tsb, tst, tsf, b, t0, T, F, wrow);
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const long plane = (long)B * T * F;
+    const float gs = -gout[1] / sums[2];
+    for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
+        const int r = i / F, c = i - r * F;
+        const int t = t0 + r;
+        if (t >= T) continue;
+        const SsimStats s = ssim_window(xs, ys, r, c, ld, w);
+        const float mu1_sq = s.mu1 * s.mu1, mu2_sq = s.mu2 * s.mu2, mu12 = s.mu1 * s.mu2;
+        const float s1 = s.e11 - mu1_sq, s2 = s.e22 - mu2_sq, s12 = s.e12 - mu12;
+        const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s1 + s2 + C2;
+        const float inv = 1.f / (B1 * B2);
+        const float m = A1 * A2 * inv;
+        const long o = ((long)b * T + t) * F + c;
+        const float dm = gs * wrow[r];
+        const float dA1 = A2 * inv, dA2 = A1 * inv, dB1 = -m / B1, dB2 = -m / B2;
+        gws[o] = dm * (2.f * s.mu2 * dA1 - 2.f * s.mu2 * dA2 + 2.f * s.mu1 * dB1 - 2.f * s.mu1 * dB2);
+        gws[plane + o] = dm * dB2;
+        gws[2 * plane + o] = dm * 2.f * dA2;
+    }
+}
+
+// backward stage 2 (terms & 2) plus the L1 term's gout[0] * sgn(pred - target) * w / sum w (terms & 1)
+__global__ __launch_bounds__(256) void svb_mel_loss_bwd2_kernel(const float* pred, long psb, long pst, long psf, const float* tgt,
+                                                                long tsb, long tst, long tsf, const float* gout,
+                                                                const float* sums, const float* gws, float* dpred, int B, int T,
+                                                                int F, float bias, int terms, SsimWin w) {
+    __shared__ float ga[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    __shared__ float gb[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    __shared__ float gc[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    __shared__ float wrow[SSIM_TT];
+    const int b = blockIdx.y, t0 = blockIdx.x * SSIM_TT;
+    const int ld = F + 2 * SSIM_R, rows = SSIM_TT + 2 * SSIM_R;
+    const long plane = (long)B * T * F;
+    const long sb = (long)T * F;
+    if (terms & 2) {
+        ssim_stage(gws, sb, F, 1, b, T, F, t0 - SSIM_R, rows, 0.f, ga, ld);
+        ssim_stage(gws + plane, sb, F, 1, b, T, F, t0 - SSIM_R, rows, 0.f, gb, ld);
+        ssim_stage(gws + 2 * plane, sb, F, 1, b, T, F, t0 - SSIM_R, rows, 0.f, gc, ld);
+    }
+    mel_speech_rows(tgt, tsb, tst, tsf, b, t0, T, F, wrow);
+    const float gl = (terms & 1) ? gout[0] / sums[2] : 0.f;
+    for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
+        const int r = i / F, c = i - r * F;
+        const int t = t0 + r;
+        if (t >= T) continue;
+        const float p = pred[(long)b * psb + (long)t * pst + (long)c * psf];
+        const float y = tgt[(long)b * tsb + (long)t * tst + (long)c * tsf];
+        float d = 0.f;
+        if (terms & 2) {
+            float fa = 0.f, fb = 0.f, fc = 0.f;
+#pragma unroll
+            for (int ii = 0; ii < SSIM_W; ++ii) {
+                const float gi = w.g[ii];
+                const int base = (r + ii) * ld + c;
+#pragma unroll
+                for (int j = 0; j < SSIM_W; ++j) {
+                    const float wij = gi * w.g[j];
+                    fa = fmaf(wij, ga[base + j], fa);
+                    fb = fmaf(wij, gb[base + j], fb);
+                    fc = fmaf(wij, gc[base + j], fc);
+                }
+            }
+            d = fa + 2.f * (p + bias) * fb + (y + bias) * fc;
+        }
+        if (terms & 1) {
+            const float df = p - y;
+            d += (df > 0.f ? gl : (df < 0.f ? -gl : 0.f)) * wrow[r];
+        }
+        dpred[((long)b * T + t) * F + c] = d;
+    }
+}
+
 static SsimWin make_window() {
     SsimWin w;
     float sum = 0.f;
@@ -176,6 +338,36 @@ extern "C" int svb_ssim_bwd(const float* pred, long psb, long pst, long psf, con
                        dmap, workspace, B, T, F, bias, w);
     hipLaunchKernelGGL(svb_ssim_bwd2_kernel, grid, dim3(256), 0, (hipStream_t)stream, pred, psb, pst, psf, tgt, tsb, tst, tsf,
                        workspace, dpred, B, T, F, bias, w);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_mel_loss_fwd(const float* pred, long psb, long pst, long psf, const float* tgt, long tsb, long tst, long tsf,
+                                float* out, float* part, int B, int T, int F, float bias, int terms, void* stream) {
+    if (!pred || !tgt || !out || !part || B <= 0 || T <= 0 || F <= 0 || F > SSIM_FMAX || B > 65535 || !(terms & 3))
+        return SVB_ERR_ARG;
+    dim3 grid(svb_cdiv(T, SSIM_TT), B);
+    hipLaunchKernelGGL(svb_mel_loss_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, pred, psb, pst, psf, tgt, tsb, tst, tsf,
+                       part, B, T, F, bias, terms, make_window());
+    hipLaunchKernelGGL(svb_mel_loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)part,
+                       (int)(grid.x * grid.y), out);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_mel_loss_bwd(const float* pred, long psb, long pst, long psf, const float* tgt, long tsb, long tst, long tsf,
+                                const float* gout, const float* sums, float* dpred, float* workspace, int B, int T, int F,
+                                float bias, int terms, void* stream) {
+    if (!pred || !tgt || !gout || !sums || !dpred || B <= 0 || T <= 0 || F <= 0 || F > SSIM_FMAX || B > 65535 || !(terms & 3) ||
+        ((terms & 2) && !workspace))
+        return SVB_ERR_ARG;
+    dim3 grid(svb_cdiv(T, SSIM_TT), B);
+    const SsimWin w = make_window();
+    if (terms & 2)
+        hipLaunchKernelGGL(svb_mel_loss_bwd1_kernel, grid, dim3(256), 0, (hipStream_t)stream, pred, psb, pst, psf, tgt, tsb, tst,
+                           tsf, gout, sums, workspace, B, T, F, bias, w);
+    hipLaunchKernelGGL(svb_mel_loss_bwd2_kernel, grid, dim3(256), 0, (hipStream_t)stream, pred, psb, pst, psf, tgt, tsb, tst, tsf,
+                       gout, sums, (const float*)workspace, dpred, B, T, F, bias, terms, w);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }

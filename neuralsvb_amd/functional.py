@@ -564,6 +564,27 @@ def ssim_map(pred, target, bias=6.0):
     return _SsimMapFn.apply(pred, target.detach(), float(bias))
 
 
+class _MelLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, bias, terms):
+        out = K.mel_loss_fwd(pred, target, bias, terms)
+        ctx.bias, ctx.terms = bias, terms
+        ctx.save_for_backward(pred, target, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target, out = ctx.saved_tensors
+        return K.mel_loss_bwd(pred, target, gout.contiguous(), out, ctx.bias, ctx.terms), None, None, None
+
+
+def mel_loss(pred, target, bias=6.0, l1=True, ssim=True):
+    """The mel loss terms of one way in one pass (reference tasks/tts/fs2.py:143-175): -> [3] =
+    (l1_loss(pred, target), ssim_loss(pred, target), sum of weights_nonzero_speech(target)); a term that is switched off is 0.
+    Gradient flows to `pred` only (element 2 carries none)."""
+    return _MelLossFn.apply(pred, target.detach(), float(bias), (1 if l1 else 0) | (2 if ssim else 0))
+
+
 class _Conv2dFn(torch.autograd.Function):
     """Small strided Conv2d = im2col + the implicit-GEMM 1x1 conv kernel (+ fused LeakyReLU epilogue).
     reference: modules/fastspeech/multi_window_disc.py:14-31 (Conv2d 3x3 stride 2 pad 1 + LeakyReLU(0.2)).
@@ -657,6 +678,39 @@ class _S2DPadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx4):
         return K.s2d_pad_bwd(dx4.contiguous(), *ctx.shape)
+
+
+class _WindowCropS2DFn(torch.autograd.Function):
+    """The critic's random-window crops of several stacked calls, for ALL window lengths, straight into the first block's
+    space-to-depth planes (reference multi_window_disc.py:131-152).  forward(cfg, *xs): cfg = (wls, starts) with
+    starts[w][k] the window start of source k for window length wls[w]; xs[k] [B,T,F] -> one [1, 4, n*B*(wl/2+1)*(F/2+1)]
+    tensor per window length.  Backward: one gather over all windows writes every source's full-size gradient."""
+
+    @staticmethod
+    def forward(ctx, cfg, *xs):
+        wls, starts = cfg
+        ctx.cfg, ctx.shape, ctx.n = cfg, tuple(xs[0].shape), len(xs)
+        outs = tuple(K.win_s2d(xs, starts[w], wl).view(1, 4, -1) for w, wl in enumerate(wls))
+        return outs
+
+    @staticmethod
+    def backward(ctx, *dplanes):
+        wls, starts = ctx.cfg
+        B, T, Fb = ctx.shape
+        # (a window length whose planes received no gradient contributes zeros)
+        dps = [d.contiguous() if d is not None else None for d in dplanes]
+        keep = [w for w, d in enumerate(dps) if d is not None]
+        if not keep:
+            return (None,) * (1 + ctx.n)
+        dx = K.win_s2d_bwd([dps[w] for w in keep], [wls[w] for w in keep], [starts[w] for w in keep], ctx.n, B, T, Fb)
+        return (None,) + tuple(dx[k] if ctx.needs_input_grad[1 + k] else None for k in range(ctx.n))
+
+
+def window_crop_s2d(xs, wls, starts):
+    """-> [(x4, planes)] per window length, ready for critic_block(x4, ..., planes=planes); planes = (n*B, 1, wl, F)."""
+    B, T, Fb = xs[0].shape
+    outs = _WindowCropS2DFn.apply((tuple(int(w) for w in wls), tuple(tuple(int(v) for v in row) for row in starts)), *xs)
+    return [(o, (len(xs) * B, 1, int(wl), Fb)) for o, wl in zip(outs, wls)]
 
 
 class _Conv2dS2Fn(torch.autograd.Function):

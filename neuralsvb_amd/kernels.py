@@ -685,6 +685,37 @@ def s2d_pad_bwd(dout, N, Cc, H, W):
     return dx
 
 
+def win_s2d(xs, starts, wl):
+    """xs: mels [B,T,F] (any strides, equal shapes); starts[k]: window start of source k -> the stacked crops
+    xs[k][:, starts[k]:starts[k]+wl] as space-to-depth planes [4, len(xs)*B, wl/2+1, F/2+1] (s2d_pad's layout, C = 1)."""
+    _f32(*xs)
+    lib, st = _prep_strided(*xs)
+    B, T, Fb = xs[0].shape
+    n = len(xs)
+    for x, s0 in zip(xs, starts):
+        if tuple(x.shape) != (B, T, Fb) or s0 < 0 or s0 + wl > T:
+            raise ValueError("win_s2d: equal-shape sources and windows inside the clip")
+    out = torch.empty((4, n * B, wl // 2 + 1, Fb // 2 + 1), device=xs[0].device, dtype=torch.float32)
+    ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    strides = (C.c_long * (3 * n))(*[v for x in xs for v in x.stride()])
+    sts = (C.c_int * n)(*[int(v) for v in starts])
+    L.check(lib.svb_win_s2d(ptrs, strides, sts, _ptr(out), n, B, int(wl), Fb, st), "svb_win_s2d")
+    return out
+
+
+def win_s2d_bwd(dplanes, wls, starts, n_src, B, T, Fb):
+    """dplanes[w]: gradient of win_s2d's output for window length wls[w]; starts[w][k] -> dx [n_src, B, T, F]."""
+    _f32(*dplanes)
+    lib, st = _prep(*dplanes)
+    nw = len(dplanes)
+    dx = torch.empty((n_src, B, T, Fb), device=dplanes[0].device, dtype=torch.float32)
+    ptrs = (C.c_void_p * nw)(*[d.data_ptr() for d in dplanes])
+    wl = (C.c_int * nw)(*[int(v) for v in wls])
+    sts = (C.c_int * (nw * n_src))(*[int(v) for row in starts for v in row])
+    L.check(lib.svb_win_s2d_bwd(ptrs, wl, sts, _ptr(dx), nw, n_src, B, T, Fb, st), "svb_win_s2d_bwd")
+    return dx
+
+
 def s2_weight(w, out=None):
     """[Cout,C,3,3] stride-2 kernel -> [Cout,4C,4], the equivalent 2x2 stride-1 kernel over the space-to-depth planes."""
     _f32(w)
@@ -790,6 +821,30 @@ def ssim_bwd(pred, target, dmap, bias=6.0):
     ws = torch.empty((3 * B * T * Fb,), device=pred.device, dtype=torch.float32)
     L.check(lib.svb_ssim_bwd(_ptr(pred), *pred.stride(), _ptr(target), *target.stride(), _ptr(dmap), _ptr(dpred), _ptr(ws),
                              B, T, Fb, float(bias), st), "svb_ssim_bwd")
+    return dpred
+
+
+def mel_loss_fwd(pred, target, bias=6.0, terms=3):
+    """pred/target [B,T,F] (any strides) -> out[3] = (masked L1 mean, masked (1-SSIM) mean, sum of speech weights)."""
+    _f32(pred, target)
+    lib, st = _prep_strided(pred, target)
+    B, T, Fb = pred.shape
+    out = torch.empty((3,), device=pred.device, dtype=torch.float32)
+    part = torch.empty((3 * B * ((T + 15) // 16),), device=pred.device, dtype=torch.float32)
+    L.check(lib.svb_mel_loss_fwd(_ptr(pred), *pred.stride(), _ptr(target), *target.stride(), _ptr(out), _ptr(part), B, T, Fb,
+                                 float(bias), int(terms), st), "svb_mel_loss_fwd")
+    return out
+
+
+def mel_loss_bwd(pred, target, gout, sums, bias=6.0, terms=3):
+    """gout: [>=2] gradients of out[0], out[1]; sums: the forward's out.  -> dpred [B,T,F]."""
+    _f32(pred, target, gout, sums)
+    lib, st = _prep_strided(pred, target, gout)
+    B, T, Fb = pred.shape
+    dpred = torch.empty((B, T, Fb), device=pred.device, dtype=torch.float32)
+    ws = torch.empty((3 * B * T * Fb,), device=pred.device, dtype=torch.float32) if terms & 2 else None
+    L.check(lib.svb_mel_loss_bwd(_ptr(pred), *pred.stride(), _ptr(target), *target.stride(), _ptr(gout), _ptr(sums), _ptr(dpred),
+                                 _ptr(ws), B, T, Fb, float(bias), int(terms), st), "svb_mel_loss_bwd")
     return dpred
 
 

@@ -37,12 +37,15 @@ def _block(blk, h, planes=None, s2d_out=False):
     return norm(SF.critic_block(h, conv.weight, conv.bias, 0.2, p, None, None))
 
 
-def _tower(tower, h, want_fmaps, fmaps):
+FUSED_CROP = True        # forward_many: crop + stack + space-to-depth of all windows in one pass per direction
+
+
+def _tower(tower, h, want_fmaps, fmaps, planes=None):
     """The three blocks of one window's tower.  Without feature maps (and without BatchNorm2d) the blocks hand each other the
-    conv's space-to-depth layout directly; the last block returns the plain feature map for the score layer."""
+    conv's space-to-depth layout directly; the last block returns the plain feature map for the score layer.
+    planes: `h` already is the first block's space-to-depth input (SF.window_crop_s2d)."""
     blocks = list(tower.model)
     chain = not want_fmaps and all(len(b) <= 3 or isinstance(b[3], nn.InstanceNorm2d) for b in blocks)
-    planes = None
     for i, blk in enumerate(blocks):
         if chain and i + 1 < len(blocks):
             N, C, H, W = planes if planes is not None else h.shape
@@ -129,7 +132,26 @@ class Discriminator(nn.Module):
         xs = [c[0][:, None] if c[0].dim() == 3 else c[0] for c in calls]
         B = xs[0].size(0)
         scores, fmaps = [], []
+        fused = None
+        if (FUSED_CROP and all(c[2] is None for c in calls) and all(x.dim() == 4 and x.size(1) == 1 for x in xs)
+                and xs[0].size(3) % 2 == 0 and all(wl % 2 == 0 for wl in self.time_lengths) and len(xs) <= 8
+                and all(len(b) <= 3 or isinstance(b[3], nn.InstanceNorm2d) for t in self.discriminator.conv_layers
+                        for b in t.model)):
+            fused = SF.window_crop_s2d([x[:, 0] for x in xs], self.time_lengths,
+                                       [[c[1][w][0] for c in calls] for w in range(len(self.time_lengths))])
         for w, (tower, wl) in enumerate(zip(self.discriminator.conv_layers, self.time_lengths)):
+            if fused is not None:
+                x4, planes = fused[w]
+                if want_fmaps:         # (feature maps are per block: the first block runs from the planes, unchained)
+                    h = _block(tower.model[0], x4, planes)
+                    fmaps.append(h)
+                    for blk in list(tower.model)[1:]:
+                        h = _block(blk, h)
+                        fmaps.append(h)
+                else:
+                    h = _tower(tower, x4, want_fmaps, fmaps, planes=planes)
+                scores.append(_adv_score(tower.adv_layer, h))
+                continue
             crops = []
             for x, (_, starts, starts_dev, _) in zip(xs, calls):
                 if starts_dev is not None:
@@ -141,5 +163,5 @@ class Discriminator(nn.Module):
             h = _tower(tower, h, want_fmaps, fmaps)
             scores.append(_adv_score(tower.adv_layer, h))
         y = torch.stack(scores, -1) if self.reduction == "stack" else sum(scores)
-        return [{"y": y[i * B:(i + 1) * B], "y_c": None, "h": fmaps, "start_frames_wins": list(c[1])}
+        return [{"y": y[i * B:(i + 1) * B], "y_c": None, "h": fmaps, "start_frames_wins": list(c[1]), "y_all": y}
                 for i, c in enumerate(calls)]

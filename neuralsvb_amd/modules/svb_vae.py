@@ -129,9 +129,11 @@ class MleSVBVAE(nn.Module):
             ca = self.prepare_condition(amateur_mel, amateur_pitch, amateur_spk_id)
             cp = self.prepare_condition(prof_mel, prof_pitch, prof_spk_id)
         self._last_conds = (ca, cp)
+        self._last_stacked_kl = None
         if stacked and "a2a" in ways and "p2p" in ways:
             o2 = self.normal_vae(torch.cat([amateur_mel, prof_mel]), c2, None if eps_a is None else torch.cat([eps_a, eps_p]),
                                  groups=2)
+            self._last_stacked_kl = o2["kl"]          # [2]: both ways' KL terms as one vector (the task sums from it)
             for i, way in enumerate(("a2a", "p2p")):
                 ret[way] = {k: (None if v is None else (v[i] if k == "kl" else v[i * B:(i + 1) * B])) for k, v in o2.items()}
         else:

@@ -28,6 +28,45 @@ from ..utils.schedulers import NoneSchedule, RSQRTSchedule
 from .base_task import BaseTask, data_loader
 
 
+class _Terms:
+    """The loss terms of one optimizer pass as a few device vectors instead of one 0-d tensor per term.
+
+    A piece is a 1-D tensor of raw terms with, per element, a key (None = slot that is neither logged nor summed), the
+    factor its logged value carries (`scale`: the reference logs `l1 * lambda`, `kl * lambda_kl`, ...) and its weight in the
+    total (`weight`: loss_weights of svb_vae_task.py:673-674).  total = dot(cat(pieces), scale*weight) and every logged
+    value = one `cat * scale` launch + views, instead of ~3 launches forward and ~3 backward per term."""
+
+    _cache = {}
+
+    def __init__(self):
+        self.vecs, self.keys, self.scale, self.weight = [], [], [], []
+
+    def add(self, vec, keys, scale, weight=None, guard=False):
+        vec = vec.reshape(-1)
+        if guard:        # a non-finite KL / MLE term contributes no gradient (svb_vae_task.py:665-672)
+            vec = torch.where(torch.isfinite(vec), vec, vec.detach())
+        self.vecs.append(vec)
+        self.keys += list(keys)
+        self.scale += [float(x) for x in scale]
+        self.weight += [1.0] * len(keys) if weight is None else [float(x) for x in weight]
+
+    def __len__(self):
+        return len(self.keys)
+
+    def _const(self, vals, device):
+        key = (tuple(vals), str(device))
+        t = _Terms._cache.get(key)
+        if t is None:
+            t = _Terms._cache[key] = torch.tensor(vals, dtype=torch.float32, device=device)
+        return t
+
+    def total_and_logs(self):
+        cat = self.vecs[0] if len(self.vecs) == 1 else torch.cat(self.vecs)
+        total = torch.dot(cat, self._const([s * w for s, w in zip(self.scale, self.weight)], cat.device))
+        logged = cat.detach() * self._const(self.scale, cat.device)
+        return total, {k: logged[i] for i, k in enumerate(self.keys) if k is not None}
+
+
 class SVBVAEMleTask(BaseTask):
     def __init__(self):
         super().__init__()
@@ -127,6 +166,21 @@ class SVBVAEMleTask(BaseTask):
                 raise NotImplementedError(name)
             losses[f"{name}{postfix}"] = l * lbd
 
+    def add_mel_terms(self, mel_out, target, terms, postfix=""):
+        """add_mel_loss into a _Terms: L1 and SSIM of a way come from ONE fused pass (SF.mel_loss) when those are the
+        configured terms (mel_loss: "ssim:0.5|l1:0.5"); anything else takes the per-term path."""
+        names = list(self.loss_and_lambda)
+        if hparams.get("fused_mel_loss", True) and names and all(n in ("l1", "ssim") for n in names):
+            v = SF.mel_loss(mel_out, target, 6.0, l1="l1" in names, ssim="ssim" in names)
+            lam = self.loss_and_lambda
+            terms.add(v, [f"l1{postfix}" if "l1" in lam else None, f"ssim{postfix}" if "ssim" in lam else None, None],
+                      [lam.get("l1", 0.0), lam.get("ssim", 0.0), 0.0], [1.0, 1.0, 0.0])
+            return
+        losses = {}
+        self.add_mel_loss(mel_out, target, losses, postfix)
+        for k, v in losses.items():
+            terms.add(v, [k], [1.0])
+
     @staticmethod
     def get_corresponding_gtmel(way, sample):
         return sample["mels"] if way in ("a2a", "p2a") else sample["prof_mels"]
@@ -210,8 +264,28 @@ class SVBVAEMleTask(BaseTask):
                 dev = self._rand_dev["starts"][r["cursor"]] if r.get("dev") else None
                 r["cursor"] += 1
                 calls.append((x, d["starts"], dev, d["longest"]))
-            return [o["y"] for o in self.mel_disc.forward_many(calls, want_fmaps=False)]
+            outs = self.mel_disc.forward_many(calls, want_fmaps=False)
+            self._y_stacked = outs[0].get("y_all")       # [n*B,1,W]: the calls' scores in one tensor (see _adv_terms)
+            return [o["y"] for o in outs]
+        self._y_stacked = None
         return [self._critic(x)["y"] for x in xs]
+
+    def _adv_terms(self, ys, keys, targets, weights, terms):
+        """LS-GAN terms mse(y_i, target_i) of several critic calls (svb_para.py:118-170).  When the calls ran as one stacked
+        pass their scores are one tensor and the terms one [n]-vector: 3 launches instead of 2 per term (ones_like + mse)."""
+        keep = [i for i, y in enumerate(ys) if y is not None]
+        if not keep:
+            return
+        ya = getattr(self, "_y_stacked", None)
+        if ya is not None and len(keep) == len(ys) and ya.shape[0] == len(ys) * ys[0].shape[0]:
+            n = len(ys)
+            tv = terms._const(targets, ya.device)
+            terms.add((ya.reshape(n, -1) - tv[:, None]).square().mean(1), keys, [1.0] * n, weights)
+            return
+        for i in keep:
+            y = ys[i]
+            t = torch.ones_like(y) if targets[i] == 1.0 else torch.zeros_like(y)
+            terms.add(self.mse_loss_fn(y, t), [keys[i]], [1.0], [weights[i]])
 
     def _critic(self, x):
         if self.critic_barrier is not None:
@@ -225,7 +299,8 @@ class SVBVAEMleTask(BaseTask):
         return self.mel_disc(x, None, start_frames_wins=d["starts"], starts_dev=dev, longest=d["longest"], want_fmaps=False)
 
     # ------------------------------------------------------------------ model run (svb_vae_task.py:120-165)
-    def run_model(self, model, sample, concurrent_ways, return_output=False, infer=False, disable_map=False, **inject):
+    def run_model(self, model, sample, concurrent_ways, return_output=False, infer=False, disable_map=False, terms=None,
+                  **inject):
         if model.vc_asr.training:          # (pinned to eval by VCASR.train(); walking its ~120 submodules every step cost 0.3 ms)
             model.vc_asr.eval()
         r = self._step_rand
@@ -240,6 +315,19 @@ class SVBVAEMleTask(BaseTask):
                        prof_pitch=sample["prof_pitch"], amateur_spk_id=spk, prof_spk_id=spk,
                        a2p_alignment=sample["a2p_f0_alignment"], p2a_alignment=None, infer=False,
                        concurrent_ways=concurrent_ways, disable_map=disable_map, **inject)
+        if terms is not None:            # training: the terms go into a few vectors (see _Terms)
+            kl_vec = getattr(model, "_last_stacked_kl", None)
+            kl_ways = [w for w in concurrent_ways if "kl" in output[w]]
+            if kl_vec is not None and kl_ways == ["a2a", "p2p"]:
+                terms.add(kl_vec, ["a2a_kl", "p2p_kl"], [hparams["lambda_kl"]] * 2, guard=True)
+            else:
+                for way in kl_ways:
+                    terms.add(output[way]["kl"], [f"{way}_kl"], [hparams["lambda_kl"]], guard=True)
+            for way in concurrent_ways:
+                if way not in ("a2a", "p2p") and hparams["cross_way_no_recon_loss"]:
+                    continue
+                self.add_mel_terms(output[way]["mel_out"], self.get_corresponding_gtmel(way, sample), terms, postfix=way)
+            return (terms, output) if return_output else terms
         losses = {}
         for way in concurrent_ways:
             if "kl" in output[way]:
@@ -273,14 +361,15 @@ class SVBVAEMleTask(BaseTask):
     # ------------------------------------------------------------------ the step (svb_vae_task.py:579-676)
     def _training_step(self, sample, batch_idx, optimizer_idx):
         self._w_cache = {}
-        log_outputs, loss_weights = {}, {}
+        terms = _Terms()
         disc_start = hparams["mel_gan"] and self.global_step > hparams["disc_start_steps"] and hparams["lambda_mel_adv"] > 0
         phase, ways = self.phase_of(self.global_step)
+        lam_adv = hparams["lambda_mel_adv"]
         if optimizer_idx == 0:
             if phase in (1, 2):
                 if self.model.z_mapping_function.training:
                     self.model.z_mapping_function.eval()
-                log_outputs, model_out = self.run_model(self.model, sample, ways, return_output=True)
+                _, model_out = self.run_model(self.model, sample, ways, return_output=True, terms=terms)
                 self.model_out = {w: {k: v.detach() for k, v in o.items() if isinstance(v, torch.Tensor)}
                                   for w, o in model_out.items()}
                 self.model_out_gt = self.model_out
@@ -301,11 +390,9 @@ class SVBVAEMleTask(BaseTask):
                         buf.copy_(o["mel_out"])
                         gt[w] = {"mel_out": buf}
                     self.model_out_gt = gt
-                if disc_start:
-                    for way, p_ in zip(ways, self._critic_many([model_out[w]["mel_out"] for w in ways])):
-                        if p_ is not None:       # gen_cheat_disc (svb_para.py:118-131), all ways in one critic pass
-                            log_outputs[f"{way}_a"] = self.mse_loss_fn(p_, torch.ones_like(p_))
-                            loss_weights[f"{way}_a"] = hparams["lambda_mel_adv"]
+                if disc_start:       # gen_cheat_disc (svb_para.py:118-131), all ways in one critic pass
+                    ys = self._critic_many([model_out[w]["mel_out"] for w in ways])
+                    self._adv_terms(ys, [f"{w}_a" for w in ways], [1.0] * len(ways), [lam_adv] * len(ways), terms)
         elif optimizer_idx == 1:
             if phase in (1, 2):
                 if self.model.z_mapping_function.training:
@@ -319,40 +406,22 @@ class SVBVAEMleTask(BaseTask):
                         for x in xs:
                             x.record_stream(torch.cuda.current_stream(x.device))
                     ys = self._critic_many(xs)   # disc_judge_gen (svb_para.py:133-170): real, fake per way, one pass
-                    for i, way in enumerate(ways):
-                        p, p_ = ys[2 * i], ys[2 * i + 1]
-                        if p_ is not None:
-                            log_outputs[f"{way}_r"] = self.mse_loss_fn(p, torch.ones_like(p))
-                            log_outputs[f"{way}_f"] = self.mse_loss_fn(p_, torch.zeros_like(p_))
+                    self._adv_terms(ys, [f"{w}_{rf}" for w in ways for rf in ("r", "f")], [1.0, 0.0] * len(ways),
+                                    [1.0] * len(ys), terms)
         elif optimizer_idx == 2:
             if phase == 3:
                 self.model.eval()
                 self.model.z_mapping_function.train()
-                log_outputs, model_out = self.run_model(self.model, sample, ["a2a", "p2p"] + ways, return_output=True)
+                _, model_out = self.run_model(self.model, sample, ["a2a", "p2p"] + ways, return_output=True, terms=terms)
                 for way in ways:
                     cross = model_out[way]
-                    log_outputs[f"{way}_mle"] = cross["mle"]
-                    loss_weights[f"{way}_mle"] = hparams["lambda_mle"]
+                    terms.add(cross["mle"], [f"{way}_mle"], [1.0], [hparams["lambda_mle"]], guard=True)
                     if not hparams["cross_way_no_disc_loss"]:
-                        p_ = self._critic(cross["mel_out"])["y"]
-                        if p_ is not None:
-                            log_outputs[f"{way}_a"] = self.mse_loss_fn(p_, torch.ones_like(p_))
-                            loss_weights[f"{way}_a"] = hparams["lambda_mel_adv"]
-        if len(log_outputs) == 0:
+                        self._y_stacked = None
+                        self._adv_terms([self._critic(cross["mel_out"])["y"]], [f"{way}_a"], [1.0], [lam_adv], terms)
+        if len(terms) == 0:
             return None
-        for way in ("a2a", "p2p", "a2p"):           # non-finite KL / MLE terms contribute no gradient (:665-672)
-            for suffix in ("kl", "mle"):
-                k = f"{way}_{suffix}"
-                if k in log_outputs:
-                    v = log_outputs[k]
-                    log_outputs[k] = torch.where(torch.isfinite(v), v, v.detach())
-        # total = sum_k weight_k * loss_k (:673-674) as one dot product: 3 launches instead of 2 per term (and as many backward)
-        keys = list(log_outputs)
-        wkey = tuple(float(loss_weights.get(k, 1)) for k in keys)
-        wt = self._lw_cache.get(wkey)
-        if wt is None:
-            wt = self._lw_cache[wkey] = torch.tensor(wkey, dtype=torch.float32, device=log_outputs[keys[0]].device)
-        total = torch.dot(torch.stack([log_outputs[k].reshape(()) for k in keys]), wt)
+        total, log_outputs = terms.total_and_logs()      # total = sum_k weight_k * loss_k (:673-674)
         log_outputs["bs"] = sample["mels"].shape[0]
         return total, log_outputs
 

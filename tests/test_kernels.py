@@ -318,6 +318,34 @@ def test_ssim_map_forward_backward(dev):
     assert rel_err(dp, pred_nct.grad.transpose(1, 2)) < 1e-4
 
 
+@pytest.mark.parametrize("terms", [(True, True), (True, False), (False, True)])
+def test_mel_loss_fused_forward_backward(dev, terms):
+    """l1_loss + ssim_loss with weights_nonzero_speech (tasks/tts/fs2.py:143-175) as one pass: values and d/d pred vs the
+    oracle's restatement; pred read through transposed strides, silent (all-zero) target frames carry no weight."""
+    from neuralsvb_amd import functional as SF
+    from oracle import modules_ref as R
+    g_ = torch.Generator().manual_seed(14)
+    B, T, Fb = 3, 41, 80
+    pred_nct = (torch.randn(B, Fb, T, generator=g_) * 0.8 - 3).requires_grad_(True)
+    tgt = torch.randn(B, T, Fb, generator=g_) * 0.8 - 3
+    tgt[1, 30:] = 0.0
+    tgt[2, 17:] = 0.0
+    tgt[0, 5, 3] = 0.0                                       # a single zero bin does not silence its frame
+    pr = pred_nct.transpose(1, 2)
+    l1, ss = R.l1_loss(pr, tgt), R.ssim_loss(pr, tgt)
+    cl1, css = 0.7, -1.3
+    ((cl1 * l1 if terms[0] else 0) + (css * ss if terms[1] else 0)).backward()
+    p = pred_nct.detach().to(dev).transpose(1, 2).requires_grad_(True)
+    out = SF.mel_loss(p, tgt.to(dev), 6.0, l1=terms[0], ssim=terms[1])
+    if terms[0]:
+        assert abs(out[0].item() - l1.item()) < 2e-6 * abs(l1.item()) + 1e-7
+    if terms[1]:
+        assert abs(out[1].item() - ss.item()) < 2e-5
+    assert out[2].item() == R.weights_nonzero_speech(tgt).sum().item()
+    (out * torch.tensor([cl1, css, 0.0], device=dev)).sum().backward()
+    assert rel_err(p.grad, pred_nct.grad.transpose(1, 2)) < 1e-4
+
+
 def test_layernorm_nct(dev):
     g_ = torch.Generator().manual_seed(8)
     x = torch.randn(3, 96, 70, generator=g_) * 2 + 0.3
