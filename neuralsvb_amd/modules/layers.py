@@ -114,9 +114,9 @@ class LinearNCT(nn.Module):
         self.bias = ref.bias if bias else None
         self.precision = None
 
-    def forward(self, x, out_act=SF.ACT_NONE, mask=None):
+    def forward(self, x, out_act=SF.ACT_NONE, mask=None, residual=None):
         with SF.precision_scope(self.precision):
-            return SF.conv1d(x, self.weight[:, :, None], self.bias, out_act=out_act, mask=mask)
+            return SF.conv1d(x, self.weight[:, :, None], self.bias, out_act=out_act, mask=mask, residual=residual)
 
 
 class LayerNormNCT(nn.Module):

@@ -21,6 +21,9 @@ from .. import kernels as K
 from .layers import Conv1d, LinearNCT, LayerNormNCT, attach_opaque
 
 
+FOLD_RESIDUALS = True    # EncoderLayer: residual adds / macaron 0.5 in the conv epilogues (False: explicit element-wise ops)
+
+
 class Prenet(nn.Module):
     def __init__(self, in_dim=80, out_dim=256, kernel=5, n_layers=3, strides=None):
         super().__init__()
@@ -56,8 +59,9 @@ class RelPositionMultiHeadedAttention(nn.Module):
         nn.init.xavier_uniform_(self.pos_bias_u)
         nn.init.xavier_uniform_(self.pos_bias_v)
 
-    def forward(self, x, pos_emb, mask):
-        """x [B,D,T]; pos_emb [1,D,T]; mask [B,T] bool (True = keep)  (espnet_transformer_attn.py:150-186)."""
+    def forward(self, x, pos_emb, mask, residual=None):
+        """x [B,D,T]; pos_emb [1,D,T]; mask [B,T] bool (True = keep)  (espnet_transformer_attn.py:150-186).
+        residual: added to the result in the output projection's epilogue (the block's `x + self_attn(...)`)."""
         B, D, T = x.shape
         h, dk = self.h, self.d_k
         q, k, v = self.linear_q(x), self.linear_k(x), self.linear_v(x)              # [B, D, T]
@@ -76,7 +80,7 @@ class RelPositionMultiHeadedAttention(nn.Module):
             # rel_shift + add + scale + key mask + softmax + mask: one HIP kernel, one pass over [B,h,T,T]
             attn = K.relpos_softmax(ac, bd.expand(B, h, T, T).contiguous(), mask.float().contiguous(), scale)
             o = torch.matmul(v.view(B, h, dk, T), attn.transpose(-1, -2)).reshape(B, D, T)
-        return self.linear_out(o)
+        return self.linear_out(o, residual=residual)
 
 
 class MultiLayeredConv1d(nn.Module):
@@ -85,8 +89,28 @@ class MultiLayeredConv1d(nn.Module):
         self.w_1 = Conv1d(in_chans, hidden_chans, kernel_size, padding=(kernel_size - 1) // 2)
         self.w_2 = Conv1d(hidden_chans, in_chans, kernel_size, padding=(kernel_size - 1) // 2)
 
-    def forward(self, x):
-        return self.w_2(self.w_1(x, out_act=SF.ACT_RELU))
+        self._half = None
+
+    def _half_w2(self):
+        """(0.5 * w_2.weight, 0.5 * w_2.bias) of a frozen layer, cached: halving is exact in binary floating point, so
+        conv(h, 0.5 W, 0.5 b) + x == x + 0.5 * conv(h, W, b) bit for bit (up to the order of the final add)."""
+        w, b = self.w_2.weight, self.w_2.bias
+        key = (w._version, w.data_ptr(), None if b is None else (b._version, b.data_ptr()))
+        if self._half is None or self._half[0] != key:
+            with torch.no_grad():
+                self._half = (key, (w * 0.5).contiguous(), None if b is None else (b * 0.5).contiguous())
+        return self._half[1], self._half[2]
+
+    def forward(self, x, half_residual=None):
+        """half_residual (frozen, no-grad use only): returns half_residual + 0.5 * ffn(x) (the macaron block's update,
+        conformer/layers.py:216-222,243-247) with the scale folded into w_2 and the add into its epilogue."""
+        h = self.w_1(x, out_act=SF.ACT_RELU)
+        if half_residual is None:
+            return self.w_2(h)
+        c = self.w_2
+        w, b = self._half_w2()
+        with SF.precision_scope(c.precision):
+            return SF.conv1d(h, w, b, c.stride, c.padding, c.dilation, c.groups, residual=half_residual)
 
 
 class ConvolutionModule(nn.Module):
@@ -97,7 +121,7 @@ class ConvolutionModule(nn.Module):
         self.norm = nn.BatchNorm1d(channels)
         self.pointwise_conv2 = Conv1d(channels, channels, 1)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         y = self.pointwise_conv1(x)
         if self.training or self.norm.training:          # (never on the hot path: VCASR pins eval mode)
             x = F.glu(y, dim=1)
@@ -107,7 +131,7 @@ class ConvolutionModule(nn.Module):
             dw, bn = self.depthwise_conv, self.norm
             x = K.glu_dwconv_bn_swish(y.contiguous(), dw.weight, dw.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                       bn.eps)
-        return self.pointwise_conv2(x)
+        return self.pointwise_conv2(x, residual=residual)
 
 
 class EncoderLayer(nn.Module):
@@ -124,10 +148,18 @@ class EncoderLayer(nn.Module):
         self.norm_conv, self.norm_final = LayerNormNCT(size), LayerNormNCT(size)
 
     def forward(self, x, pos_emb, mask):
-        x = x + 0.5 * self.feed_forward_macaron(self.norm_ff_macaron(x))
-        x = x + self.self_attn(self.norm_mha(x), pos_emb, mask)
-        x = x + self.conv_module(self.norm_conv(x))
-        x = x + 0.5 * self.feed_forward(self.norm_ff(x))
+        if not FOLD_RESIDUALS:
+            x = x + 0.5 * self.feed_forward_macaron(self.norm_ff_macaron(x))
+            x = x + self.self_attn(self.norm_mha(x), pos_emb, mask)
+            x = x + self.conv_module(self.norm_conv(x))
+            x = x + 0.5 * self.feed_forward(self.norm_ff(x))
+            return self.norm_final(x)
+        # (forward-only frozen encoder) every residual add -- and the macaron halves' 0.5 -- rides in the epilogue of the
+        # sub-block's last conv (6 element-wise launches per block less)
+        x = self.feed_forward_macaron(self.norm_ff_macaron(x), half_residual=x)
+        x = self.self_attn(self.norm_mha(x), pos_emb, mask, residual=x)
+        x = self.conv_module(self.norm_conv(x), residual=x)
+        x = self.feed_forward(self.norm_ff(x), half_residual=x)
         return self.norm_final(x)
 
 

@@ -236,3 +236,25 @@ def test_stacked_voices_equal_separate_calls(dev):
     for (k, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
         if b1.is_floating_point():
             assert torch.allclose(b1, b2, rtol=1e-4, atol=1e-5), k          # BatchNorm running_mean / running_var
+
+
+def test_conformer_block_residual_epilogues_equal_explicit_adds(dev):
+    """Frozen PPG encoder block (conformer/layers.py:182-258): the no-grad path folds every residual add -- and the macaron
+    halves' 0.5 -- into the last conv's epilogue; it must reproduce the explicit `x + 0.5 * ff(x)` form (halving is exact)."""
+    from neuralsvb_amd.modules.vc_asr import ConformerLayers
+    torch.manual_seed(3)
+    enc = ConformerLayers(64, 2, kernel_size=7, num_heads=2).to(dev).eval()
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    x = torch.randn(2, 64, 37, device=dev)
+    x[1, :, 30:] = 0.0
+    from neuralsvb_amd.modules import vc_asr
+    with torch.no_grad():
+        y_fused = enc(x)
+        vc_asr.FOLD_RESIDUALS = False
+        try:
+            y_plain = enc(x)
+        finally:
+            vc_asr.FOLD_RESIDUALS = True
+    assert (y_fused - y_plain).abs().max().item() < 1e-5 * y_plain.abs().max().item()
