@@ -272,6 +272,27 @@ int svb_mel_loss_bwd(const float* pred, long psb, long pst, long psf, const floa
                      const float* gout, const float* sums, float* dpred, float* workspace, int B, int T, int F, float bias,
                      int terms, void* stream);
 
+/* ---- Latent head of the global VAE encoder (reference modules/voice_conversion/vae_models.py:24-41,100-105):
+ * xp [N][2L][Tp] pooled features -> m = mean_t xp[:, :L], lg = mean_t xp[:, L:];  z = m + eps exp(lg)  (eps [N][L]);
+ * lq = lg where exp(lg) > 0 else 0 (the positivity guard);  kl[g] = sum_{n in g}(sum_l KL_nl)(sum_t mask[n]) /
+ * sum_{n in g} sum_t mask[n] / L with KL_nl = 0.5 (exp(2 lq) + m^2 - 1) - lq, over `groups` equal slices of N (stacked
+ * independent calls); mask [N][Tq].  z, mq, lq: [N][L]; kl [groups]; stat [N][2] scratch kept for the backward pass.
+ * _bwd: cotangents gz / gm / glq [N][L] and gkl [groups] (each may be NULL = zero) -> dxp [N][2L][Tp].              */
+int svb_vae_head_fwd(const float* xp, const float* eps, const float* mask, float* z, float* mq, float* lq, float* kl, float* stat,
+                     int N, int groups, int L, int Tp, int Tq, void* stream);
+int svb_vae_head_bwd(const float* xp, const float* eps, const float* stat, const float* gz, const float* gm, const float* glq,
+                     const float* gkl, float* dxp, int N, int groups, int L, int Tp, void* stream);
+
+/* ---- GroupNorm + ReLU (+ residual) over [B][C][T] (reference modules/commons/common_layers.py:739-773 ConvBlock with
+ * norm 'gn', inside ConvStacks :688-707 with res=True):  y = (res ? res : 0) + relu(GroupNorm_G(h) * gamma + beta), biased
+ * variance, two-pass statistics; stats [B*G][2] = (mean, rstd).  C/G <= 64.
+ * _bwd: gy = d/dy -> dh; dgb [2][B][C] = per-clip partial sums (sum_t g xhat, sum_t g) of dgamma / dbeta, g = gy gated
+ * by the ReLU (sum them over B on the host side of the ABI); the residual's gradient is gy itself.                  */
+int svb_gn_relu_fwd(const float* h, const float* res, const float* gamma, const float* beta, float* y, float* stats, int B, int C,
+                    int T, int G, float eps, void* stream);
+int svb_gn_relu_bwd(const float* gy, const float* h, const float* gamma, const float* beta, const float* stats, float* dh,
+                    float* dgb, int B, int C, int T, int G, void* stream);
+
 /* ---- STFT magnitude + mel filterbank + log, one kernel (reference data_gen/tts/data_gen_utils.py:123-134 and
  * modules/hifigan/mel_utils.py:45-79).  wav: [B, N].  mode 0 = offline front-end: zero-pad n_fft/2 both sides
  * ("center", pad_mode constant), frames = 1 + N/hop, |X|, log10(max(eps, mel)), out [B, frames, n_mels];

@@ -74,6 +74,10 @@ SIGNATURES = {
     "svb_plane_score_bwd": (I, [P, P, C.c_long, C.c_long, P, P, P, P, I, I, I, P]),
     "svb_ssim_fwd": (I, [P, C.c_long, C.c_long, C.c_long, P, C.c_long, C.c_long, C.c_long, P, I, I, I, F, P]),
     "svb_ssim_bwd": (I, [P, C.c_long, C.c_long, C.c_long, P, C.c_long, C.c_long, C.c_long, P, P, P, I, I, I, F, P]),
+    "svb_vae_head_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "svb_vae_head_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "svb_gn_relu_fwd": (I, [P, P, P, P, P, P, I, I, I, I, F, P]),
+    "svb_gn_relu_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
     "svb_mel_loss_fwd": (I, [P, C.c_long, C.c_long, C.c_long, P, C.c_long, C.c_long, C.c_long, P, P, I, I, I, F, I, P]),
     "svb_mel_loss_bwd": (I, [P, C.c_long, C.c_long, C.c_long, P, C.c_long, C.c_long, C.c_long, P, P, P, P, I, I, I, F, I, P]),
     "svb_stft_mel": (I, [P, P, P, P, I, I, I, I, I, I, I, F, P]),

@@ -564,6 +564,52 @@ def ssim_map(pred, target, bias=6.0):
     return _SsimMapFn.apply(pred, target.detach(), float(bias))
 
 
+class _VaeHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xp, eps, mask, groups):
+        xp, eps, mask = _c(xp), _c(eps), _c(mask)
+        z, mq, lq, kl, stat = K.vae_head_fwd(xp, eps, mask, groups)
+        ctx.groups = groups
+        ctx.set_materialize_grads(False)         # an unused output's cotangent arrives as None, not as a zero-filled tensor
+        ctx.save_for_backward(xp, eps, stat)
+        return z, mq, lq, kl
+
+    @staticmethod
+    def backward(ctx, gz, gm, glq, gkl):
+        xp, eps, stat = ctx.saved_tensors
+        return K.vae_head_bwd(xp, eps, stat, _c(gz), _c(gm), _c(glq), _c(gkl), ctx.groups), None, None, None
+
+
+def vae_head(xp, eps, mask, groups=1):
+    """Latent head of the global VAE encoder (reference vae_models.py:24-41,100-105) in one pass: time mean of the pooled
+    features xp [N,2L,Tp], (m_q, logs_q) split, z = m_q + eps * exp(logs_q), the positivity guard on logs_q and the masked
+    KL mean per stacked call.  -> z, m_q, logs_q [N,L,1], kl [groups].  eps [N,L,1] and mask [N,Tq] carry no gradient."""
+    return _VaeHeadFn.apply(xp, eps.detach(), mask.detach(), int(groups))
+
+
+class _GNReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, res, gamma, beta, G, eps):
+        h, res, gamma, beta = _c(h), _c(res), _c(gamma), _c(beta)
+        y, stats = K.gn_relu_fwd(h, res, gamma, beta, G, eps)
+        ctx.G, ctx.has_res = G, res is not None
+        ctx.save_for_backward(h, gamma, beta, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        h, gamma, beta, stats = ctx.saved_tensors
+        gy = gy.contiguous()
+        dh, dgb = K.gn_relu_bwd(gy, h, gamma, beta, stats, ctx.G)
+        dg, db = dgb.sum(1).unbind(0)
+        return dh, (gy if ctx.has_res else None), dg, db, None, None
+
+
+def group_norm_relu(h, gamma, beta, num_groups, eps=1e-5, residual=None):
+    """residual + relu(GroupNorm(h)) on [B,C,T] (reference common_layers.py:739-773 inside ConvStacks :688-707)."""
+    return _GNReluFn.apply(h, residual, gamma, beta, int(num_groups), float(eps))
+
+
 class _MelLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target, bias, terms):
@@ -690,6 +736,7 @@ class _WindowCropS2DFn(torch.autograd.Function):
     def forward(ctx, cfg, *xs):
         wls, starts = cfg
         ctx.cfg, ctx.shape, ctx.n = cfg, tuple(xs[0].shape), len(xs)
+        ctx.set_materialize_grads(False)
         outs = tuple(K.win_s2d(xs, starts[w], wl).view(1, 4, -1) for w, wl in enumerate(wls))
         return outs
 

@@ -848,6 +848,54 @@ def mel_loss_bwd(pred, target, gout, sums, bias=6.0, terms=3):
     return dpred
 
 
+def vae_head_fwd(xp, eps, mask, groups):
+    """xp [N,2L,Tp], eps [N,L,1], mask [N,Tq] -> z, m_q, logs_q (guarded) [N,L,1], kl [groups], stat."""
+    _f32(xp, eps, mask)
+    lib, st = _prep(xp, eps, mask)
+    N, L2, Tp = xp.shape
+    Lc = L2 // 2
+    z, mq, lq = (torch.empty((N, Lc, 1), device=xp.device, dtype=torch.float32) for _ in range(3))
+    kl = torch.empty((groups,), device=xp.device, dtype=torch.float32)
+    stat = torch.empty((N, 2), device=xp.device, dtype=torch.float32)
+    L.check(lib.svb_vae_head_fwd(_ptr(xp), _ptr(eps), _ptr(mask), _ptr(z), _ptr(mq), _ptr(lq), _ptr(kl), _ptr(stat), N, groups, Lc,
+                                 Tp, mask.shape[1], st), "svb_vae_head_fwd")
+    return z, mq, lq, kl, stat
+
+
+def vae_head_bwd(xp, eps, stat, gz, gm, glq, gkl, groups):
+    _f32(xp, eps, stat, gz, gm, glq, gkl)
+    lib, st = _prep(xp, eps, stat, gz, gm, glq, gkl)
+    N, L2, Tp = xp.shape
+    dxp = torch.empty_like(xp)
+    L.check(lib.svb_vae_head_bwd(_ptr(xp), _ptr(eps), _ptr(stat), _ptr(gz), _ptr(gm), _ptr(glq), _ptr(gkl), _ptr(dxp), N, groups,
+                                 L2 // 2, Tp, st), "svb_vae_head_bwd")
+    return dxp
+
+
+def gn_relu_fwd(h, res, gamma, beta, G, eps):
+    """y = (res or 0) + relu(GroupNorm_G(h)); h/res [B,C,T] contiguous -> y, stats [B*G,2]."""
+    _f32(h, res, gamma, beta)
+    lib, st = _prep(h, res, gamma, beta)
+    B, Cc, T = h.shape
+    y = torch.empty_like(h)
+    stats = torch.empty((B * G, 2), device=h.device, dtype=torch.float32)
+    L.check(lib.svb_gn_relu_fwd(_ptr(h), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), B, Cc, T, G, float(eps), st),
+            "svb_gn_relu_fwd")
+    return y, stats
+
+
+def gn_relu_bwd(gy, h, gamma, beta, stats, G):
+    """-> dh [B,C,T], dgb [2,B,C] (per-clip partial sums of dgamma, dbeta)."""
+    _f32(gy, h, gamma, beta, stats)
+    lib, st = _prep(gy, h, gamma, beta, stats)
+    B, Cc, T = h.shape
+    dh = torch.empty_like(h)
+    dgb = torch.empty((2, B, Cc), device=h.device, dtype=torch.float32)
+    L.check(lib.svb_gn_relu_bwd(_ptr(gy), _ptr(h), _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(dh), _ptr(dgb), B, Cc, T, G, st),
+            "svb_gn_relu_bwd")
+    return dh, dgb
+
+
 def stft_mel(wav, window, mel_basis, n_fft, hop, mode, eps):
     """wav [B, N] -> mode 0: [B, 1+N//hop, n_mels] log10 ; mode 1: [B, n_mels, N//hop] ln."""
     _f32(wav, window, mel_basis)

@@ -15,6 +15,9 @@ from .. import functional as SF
 from .layers import Conv1d, ConvTranspose1d
 
 
+FUSED_HEAD = True        # GlobalFVAEEncoder: latent head (mean, split, draw, guard, KL) as one HIP pass per direction
+
+
 class WN(nn.Module):
     def __init__(self, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0, p_dropout=0):
         super().__init__()
@@ -62,6 +65,7 @@ class GlobalFVAEEncoder(nn.Module):
         self.wn = WN(hidden_channels, kernel_size, 1, n_layers, gin_channels, p_dropout)
         self.out_proj = Conv1d(hidden_channels, latent_channels * 2, 1)
         c2 = latent_channels * 2
+        self._head_kl = None
         self.poolings = nn.Sequential(
             Conv1d(c2, c2, 3, stride=2), nn.ReLU(), nn.BatchNorm1d(c2),
             Conv1d(c2, c2, 3, stride=2), nn.ReLU(), nn.BatchNorm1d(c2),
@@ -86,6 +90,14 @@ class GlobalFVAEEncoder(nn.Module):
         x = bn_groups(p[2], p[0](x, out_act=SF.ACT_RELU), groups)
         x = bn_groups(p[5], p[3](x, out_act=SF.ACT_RELU), groups)
         x = p[6](x)
+        self._head_kl = None
+        if FUSED_HEAD:
+            # time mean, (m_q, logs_q) split, re-parameterised draw, positivity guard and the masked KL mean in one pass
+            # (logs_q comes back already guarded; GlobalFVAE.forward picks the KL up from _head_kl)
+            if eps is None:
+                eps = torch.randn((x.shape[0], self.latent_channels, 1), device=x.device, dtype=x.dtype)
+            z, m_q, logs_q, self._head_kl = SF.vae_head(x, eps, m, groups)
+            return z, m_q, logs_q, m[:, None, :]
         x = x.mean(-1, keepdim=True)
         m_q, logs_q = torch.split(x, self.latent_channels, dim=1)
         if eps is None:
@@ -150,6 +162,9 @@ class GlobalFVAE(nn.Module):
             raise NotImplementedError("run_model always passes infer=False (svb_vae_task.py:148; SURVEY Appendix A.1)")
         z_q, m_q, logs_q, mask_sqz = self.encoder(x, x_mask, g_sqz, eps, groups)
         x_recon = self.decoder(z_q, x_mask, g)
+        if self.encoder._head_kl is not None:
+            kl, self.encoder._head_kl = self.encoder._head_kl, None
+            return x_recon, (kl[0] if groups == 1 else kl), None, m_q, logs_q, mask_sqz, z_q
         with torch.no_grad():  # positivity guard of vae_models.py:24-30 (unconditional select: no device->host sync)
             bad = ~(logs_q.exp() > 0)
         logs_q = torch.where(bad, torch.zeros_like(logs_q), logs_q)

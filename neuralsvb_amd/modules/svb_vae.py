@@ -16,6 +16,9 @@ from .layers import Conv1d, LinearNCT
 from .vc_asr import VCASR
 
 
+FUSED_GN = True          # ConvBlock: GroupNorm + ReLU + residual as one HIP pass per direction
+
+
 class _ConvNorm(nn.Module):          # reference common_layers.ConvNorm: holds `.conv`
     def __init__(self, cin, cout, k):
         super().__init__()
@@ -31,8 +34,14 @@ class ConvBlock(nn.Module):
         self.conv = _ConvNorm(n_chans, n_chans, kernel_size)
         self.norm = nn.GroupNorm(n_chans // 16, n_chans)
 
-    def forward(self, x):
-        return F.relu(self.norm(self.conv.conv(x)))
+    def forward(self, x, residual=None):
+        """residual: added to the block's output (ConvStacks' `x + f(x)`) inside the GroupNorm+ReLU pass."""
+        h = self.conv.conv(x)
+        n = self.norm
+        if FUSED_GN and n.affine and n.num_channels // n.num_groups <= 64:
+            return SF.group_norm_relu(h, n.weight, n.bias, n.num_groups, n.eps, residual=residual)
+        y = F.relu(n(h))
+        return y if residual is None else residual + y
 
 
 class ConvStacks(nn.Module):
@@ -46,7 +55,7 @@ class ConvStacks(nn.Module):
         """x [B,C,T] -> [B,odim,T]   (common_layers.py:688-707, res=True)."""
         x = self.in_proj(x)
         for f in self.conv:
-            x = x + f(x)
+            x = f(x, residual=x)
         return self.out_proj(x)
 
 

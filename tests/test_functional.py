@@ -516,3 +516,69 @@ def test_persistent_weight_images_and_multi_tensor_repack(dev):
         K.weight_pack_q_into, K.weight_pack_q_multi = o_into, o_multi
         SF.end_weight_epoch()
         SF.set_precision("fp32")
+
+
+def test_group_norm_relu_residual_matches_torch(dev):
+    """ConvBlock's GroupNorm(C/16) + ReLU and ConvStacks' residual (common_layers.py:688-707,739-773): values and all
+    gradients against stock torch fp32."""
+    import torch.nn.functional as F
+    g_ = torch.Generator().manual_seed(21)
+    B, Cc, T, G = 3, 48, 37, 3
+    h = (torch.randn(B, Cc, T, generator=g_) * 1.7 + 0.3).requires_grad_(True)
+    res = torch.randn(B, Cc, T, generator=g_).requires_grad_(True)
+    gm = (torch.rand(Cc, generator=g_) + 0.5).requires_grad_(True)
+    bt = (torch.randn(Cc, generator=g_) * 0.3).requires_grad_(True)
+    ref = res + F.relu(F.group_norm(h, G, gm, bt, 1e-5))
+    gy = torch.randn(ref.shape, generator=g_)
+    ref.backward(gy)
+    hd, rd, gd, bd = (t.detach().to(dev).requires_grad_(True) for t in (h, res, gm, bt))
+    y = SF.group_norm_relu(hd, gd, bd, G, 1e-5, residual=rd)
+    assert (y.cpu() - ref.detach()).abs().max() < 2e-5
+    y.backward(gy.to(dev))
+    for mine, r in ((hd, h), (rd, res), (gd, gm), (bd, bt)):
+        assert (mine.grad.cpu() - r.grad).abs().max() < 3e-5 * max(1.0, r.grad.abs().max().item())
+    y2 = SF.group_norm_relu(hd.detach(), gd.detach(), bd.detach(), G, 1e-5)
+    assert (y2.cpu() - F.relu(F.group_norm(h, G, gm, bt, 1e-5)).detach()).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_vae_latent_head_matches_torch(dev, groups):
+    """Latent head of the global VAE encoder + KL (vae_models.py:24-41,100-105) against the stock-torch expression, incl.
+    the positivity guard (a logs_q whose exp underflows) and every gradient."""
+    g_ = torch.Generator().manual_seed(22)
+    N, Lc, Tp, Tq = 4, 24, 9, 13
+    xp = torch.randn(N, 2 * Lc, Tp, generator=g_)
+    xp[1, Lc + 3] = -200.0                                    # exp underflows: guarded
+    xp = xp.requires_grad_(True)
+    eps = torch.randn(N, Lc, 1, generator=g_)
+    mask = (torch.rand(N, Tq, generator=g_) > 0.3).float()
+
+    def ref_fn(x):
+        xm = x.mean(-1, keepdim=True)
+        m_q, logs_q = torch.split(xm, Lc, dim=1)
+        z = m_q + eps * torch.exp(logs_q)
+        with torch.no_grad():
+            bad = ~(logs_q.exp() > 0)
+        lq = torch.where(bad, torch.zeros_like(logs_q), logs_q)
+        kl = 0.5 * (torch.exp(2 * lq) + m_q ** 2 - 1.0) - lq
+        ms = mask[:, None, :]
+        klm = ((kl * ms).reshape(groups, -1).sum(1) / ms.reshape(groups, -1).sum(1)) / Lc
+        return z, m_q, lq, klm
+    z, mq, lq, kl = ref_fn(xp)
+    cz, cm, cl = (torch.randn(N, Lc, 1, generator=g_) for _ in range(3))
+    ck = torch.randn(groups, generator=g_)
+    ((z * cz).sum() + (mq * cm).sum() + (lq * cl).sum() + (kl * ck).sum()).backward()
+    xd = xp.detach().to(dev).requires_grad_(True)
+    z2, mq2, lq2, kl2 = SF.vae_head(xd, eps.to(dev), mask.to(dev), groups)
+    for a, b in ((z2, z), (mq2, mq), (lq2, lq), (kl2, kl)):
+        assert (a.cpu() - b.detach()).abs().max() < 1e-5 * max(1.0, b.detach().abs().max().item())
+    ((z2 * cz.to(dev)).sum() + (mq2 * cm.to(dev)).sum() + (lq2 * cl.to(dev)).sum() + (kl2 * ck.to(dev)).sum()).backward()
+    assert (xd.grad.cpu() - xp.grad).abs().max() < 1e-5 * max(1.0, xp.grad.abs().max().item())
+    # only z and kl used (the phase-2 step): absent cotangents are zeros
+    xd2 = xp.detach().to(dev).requires_grad_(True)
+    z3, _, _, kl3 = SF.vae_head(xd2, eps.to(dev), mask.to(dev), groups)
+    ((z3 * cz.to(dev)).sum() + (kl3 * ck.to(dev)).sum()).backward()
+    xr = xp.detach().clone().requires_grad_(True)
+    zr, _, _, klr = ref_fn(xr)
+    ((zr * cz).sum() + (klr * ck).sum()).backward()
+    assert (xd2.grad.cpu() - xr.grad).abs().max() < 1e-5 * max(1.0, xr.grad.abs().max().item())
