@@ -26,11 +26,11 @@ def _oracle_mel_fn(hp):
     return fn
 
 
-def _setup(tmp_path, dev):
+def _setup(tmp_path, dev, extra=""):
     from neuralsvb_amd.utils.hparams import set_hparams, hparams
     from neuralsvb_amd.utils import synth
     set_hparams(config=os.path.join(ROOT, "egs/datasets/audio/PopBuTFy/vae_global_mle_eng.yaml"), exp_name="",
-                hparams_str=SMALL, print_hparams=False)
+                hparams_str=SMALL + extra, print_hparams=False)
     hparams["binary_data_dir"] = str(tmp_path / "bin")
     hparams["pretrain_asr_ckpt"] = str(tmp_path / "asr")
     hparams["work_dir"] = str(tmp_path / "ckpt")
@@ -148,3 +148,78 @@ def test_hipgraph_replay_matches_eager_steps(gpu_only, tmp_path):
             assert abs(le[k] - lg[k]) <= 1e-5 * max(1.0, abs(le[k])), (step, k, le[k], lg[k])
     for k, v in results["eager"][1].items():
         assert torch.allclose(v, results["graph"][1][k], rtol=1e-4, atol=1e-6), k
+
+
+def _grads_after_passes(task, trainer, batch, dev, global_step, eps, seed):
+    """One training step at `global_step`; -> (logged terms per pass, gradient of every parameter right before each
+    optimizer step)."""
+    terms, grads = {}, {}
+    o_ts, o_before, o_run = task._training_step, task.on_before_optimization, task.run_model
+
+    def _ts(sample, batch_idx, opt_idx, _o=o_ts):
+        ret = _o(sample, batch_idx, opt_idx)
+        if ret is not None:
+            terms[opt_idx] = {k: float(v) for k, v in ret[1].items()}
+            terms[opt_idx]["total"] = float(ret[0])
+        return ret
+
+    def _before(opt_idx, _o=o_before):
+        grads[opt_idx] = {n: p.grad.detach().cpu().clone() for n, p in task.named_parameters()
+                          if p.grad is not None and p.requires_grad}
+        return _o(opt_idx)
+    task._training_step, task.on_before_optimization = _ts, _before
+    task.run_model = lambda *a, **k: o_run(*a, eps_a2a=eps[0].to(dev), eps_p2p=eps[1].to(dev), **k)
+    np.random.seed(seed)
+    task.global_step = trainer.global_step = global_step
+    try:
+        trainer.run_training_batch(0, batch)
+    finally:
+        task._training_step, task.on_before_optimization, task.run_model = o_ts, o_before, o_run
+    return terms, grads
+
+
+@pytest.mark.parametrize("phase", [2, 3])
+def test_fused_step_paths_equal_elementwise_paths(dev, tmp_path, phase):
+    """The fused passes of a step (mel loss, latent head + KL, GroupNorm+ReLU+residual, window crops, conformer residual
+    epilogues) against the same step with each of them switched back to its stock element-wise form: every logged term
+    and every gradient of the pass, in phase 2 (generator + critic) and phase 3 (latent map incl. the a2p way)."""
+    from neuralsvb_amd.modules import fs2_vae, mel_disc, svb_vae, vc_asr
+    # (the latent map's speaker projection is Conv1d(256, .) on h_style: phase 3 needs the real hidden_size -- 5 minutes on
+    #  the CPU lane emulator, so that variant only runs there on request; the MI355X variant always runs)
+    if phase == 3 and dev.type == "cpu" and os.environ.get("SVB_SLOW_TESTS", "0") != "1":
+        pytest.skip("phase-3 step at hidden_size 256 on the lane emulator: set SVB_SLOW_TESTS=1 (passes; ~5 min)")
+    task, trainer, batch, hp = _setup(tmp_path, dev, ",hidden_size=256" if phase == 3 else "")
+    hp["phase_2_steps"] = 2 if phase == 3 else 10 ** 6
+    gs = 3 if phase == 3 else 2
+    L = hp["latent_size"]
+    g = torch.Generator().manual_seed(5)
+    eps = (torch.randn(2, L, 1, generator=g), torch.randn(2, L, 1, generator=g))
+    sd0 = {k: v.detach().clone() for k, v in task.state_dict().items()}
+    opt0 = [None if o is None else {"state": {}, "param_groups": o.state_dict()["param_groups"]} for o in trainer.optimizers]
+
+    def run(fused):
+        task.load_state_dict(sd0)
+        from neuralsvb_amd import functional as SF
+        SF.note_weights_updated()
+        for o, s in zip(trainer.optimizers, opt0):
+            if o is not None:
+                o.load_state_dict(s)
+        hp["fused_mel_loss"] = fused
+        fs2_vae.FUSED_HEAD = svb_vae.FUSED_GN = mel_disc.FUSED_CROP = vc_asr.FOLD_RESIDUALS = fused
+        try:
+            return _grads_after_passes(task, trainer, batch, dev, gs, eps, 77)
+        finally:
+            hp["fused_mel_loss"] = True
+            fs2_vae.FUSED_HEAD = svb_vae.FUSED_GN = mel_disc.FUSED_CROP = vc_asr.FOLD_RESIDUALS = True
+    t1, g1 = run(True)
+    t0, g0 = run(False)
+    assert sorted(t1) == sorted(t0) and len(t1) >= 1
+    assert (2 in t1) == (phase == 3)
+    for oi in t0:
+        assert set(t1[oi]) == set(t0[oi]), (oi, set(t1[oi]) ^ set(t0[oi]))
+        for k, v in t0[oi].items():
+            assert abs(t1[oi][k] - v) <= 1e-5 * max(1.0, abs(v)), (oi, k, t1[oi][k], v)
+        assert set(g1[oi]) == set(g0[oi])
+        for n, r in g0[oi].items():
+            err = (g1[oi][n] - r).abs().max().item()
+            assert err <= 2e-4 * max(r.abs().max().item(), 1e-3), (oi, n, err, r.abs().max().item())
