@@ -128,8 +128,8 @@ int svb_conv1d_wgrad_bf16x3(const float* a, const float* b, float* part, int B, 
  * gradient partials (reference: autograd of the `bias` argument of F.conv1d); svb_wgrad_reduce sums them into db.     */
 /* Stage 2: reduce partials (+ WeightNorm backward: dv, dg from dW).  rows = d0, rowlen = d1*k.
  * bias_part/db (optional): also sum the [nsplit][rows] bias-gradient partials of stage 1 into db[rows].
- * accumulate: add into dv / dg / db instead of overwriting them (gradients written straight into `.grad` buffers); with
- * weight_norm this needs 16-byte aligned rows and rowlen <= 4096 (SVB_ERR_UNSUPPORTED otherwise).                */
+ * accumulate: 1 = add into dv / dg / db instead of overwriting them (gradients written straight into `.grad` buffers; with
+ * weight_norm this needs 16-byte aligned rows and rowlen <= 4096, SVB_ERR_UNSUPPORTED otherwise); 2 = add into db only. */
 int svb_wgrad_reduce(const float* part, int nsplit, const float* v, const float* g, float* dv, float* dg, int rows,
                      int rowlen, int weight_norm, int accumulate, const float* bias_part, float* db, void* stream);
 /* db[c] = sum_{b,t} dy[b,c,t] * gate'(gate[b,c,t])                                                          */
@@ -238,7 +238,8 @@ int svb_win_s2d_bwd(const float* const* dplanes, const int* wls, const int* star
  *                     space-to-depth layout [4C][N][Ho/2+1][Wo/2+1] (svb_s2d_pad's), so no separate re-layout pass runs
  *                     between two blocks (the strides of dout are ignored then).
  * svb_plane_score_fwd/bwd: score[n] = bias + sum_{c,e} h[n][c][e] * w[c*HW+e] over contiguous (h,w) planes with element
- *                     strides sn / sc; backward writes dh with the same strides, dw [C*HW], db [1] (each optional).      */
+ *                     strides sn / sc; backward reads ds[n * sds] (a column of the stacked window scores) and writes dh
+ *                     with the same strides, dw [C*HW], db [1] (each optional).                                          */
 int svb_s2_weight(const float* w, float* w4, int cout, int c, void* stream);
 int svb_s2_weight_bwd(const float* dwa, const float* dwb, float* dw, int cout, int c, int accumulate, void* stream);
 int svb_crop_drop_inorm_fwd(const float* y4, const float* keep, const float* gamma, const float* beta, float eps, float* out,
@@ -248,8 +249,8 @@ int svb_crop_drop_inorm_bwd(const float* dout, long sn, long sc, long sh, long s
                             int s2d, void* stream);
 int svb_plane_score_fwd(const float* h, long sn, long sc, const float* w, const float* bias, float* score, int N, int C, int HW,
                         void* stream);
-int svb_plane_score_bwd(const float* ds, const float* h, long sn, long sc, const float* w, float* dh, float* dw, float* db, int N,
-                        int C, int HW, void* stream);
+int svb_plane_score_bwd(const float* ds, long sds, const float* h, long sn, long sc, const float* w, float* dh, float* dw,
+                        float* db, int N, int C, int HW, void* stream);
 
 /* ---- SSIM map of two [B, T, F] mel images (+bias), 11x11 gaussian sigma 1.5, zero padding, C1=1e-4, C2=9e-4
  * (reference modules/commons/ssim.py:331-351 via tasks/tts/fs2.py:166-175).  Inputs are addressed with element

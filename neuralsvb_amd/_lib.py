@@ -71,7 +71,7 @@ SIGNATURES = {
     "svb_crop_drop_inorm_fwd": (I, [P, P, P, P, C.c_float, P, P, I, I, I, I, I, P]),
     "svb_crop_drop_inorm_bwd": (I, [P, C.c_long, C.c_long, C.c_long, C.c_long, P, P, P, P, P, P, I, I, I, I, I, P]),
     "svb_plane_score_fwd": (I, [P, C.c_long, C.c_long, P, P, P, I, I, I, P]),
-    "svb_plane_score_bwd": (I, [P, P, C.c_long, C.c_long, P, P, P, P, I, I, I, P]),
+    "svb_plane_score_bwd": (I, [P, C.c_long, P, C.c_long, C.c_long, P, P, P, P, I, I, I, P]),
     "svb_ssim_fwd": (I, [P, C.c_long, C.c_long, C.c_long, P, C.c_long, C.c_long, C.c_long, P, I, I, I, F, P]),
     "svb_ssim_bwd": (I, [P, C.c_long, C.c_long, C.c_long, P, C.c_long, C.c_long, C.c_long, P, P, P, I, I, I, F, P]),
     "svb_vae_head_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),

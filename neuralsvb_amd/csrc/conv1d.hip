@@ -426,6 +426,8 @@ __global__ __launch_bounds__(256) void svb_wgrad_reduce_kernel(const float* part
                                                                const float* v, const float* gnorm, float* dv, float* dg,
                                                                int rowlen, int weight_norm, int accumulate,
                                                                const float* bias_part, float* db, int rows, int vec) {
+    const int acc_b = (accumulate & 3) != 0;      // bit 1: accumulate into db only
+    accumulate &= 1;
     __shared__ float red[8];
     const int row = blockIdx.x;
     const size_t base = (size_t)row * rowlen;
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(256) void svb_wgrad_reduce_kernel(const float* part
         float b = 0.f;
         for (int sp = threadIdx.x; sp < nsplit; sp += 256) b += bias_part[(size_t)sp * rows + row];
         b = svb_block_sum<256>(b, red);
-        if (threadIdx.x == 0) db[row] = accumulate ? db[row] + b : b;
+        if (threadIdx.x == 0) db[row] = acc_b ? db[row] + b : b;
     }
     if (!weight_norm) return;
     dot = svb_block_sum<256>(dot, red);

@@ -437,12 +437,12 @@ __global__ __launch_bounds__(256) void svb_plane_score_fwd_kernel(const float* h
     if (threadIdx.x == 0) score[n] = acc + (bias ? bias[0] : 0.f);
 }
 
-__global__ __launch_bounds__(256) void svb_plane_score_bwd_kernel(const float* ds, const float* h, long sn, long sc, const float* w,
+__global__ __launch_bounds__(256) void svb_plane_score_bwd_kernel(const float* ds, long sds, const float* h, long sn, long sc, const float* w,
                                                                   float* dh, float* dw, float* db, int N, int C, int HW) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k == 0 && db) {
         float t = 0.f;
-        for (int n = 0; n < N; ++n) t += ds[n];
+        for (int n = 0; n < N; ++n) t += ds[(long)n * sds];
         db[0] = t;
     }
     if (k >= C * HW) return;
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void svb_plane_score_bwd_kernel(const float* d
     float acc = 0.f;
     for (int n = 0; n < N; ++n) {
         const long o = (long)n * sn + (long)c * sc + e;
-        const float d = ds[n];
+        const float d = ds[(long)n * sds];
         if (dw) acc += d * h[o];
         if (dh) dh[o] = d * wk;
     }
@@ -466,10 +466,10 @@ extern "C" int svb_plane_score_fwd(const float* h, long sn, long sc, const float
     return SVB_OK;
 }
 
-extern "C" int svb_plane_score_bwd(const float* ds, const float* h, long sn, long sc, const float* w, float* dh, float* dw, float* db,
+extern "C" int svb_plane_score_bwd(const float* ds, long sds, const float* h, long sn, long sc, const float* w, float* dh, float* dw, float* db,
                                    int N, int C, int HW, void* stream) {
     if (!ds || !h || !w || N <= 0 || C <= 0 || HW <= 0) return SVB_ERR_ARG;
-    hipLaunchKernelGGL(svb_plane_score_bwd_kernel, dim3(svb_cdiv(C * HW, 256)), dim3(256), 0, (hipStream_t)stream, ds, h, sn, sc, w,
+    hipLaunchKernelGGL(svb_plane_score_bwd_kernel, dim3(svb_cdiv(C * HW, 256)), dim3(256), 0, (hipStream_t)stream, ds, sds, h, sn, sc, w,
                        dh, dw, db, N, C, HW);
     SVB_CHECK_LAUNCH();
     return SVB_OK;

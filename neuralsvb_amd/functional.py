@@ -610,6 +610,37 @@ def group_norm_relu(h, gamma, beta, num_groups, eps=1e-5, residual=None):
     return _GNReluFn.apply(h, residual, gamma, beta, int(num_groups), float(eps))
 
 
+class _SplitStackedFn(torch.autograd.Function):
+    """x [n*B, C, T] (the stacked ways' decoder output) -> n tensors [B, T, C]: way i's slice as the transposed view the
+    reference API returns.  Forward is free (views); backward assembles the ways' gradients straight into ONE [n*B, C, T]
+    buffer -- instead of, per way, a zero-filled full-size gradient + copy (slice backward), the add of the ways' buffers and
+    the re-layout copy in front of the conv's data gradient."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.shape = n, tuple(x.shape)
+        ctx.set_materialize_grads(False)
+        B = x.shape[0] // n
+        return tuple(x[i * B:(i + 1) * B].transpose(1, 2) for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        NB, Cc, T = ctx.shape
+        B = NB // ctx.n
+        dx = torch.empty(ctx.shape, device=next(g for g in gs if g is not None).device, dtype=torch.float32)
+        for i, g in enumerate(gs):
+            if g is None:
+                dx[i * B:(i + 1) * B].zero_()
+            else:
+                dx[i * B:(i + 1) * B].transpose(1, 2).copy_(g)
+        return dx, None
+
+
+def split_stacked_ways(x, n):
+    """x [n*B, C, T] -> tuple of n [B, T, C] views (see _SplitStackedFn)."""
+    return _SplitStackedFn.apply(x, int(n))
+
+
 class _MelLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target, bias, terms):
@@ -798,12 +829,10 @@ class _Conv2dS2Fn(torch.autograd.Function):
             bsink = _gbuf(ctx.bias_ref()) if want_b and ctx.bias_ref is not None else None
             # (both results accumulate into gradient buffers: the three launches may run beside the data gradient above)
             with K.side_work(dy4, x4, yact) if (sink is not None and (not want_b or bsink is not None)) else _NoSide():
-                ra = K.conv1d_wgrad(dy4, x4, 2, 1, -ctx.offsets[0], 1, 1, a_gate=yact, a_slope=a_slope, want_bias=want_b)
+                ra = K.conv1d_wgrad(dy4, x4, 2, 1, -ctx.offsets[0], 1, 1, a_gate=yact, a_slope=a_slope, want_bias=want_b,
+                                    bias_sink=bsink)          # (the reduce kernel adds the bias gradient into its buffer)
                 if want_b:
                     ra, db = ra
-                    if bsink is not None:
-                        bsink.add_(db)
-                        db = None
                 rb = K.conv1d_wgrad(dy4, x4, 2, 1, -ctx.offsets[2], 1, 1, a_gate=yact, a_slope=a_slope)
                 dw = K.s2_weight_bwd(ra, rb, cout, C, into=sink)
             _notify((sink, bsink), (weight, ctx.bias_ref() if ctx.bias_ref is not None else None), (dw, db))
@@ -850,7 +879,7 @@ class _PlaneScoreFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ds):
         h, w = ctx.saved_tensors
-        dh, dw, db = K.plane_score_bwd(ds.contiguous().view(-1), h, w, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+        dh, dw, db = K.plane_score_bwd(ds.reshape(-1), h, w, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                        ctx.has_bias and ctx.needs_input_grad[2])
         return dh, (dw.view(ctx.wshape) if dw is not None else None), db
 

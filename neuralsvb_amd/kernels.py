@@ -367,7 +367,7 @@ class side_work:
 
 
 def conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0, b_gate=None, b_slope=0.0,
-                 v=None, g=None, accumulate_into=None, bf16x3=None, want_bias=False, sinks=None):
+                 v=None, g=None, accumulate_into=None, bf16x3=None, want_bias=False, sinks=None, bias_sink=None):
     """Weight gradient (see _conv1d_wgrad).  With WGRAD_STREAM set and every result going into a sink, the launches are
     issued on the side stream: it first waits for everything enqueued on the current stream so far (the producers of a / b);
     the inputs are marked as in use there (the caching allocator must not recycle them when autograd drops them)."""
@@ -389,7 +389,7 @@ def conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0
             return _conv1d_wgrad(a, b, k, sx, pad, dil, groups, a_gate, a_slope, b_gate, b_slope, v, g, accumulate_into,
                                  bf16x3, want_bias, sinks, _side=side)
     return _conv1d_wgrad(a, b, k, sx, pad, dil, groups, a_gate, a_slope, b_gate, b_slope, v, g, accumulate_into, bf16x3,
-                         want_bias, sinks)
+                         want_bias, sinks, bias_sink=bias_sink)
 
 
 _SIDE_WS = {}            # (device index, slot) -> grow-only fp32 workspace of the side stream (its launches are serialised)
@@ -405,7 +405,7 @@ def _side_ws(side, dev, slot, n):
 
 
 def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0, b_gate=None, b_slope=0.0,
-                  v=None, g=None, accumulate_into=None, bf16x3=None, want_bias=False, sinks=None, _side=None):
+                  v=None, g=None, accumulate_into=None, bf16x3=None, want_bias=False, sinks=None, _side=None, bias_sink=None):
     """dW[ca, cb/groups, k] = sum_{n,q} a[n,ca,q] * b[n,cb,q*sx + j*dil - pad].
 
     With (v, g) given returns (dv, dg) of the weight-normalised parametrisation instead of dW.  want_bias: also return
@@ -413,7 +413,8 @@ def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.
     bf16x3 path it comes out of the same two launches.
 
     sinks = (grad_v, grad_g, grad_b): existing gradient buffers (e.g. `param.grad`) to ACCUMULATE into; outputs that
-    went into a sink are returned as None (the caller hands None to autograd, which skips its own `grad += new`)."""
+    went into a sink are returned as None (the caller hands None to autograd, which skips its own `grad += new`).
+    bias_sink: a buffer for the bias gradient ALONE (the weight gradient is returned; the critic's re-laid-out kernels)."""
     _f32(a, b, a_gate, b_gate, v, g)
     lib, st = _prep(a, b, a_gate, b_gate, v, g, accumulate_into)
     if _side is not None:
@@ -463,17 +464,25 @@ def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.
         else:
             dw, acc = torch.empty((ca, cb // groups, k), device=a.device, dtype=torch.float32), 0
         dg = torch.empty_like(g) if wn else None
-        db = torch.empty((ca,), device=a.device, dtype=torch.float32) if bias_part is not None else None
+        if bias_part is not None and bias_sink is not None:
+            db, acc = bias_sink, acc | 2          # the bias gradient alone goes straight into its `.grad` buffer
+        else:
+            db = torch.empty((ca,), device=a.device, dtype=torch.float32) if bias_part is not None else None
     L.check(lib.svb_wgrad_reduce(_ptr(part), ns.value, _ptr(v), _ptr(g), _ptr(dw), _ptr(dg), rows, rowlen, int(wn),
                                  acc, _ptr(bias_part), _ptr(db), st), "svb_wgrad_reduce")
     if sink:
         dw = dg = None
         db = None if bias_part is not None else db
+    elif bias_part is not None and bias_sink is not None:
+        db = None
     if want_bias:
         if bias_part is None:
             db = bias_grad(a, a_gate, a_slope)
             if sink and sb is not None:
                 sb.add_(db)
+                db = None
+            elif bias_sink is not None:
+                bias_sink.add_(db)
                 db = None
         return (dw, dg, db) if wn else (dw, db)
     return (dw, dg) if wn else dw
@@ -779,13 +788,14 @@ def plane_score(h, w, bias):
 
 
 def plane_score_bwd(ds, h, w, want_dh, want_dw, want_db):
+    """ds: [N] score cotangents with any element stride (a column of the stacked [N,1,windows] scores)."""
     _f32(ds, h, w)
     lib, st = _prep_strided(h, ds)
     N, Cc, H, W = h.shape
     dh = torch.empty_strided(h.shape, h.stride(), device=h.device, dtype=torch.float32) if want_dh else None
     dw = torch.empty((Cc * H * W,), device=h.device, dtype=torch.float32) if want_dw else None
     db = torch.empty((1,), device=h.device, dtype=torch.float32) if want_db else None
-    L.check(lib.svb_plane_score_bwd(_ptr(ds), _ptr(h), h.stride(0), h.stride(1), _ptr(w), _ptr(dh), _ptr(dw), _ptr(db), N, Cc,
+    L.check(lib.svb_plane_score_bwd(_ptr(ds), ds.stride(0), _ptr(h), h.stride(0), h.stride(1), _ptr(w), _ptr(dh), _ptr(dw), _ptr(db), N, Cc,
                                     H * W, st), "svb_plane_score_bwd")
     return dh, dw, db
 

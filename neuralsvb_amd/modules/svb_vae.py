@@ -16,6 +16,7 @@ from .layers import Conv1d, LinearNCT
 from .vc_asr import VCASR
 
 
+SPLIT_STACKED = True     # stacked ways: per-way mel_out views through SF.split_stacked_ways (one gradient buffer for both)
 FUSED_GN = True          # ConvBlock: GroupNorm + ReLU + residual as one HIP pass per direction
 
 
@@ -114,8 +115,12 @@ class MleSVBVAE(nn.Module):
         cond = self._cond_sum(c["h_pitch"], c["h_content"], c["h_style"])
         mel_out, kl, z_p, m_q, logs_q, mask_sqz, z_q = self.vae_model(
             tgt_mel.transpose(1, 2).contiguous(), c["tgt_nonpadding"], g=cond, eps=eps, groups=groups)
-        return {"mel_out": mel_out.transpose(1, 2), "kl": kl, "z_p": z_p, "m_q": m_q, "logs_q": logs_q,
-                "x_mask_sqz": mask_sqz, "z_q": z_q}
+        out = {"mel_out": mel_out.transpose(1, 2), "kl": kl, "z_p": z_p, "m_q": m_q, "logs_q": logs_q,
+               "x_mask_sqz": mask_sqz, "z_q": z_q}
+        if groups > 1 and SPLIT_STACKED:
+            # the ways' [B,T,80] outputs as views whose gradients are assembled in one [groups*B,80,T] buffer
+            out["_mel_ways"] = SF.split_stacked_ways(mel_out, groups)
+        return out
 
     def forward(self, amateur_mel=None, prof_mel=None, amateur_pitch=None, prof_pitch=None, amateur_spk_id=None,
                 prof_spk_id=None, a2p_alignment=None, p2a_alignment=None, infer=False, disable_map=False, **kwargs):
@@ -143,8 +148,11 @@ class MleSVBVAE(nn.Module):
             o2 = self.normal_vae(torch.cat([amateur_mel, prof_mel]), c2, None if eps_a is None else torch.cat([eps_a, eps_p]),
                                  groups=2)
             self._last_stacked_kl = o2["kl"]          # [2]: both ways' KL terms as one vector (the task sums from it)
+            mel_ways = o2.pop("_mel_ways", None)
             for i, way in enumerate(("a2a", "p2p")):
                 ret[way] = {k: (None if v is None else (v[i] if k == "kl" else v[i * B:(i + 1) * B])) for k, v in o2.items()}
+                if mel_ways is not None:
+                    ret[way]["mel_out"] = mel_ways[i]
         else:
             if "a2a" in ways:
                 ret["a2a"] = self.normal_vae(amateur_mel, ca, eps_a)

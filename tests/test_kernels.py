@@ -448,6 +448,21 @@ def test_conv1d_wgrad_bf16x3(dev, case):
     assert rel_err(db, dy.sum((0, 2))) < 1e-5          # bias-gradient partials fused into the same two launches
 
 
+@pytest.mark.parametrize("bf16x3", [True, False])
+def test_conv1d_wgrad_bias_sink_only(dev, bf16x3):
+    """bias_sink: the bias gradient alone is accumulated into an existing buffer (svb_wgrad_reduce accumulate = 2) while the
+    weight gradient is returned -- the critic's convs, whose weight gradient still passes through a re-layout."""
+    g_ = torch.Generator().manual_seed(12)
+    B, Cin, Cout, T, k = 2, 12, 20, 97, 2
+    x, dy = torch.randn(B, Cin, T, generator=g_), torch.randn(B, Cout, T, generator=g_)
+    dw0, db0 = K.conv1d_wgrad(dy.to(dev), x.to(dev), k, 1, 0, 1, 1, bf16x3=bf16x3, want_bias=True)
+    sink = torch.full((Cout,), 0.5, device=dev)
+    dw1, db1 = K.conv1d_wgrad(dy.to(dev), x.to(dev), k, 1, 0, 1, 1, bf16x3=bf16x3, want_bias=True, bias_sink=sink)
+    assert db1 is None and torch.equal(dw1, dw0)
+    assert (sink - 0.5 - db0).abs().max() < 1e-5 * db0.abs().max()
+    assert rel_err(db0, dy.sum((0, 2))) < 1e-5
+
+
 def test_conv1d_wgrad_bf16x3_gates_and_weight_norm(dev):
     g_ = torch.Generator().manual_seed(11)
     B, Cin, Cout, T, k = 2, 10, 14, 145, 3

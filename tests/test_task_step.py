@@ -205,12 +205,12 @@ def test_fused_step_paths_equal_elementwise_paths(dev, tmp_path, phase):
             if o is not None:
                 o.load_state_dict(s)
         hp["fused_mel_loss"] = fused
-        fs2_vae.FUSED_HEAD = svb_vae.FUSED_GN = mel_disc.FUSED_CROP = vc_asr.FOLD_RESIDUALS = fused
+        fs2_vae.FUSED_HEAD = svb_vae.FUSED_GN = svb_vae.SPLIT_STACKED = mel_disc.FUSED_CROP = vc_asr.FOLD_RESIDUALS = fused
         try:
             return _grads_after_passes(task, trainer, batch, dev, gs, eps, 77)
         finally:
             hp["fused_mel_loss"] = True
-            fs2_vae.FUSED_HEAD = svb_vae.FUSED_GN = mel_disc.FUSED_CROP = vc_asr.FOLD_RESIDUALS = True
+            fs2_vae.FUSED_HEAD = svb_vae.FUSED_GN = svb_vae.SPLIT_STACKED = mel_disc.FUSED_CROP = vc_asr.FOLD_RESIDUALS = True
     t1, g1 = run(True)
     t0, g0 = run(False)
     assert sorted(t1) == sorted(t0) and len(t1) >= 1
