@@ -346,7 +346,7 @@ def test_plane_score_autograd(dev):
     assert rel_err(hb.grad.permute(1, 0, 2, 3), hr.grad) < 2e-5
     assert rel_err(wd.grad, rl[1].grad) < 2e-5 and rel_err(bd.grad, rl[2].grad) < 2e-5
     # the score's cotangent as a strided column of the stacked [N,1,windows] scores (no re-layout copy in backward)
-    hb2, wd2, bd2 = base.to(dev).requires_grad_(True), _leaf(wt, dev), _leaf(bs, dev)
+    hb2, wd2, bd2 = base.detach().clone().to(dev).requires_grad_(True), _leaf(wt, dev), _leaf(bs, dev)
     y3 = torch.stack([SF.plane_score(hb2.permute(1, 0, 2, 3), wd2, bd2), torch.zeros(N, 1, device=dev)], -1)
     dy3 = torch.zeros(N, 1, 2)
     dy3[:, :, 0] = dy
