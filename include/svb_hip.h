@@ -132,6 +132,14 @@ int svb_conv1d_wgrad_bf16x3(const float* a, const float* b, float* part, int B, 
  * weight_norm this needs 16-byte aligned rows and rowlen <= 4096, SVB_ERR_UNSUPPORTED otherwise); 2 = add into db only. */
 int svb_wgrad_reduce(const float* part, int nsplit, const float* v, const float* g, float* dv, float* dg, int rows,
                      int rowlen, int weight_norm, int accumulate, const float* bias_part, float* db, void* stream);
+/* Several stage-2 reduces in one launch per 24 descriptors (a backward pass can defer all of its reduces to its end): each
+ * descriptor = the arguments of one svb_wgrad_reduce call (part is [nsplit][rows][rowlen]); `descs` is a HOST array (it is
+ * passed through the kernel-argument segment); row_start is filled in by the call.                                    */
+typedef struct SvbReduceDesc {
+    const float* part; const float* v; const float* g; float* dv; float* dg; const float* bias_part; float* db;
+    int nsplit, rows, rowlen, weight_norm, accumulate, row_start;
+} SvbReduceDesc;
+int svb_wgrad_reduce_multi(const SvbReduceDesc* descs, int n, void* stream);
 /* db[c] = sum_{b,t} dy[b,c,t] * gate'(gate[b,c,t])                                                          */
 int svb_bias_grad(const float* dy, const float* gate, float slope, float* db, int B, int C, int T, void* stream);
 

@@ -27,6 +27,12 @@ class SvbPackDesc(C.Structure):
                 ("weight_norm", C.c_int), ("row_start", C.c_int)]
 
 
+class SvbReduceDesc(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("v", C.c_void_p), ("g", C.c_void_p), ("dv", C.c_void_p), ("dg", C.c_void_p),
+                ("bias_part", C.c_void_p), ("db", C.c_void_p), ("nsplit", C.c_int), ("rows", C.c_int), ("rowlen", C.c_int),
+                ("weight_norm", C.c_int), ("accumulate", C.c_int), ("row_start", C.c_int)]
+
+
 I, F, P, SZ, I64 = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_int64
 
 # name -> (restype, argtypes)   -- must mirror include/svb_hip.h exactly
@@ -48,6 +54,7 @@ SIGNATURES = {
     "svb_conv1d_wgrad_bf16x3": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, P, F, P, F, I, P, P]),
     "svb_debug_set_timing_buffer": (None, [P]),
     "svb_wgrad_reduce": (I, [P, I, P, P, P, P, I, I, I, I, P, P, P]),
+    "svb_wgrad_reduce_multi": (I, [P, I, P]),
     "svb_bias_grad": (I, [P, P, F, P, I, I, I, P]),
     "svb_wn_gate_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "svb_wn_gate_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),

@@ -422,14 +422,12 @@ __global__ __launch_bounds__(256) void svb_conv1d_wgrad_kernel(SvbWgradArgs a) {
 // layers also apply d(g v/||v||): dg = <v,dW>/||v||, dv = g/||v|| dW - g <v,dW>/||v||^3 v
 // (torch.nn.utils.weight_norm, dim=0 -- reference fs2_vae.py:42,48,58 / hifigan.py:33-50).
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void svb_wgrad_reduce_kernel(const float* part, int nsplit, size_t split_stride,
-                                                               const float* v, const float* gnorm, float* dv, float* dg,
-                                                               int rowlen, int weight_norm, int accumulate,
-                                                               const float* bias_part, float* db, int rows, int vec) {
+__device__ __forceinline__ void svb_wgrad_reduce_row(const float* part, int nsplit, size_t split_stride, const float* v,
+                                                     const float* gnorm, float* dv, float* dg, int rowlen, int weight_norm,
+                                                     int accumulate, const float* bias_part, float* db, int rows, int vec,
+                                                     int row, float* red) {
     const int acc_b = (accumulate & 3) != 0;      // bit 1: accumulate into db only
     accumulate &= 1;
-    __shared__ float red[8];
-    const int row = blockIdx.x;
     const size_t base = (size_t)row * rowlen;
     float dot = 0.f, vv = 0.f;
     float4 sreg[4];                                           // vec path: this thread's first 4 summed float4s of the row
@@ -531,6 +529,30 @@ __global__ __launch_bounds__(256) void svb_wgrad_reduce_kernel(const float* part
     } else {
         for (int e = threadIdx.x; e < rowlen; e += 256) dv[base + e] = sa * dv[base + e] - sb * v[base + e];
     }
+}
+
+__global__ __launch_bounds__(256) void svb_wgrad_reduce_kernel(const float* part, int nsplit, size_t split_stride,
+                                                               const float* v, const float* gnorm, float* dv, float* dg,
+                                                               int rowlen, int weight_norm, int accumulate,
+                                                               const float* bias_part, float* db, int rows, int vec) {
+    __shared__ float red[8];
+    svb_wgrad_reduce_row(part, nsplit, split_stride, v, gnorm, dv, dg, rowlen, weight_norm, accumulate, bias_part, db, rows, vec,
+                         blockIdx.x, red);
+}
+
+// Many weight gradients finished by ONE launch (the reduces of a whole backward pass, deferred to its end): the descriptors
+// travel in the kernel-argument segment (no device-side table, no upload); block -> (descriptor, row) by the cumulative row
+// counts.  `vec` of a descriptor is filled in by the host entry point.
+#define SVB_REDUCE_BATCH 24
+struct SvbReduceBatch { SvbReduceDesc d[SVB_REDUCE_BATCH]; int vec[SVB_REDUCE_BATCH]; int n; };
+
+__global__ __launch_bounds__(256) void svb_wgrad_reduce_multi_kernel(SvbReduceBatch bt) {
+    __shared__ float red[8];
+    int i = 0;
+    while (i + 1 < bt.n && bt.d[i + 1].row_start <= (int)blockIdx.x) ++i;
+    const SvbReduceDesc& r = bt.d[i];
+    svb_wgrad_reduce_row(r.part, r.nsplit, (size_t)r.rows * r.rowlen, r.v, r.g, r.dv, r.dg, r.rowlen, r.weight_norm, r.accumulate,
+                         r.bias_part, r.db, r.rows, bt.vec[i], (int)blockIdx.x - r.row_start, red);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -830,6 +852,30 @@ extern "C" int svb_wgrad_reduce(const float* part, int nsplit, const float* v, c
     if (weight_norm && accumulate && !(vec && rowlen <= 4096)) return SVB_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(svb_wgrad_reduce_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, part, nsplit,
                        (size_t)rows * rowlen, v, g, dv, dg, rowlen, weight_norm, accumulate, bias_part, db, rows, vec);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_wgrad_reduce_multi(const SvbReduceDesc* descs, int n, void* stream) {
+    if (!descs || n <= 0) return SVB_ERR_ARG;
+    for (int i0 = 0; i0 < n; i0 += SVB_REDUCE_BATCH) {
+        SvbReduceBatch bt;
+        bt.n = n - i0 < SVB_REDUCE_BATCH ? n - i0 : SVB_REDUCE_BATCH;
+        int rows = 0;
+        for (int i = 0; i < bt.n; ++i) {
+            SvbReduceDesc r = descs[i0 + i];
+            if (!r.part || !r.dv || r.rows <= 0 || r.rowlen <= 0 || r.nsplit <= 0) return SVB_ERR_ARG;
+            if (r.weight_norm && (!r.v || !r.g || !r.dg)) return SVB_ERR_ARG;
+            if (r.bias_part && !r.db) return SVB_ERR_ARG;
+            const int vec = (r.rowlen & 3) == 0 && (((uintptr_t)r.part | (uintptr_t)r.dv | (uintptr_t)r.v) & 15) == 0;
+            if (r.weight_norm && (r.accumulate & 1) && !(vec && r.rowlen <= 4096)) return SVB_ERR_UNSUPPORTED;
+            r.row_start = rows;
+            rows += r.rows;
+            bt.d[i] = r;
+            bt.vec[i] = vec;
+        }
+        hipLaunchKernelGGL(svb_wgrad_reduce_multi_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, bt);
+    }
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }

@@ -404,6 +404,61 @@ def _side_ws(side, dev, slot, n):
     return ws[:n]
 
 
+# ---- deferred stage-2 reduces: inside a Trainer-managed backward pass (one process, eager launches) every weight gradient
+# whose results accumulate straight into `.grad` buffers leaves its split-K partials in an arena and only records a
+# descriptor; flush_deferred_reduces() finishes all of them with one svb_wgrad_reduce_multi call (one launch per 24) on the
+# stream the partials were produced on -- ~60 reduce launches per step become 3.
+_DEFERRED = None         # None: off;  else {"descs": [...], "keep": [...], "stream": raw handle, "side": Stream|None, "dev": device}
+_ARENA = {}              # (device index, on side stream) -> [tensor, used floats]
+ARENA_MIN_FLOATS = 64 << 20
+
+
+def begin_deferred_reduces():
+    global _DEFERRED
+    _DEFERRED = {"descs": [], "keep": [], "stream": None, "side": None, "dev": None}
+
+
+def _arena_take(dev, side, n):
+    """n floats (64-byte aligned) of the arena of (device, stream kind); None when it does not fit (the caller flushes)."""
+    key = (dev.index, side is not None)
+    ent = _ARENA.get(key)
+    n = (n + 15) & ~15
+    if ent is None or ent[1] + n > ent[0].numel():
+        return None
+    out = ent[0][ent[1]:ent[1] + n]
+    ent[1] += n
+    return out
+
+
+def _arena_grow(dev, side, n):
+    key = (dev.index, side is not None)
+    ent = _ARENA.get(key)
+    want = max(ARENA_MIN_FLOATS, 2 * (ent[0].numel() if ent is not None else 0), 2 * n)
+    if side is not None:
+        with torch.cuda.stream(side):
+            t = torch.empty((want,), device=dev, dtype=torch.float32)
+    else:
+        t = torch.empty((want,), device=dev, dtype=torch.float32)
+    _ARENA[key] = [t, 0]
+
+
+def flush_deferred_reduces(end=True):
+    """Finish every recorded weight gradient (see above); end=True also leaves deferred mode."""
+    global _DEFERRED
+    d = _DEFERRED
+    if d is None:
+        return
+    if d["descs"]:
+        lib = L.get_lib()
+        arr = (L.SvbReduceDesc * len(d["descs"]))(*d["descs"])
+        L.check(lib.svb_wgrad_reduce_multi(arr, len(d["descs"]), d["stream"]), "svb_wgrad_reduce_multi")
+        d["descs"], d["keep"] = [], []
+    for ent in _ARENA.values():
+        ent[1] = 0
+    if end:
+        _DEFERRED = None
+
+
 def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0, b_gate=None, b_slope=0.0,
                   v=None, g=None, accumulate_into=None, bf16x3=None, want_bias=False, sinks=None, _side=None, bias_sink=None):
     """dW[ca, cb/groups, k] = sum_{n,q} a[n,ca,q] * b[n,cb,q*sx + j*dil - pad].
@@ -426,6 +481,42 @@ def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.
     if WGRAD_BF16X3 if bf16x3 is None else bf16x3:
         nfl = lib.svb_conv1d_wgrad_bf16x3_workspace_floats(B, ca, cb, groups, ta, k, sx, pad, dil, C.byref(ns))
     wflops = 2.0 * B * ca * ta * (cb // groups) * k
+    rows, rowlen = ca, (cb // groups) * k
+    wn = g is not None
+    sv, sg, sb = sinks if sinks is not None else (None, None, None)
+    dfr = _DEFERRED
+    if dfr is not None and nfl and (a.is_cuda or L.lib_is_emulator()):
+        # every result goes into a gradient buffer: leave the partials in the arena, record the reduce, finish it later
+        ok = sv is not None and accumulate_into is None and (not wn or sg is not None) and (not want_bias or sb is not None)
+        if ok and wn:
+            ok = rowlen % 4 == 0 and rowlen <= 4096 and sv.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
+        if ok and dfr["descs"] and (dfr["stream"] != st or dfr["dev"] != a.device):
+            flush_deferred_reduces(end=False)            # (a different stream: finish what was recorded on the other one)
+        if ok:
+            need = ((nfl + 15) & ~15) + (((ns.value * ca + 15) & ~15) if want_bias else 0)
+            part = _arena_take(a.device, _side, nfl)
+            bias_part = _arena_take(a.device, _side, ns.value * ca) if (want_bias and part is not None) else None
+            if part is None or (want_bias and bias_part is None):
+                flush_deferred_reduces(end=False)
+                key = (a.device.index, _side is not None)
+                if key not in _ARENA or _ARENA[key][0].numel() < need:
+                    _arena_grow(a.device, _side, need)
+                part = _arena_take(a.device, _side, nfl)
+                bias_part = _arena_take(a.device, _side, ns.value * ca) if want_bias else None
+            probe = _ConvProbe(lib, a, 0, 0, wflops, family="svb_conv1d_wgrad_bf16x3_kernel",
+                               tag=("wgrad", B, ca, cb, groups, ta, k, sx, dil))
+            L.check(lib.svb_conv1d_wgrad_bf16x3(_ptr(a), _ptr(b), _ptr(part), B, ca, cb, groups, ta, tb, k, sx, pad, dil,
+                                                _ptr(a_gate), float(a_slope), _ptr(b_gate), float(b_slope), ns.value,
+                                                _ptr(bias_part), st), "svb_conv1d_wgrad_bf16x3")
+            probe.done()
+            dsc = L.SvbReduceDesc(_ptr(part), _ptr(v), _ptr(g), _ptr(sv), _ptr(sg) if wn else None, _ptr(bias_part),
+                                  _ptr(sb) if want_bias else None, ns.value, rows, rowlen, int(wn), 1, 0)
+            dfr["descs"].append(dsc)
+            dfr["keep"].append((v, g, sv, sg, sb))
+            dfr["stream"], dfr["side"], dfr["dev"] = st, _side, a.device
+            if want_bias:
+                return (None, None, None) if wn else (None, None)
+            return (None, None) if wn else None
     if nfl:
         if _side is not None:
             part = _side_ws(_side, a.device, 0, nfl)
@@ -448,9 +539,6 @@ def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.
                                      _ptr(a_gate), float(a_slope), _ptr(b_gate), float(b_slope), ns.value, st),
                 "svb_conv1d_wgrad")
         probe.done()
-    rows, rowlen = ca, (cb // groups) * k
-    wn = g is not None
-    sv, sg, sb = sinks if sinks is not None else (None, None, None)
     sink = (sv is not None and accumulate_into is None and (not wn or sg is not None)
             and (bias_part is None or sb is not None))
     if sink and wn:      # the accumulate-with-WeightNorm reduce needs 16-byte rows that fit the thread's registers

@@ -425,8 +425,19 @@ class Trainer:
         if loss is not None:
             loss = loss / self.accumulate_grad_batches
             if loss.requires_grad:
-                loss.backward()
+                from .. import functional as _SF
                 from .. import kernels as _K
+                # one process, eager launches: the stage-2 reduces of this pass's weight gradients are finished by one
+                # multi-tensor launch at its end (with a gradient exchange they must be final when they are announced)
+                defer = (hparams.get("defer_wgrad_reduce", True) and _SF.GRAD_READY is None and not _SF.CAPTURING
+                         and self.world_size == 1 and not (self.hip_graph and self.on_gpu))
+                if defer:
+                    _K.begin_deferred_reduces()
+                try:
+                    loss.backward()
+                finally:
+                    if defer:
+                        _K.flush_deferred_reduces()
                 if _K.WGRAD_STREAM is not None:          # weight gradients enqueued beside the data-gradient chain
                     torch.cuda.current_stream().wait_stream(_K.WGRAD_STREAM)
         return out

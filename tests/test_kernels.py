@@ -585,3 +585,45 @@ def test_glu_dwconv_bn_swish(dev):
         ref = z * torch.sigmoid(z)
         out = K.glu_dwconv_bn_swish(y.to(dev), w.to(dev), b.to(dev), bw.to(dev), bb.to(dev), mean.to(dev), var.to(dev), 1e-5)
         assert (out.cpu() - ref).abs().max() < 2e-5, (B, C, T, k)
+
+
+def test_deferred_wgrad_reduces_equal_immediate(dev):
+    """Weight gradients recorded in deferred mode (partials left in the arena, one svb_wgrad_reduce_multi call at the end)
+    against the immediate two-launch form: plain, weight-normalised and biased layers, more than one 24-descriptor batch,
+    and an arena that has to grow (flush in the middle)."""
+    g_ = torch.Generator().manual_seed(31)
+    layers = []
+    for i in range(27):
+        cin, cout, k = [(8, 12, 3), (16, 8, 1), (12, 20, 5)][i % 3]
+        wn = i % 2 == 0
+        layers.append((torch.randn(2, cin, 60 + i, generator=g_), torch.randn(2, cout, 60 + i, generator=g_),
+                       torch.randn(cout, cin, k, generator=g_) * 0.3, (torch.rand(cout, 1, 1, generator=g_) + 0.5) if wn else None, k))
+
+    def run(deferred):
+        sinks_all = []
+        old_min = K.ARENA_MIN_FLOATS
+        K._ARENA.clear()
+        K.ARENA_MIN_FLOATS = 1 << 12          # small: the arena must grow while descriptors are pending
+        if deferred:
+            K.begin_deferred_reduces()
+        try:
+            for x, dy, v, gn, k in layers:
+                sk = (torch.full(v.shape, 0.25, device=dev), torch.full(gn.shape, -0.5, device=dev) if gn is not None else None,
+                      torch.full((v.shape[0],), 1.5, device=dev))
+                r = K.conv1d_wgrad(dy.to(dev), x.to(dev), k, 1, (k - 1) // 2, 1, 1, v=v.to(dev) if gn is not None else None,
+                                   g=gn.to(dev) if gn is not None else None, bf16x3=True, want_bias=True, sinks=sk)
+                assert all(t is None for t in r)
+                sinks_all.append(sk)
+            if deferred:
+                assert K._DEFERRED["descs"]            # still pending
+        finally:
+            if deferred:
+                K.flush_deferred_reduces()
+            K.ARENA_MIN_FLOATS = old_min
+        assert K._DEFERRED is None
+        return sinks_all
+    now, later = run(False), run(True)
+    for a_, b_ in zip(now, later):
+        for t0, t1 in zip(a_, b_):
+            if t0 is not None:
+                assert torch.equal(t0, t1)

@@ -188,7 +188,9 @@ def test_fused_step_paths_equal_elementwise_paths(dev, tmp_path, phase):
     #  the CPU lane emulator, so that variant only runs there on request; the MI355X variant always runs)
     if phase == 3 and dev.type == "cpu" and os.environ.get("SVB_SLOW_TESTS", "0") != "1":
         pytest.skip("phase-3 step at hidden_size 256 on the lane emulator: set SVB_SLOW_TESTS=1 (passes; ~5 min)")
-    task, trainer, batch, hp = _setup(tmp_path, dev, ",hidden_size=256" if phase == 3 else "")
+    # phase 2 runs in the bench's arithmetic (bf16x3: also the deferred multi-tensor reduce of the weight gradients, which only
+    # exists on that path), phase 3 in fp32
+    task, trainer, batch, hp = _setup(tmp_path, dev, ",hidden_size=256" if phase == 3 else ",conv_precision=bf16x3")
     hp["phase_2_steps"] = 2 if phase == 3 else 10 ** 6
     gs = 3 if phase == 3 else 2
     L = hp["latent_size"]
@@ -204,15 +206,31 @@ def test_fused_step_paths_equal_elementwise_paths(dev, tmp_path, phase):
         for o, s in zip(trainer.optimizers, opt0):
             if o is not None:
                 o.load_state_dict(s)
-        hp["fused_mel_loss"] = fused
+        hp["fused_mel_loss"] = hp["defer_wgrad_reduce"] = fused
         fs2_vae.FUSED_HEAD = svb_vae.FUSED_GN = svb_vae.SPLIT_STACKED = mel_disc.FUSED_CROP = vc_asr.FOLD_RESIDUALS = fused
+        from neuralsvb_amd import kernels as K
+        n_deferred = [0]
+        o_flush = K.flush_deferred_reduces
+
+        def counting_flush(end=True):
+            n_deferred[0] += len(K._DEFERRED["descs"]) if K._DEFERRED is not None else 0
+            return o_flush(end)
+        K.flush_deferred_reduces = counting_flush
         try:
-            return _grads_after_passes(task, trainer, batch, dev, gs, eps, 77)
+            out = _grads_after_passes(task, trainer, batch, dev, gs, eps, 77)
+            if phase == 2:           # (bf16x3: the generator's weight gradients all go through the deferred reduce)
+                assert (n_deferred[0] > 20) == bool(fused), n_deferred
+            return out
         finally:
-            hp["fused_mel_loss"] = True
+            K.flush_deferred_reduces = o_flush
+            hp["fused_mel_loss"] = hp["defer_wgrad_reduce"] = True
             fs2_vae.FUSED_HEAD = svb_vae.FUSED_GN = svb_vae.SPLIT_STACKED = mel_disc.FUSED_CROP = vc_asr.FOLD_RESIDUALS = True
-    t1, g1 = run(True)
-    t0, g0 = run(False)
+    try:
+        t1, g1 = run(True)
+        t0, g0 = run(False)
+    finally:
+        from neuralsvb_amd import functional as SF
+        SF.set_precision("fp32")
     assert sorted(t1) == sorted(t0) and len(t1) >= 1
     assert (2 in t1) == (phase == 3)
     for oi in t0:
