@@ -409,7 +409,7 @@ def _side_ws(side, dev, slot, n):
 # descriptor; flush_deferred_reduces() finishes all of them with one svb_wgrad_reduce_multi call (one launch per 24) on the
 # stream the partials were produced on -- ~60 reduce launches per step become 3.
 _DEFERRED = None         # None: off;  else {"descs": [...], "keep": [...], "stream": raw handle, "side": Stream|None, "dev": device}
-_ARENA = {}              # (device index, on side stream) -> [tensor, used floats]
+_ARENA = {}              # (device index, raw stream handle) -> [tensor, used floats]: an arena is only ever touched by one stream
 ARENA_MIN_FLOATS = 64 << 20
 
 
@@ -418,9 +418,9 @@ def begin_deferred_reduces():
     _DEFERRED = {"descs": [], "keep": [], "stream": None, "side": None, "dev": None}
 
 
-def _arena_take(dev, side, n):
-    """n floats (64-byte aligned) of the arena of (device, stream kind); None when it does not fit (the caller flushes)."""
-    key = (dev.index, side is not None)
+def _arena_take(dev, st, n):
+    """n floats (64-byte aligned) of the arena of (device, stream); None when it does not fit (the caller flushes)."""
+    key = (dev.index, st)
     ent = _ARENA.get(key)
     n = (n + 15) & ~15
     if ent is None or ent[1] + n > ent[0].numel():
@@ -430,8 +430,8 @@ def _arena_take(dev, side, n):
     return out
 
 
-def _arena_grow(dev, side, n):
-    key = (dev.index, side is not None)
+def _arena_grow(dev, side, st, n):
+    key = (dev.index, st)
     ent = _ARENA.get(key)
     want = max(ARENA_MIN_FLOATS, 2 * (ent[0].numel() if ent is not None else 0), 2 * n)
     if side is not None:
@@ -494,15 +494,15 @@ def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.
             flush_deferred_reduces(end=False)            # (a different stream: finish what was recorded on the other one)
         if ok:
             need = ((nfl + 15) & ~15) + (((ns.value * ca + 15) & ~15) if want_bias else 0)
-            part = _arena_take(a.device, _side, nfl)
-            bias_part = _arena_take(a.device, _side, ns.value * ca) if (want_bias and part is not None) else None
+            part = _arena_take(a.device, st, nfl)
+            bias_part = _arena_take(a.device, st, ns.value * ca) if (want_bias and part is not None) else None
             if part is None or (want_bias and bias_part is None):
                 flush_deferred_reduces(end=False)
-                key = (a.device.index, _side is not None)
+                key = (a.device.index, st)
                 if key not in _ARENA or _ARENA[key][0].numel() < need:
-                    _arena_grow(a.device, _side, need)
-                part = _arena_take(a.device, _side, nfl)
-                bias_part = _arena_take(a.device, _side, ns.value * ca) if want_bias else None
+                    _arena_grow(a.device, _side, st, need)
+                part = _arena_take(a.device, st, nfl)
+                bias_part = _arena_take(a.device, st, ns.value * ca) if want_bias else None
             probe = _ConvProbe(lib, a, 0, 0, wflops, family="svb_conv1d_wgrad_bf16x3_kernel",
                                tag=("wgrad", B, ca, cb, groups, ta, k, sx, dil))
             L.check(lib.svb_conv1d_wgrad_bf16x3(_ptr(a), _ptr(b), _ptr(part), B, ca, cb, groups, ta, tb, k, sx, pad, dil,
