@@ -415,7 +415,7 @@ ARENA_MIN_FLOATS = 64 << 20
 
 def begin_deferred_reduces():
     global _DEFERRED
-    _DEFERRED = {"descs": [], "keep": [], "stream": None, "side": None, "dev": None}
+    _DEFERRED = {"descs": [], "keep": [], "sinks": set(), "stream": None, "side": None, "dev": None}
 
 
 def _arena_take(dev, st, n):
@@ -453,6 +453,7 @@ def flush_deferred_reduces(end=True):
         arr = (L.SvbReduceDesc * len(d["descs"]))(*d["descs"])
         L.check(lib.svb_wgrad_reduce_multi(arr, len(d["descs"]), d["stream"]), "svb_wgrad_reduce_multi")
         d["descs"], d["keep"] = [], []
+        d["sinks"].clear()
     for ent in _ARENA.values():
         ent[1] = 0
     if end:
@@ -492,6 +493,13 @@ def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.
             ok = rowlen % 4 == 0 and rowlen <= 4096 and sv.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
         if ok and dfr["descs"] and (dfr["stream"] != st or dfr["dev"] != a.device):
             flush_deferred_reduces(end=False)            # (a different stream: finish what was recorded on the other one)
+        if ok:
+            # a weight used twice in one pass (a discriminator applied to real and generated audio, the decoder of the a2p
+            # way): two recorded reduces would accumulate into the same rows from concurrent workgroups -- finish the first
+            mine = {t.data_ptr() for t in (sv, sg if wn else None, sb if want_bias else None) if t is not None}
+            if mine & dfr["sinks"]:
+                flush_deferred_reduces(end=False)
+            dfr["sinks"] |= mine
         if ok:
             need = ((nfl + 15) & ~15) + (((ns.value * ca + 15) & ~15) if want_bias else 0)
             part = _arena_take(a.device, st, nfl)

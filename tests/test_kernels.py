@@ -627,3 +627,21 @@ def test_deferred_wgrad_reduces_equal_immediate(dev):
         for t0, t1 in zip(a_, b_):
             if t0 is not None:
                 assert torch.equal(t0, t1)
+
+    # the same sinks used twice in one pass (shared weights): the second record must not race the first
+    x, dy, v, gn, k = layers[0]
+
+    def twice(deferred):
+        sk = (torch.zeros(v.shape, device=dev), torch.zeros(gn.shape, device=dev), torch.zeros((v.shape[0],), device=dev))
+        if deferred:
+            K.begin_deferred_reduces()
+        try:
+            for sgn in (1.0, -0.5):
+                K.conv1d_wgrad((dy * sgn).to(dev), x.to(dev), k, 1, (k - 1) // 2, 1, 1, v=v.to(dev), g=gn.to(dev), bf16x3=True,
+                               want_bias=True, sinks=sk)
+        finally:
+            if deferred:
+                K.flush_deferred_reduces()
+        return sk
+    for t0, t1 in zip(twice(False), twice(True)):
+        assert torch.equal(t0, t1)
