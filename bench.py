@@ -380,6 +380,7 @@ def main():
     ap.add_argument("--legacy-paths", action="store_true",
                     help="A/B switch: the step's fused passes (mel loss, latent head, GroupNorm+ReLU, window crops, conformer "
                          "residual epilogues, stacked-way split, deferred weight-gradient reduces) back on their element-wise forms")
+    ap.add_argument("--extra-hparams", default="", help="A/B switch: appended to the task's hparams string (k=v,k=v)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true",
@@ -410,11 +411,11 @@ def main():
     if args.use_q:
         from neuralsvb_amd import functional as SF
         SF.USE_Q = True
-    extra = ""
+    extra = ("," + args.extra_hparams) if args.extra_hparams else ""
     if args.legacy_paths:
         from neuralsvb_amd.modules import fs2_vae, mel_disc, svb_vae, vc_asr
         fs2_vae.FUSED_HEAD = svb_vae.FUSED_GN = svb_vae.SPLIT_STACKED = mel_disc.FUSED_CROP = vc_asr.FOLD_RESIDUALS = False
-        extra = ",fused_mel_loss=False,defer_wgrad_reduce=False"
+        extra += ",fused_mel_loss=False,defer_wgrad_reduce=False"
     with tempfile.TemporaryDirectory() as tmp:
         log("building synthetic dataset + task")
         task, trainer, batch, hp = build_task(args, rank, world, device, tmp, extra)
