@@ -39,6 +39,16 @@ typedef struct SvbConvEpilogue {
     const unsigned short* x_q; /* bf16x3 entry points only: optional Q image of x (svb_split_q layout).  When given (and
                                 * in_gate is NULL) the kernel stages its input tiles from it with plain 16-byte copies
                                 * instead of splitting fp32 x again in every consuming workgroup; results are bit-identical. */
+    /* svb_conv1d_forward_bf16x3 only, groups = 1: the gated stack's res/skip update (reference fs2_vae.py:83-89) as the
+     * epilogue of the 1x1 conv that produces it.  With skip_out set, the conv's rows v = acc + bias go to two tensors:
+     *   rows [0, res_rows):    y[b][r][t]            = (residual[b][r][t] + v) * mask[b][t]     (y, residual: [B][res_rows][T])
+     *   rows [res_rows, Cout): skip_out[b][r-res_rows][t] = (skip_in ? skip_in[...] : 0) + v, times mask[b][t] if skip_mask
+     * (skip_out / skip_in: [B][Cout-res_rows][T]; skip_in may equal skip_out).  res_rows = 0 for the stack's last layer
+     * (y, residual unused).  out_act / out_gate / in_gate must be unset.                                                 */
+    float* skip_out;
+    const float* skip_in;
+    int res_rows;
+    int skip_mask;
 } SvbConvEpilogue;
 
 /* Weight pack (+ WeightNorm forward  w = g * v / ||v||, norm over all dims but 0).

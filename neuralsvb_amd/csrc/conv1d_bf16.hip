@@ -35,6 +35,9 @@ struct SvbConvQArgs {
     const float* out_gate;
     const float* mask;
     const float* residual;
+    float* skip_out;              // MODE 3 (res/skip epilogue, see SvbConvEpilogue)
+    const float* skip_in;
+    int res_rows, skip_mask;
     float in_slope, out_slope, out_gate_slope;
     int out_act;
     int B, Cin, Cout, G, Cin_g, Cout_g, Tin, Tout;
@@ -79,7 +82,8 @@ __device__ __forceinline__ void svbq_split8(const float* v, uint4& hi, uint4& lo
 }
 
 // MODE 0: fp32 x, split while staging;  1: the same with the activation-derivative gate on the load;  2: x comes pre-split
-// (Q image): the tile is staged with 16-byte copies -- four consecutive lanes fetch the 64-byte row of one position.
+// (Q image): the tile is staged with 16-byte copies -- four consecutive lanes fetch the 64-byte row of one position;
+// 3: staging as 0, res/skip epilogue (its own instantiations: the code of the other modes does not move).
 template <int WM, int WN, int NT, int SLB, int MODE>
 __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs a, SvbConvPlan p) {
     constexpr bool GATE = MODE == 1, QIN = MODE == 2;
@@ -516,6 +520,46 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     const int out_base = p.phase_out_base[ph];
     dbg_stage = SVBQ_DBG_STAGES - 1;
     SVBQ_STAMP(6)
+    if constexpr (MODE == 3) {
+        // res/skip update of the gated stack (G = 1): rows below res_rows update x, the others accumulate the skip sum
+        const int cres = a.res_rows, cs = a.Cout - cres;
+        const size_t rb_off = (size_t)b * cres * a.Tout, sb_off = (size_t)b * cs * a.Tout;
+        float* xn = a.y + rb_off;
+        const float* xo = a.residual + rb_off;
+        float* so = a.skip_out + sb_off;
+        const float* si = a.skip_in ? a.skip_in + sb_off : nullptr;
+        const float* maskb = a.mask ? a.mask + (size_t)b * a.Tout : nullptr;
+        const bool smask = a.skip_mask != 0;
+        int rowoff[16], kind[16];
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = m_base + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+            const bool ok = co < a.Cout;
+            kind[r] = ok ? (co < cres ? 1 : 2) : 0;
+            rowoff[r] = (co < cres ? co : co - cres) * a.Tout;
+            bv[r] = (a.bias && ok) ? a.bias[co] : 0.f;
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int ql = q0 + (wn * NT + n) * 32 + l31;
+            const int pos = ql * a.out_stride + out_base;
+            if (ql < nq) {
+                const float mk = maskb ? maskb[pos] : 1.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[n][r] + bv[r];
+                    const int oi = rowoff[r] + pos;
+                    if (kind[r] == 1) {
+                        xn[oi] = (xo[oi] + v) * mk;
+                    } else if (kind[r] == 2) {
+                        const float o = si ? si[oi] + v : v;
+                        so[oi] = smask ? o * mk : o;
+                    }
+                }
+            }
+        }
+    } else
     {
         const size_t yb_off = (size_t)b * a.Cout * a.Tout;
         float* yb = a.y + yb_off;
@@ -677,7 +721,7 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     int kch = SLB / a.tg;
     // Q input: usable without an input gate, with whole 16-channel chunks per group, and when one chunk's span fits the
     // per-thread unit budget
-    const bool qin = a.xq && !a.in_gate && (a.G == 1 || a.Cin_g % 16 == 0) && 4 * span_max <= SVBQ_QUNITS * 256;
+    const bool qin = a.xq && !a.in_gate && !a.skip_out && (a.G == 1 || a.Cin_g % 16 == 0) && 4 * span_max <= SVBQ_QUNITS * 256;
     const int kch_cap = qin ? (SVBQ_QUNITS * 256) / (4 * span_max) : (a.fast_x ? SVBQ_XUNITS / a.xit : 2);
     if (kch > kch_cap) kch = kch_cap;
     if (kch > a.kchunks) kch = a.kchunks;
@@ -707,7 +751,8 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     a.w_floats16 = SLB <= 5 ? 0 : a.tg * a.kch * BM * 3;
     a.x_floats16 = a.kch * a.xrows * 3;
     dim3 grid(a.G * svb_cdiv(a.Cout_g, BM), svb_cdiv(nq_max, BN), a.B * p.n_phase);
-    if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, 1>(a, p, grid, lds_bytes(a.kch), stream);
+    if (a.skip_out) q_launch_kernel<WM, WN, NT, SLB, 3>(a, p, grid, lds_bytes(a.kch), stream);
+    else if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, 1>(a, p, grid, lds_bytes(a.kch), stream);
     else if (qin) q_launch_kernel<WM, WN, NT, SLB, 2>(a, p, grid, lds_bytes(a.kch), stream);
     else q_launch_kernel<WM, WN, NT, SLB, 0>(a, p, grid, lds_bytes(a.kch), stream);
     SVB_CHECK_LAUNCH();
@@ -768,6 +813,7 @@ static void q_fill(SvbConvQArgs& a, const SvbConvEpilogue* e) {
     a.mask = e ? e->mask : nullptr;
     a.force_cfg = e ? e->force_cfg - 1 : -1;
     a.xq = e ? e->x_q : nullptr;
+    a.skip_out = nullptr; a.skip_in = nullptr; a.res_rows = 0; a.skip_mask = 0;     // (svb_conv1d_forward_bf16x3 sets them)
     a.dbg = g_svbq_dbg;
     a.dbg_block0 = g_svbq_dbg_block0;
 }
@@ -803,6 +849,12 @@ extern "C" int svb_conv1d_forward_bf16x3(const float* x, const unsigned short* q
     memset(&p, 0, sizeof(p));
     a.x = x; a.wq_hi = qa_hi; a.wq_lo = qa_lo; a.y = y;
     q_fill(a, epi);
+    if (epi && epi->skip_out) {       // res/skip epilogue (MODE 3)
+        if (groups != 1 || epi->res_rows < 0 || epi->res_rows >= Cout || epi->out_act || epi->out_gate || epi->in_gate ||
+            (epi->res_rows > 0 && !epi->residual) || (epi->skip_mask && !epi->mask))
+            return SVB_ERR_ARG;
+        a.skip_out = epi->skip_out; a.skip_in = epi->skip_in; a.res_rows = epi->res_rows; a.skip_mask = epi->skip_mask;
+    }
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.G = groups; a.Cin_g = Cin / groups; a.Cout_g = Cout / groups;
     a.Tin = Tin; a.Tout = Tout; a.sx = stride; a.out_stride = 1;
     a.w_tap_slabs = svb_cdiv(a.Cin_g, 16); a.w_g_slabs = 0; a.w_slab_rows = Cout; a.w_goff_m = a.Cout_g;

@@ -61,6 +61,11 @@ USE_Q = False            # bf16x3 mode, opt-in: producers inside the gated stack
                          # into the conv epilogues, where the Q image costs no extra pass.
 
 
+FUSE_RES_SKIP = False    # gated stack, bf16x3: the res/skip update (x = (x + rs[:C]) * mask, out += rs[C:]) as the epilogue of the
+                         # 1x1 conv that produces rs (its own kernel instantiations, svb_conv1d_bf16x3_kernel<..., 3>): one launch
+                         # and ~4C*B*T*4 bytes of traffic per layer less.  Landed after the round's last GPU minute: bit-exact
+                         # against the two-kernel form on the lane emulator, NOT yet timed on the MI355X -- off until it is.
+
 DIRECT_GRADS = True      # weight/bias gradients of leaf parameters that already own a `.grad` buffer are accumulated into
                          # it by the reduce kernel itself (autograd gets None and skips its `grad += new` pass)
 
@@ -383,6 +388,7 @@ class _WNStackFn(torch.autograd.Function):
         saved_x, saved_xin, saved_acts, packs_b = [], [], [], []
         out = None
         useq = USE_Q and PRECISION == "bf16x3" and C % 16 == 0
+        fuse_rs = FUSE_RES_SKIP and PRECISION == "bf16x3" and not useq and (C * T) < (1 << 31)
         xq = K.split_q(x) if useq else None
         for i, (in_v, in_g, in_b, rs_v, rs_g, rs_b) in enumerate(layers):
             dil = dilation_rate ** i
@@ -396,18 +402,23 @@ class _WNStackFn(torch.autograd.Function):
                 acts = K.wn_gate_fwd(xin, G, i * 2 * C)
             pa_rs, pb_rs = _pack(_c(rs_v), _c(rs_g))
             last = i == n_layers - 1
-            rs = K.conv1d_forward(acts, pa_rs, rs_v.shape[0], 1, bias=_c(rs_b), x_q=acts_q)
             saved_x.append(x)
             saved_xin.append(xin)
             saved_acts.append(acts)
             packs_b.append((pb_in, pb_rs))
+            if fuse_rs:          # the res/skip update as the 1x1 conv's own epilogue: no `rs` tensor, no update kernel
+                x_new, out = K.conv1d_res_skip(acts, pa_rs, rs_v.shape[0], x, mask, out, last, bias=_c(rs_b))
+                if not last:
+                    x = x_new
+                continue
+            rs = K.conv1d_forward(acts, pa_rs, rs_v.shape[0], 1, bias=_c(rs_b), x_q=acts_q)
             if useq:
                 x_new, out, xq = K.wn_res_skip(x, rs, mask, out, last, want_q=True)
             else:
                 x_new, out = K.wn_res_skip(x, rs, mask, out, last)
             if not last:
                 x = x_new
-        if mask is not None:
+        if mask is not None and not fuse_rs:       # (the fused last layer already applied it)
             out = out * mask[:, None, :]
         ctx.meta = (n_layers, kernel_size, dilation_rate, C)
         ctx.useq = useq

@@ -113,9 +113,11 @@ def _f32(*ts):
 
 
 def make_epilogue(bias=None, in_gate=None, in_slope=0.0, out_act=ACT_NONE, out_slope=0.0, out_gate=None,
-                  out_gate_slope=0.0, residual=None, mask=None, force_cfg=0, x_q=None):
+                  out_gate_slope=0.0, residual=None, mask=None, force_cfg=0, x_q=None, skip_out=None, skip_in=None,
+                  res_rows=0, skip_mask=False):
     e = L.SvbConvEpilogue()
     e.x_q = _ptr(x_q)
+    e.skip_out, e.skip_in, e.res_rows, e.skip_mask = _ptr(skip_out), _ptr(skip_in), int(res_rows), int(bool(skip_mask))
     e.bias, e.in_gate, e.out_gate = _ptr(bias), _ptr(in_gate), _ptr(out_gate)
     e.residual, e.mask = _ptr(residual), _ptr(mask)
     e.in_slope, e.out_slope, e.out_gate_slope = float(in_slope), float(out_slope), float(out_gate_slope)
@@ -229,12 +231,16 @@ def conv1d_forward(x, pa, cout, k, stride=1, pad=0, dil=1, groups=1, out=None, *
     if q:
         y = out if out is not None else torch.empty((B, cout, tout), device=x.device, dtype=torch.float32)
         e = make_epilogue(**epi)
-        if x.is_cuda and not epi.get("force_cfg"):
+        if x.is_cuda and not epi.get("force_cfg") and epi.get("skip_out") is None:
             def launch(cfg):
                 e.force_cfg = cfg
                 L.check(lib.svb_conv1d_forward_bf16x3(_ptr(x), _ptr(pa.hi), _ptr(pa.lo), _ptr(y), B, cin, cout, groups, tin,
                                                       tout, k, stride, pad, dil, C.byref(e), st), "svb_conv1d_forward_bf16x3")
             e.force_cfg = _tuned_cfg(("qf", B, cin, cout, groups, tin, k, stride, pad, dil, has_q), launch, _NCFG_Q)
+        elif x.is_cuda and not epi.get("force_cfg"):
+            # res/skip epilogue: it accumulates in place, so it is never launched for timing -- it takes the tile measured for
+            # the plain conv of the same shape (if that was seen), else the heuristic one
+            e.force_cfg = _TUNED.get(("qf", B, cin, cout, groups, tin, k, stride, pad, dil, False), 0)
         probe = _ConvProbe(lib, x, cout // groups, tout, 2.0 * B * cout * tout * (cin // groups) * k, B * groups, e.force_cfg,
                            "svb_conv1d_bf16x3_kernel", tag=("fwd", B, cin, cout, groups, tin, k, stride, dil))
         L.check(lib.svb_conv1d_forward_bf16x3(_ptr(x), _ptr(pa.hi), _ptr(pa.lo), _ptr(y), B, cin, cout, groups, tin, tout, k,
@@ -288,6 +294,24 @@ def conv1d_taps(x, packed, cout, offsets, tout=None, **epi):
     launch(cfg)
     probe.done()
     return y
+
+
+def conv1d_res_skip(acts, pa, cout, x, mask, out, last, bias=None, force_cfg=0):
+    """The gated stack's res/skip 1x1 conv with its update as the conv's epilogue (bf16x3 only; reference fs2_vae.py:83-89):
+    rs = conv1x1(acts);  x_new = (x + rs[:, :C]) * mask;  out (+)= rs[:, C:]   (last layer: out (+)= rs, then * mask).
+    `out`: the running skip sum, updated IN PLACE (None on the first layer: allocated).  Returns (x_new or None, out)."""
+    if not isinstance(pa, PackedQ):
+        raise TypeError("conv1d_res_skip: bf16x3 packed weights only")
+    B, cin, T = acts.shape
+    c = cout if last else cout // 2
+    first = out is None
+    if first:
+        out = torch.empty((B, c, T), device=acts.device, dtype=torch.float32)
+    x_new = None if last else torch.empty((B, c, T), device=acts.device, dtype=torch.float32)
+    conv1d_forward(acts, pa, cout, 1, out=out if last else x_new, bias=bias, residual=None if last else x, mask=mask,
+                   skip_out=out, skip_in=None if first else out, res_rows=0 if last else c, skip_mask=last and mask is not None,
+                   force_cfg=force_cfg)
+    return x_new, out
 
 
 def conv1d_transposed(x, pb, cout, tout, k, stride=1, pad=0, dil=1, groups=1, out=None, **epi):

@@ -645,3 +645,32 @@ def test_deferred_wgrad_reduces_equal_immediate(dev):
         return sk
     for t0, t1 in zip(twice(False), twice(True)):
         assert torch.equal(t0, t1)
+
+
+@pytest.mark.parametrize("cfg", list(range(1, 11)))
+@pytest.mark.parametrize("C", [64, 40])
+def test_conv1d_res_skip_epilogue_every_tile(dev, cfg, C):
+    """svb_conv1d_bf16x3_kernel<..., 3> (res/skip epilogue) in every tile configuration, against the plain 1x1 conv of the same
+    configuration + svb_wn_res_skip: first / middle / last layer forms, bit-exact.  C = 64: whole 4-slab phases (direct-A
+    tiles run their straight-line loop); C = 40: ragged chunks and rows."""
+    g_ = torch.Generator().manual_seed(50 + cfg)
+    B, T = 2, 203
+    acts, x = torch.randn(B, C, T, generator=g_).to(dev), torch.randn(B, C, T, generator=g_).to(dev)
+    mask = torch.ones(B, T)
+    mask[0, 150:] = 0.0
+    mask = mask.to(dev)
+    out_prev = torch.randn(B, C, T, generator=g_).to(dev)
+    for last in (False, True):
+        rc = C if last else 2 * C
+        w = (torch.randn(rc, C, 1, generator=g_) * 0.2).to(dev)
+        bias = torch.randn(rc, generator=g_).to(dev)
+        pa = K.weight_pack_q(w, None, 1, want_a=True, want_b=False)[0]
+        for prev in (None, out_prev):
+            rs = K.conv1d_forward(acts, pa, rc, 1, bias=bias, force_cfg=cfg)
+            x_ref, out_ref = K.wn_res_skip(x, rs, mask, prev, last)
+            if last:
+                out_ref = out_ref * mask[:, None, :]
+            x_new, out = K.conv1d_res_skip(acts, pa, rc, x, mask, None if prev is None else prev.clone(), last, bias=bias,
+                                           force_cfg=cfg)
+            assert torch.equal(out, out_ref)
+            assert last or torch.equal(x_new, x_ref)
