@@ -49,6 +49,17 @@ typedef struct SvbConvEpilogue {
     const float* skip_in;
     int res_rows;
     int skip_mask;
+    /* svb_conv1d_forward_bf16x3 only, groups = 1, Cout = 2C: the gated stack's gate (reference fs2_vae.py:10-16,75-80) as the
+     * epilogue of the in-layer conv.  With gate_acts set, y [B][2C][T] receives the conv output as usual and
+     *   gate_acts[b][c][t] = tanh(y[b][c][t] + g[b][goff+c][t]) * sigmoid(y[b][C+c][t] + g[b][goff+C+c][t])
+     * with g = gate_g [B][gate_gch][T] (NULL: no conditioning term).  The kernel reads the weight rows of a tile interleaved
+     * (tanh row c, sigmoid row C+c, tanh row c+1, ...) so that both halves of a channel are adjacent accumulator registers
+     * of one lane; only the tile shapes that read their weight fragments straight from global memory implement it (another
+     * force_cfg is replaced by the 128x96 tile).  Exclusive with skip_out / out_act / out_gate / residual / mask.        */
+    float* gate_acts;
+    const float* gate_g;
+    int gate_gch;
+    int gate_goff;
 } SvbConvEpilogue;
 
 /* Weight pack (+ WeightNorm forward  w = g * v / ||v||, norm over all dims but 0).

@@ -38,6 +38,9 @@ struct SvbConvQArgs {
     float* skip_out;              // MODE 3 (res/skip epilogue, see SvbConvEpilogue)
     const float* skip_in;
     int res_rows, skip_mask;
+    float* gate_acts;             // MODE 4 (gate epilogue)
+    const float* gate_g;
+    int gate_gch, gate_goff;
     float in_slope, out_slope, out_gate_slope;
     int out_act;
     int B, Cin, Cout, G, Cin_g, Cout_g, Tin, Tout;
@@ -83,7 +86,8 @@ __device__ __forceinline__ void svbq_split8(const float* v, uint4& hi, uint4& lo
 
 // MODE 0: fp32 x, split while staging;  1: the same with the activation-derivative gate on the load;  2: x comes pre-split
 // (Q image): the tile is staged with 16-byte copies -- four consecutive lanes fetch the 64-byte row of one position;
-// 3: staging as 0, res/skip epilogue (its own instantiations: the code of the other modes does not move).
+// 3: staging as 0, res/skip epilogue (its own instantiations: the code of the other modes does not move);
+// 4: staging as 0, gate epilogue over interleaved weight rows (direct-A tiles only).
 template <int WM, int WN, int NT, int SLB, int MODE>
 __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs a, SvbConvPlan p) {
     constexpr bool GATE = MODE == 1, QIN = MODE == 2;
@@ -301,7 +305,14 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     // phase s right after their last use (rolling prefetch), so they have a whole phase to arrive.
     uint4 wfh[SLB], wfl[SLB];
     const int wf_row = wm * 32 + l31;
-    const int wf_lane16 = (wf_row < m_valid ? wf_row : 0) * 2 + kb;                 // 16-byte units inside a slab
+    int wf_lane16 = (wf_row < m_valid ? wf_row : 0) * 2 + kb;                       // 16-byte units inside a slab
+    if constexpr (MODE == 4) {
+        // gate epilogue: tile row i is weight row (i & 1 ? C : 0) + (m_base + i) / 2 -- tanh row c and sigmoid row C + c of a
+        // channel become accumulator rows 2j, 2j+1, i.e. adjacent registers of one lane (w_off0 already holds m_base)
+        const int chalf = a.Cout_g >> 1, pair = (m_base + wf_row) >> 1;
+        const int wrow = pair < chalf ? (wf_row & 1) * chalf + pair : m_base;
+        wf_lane16 = (wrow - m_base) * 2 + kb;
+    }
     auto load_wf = [&](int i, int kc0, int tg0) {          // slab i = (tap i / kch, chunk i % kch) of phase (kc0, tg0)
         const int nt_here = min(a.tg, ntap - tg0);
         const int kch_here = min(a.kch, a.kchunks - kc0);
@@ -520,7 +531,44 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     const int out_base = p.phase_out_base[ph];
     dbg_stage = SVBQ_DBG_STAGES - 1;
     SVBQ_STAMP(6)
-    if constexpr (MODE == 3) {
+    if constexpr (MODE == 4) {
+        // gate of the gated stack (G = 1, Cout = 2C, interleaved rows): registers r, r+1 (r even) of a lane are the tanh and
+        // the sigmoid pre-activation of channel `pair`
+        const int chalf = a.Cout >> 1;
+        float* yb = a.y + (size_t)b * a.Cout * a.Tout;
+        float* ab = a.gate_acts + (size_t)b * chalf * a.Tout;
+        const float* gbase = a.gate_g ? a.gate_g + ((size_t)b * a.gate_gch + a.gate_goff) * a.Tout : nullptr;
+        int poff[8];
+        float ba[8], bb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 2 * j;
+            const int pair = (m_base + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb) >> 1;
+            const bool ok = pair < chalf;
+            poff[j] = ok ? pair * a.Tout : -1;
+            ba[j] = (a.bias && ok) ? a.bias[pair] : 0.f;
+            bb[j] = (a.bias && ok) ? a.bias[chalf + pair] : 0.f;
+        }
+        const int hoff = chalf * a.Tout;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int ql = q0 + (wn * NT + n) * 32 + l31;
+            const int pos = ql * a.out_stride + out_base;
+            if (ql < nq) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (poff[j] >= 0) {
+                        const int oi = poff[j] + pos;
+                        const float va = acc[n][2 * j] + ba[j], vb = acc[n][2 * j + 1] + bb[j];
+                        yb[oi] = va;
+                        yb[oi + hoff] = vb;
+                        const float ga = gbase ? gbase[oi] : 0.f, gs = gbase ? gbase[oi + hoff] : 0.f;
+                        ab[oi] = tanhf(va + ga) * svb_sigmoid(vb + gs);
+                    }
+                }
+            }
+        }
+    } else if constexpr (MODE == 3) {
         // res/skip update of the gated stack (G = 1): rows below res_rows update x, the others accumulate the skip sum
         const int cres = a.res_rows, cs = a.Cout - cres;
         const size_t rb_off = (size_t)b * cres * a.Tout, sb_off = (size_t)b * cs * a.Tout;
@@ -721,7 +769,7 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     int kch = SLB / a.tg;
     // Q input: usable without an input gate, with whole 16-channel chunks per group, and when one chunk's span fits the
     // per-thread unit budget
-    const bool qin = a.xq && !a.in_gate && !a.skip_out && (a.G == 1 || a.Cin_g % 16 == 0) && 4 * span_max <= SVBQ_QUNITS * 256;
+    const bool qin = a.xq && !a.in_gate && !a.skip_out && !a.gate_acts && (a.G == 1 || a.Cin_g % 16 == 0) && 4 * span_max <= SVBQ_QUNITS * 256;
     const int kch_cap = qin ? (SVBQ_QUNITS * 256) / (4 * span_max) : (a.fast_x ? SVBQ_XUNITS / a.xit : 2);
     if (kch > kch_cap) kch = kch_cap;
     if (kch > a.kchunks) kch = a.kchunks;
@@ -751,7 +799,10 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     a.w_floats16 = SLB <= 5 ? 0 : a.tg * a.kch * BM * 3;
     a.x_floats16 = a.kch * a.xrows * 3;
     dim3 grid(a.G * svb_cdiv(a.Cout_g, BM), svb_cdiv(nq_max, BN), a.B * p.n_phase);
-    if (a.skip_out) q_launch_kernel<WM, WN, NT, SLB, 3>(a, p, grid, lds_bytes(a.kch), stream);
+    if (a.gate_acts) {
+        if constexpr (SLB <= 5) q_launch_kernel<WM, WN, NT, SLB, 4>(a, p, grid, lds_bytes(a.kch), stream);
+        else return SVB_ERR_UNSUPPORTED;
+    } else if (a.skip_out) q_launch_kernel<WM, WN, NT, SLB, 3>(a, p, grid, lds_bytes(a.kch), stream);
     else if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, 1>(a, p, grid, lds_bytes(a.kch), stream);
     else if (qin) q_launch_kernel<WM, WN, NT, SLB, 2>(a, p, grid, lds_bytes(a.kch), stream);
     else q_launch_kernel<WM, WN, NT, SLB, 0>(a, p, grid, lds_bytes(a.kch), stream);
@@ -781,6 +832,7 @@ static int q_dispatch(SvbConvQArgs& a, const SvbConvPlan& p, hipStream_t stream)
     if ((long)a.Cout * a.Tout > 0x7fffffffL) return SVB_ERR_UNSUPPORTED;      // the epilogue's per-clip offsets are 32-bit
     int cfg = q_pick(a.Cout_g, nq_max, (long)a.B * p.n_phase * a.G);
     if (a.force_cfg >= 0 && a.force_cfg < SVBQ_NCFG) cfg = a.force_cfg;
+    if (a.gate_acts && !(cfg == 1 || cfg == 2 || cfg >= 7)) cfg = 1;      // gate epilogue: direct-A tiles only
     for (int attempt = 0; attempt < 2; ++attempt) {
         int rc;
         switch (cfg) {
@@ -814,6 +866,7 @@ static void q_fill(SvbConvQArgs& a, const SvbConvEpilogue* e) {
     a.force_cfg = e ? e->force_cfg - 1 : -1;
     a.xq = e ? e->x_q : nullptr;
     a.skip_out = nullptr; a.skip_in = nullptr; a.res_rows = 0; a.skip_mask = 0;     // (svb_conv1d_forward_bf16x3 sets them)
+    a.gate_acts = nullptr; a.gate_g = nullptr; a.gate_gch = 0; a.gate_goff = 0;
     a.dbg = g_svbq_dbg;
     a.dbg_block0 = g_svbq_dbg_block0;
 }
@@ -854,6 +907,12 @@ extern "C" int svb_conv1d_forward_bf16x3(const float* x, const unsigned short* q
             (epi->res_rows > 0 && !epi->residual) || (epi->skip_mask && !epi->mask))
             return SVB_ERR_ARG;
         a.skip_out = epi->skip_out; a.skip_in = epi->skip_in; a.res_rows = epi->res_rows; a.skip_mask = epi->skip_mask;
+    }
+    if (epi && epi->gate_acts) {      // gate epilogue (MODE 4)
+        if (groups != 1 || (Cout & 1) || epi->skip_out || epi->out_act || epi->out_gate || epi->in_gate || epi->residual ||
+            epi->mask || (epi->gate_g && (epi->gate_goff < 0 || epi->gate_goff + Cout > epi->gate_gch)))
+            return SVB_ERR_ARG;
+        a.gate_acts = epi->gate_acts; a.gate_g = epi->gate_g; a.gate_gch = epi->gate_gch; a.gate_goff = epi->gate_goff;
     }
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.G = groups; a.Cin_g = Cin / groups; a.Cout_g = Cout / groups;
     a.Tin = Tin; a.Tout = Tout; a.sx = stride; a.out_stride = 1;

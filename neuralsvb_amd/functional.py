@@ -66,6 +66,10 @@ FUSE_RES_SKIP = False    # gated stack, bf16x3: the res/skip update (x = (x + rs
                          # and ~4C*B*T*4 bytes of traffic per layer less.  Landed after the round's last GPU minute: bit-exact
                          # against the two-kernel form on the lane emulator, NOT yet timed on the MI355X -- off until it is.
 
+FUSE_GATE = False         # gated stack, bf16x3: tanh(a + g) * sigmoid(b + g) as the epilogue of the in-layer conv
+                         # (svb_conv1d_bf16x3_kernel<..., 4>: interleaved weight rows put both halves of a channel in adjacent
+                         # accumulator registers of one lane).  Same status as FUSE_RES_SKIP: bit-exact on the emulator, untimed.
+
 DIRECT_GRADS = True      # weight/bias gradients of leaf parameters that already own a `.grad` buffer are accumulated into
                          # it by the reduce kernel itself (autograd gets None and skips its `grad += new` pass)
 
@@ -389,17 +393,21 @@ class _WNStackFn(torch.autograd.Function):
         out = None
         useq = USE_Q and PRECISION == "bf16x3" and C % 16 == 0
         fuse_rs = FUSE_RES_SKIP and PRECISION == "bf16x3" and not useq and (C * T) < (1 << 31)
+        fuse_gate = FUSE_GATE and PRECISION == "bf16x3" and not useq
         xq = K.split_q(x) if useq else None
         for i, (in_v, in_g, in_b, rs_v, rs_g, rs_b) in enumerate(layers):
             dil = dilation_rate ** i
             pad = (kernel_size * dil - dil) // 2
             pa_in, pb_in = _pack(_c(in_v), _c(in_g))
-            xin = K.conv1d_forward(x, pa_in, 2 * C, kernel_size, 1, pad, dil, 1, bias=_c(in_b), x_q=xq)
             acts_q = None
-            if useq:
-                acts, acts_q = K.wn_gate_fwd(xin, G, i * 2 * C, want_q=True)
+            if fuse_gate:        # the gate as the in-layer conv's own epilogue: no gate kernel, xin is not read back
+                xin, acts = K.conv1d_gate(x, pa_in, 2 * C, kernel_size, pad, dil, bias=_c(in_b), g=G, g_off=i * 2 * C)
             else:
-                acts = K.wn_gate_fwd(xin, G, i * 2 * C)
+                xin = K.conv1d_forward(x, pa_in, 2 * C, kernel_size, 1, pad, dil, 1, bias=_c(in_b), x_q=xq)
+                if useq:
+                    acts, acts_q = K.wn_gate_fwd(xin, G, i * 2 * C, want_q=True)
+                else:
+                    acts = K.wn_gate_fwd(xin, G, i * 2 * C)
             pa_rs, pb_rs = _pack(_c(rs_v), _c(rs_g))
             last = i == n_layers - 1
             saved_x.append(x)

@@ -114,9 +114,11 @@ def _f32(*ts):
 
 def make_epilogue(bias=None, in_gate=None, in_slope=0.0, out_act=ACT_NONE, out_slope=0.0, out_gate=None,
                   out_gate_slope=0.0, residual=None, mask=None, force_cfg=0, x_q=None, skip_out=None, skip_in=None,
-                  res_rows=0, skip_mask=False):
+                  res_rows=0, skip_mask=False, gate_acts=None, gate_g=None, gate_goff=0):
     e = L.SvbConvEpilogue()
     e.x_q = _ptr(x_q)
+    e.gate_acts, e.gate_g, e.gate_goff = _ptr(gate_acts), _ptr(gate_g), int(gate_goff)
+    e.gate_gch = int(gate_g.shape[1]) if gate_g is not None else 0
     e.skip_out, e.skip_in, e.res_rows, e.skip_mask = _ptr(skip_out), _ptr(skip_in), int(res_rows), int(bool(skip_mask))
     e.bias, e.in_gate, e.out_gate = _ptr(bias), _ptr(in_gate), _ptr(out_gate)
     e.residual, e.mask = _ptr(residual), _ptr(mask)
@@ -231,7 +233,12 @@ def conv1d_forward(x, pa, cout, k, stride=1, pad=0, dil=1, groups=1, out=None, *
     if q:
         y = out if out is not None else torch.empty((B, cout, tout), device=x.device, dtype=torch.float32)
         e = make_epilogue(**epi)
-        if x.is_cuda and not epi.get("force_cfg") and epi.get("skip_out") is None:
+        if x.is_cuda and not epi.get("force_cfg") and epi.get("gate_acts") is not None:
+            # gate epilogue: only the tiles that read their weight fragments from global memory implement it -- the one
+            # measured for the plain conv of this shape if it is such a tile, else 128x96
+            best = _TUNED.get(("qf", B, cin, cout, groups, tin, k, stride, pad, dil, False), 0)
+            e.force_cfg = best if best in (2, 3, 8, 9, 10) else 2
+        elif x.is_cuda and not epi.get("force_cfg") and epi.get("skip_out") is None:
             def launch(cfg):
                 e.force_cfg = cfg
                 L.check(lib.svb_conv1d_forward_bf16x3(_ptr(x), _ptr(pa.hi), _ptr(pa.lo), _ptr(y), B, cin, cout, groups, tin,
@@ -294,6 +301,18 @@ def conv1d_taps(x, packed, cout, offsets, tout=None, **epi):
     launch(cfg)
     probe.done()
     return y
+
+
+def conv1d_gate(x, pa, c2, k, pad, dil, bias=None, g=None, g_off=0, force_cfg=0):
+    """The gated stack's in-layer conv with the gate as its epilogue (bf16x3 only; reference fs2_vae.py:10-16,73-80):
+    xin = conv(x) [B,2C,T];  acts = tanh(xin[:, :C] + g[:, off:off+C]) * sigmoid(xin[:, C:] + g[:, off+C:off+2C]).
+    Returns (xin, acts) -- xin is what the backward pass reads."""
+    if not isinstance(pa, PackedQ):
+        raise TypeError("conv1d_gate: bf16x3 packed weights only")
+    B, cin, T = x.shape
+    acts = torch.empty((B, c2 // 2, T), device=x.device, dtype=torch.float32)
+    xin = conv1d_forward(x, pa, c2, k, 1, pad, dil, 1, bias=bias, gate_acts=acts, gate_g=g, gate_goff=g_off, force_cfg=force_cfg)
+    return xin, acts
 
 
 def conv1d_res_skip(acts, pa, cout, x, mask, out, last, bias=None, force_cfg=0):

@@ -391,10 +391,12 @@ def test_wn_stack_bf16x3_mode(dev):
 
 
 @pytest.mark.parametrize("masked", [True, False])
-def test_wn_stack_fused_res_skip_epilogue_is_bit_exact(dev, masked):
-    """SF.FUSE_RES_SKIP (bf16x3): the res/skip update as the epilogue of the 1x1 conv that produces it (reference
-    fs2_vae.py:83-89) must give bit-identical outputs and gradients to the conv + svb_wn_res_skip form -- three layers
-    (first: no skip sum yet; middle; last: skip rows only, mask folded in), ragged channel / time tails."""
+@pytest.mark.parametrize("which", ["res_skip", "gate", "both"])
+def test_wn_stack_fused_res_skip_epilogue_is_bit_exact(dev, masked, which):
+    """SF.FUSE_RES_SKIP / SF.FUSE_GATE (bf16x3): the res/skip update as the epilogue of the 1x1 conv that produces it, the gate
+    as the epilogue of the in-layer conv (reference fs2_vae.py:10-16,73-89) must give bit-identical outputs and gradients to
+    the conv + svb_wn_gate_fwd / svb_wn_res_skip form -- three layers (first: no skip sum yet; middle; last: skip rows only,
+    mask folded in), ragged channel / time tails."""
     g_ = torch.Generator().manual_seed(34)
     B, C, T, gin, n, ks = 2, 24, 77, 12, 3, 3
     x = torch.randn(B, C, T, generator=g_)
@@ -414,7 +416,8 @@ def test_wn_stack_fused_res_skip_epilogue_is_bit_exact(dev, masked):
     SF.set_precision("bf16x3")
     try:
         for fused in (False, True):
-            SF.FUSE_RES_SKIP = fused
+            SF.FUSE_RES_SKIP = fused and which in ("res_skip", "both")
+            SF.FUSE_GATE = fused and which in ("gate", "both")
             xd = _leaf(x, dev)
             cd = [_leaf(t, dev) for t in cond]
             ld = [[_leaf(t, dev) for t in lp] for lp in layers]
@@ -422,7 +425,7 @@ def test_wn_stack_fused_res_skip_epilogue_is_bit_exact(dev, masked):
             y.backward(dy.to(dev))
             res[fused] = [y.detach(), xd.grad] + [t.grad for t in cd] + [t.grad for lp in ld for t in lp]
     finally:
-        SF.FUSE_RES_SKIP = False
+        SF.FUSE_RES_SKIP = SF.FUSE_GATE = False
         SF.set_precision("fp32")
     for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)

@@ -674,3 +674,27 @@ def test_conv1d_res_skip_epilogue_every_tile(dev, cfg, C):
                                            force_cfg=cfg)
             assert torch.equal(out, out_ref)
             assert last or torch.equal(x_new, x_ref)
+
+
+@pytest.mark.parametrize("cfg", [2, 3, 8, 9, 10, 1])
+@pytest.mark.parametrize("shape", [(64, 5, 1), (80, 3, 2), (40, 5, 1)])
+def test_conv1d_gate_epilogue_every_direct_tile(dev, cfg, shape):
+    """svb_conv1d_bf16x3_kernel<..., 4> (gate epilogue over interleaved weight rows) in every tile configuration that implements
+    it (a staged-weight configuration, here 1, is replaced by the 128x96 tile), against the plain conv of the same configuration
+    + svb_wn_gate_fwd, with and without a conditioning tensor: xin and acts bit-exact."""
+    C, k, dil = shape
+    g_ = torch.Generator().manual_seed(70 + cfg)
+    B, T = 2, 131
+    x = torch.randn(B, C, T, generator=g_).to(dev)
+    w = (torch.randn(2 * C, C, k, generator=g_) * 0.2).to(dev)
+    bias = torch.randn(2 * C, generator=g_).to(dev)
+    G = torch.randn(B, 6 * C, T, generator=g_).to(dev)
+    pa = K.weight_pack_q(w, None, 1, want_a=True, want_b=False)[0]
+    pad = (k * dil - dil) // 2
+    ref_cfg = cfg if cfg != 1 else 2
+    xin_ref = K.conv1d_forward(x, pa, 2 * C, k, 1, pad, dil, 1, bias=bias, force_cfg=ref_cfg)
+    for g, off in ((G, 2 * C), (None, 0)):
+        acts_ref = K.wn_gate_fwd(xin_ref, g, off)
+        xin, acts = K.conv1d_gate(x, pa, 2 * C, k, pad, dil, bias=bias, g=g, g_off=off, force_cfg=cfg)
+        assert torch.equal(xin, xin_ref)
+        assert torch.equal(acts, acts_ref)
