@@ -647,6 +647,15 @@ def test_deferred_wgrad_reduces_equal_immediate(dev):
         assert torch.equal(t0, t1)
 
 
+def _same(a, b):
+    """Bit-identical on the lane emulator (the fused epilogues perform the same fp32 operations in the same order as the
+    two-kernel forms); on the MI355X -- where these epilogues have not run yet -- a 1-ulp-scale bound, in case the device
+    compiler schedules a transcendental differently in the two contexts."""
+    if a.device.type == "cpu":
+        return torch.equal(a, b)
+    return torch.allclose(a, b, rtol=2e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("cfg", list(range(1, 11)))
 @pytest.mark.parametrize("C", [64, 40])
 def test_conv1d_res_skip_epilogue_every_tile(dev, cfg, C):
@@ -672,8 +681,8 @@ def test_conv1d_res_skip_epilogue_every_tile(dev, cfg, C):
                 out_ref = out_ref * mask[:, None, :]
             x_new, out = K.conv1d_res_skip(acts, pa, rc, x, mask, None if prev is None else prev.clone(), last, bias=bias,
                                            force_cfg=cfg)
-            assert torch.equal(out, out_ref)
-            assert last or torch.equal(x_new, x_ref)
+            assert _same(out, out_ref)
+            assert last or _same(x_new, x_ref)
 
 
 @pytest.mark.parametrize("cfg", [2, 3, 8, 9, 10, 1])
@@ -696,5 +705,5 @@ def test_conv1d_gate_epilogue_every_direct_tile(dev, cfg, shape):
     for g, off in ((G, 2 * C), (None, 0)):
         acts_ref = K.wn_gate_fwd(xin_ref, g, off)
         xin, acts = K.conv1d_gate(x, pa, 2 * C, k, pad, dil, bias=bias, g=g, g_off=off, force_cfg=cfg)
-        assert torch.equal(xin, xin_ref)
-        assert torch.equal(acts, acts_ref)
+        assert _same(xin, xin_ref)
+        assert _same(acts, acts_ref)
