@@ -60,6 +60,15 @@ typedef struct SvbConvEpilogue {
     const float* gate_g;
     int gate_gch;
     int gate_goff;
+    /* svb_conv1d_transposed_bf16x3 only, groups = 1, k = 1, stride 1: the gate's backward as the epilogue of the res/skip conv's
+     * data gradient.  With gateb_xin set (xin [B][2C][T], the in-layer conv's output; C = Cout of this call) the accumulator
+     * d = d(acts)[b][c][t] is not stored; instead, with a = xin[b][c][t] + g[b][goff+c][t], s = xin[b][C+c][t] + g[b][goff+C+c][t]
+     * (g = gate_g / gate_gch / gate_goff as above, NULL: no term):
+     *   y[b][c][t]   = d * sigmoid(s) * (1 - tanh(a)^2)            (y is [B][2C][T] here: d(xin))
+     *   y[b][C+c][t] = d * tanh(a) * sigmoid(s) * (1 - sigmoid(s))
+     * and, if gateb_dg is set ([B][gate_gch][T], the gradient of g), the same two values at channels goff+c / goff+C+c.      */
+    const float* gateb_xin;
+    float* gateb_dg;
 } SvbConvEpilogue;
 
 /* Weight pack (+ WeightNorm forward  w = g * v / ||v||, norm over all dims but 0).

@@ -41,6 +41,8 @@ struct SvbConvQArgs {
     float* gate_acts;             // MODE 4 (gate epilogue)
     const float* gate_g;
     int gate_gch, gate_goff;
+    const float* gateb_xin;       // MODE 5 (gate-backward epilogue)
+    float* gateb_dg;
     float in_slope, out_slope, out_gate_slope;
     int out_act;
     int B, Cin, Cout, G, Cin_g, Cout_g, Tin, Tout;
@@ -87,7 +89,8 @@ __device__ __forceinline__ void svbq_split8(const float* v, uint4& hi, uint4& lo
 // MODE 0: fp32 x, split while staging;  1: the same with the activation-derivative gate on the load;  2: x comes pre-split
 // (Q image): the tile is staged with 16-byte copies -- four consecutive lanes fetch the 64-byte row of one position;
 // 3: staging as 0, res/skip epilogue (its own instantiations: the code of the other modes does not move);
-// 4: staging as 0, gate epilogue over interleaved weight rows (direct-A tiles only).
+// 4: staging as 0, gate epilogue over interleaved weight rows (direct-A tiles only);
+// 5: staging as 0, gate-backward epilogue (the accumulator is d(acts); d(xin) -- twice the rows -- is what gets stored).
 template <int WM, int WN, int NT, int SLB, int MODE>
 __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs a, SvbConvPlan p) {
     constexpr bool GATE = MODE == 1, QIN = MODE == 2;
@@ -568,6 +571,45 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
                 }
             }
         }
+    } else if constexpr (MODE == 5) {
+        // backward of the gate: the accumulator row c is d(acts)[c]; with the saved pre-activations (+ conditioning) it
+        // becomes the two rows c, C + c of d(xin) (and of d(g))
+        const int C = a.Cout;
+        const size_t xb_off = (size_t)b * 2 * C * a.Tout;
+        float* yb = a.y + xb_off;
+        const float* xin = a.gateb_xin + xb_off;
+        const size_t gb_off = ((size_t)b * a.gate_gch + a.gate_goff) * a.Tout;
+        const float* gbase = a.gate_g ? a.gate_g + gb_off : nullptr;
+        float* dgb = a.gateb_dg ? a.gateb_dg + gb_off : nullptr;
+        const int hoff = C * a.Tout;
+        int rowoff[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = m_base + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+            rowoff[r] = co < C ? co * a.Tout : -1;
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int ql = q0 + (wn * NT + n) * 32 + l31;
+            const int pos = ql * a.out_stride + out_base;
+            if (ql < nq) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (rowoff[r] >= 0) {
+                        const int oi = rowoff[r] + pos;
+                        float av = xin[oi], sv = xin[oi + hoff];
+                        if (gbase) { av += gbase[oi]; sv += gbase[oi + hoff]; }
+                        const float d = acc[n][r];
+                        const float th = tanhf(av), sg = svb_sigmoid(sv);
+                        const float da = d * sg * (1.f - th * th);
+                        const float ds = d * th * sg * (1.f - sg);
+                        yb[oi] = da;
+                        yb[oi + hoff] = ds;
+                        if (dgb) { dgb[oi] = da; dgb[oi + hoff] = ds; }
+                    }
+                }
+            }
+        }
     } else if constexpr (MODE == 3) {
         // res/skip update of the gated stack (G = 1): rows below res_rows update x, the others accumulate the skip sum
         const int cres = a.res_rows, cs = a.Cout - cres;
@@ -769,7 +811,7 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     int kch = SLB / a.tg;
     // Q input: usable without an input gate, with whole 16-channel chunks per group, and when one chunk's span fits the
     // per-thread unit budget
-    const bool qin = a.xq && !a.in_gate && !a.skip_out && !a.gate_acts && (a.G == 1 || a.Cin_g % 16 == 0) && 4 * span_max <= SVBQ_QUNITS * 256;
+    const bool qin = a.xq && !a.in_gate && !a.skip_out && !a.gate_acts && !a.gateb_xin && (a.G == 1 || a.Cin_g % 16 == 0) && 4 * span_max <= SVBQ_QUNITS * 256;
     const int kch_cap = qin ? (SVBQ_QUNITS * 256) / (4 * span_max) : (a.fast_x ? SVBQ_XUNITS / a.xit : 2);
     if (kch > kch_cap) kch = kch_cap;
     if (kch > a.kchunks) kch = a.kchunks;
@@ -802,7 +844,8 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     if (a.gate_acts) {
         if constexpr (SLB <= 5) q_launch_kernel<WM, WN, NT, SLB, 4>(a, p, grid, lds_bytes(a.kch), stream);
         else return SVB_ERR_UNSUPPORTED;
-    } else if (a.skip_out) q_launch_kernel<WM, WN, NT, SLB, 3>(a, p, grid, lds_bytes(a.kch), stream);
+    } else if (a.gateb_xin) q_launch_kernel<WM, WN, NT, SLB, 5>(a, p, grid, lds_bytes(a.kch), stream);
+    else if (a.skip_out) q_launch_kernel<WM, WN, NT, SLB, 3>(a, p, grid, lds_bytes(a.kch), stream);
     else if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, 1>(a, p, grid, lds_bytes(a.kch), stream);
     else if (qin) q_launch_kernel<WM, WN, NT, SLB, 2>(a, p, grid, lds_bytes(a.kch), stream);
     else q_launch_kernel<WM, WN, NT, SLB, 0>(a, p, grid, lds_bytes(a.kch), stream);
@@ -867,6 +910,7 @@ static void q_fill(SvbConvQArgs& a, const SvbConvEpilogue* e) {
     a.xq = e ? e->x_q : nullptr;
     a.skip_out = nullptr; a.skip_in = nullptr; a.res_rows = 0; a.skip_mask = 0;     // (svb_conv1d_forward_bf16x3 sets them)
     a.gate_acts = nullptr; a.gate_g = nullptr; a.gate_gch = 0; a.gate_goff = 0;
+    a.gateb_xin = nullptr; a.gateb_dg = nullptr;        // (svb_conv1d_transposed_bf16x3 sets them)
     a.dbg = g_svbq_dbg;
     a.dbg_block0 = g_svbq_dbg_block0;
 }
@@ -961,6 +1005,15 @@ extern "C" int svb_conv1d_transposed_bf16x3(const float* x, const unsigned short
     memset(&p, 0, sizeof(p));
     a.x = x; a.wq_hi = qb_hi; a.wq_lo = qb_lo; a.y = y;
     q_fill(a, epi);
+    if (epi && epi->gateb_xin) {      // gate-backward epilogue (MODE 5)
+        if (groups != 1 || k != 1 || stride != 1 || pad != 0 || Tin != Tout || epi->bias || epi->out_act || epi->out_gate ||
+            epi->in_gate || epi->residual || epi->mask || epi->skip_out || epi->gate_acts ||
+            ((epi->gate_g || epi->gateb_dg) && (epi->gate_goff < 0 || epi->gate_goff + 2 * Cout > epi->gate_gch)) ||
+            (long)2 * Cout * Tout > 0x7fffffffL)
+            return SVB_ERR_ARG;
+        a.gateb_xin = epi->gateb_xin; a.gateb_dg = epi->gateb_dg;
+        a.gate_g = epi->gate_g; a.gate_gch = epi->gate_gch; a.gate_goff = epi->gate_goff;
+    }
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.G = groups; a.Cin_g = Cin / groups; a.Cout_g = Cout / groups;
     a.Tin = Tin; a.Tout = Tout; a.sx = 1; a.out_stride = stride;
     const int kchb = svb_cdiv(a.Cin_g, 16);

@@ -68,7 +68,8 @@ FUSE_RES_SKIP = False    # gated stack, bf16x3: the res/skip update (x = (x + rs
 
 FUSE_GATE = False         # gated stack, bf16x3: tanh(a + g) * sigmoid(b + g) as the epilogue of the in-layer conv
                          # (svb_conv1d_bf16x3_kernel<..., 4>: interleaved weight rows put both halves of a channel in adjacent
-                         # accumulator registers of one lane).  Same status as FUSE_RES_SKIP: bit-exact on the emulator, untimed.
+                         # accumulator registers of one lane) and its backward as the epilogue of the res/skip conv's data
+                         # gradient (<..., 5>).  Same status as FUSE_RES_SKIP: bit-exact on the emulator, untimed.
 
 DIRECT_GRADS = True      # weight/bias gradients of leaf parameters that already own a `.grad` buffer are accumulated into
                          # it by the reduce kernel itself (autograd gets None and skips its `grad += new` pass)
@@ -490,12 +491,16 @@ class _WNStackFn(torch.autograd.Function):
             if not (need_in_w or need_dG or need_dx):
                 dx_next = None
                 continue
-            dacts = K.conv1d_transposed(drs, pb_rs, C, acts.shape[2], 1, x_q=drs_q)
             dxin_q = None
-            if useq and need_dx:
-                dxin, dxin_q = K.wn_gate_bwd(xin, G, dacts, i * 2 * C, dg=dG, want_q=True)
+            if FUSE_GATE and not useq and isinstance(pb_rs, K.PackedQ):
+                # the gate's backward as the epilogue of the res/skip conv's data gradient: d(acts) is never written
+                dxin = K.conv1d_gate_bwd(drs, pb_rs, C, xin, G, i * 2 * C, dG)
             else:
-                dxin = K.wn_gate_bwd(xin, G, dacts, i * 2 * C, dg=dG)
+                dacts = K.conv1d_transposed(drs, pb_rs, C, acts.shape[2], 1, x_q=drs_q)
+                if useq and need_dx:
+                    dxin, dxin_q = K.wn_gate_bwd(xin, G, dacts, i * 2 * C, dg=dG, want_q=True)
+                else:
+                    dxin = K.wn_gate_bwd(xin, G, dacts, i * 2 * C, dg=dG)
             if need_in_w:
                 sk = _sinks(in_v, in_g, in_b)
                 r = K.conv1d_wgrad(dxin, x_i, ks, 1, pad, dil, v=in_v if in_g is not None else None, g=in_g, want_bias=True,

@@ -114,11 +114,15 @@ def _f32(*ts):
 
 def make_epilogue(bias=None, in_gate=None, in_slope=0.0, out_act=ACT_NONE, out_slope=0.0, out_gate=None,
                   out_gate_slope=0.0, residual=None, mask=None, force_cfg=0, x_q=None, skip_out=None, skip_in=None,
-                  res_rows=0, skip_mask=False, gate_acts=None, gate_g=None, gate_goff=0):
+                  res_rows=0, skip_mask=False, gate_acts=None, gate_g=None, gate_goff=0, gateb_xin=None, gateb_dg=None):
     e = L.SvbConvEpilogue()
     e.x_q = _ptr(x_q)
+    e.gateb_xin, e.gateb_dg = _ptr(gateb_xin), _ptr(gateb_dg)
+    if gate_g is None and gateb_dg is not None:
+        e.gate_gch = int(gateb_dg.shape[1])
     e.gate_acts, e.gate_g, e.gate_goff = _ptr(gate_acts), _ptr(gate_g), int(gate_goff)
-    e.gate_gch = int(gate_g.shape[1]) if gate_g is not None else 0
+    if gate_g is not None:
+        e.gate_gch = int(gate_g.shape[1])
     e.skip_out, e.skip_in, e.res_rows, e.skip_mask = _ptr(skip_out), _ptr(skip_in), int(res_rows), int(bool(skip_mask))
     e.bias, e.in_gate, e.out_gate = _ptr(bias), _ptr(in_gate), _ptr(out_gate)
     e.residual, e.mask = _ptr(residual), _ptr(mask)
@@ -313,6 +317,18 @@ def conv1d_gate(x, pa, c2, k, pad, dil, bias=None, g=None, g_off=0, force_cfg=0)
     acts = torch.empty((B, c2 // 2, T), device=x.device, dtype=torch.float32)
     xin = conv1d_forward(x, pa, c2, k, 1, pad, dil, 1, bias=bias, gate_acts=acts, gate_g=g, gate_goff=g_off, force_cfg=force_cfg)
     return xin, acts
+
+
+def conv1d_gate_bwd(drs, pb, c, xin, g=None, g_off=0, dg=None, force_cfg=0):
+    """The gate's backward as the epilogue of the res/skip conv's data gradient (bf16x3 only): d(acts) = conv1x1^T(drs) stays
+    in the accumulators; returns d(xin) [B,2C,T] (wn_gate_bwd's result) and writes the same values into dg's channels
+    [g_off, g_off+2C) when dg is given."""
+    if not isinstance(pb, PackedQ):
+        raise TypeError("conv1d_gate_bwd: bf16x3 packed weights only")
+    B, _, T = drs.shape
+    dxin = torch.empty((B, 2 * c, T), device=drs.device, dtype=torch.float32)
+    conv1d_transposed(drs, pb, c, T, 1, out=dxin, gateb_xin=xin, gateb_dg=dg, gate_g=g, gate_goff=g_off, force_cfg=force_cfg)
+    return dxin
 
 
 def conv1d_res_skip(acts, pa, cout, x, mask, out, last, bias=None, force_cfg=0):

@@ -707,3 +707,26 @@ def test_conv1d_gate_epilogue_every_direct_tile(dev, cfg, shape):
         xin, acts = K.conv1d_gate(x, pa, 2 * C, k, pad, dil, bias=bias, g=g, g_off=off, force_cfg=cfg)
         assert _same(xin, xin_ref)
         assert _same(acts, acts_ref)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 4, 6, 9])
+@pytest.mark.parametrize("C", [64, 40])
+def test_conv1d_gate_backward_epilogue(dev, cfg, C):
+    """svb_conv1d_bf16x3_kernel<..., 5>: the gate's backward as the epilogue of the res/skip conv's data gradient, against the
+    plain transposed 1x1 conv + svb_wn_gate_bwd: d(xin) and the d(g) slice, with and without conditioning."""
+    g_ = torch.Generator().manual_seed(90 + cfg)
+    B, T = 2, 157
+    drs = torch.randn(B, 2 * C, T, generator=g_).to(dev)
+    xin = torch.randn(B, 2 * C, T, generator=g_).to(dev)
+    w = (torch.randn(2 * C, C, 1, generator=g_) * 0.2).to(dev)
+    G = torch.randn(B, 6 * C, T, generator=g_).to(dev)
+    pb = K.weight_pack_q(w, None, 1, want_a=False, want_b=True)[1]
+    dacts = K.conv1d_transposed(drs, pb, C, T, 1, force_cfg=cfg)
+    for g, off in ((G, 4 * C), (None, 0)):
+        dg_ref = torch.zeros_like(G) if g is not None else None
+        ref = K.wn_gate_bwd(xin, g, dacts, off, dg=dg_ref)
+        dg = torch.zeros_like(G) if g is not None else None
+        dxin = K.conv1d_gate_bwd(drs, pb, C, xin, g, off, dg, force_cfg=cfg)
+        assert _same(dxin, ref)
+        if g is not None:
+            assert _same(dg, dg_ref)
