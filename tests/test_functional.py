@@ -397,6 +397,8 @@ def test_wn_stack_fused_res_skip_epilogue_is_bit_exact(dev, masked, which):
     as the epilogue of the in-layer conv (reference fs2_vae.py:10-16,73-89) must give bit-identical outputs and gradients to
     the conv + svb_wn_gate_fwd / svb_wn_res_skip form -- three layers (first: no skip sum yet; middle; last: skip rows only,
     mask folded in), ragged channel / time tails."""
+    from tests.test_kernels import _untimed_on_gpu
+    _untimed_on_gpu(dev)
     g_ = torch.Generator().manual_seed(34)
     B, C, T, gin, n, ks = 2, 24, 77, 12, 3, 3
     x = torch.randn(B, C, T, generator=g_)

@@ -6,7 +6,7 @@ set -x
 mkdir -p gpurun_out/r03_start
 cd /root/repo
 export TMPDIR=/tmp
-(timeout 120 python -m pytest tests/test_kernels.py tests/test_functional.py -m gpu -q \
+(SVB_TEST_UNTIMED=1 timeout 120 python -m pytest tests/test_kernels.py tests/test_functional.py -m gpu -q \
    -k "res_skip_epilogue or gate_epilogue or gate_backward or fused_res_skip" 2>&1 | tail -8) > gpurun_out/r03_start/pytest_epilogues.log
 bash tools/ab_bench.sh "" "wn_fuse_res_skip=True" "wn_fuse_gate=True" "wn_fuse_res_skip=True,wn_fuse_gate=True" "" \
    > gpurun_out/r03_start/ab.log 2>&1
