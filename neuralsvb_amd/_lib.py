@@ -137,6 +137,12 @@ def lib_is_emulator():
     return _LIB_IS_EMU
 
 
+def device_type():
+    """Memory space the bound library's pointers refer to: "cuda" for libsvb_hip.so (the product; nothing else is ever
+    loaded by this package).  A harness that binds another build of the same sources says so through _LIB_IS_EMU."""
+    return "cpu" if _LIB_IS_EMU else "cuda"
+
+
 class SvbError(RuntimeError):
     pass
 

@@ -75,6 +75,17 @@ DIRECT_GRADS = True      # weight/bias gradients of leaf parameters that already
                          # it by the reduce kernel itself (autograd gets None and skips its `grad += new` pass)
 
 
+def reset_runtime_state():
+    """Arithmetic mode, optional fusions and the Trainer-set routing state back to their import-time values (see
+    kernels.reset_runtime_state)."""
+    global USE_Q, FUSE_RES_SKIP, FUSE_GATE, DIRECT_GRADS, GRAD_READY, CAPTURING, PACK_CACHE, PACK_REGISTRY, PACK_EPOCH
+    set_precision("fp32")
+    USE_Q = FUSE_RES_SKIP = FUSE_GATE = False
+    DIRECT_GRADS = PACK_CACHE = PACK_REGISTRY = True
+    GRAD_READY = PACK_EPOCH = None
+    CAPTURING = False
+
+
 def _gbuf(p):
     if not DIRECT_GRADS or p is None or not p.is_leaf or p.grad is None or not p.requires_grad:
         return None      # (a frozen parameter may still own a flat-buffer `.grad` view: never accumulate into it)
@@ -282,6 +293,12 @@ class _Conv1dFn(torch.autograd.Function):
         if mask is not None:
             dy = dy * mask[:, None, :]
         d_res = dy if ctx.has_res else None
+        if d_res is not None and K.WGRAD_STREAM is not None and ctx.needs_input_grad[1]:
+            # the weight gradient below may read dy on the side stream while autograd accumulates the residual branch's
+            # second gradient INTO the tensor handed back here (InputBuffer adds in place when it holds the only reference;
+            # record_stream guards reuse of the memory, not writes to it): never hand autograd a tensor a side-stream
+            # kernel still reads
+            d_res = dy.clone()
         cout, cin_g, k = v.shape
         a_slope = 0.0 if out_act == ACT_RELU else out_slope
         dx = dv = dg = db = None
@@ -700,7 +717,8 @@ class _Conv2dFn(torch.autograd.Function):
         weight = weight.contiguous()
         B, C, H, W = x.shape
         cout, _, KH, KW = weight.shape
-        cols, Ho, Wo = K.im2col(x, KH, KW, stride, stride, pad, pad, fold_batch=True)
+        ph, pw = pad if isinstance(pad, tuple) else (pad, pad)
+        cols, Ho, Wo = K.im2col(x, KH, KW, stride, stride, ph, pw, fold_batch=True)
         w3 = weight.view(cout, C * KH * KW, 1)
         pa, pb = _pack(w3, None, 1, want_a=True, want_b=ctx.needs_input_grad[0])
         y = K.conv1d_forward(cols, pa, cout, 1, bias=bias, out_act=ACT_LRELU if slope is not None else ACT_NONE,
@@ -723,7 +741,8 @@ class _Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dcols = K.conv1d_transposed(dy, pb, C * KH * KW, B * Ho * Wo, 1, in_gate=yact, in_slope=a_slope)
-            dx = K.col2im(dcols, B, C, H, W, KH, KW, stride, stride, pad, pad, fold_batch=True)
+            ph, pw = pad if isinstance(pad, tuple) else (pad, pad)
+            dx = K.col2im(dcols, B, C, H, W, KH, KW, stride, stride, ph, pw, fold_batch=True)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             r = K.conv1d_wgrad(dy, cols, 1, a_gate=yact, a_slope=a_slope, want_bias=want_b)
@@ -965,8 +984,9 @@ def conv2d_lrelu(x, weight, bias, stride, padding, lrelu_slope=None):
     """x [B,C,H,W]; weight [Cout,C,KH,KW]; returns leaky_relu(conv2d(x)) (or conv2d(x) when lrelu_slope is None).
     Result: a [B,Cout,Ho,Wo] strided view of channel-major memory."""
     N, C, H, W = x.shape
-    if (CONV2D_S2D and tuple(weight.shape[2:]) == (3, 3) and int(stride) == 2 and int(padding) == 1 and H % 2 == 0
+    pad = tuple(int(p) for p in padding) if isinstance(padding, (tuple, list)) else (int(padding), int(padding))
+    if (CONV2D_S2D and tuple(weight.shape[2:]) == (3, 3) and int(stride) == 2 and pad == (1, 1) and H % 2 == 0
             and W % 2 == 0):
         y4 = _Conv2dS2Fn.apply(_S2DPadFn.apply(x), weight, bias, (N, C, H, W, lrelu_slope))
         return _CropDropNormFn.apply(y4, None, None, None, (N, weight.shape[0], H // 2, W // 2, 1e-5, False))
-    return _Conv2dFn.apply(x, weight, bias, (int(stride), int(padding), lrelu_slope))
+    return _Conv2dFn.apply(x, weight, bias, (int(stride), pad, lrelu_slope))

@@ -97,13 +97,10 @@ def _prep(*tensors):
             raise ValueError(f"tensors on different devices: {dev} vs {t.device}")
     if dev is None:
         raise ValueError("no tensors")
-    if dev.type == "cuda":
-        if L.lib_is_emulator():
-            raise RuntimeError("CPU emulator library is loaded but tensors are on the GPU")
-        return lib, _raw_stream(dev)
-    if not L.lib_is_emulator():
-        raise RuntimeError("neuralsvb_amd kernels run on the MI355X only (got CPU tensors); there is no CPU fallback")
-    return lib, None
+    if dev.type != L.device_type():
+        raise RuntimeError(f"neuralsvb_amd kernels run on the MI355X only (got {dev.type} tensors for a {L.device_type()} "
+                           f"library); there is no CPU fallback")
+    return lib, (_raw_stream(dev) if dev.type == "cuda" else None)
 
 
 def _f32(*ts):
@@ -519,6 +516,26 @@ def flush_deferred_reduces(end=True):
         _DEFERRED = None
 
 
+def abort_deferred_reduces():
+    """Leave deferred mode without finishing what was recorded (the pass that recorded it raised)."""
+    global _DEFERRED
+    if _DEFERRED is not None:
+        _DEFERRED = None
+        for ent in _ARENA.values():
+            ent[1] = 0
+
+
+def reset_runtime_state():
+    """Routing state back to its import-time values: no side stream, no deferred reduces, no arenas or side workspaces, no
+    profiler.  For callers that own the process between independent pieces of work (the test harness does this per test)."""
+    global WGRAD_STREAM, _DEFERRED, PROFILE
+    WGRAD_STREAM = None
+    _DEFERRED = None
+    PROFILE = None
+    _ARENA.clear()
+    _SIDE_WS.clear()
+
+
 def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0, b_gate=None, b_slope=0.0,
                   v=None, g=None, accumulate_into=None, bf16x3=None, want_bias=False, sinks=None, _side=None, bias_sink=None):
     """dW[ca, cb/groups, k] = sum_{n,q} a[n,ca,q] * b[n,cb,q*sx + j*dil - pad].
@@ -540,12 +557,16 @@ def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.
     nfl = 0
     if WGRAD_BF16X3 if bf16x3 is None else bf16x3:
         nfl = lib.svb_conv1d_wgrad_bf16x3_workspace_floats(B, ca, cb, groups, ta, k, sx, pad, dil, C.byref(ns))
+    if _side is not None and not nfl:
+        # outside the bf16x3 kernel's envelope: the fp32 form allocates its workspace from the current stream's pool, so it
+        # also runs there (the side stream has already caught up with it; that wait is harmless)
+        _side, st = None, (_raw_stream(a.device) if a.is_cuda else None)
     wflops = 2.0 * B * ca * ta * (cb // groups) * k
     rows, rowlen = ca, (cb // groups) * k
     wn = g is not None
     sv, sg, sb = sinks if sinks is not None else (None, None, None)
     dfr = _DEFERRED
-    if dfr is not None and nfl and (a.is_cuda or L.lib_is_emulator()):
+    if dfr is not None and nfl:
         # every result goes into a gradient buffer: leave the partials in the arena, record the reduce, finish it later
         ok = sv is not None and accumulate_into is None and (not wn or sg is not None) and (not want_bias or sb is not None)
         if ok and wn:
@@ -959,11 +980,10 @@ def _prep_strided(*tensors):
     """like _prep but allows non-contiguous tensors (kernels that take element strides)."""
     lib = L.get_lib()
     dev = next(t.device for t in tensors if t is not None)
-    if dev.type == "cuda":
-        return lib, _raw_stream(dev)
-    if not L.lib_is_emulator():
-        raise RuntimeError("neuralsvb_amd kernels run on the MI355X only (got CPU tensors); there is no CPU fallback")
-    return lib, None
+    if dev.type != L.device_type():
+        raise RuntimeError(f"neuralsvb_amd kernels run on the MI355X only (got {dev.type} tensors for a {L.device_type()} "
+                           f"library); there is no CPU fallback")
+    return lib, (_raw_stream(dev) if dev.type == "cuda" else None)
 
 
 def ssim_fwd(pred, target, bias=6.0):

@@ -26,15 +26,29 @@ def _adv_score(adv_layer, h):
 
 def _block(blk, h, planes=None, s2d_out=False):
     """Conv2d 3x3 s2 p1 -> LeakyReLU(0.2) -> Dropout2d [-> InstanceNorm2d | BatchNorm2d] (multi_window_disc.py:14-31).
-    planes / s2d_out: the block reads / writes the space-to-depth layout of the conv directly (SF.critic_block)."""
+    planes / s2d_out: the block reads / writes the space-to-depth layout of the conv directly (SF.critic_block).
+    Odd planes (a window length such as 20 or 36 reaches them at the 2nd / 3rd block, or an odd number of mel bins) and
+    kernels other than 3x3 are legal in the reference: they take the general im2col conv + the per-(clip, channel) factor of
+    Dropout2d + the stock norm module."""
     conv, drop = blk[0], blk[2]
     norm = blk[3] if len(blk) > 3 else None
     p = drop.p if drop.training else 0.0
+    N, C, H, W = planes if planes is not None else h.shape
+    if not (_fast_plane(conv, H, W)):
+        assert planes is None and not s2d_out
+        h = SF.conv2d_lrelu(h, conv.weight, conv.bias, 2, tuple(conv.padding), 0.2)
+        if p:
+            h = h * SF.dropout2d_keep(h.size(0), h.size(1), p, h.device)[:, :, None, None]
+        return norm(h) if norm is not None else h
     if norm is None or isinstance(norm, nn.InstanceNorm2d):
         gamma, beta, eps = (norm.weight, norm.bias, norm.eps) if norm is not None else (None, None, 1e-5)
         return SF.critic_block(h, conv.weight, conv.bias, 0.2, p, gamma, beta, eps, planes=planes, s2d_out=s2d_out)
     assert planes is None and not s2d_out
     return norm(SF.critic_block(h, conv.weight, conv.bias, 0.2, p, None, None))
+
+
+def _fast_plane(conv, H, W):
+    return tuple(conv.kernel_size) == (3, 3) and H % 2 == 0 and W % 2 == 0
 
 
 FUSED_CROP = True        # forward_many: crop + stack + space-to-depth of all windows in one pass per direction
@@ -49,7 +63,7 @@ def _tower(tower, h, want_fmaps, fmaps, planes=None):
     for i, blk in enumerate(blocks):
         if chain and i + 1 < len(blocks):
             N, C, H, W = planes if planes is not None else h.shape
-            if (H // 2) % 2 == 0 and (W // 2) % 2 == 0:
+            if _fast_plane(blk[0], H, W) and (H // 2) % 2 == 0 and (W // 2) % 2 == 0:
                 h, planes = _block(blk, h, planes, s2d_out=True)
                 continue
         h = _block(blk, h, planes)
@@ -135,6 +149,7 @@ class Discriminator(nn.Module):
         fused = None
         if (FUSED_CROP and all(c[2] is None for c in calls) and all(x.dim() == 4 and x.size(1) == 1 for x in xs)
                 and xs[0].size(3) % 2 == 0 and all(wl % 2 == 0 for wl in self.time_lengths) and len(xs) <= 8
+                and all(tuple(t.model[0][0].kernel_size) == (3, 3) for t in self.discriminator.conv_layers)
                 and all(len(b) <= 3 or isinstance(b[3], nn.InstanceNorm2d) for t in self.discriminator.conv_layers
                         for b in t.model)):
             fused = SF.window_crop_s2d([x[:, 0] for x in xs], self.time_lengths,

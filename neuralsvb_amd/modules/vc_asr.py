@@ -108,6 +108,8 @@ class MultiLayeredConv1d(nn.Module):
         if half_residual is None:
             return self.w_2(h)
         c = self.w_2
+        if torch.is_grad_enabled() and (c.weight.requires_grad or (c.bias is not None and c.bias.requires_grad)):
+            return half_residual + 0.5 * self.w_2(h)      # trainable (ASR pre-training): the folded copy would cut the gradient
         w, b = self._half_w2()
         with SF.precision_scope(c.precision):
             return SF.conv1d(h, w, b, c.stride, c.padding, c.dilation, c.groups, residual=half_residual)

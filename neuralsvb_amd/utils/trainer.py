@@ -102,6 +102,10 @@ class FlatGradSync:
             self.buckets.append((start, off))
         self._profiles = {}              # pass key -> announcements per bucket (recorded on the key's first step)
         self._key = self._counts = self._expected = self._work = None
+        self._next = -1
+        self._comm_stream = None
+        self.order = []                  # bucket indices in the order their collectives were issued (last 64; tests read it)
+        self.measure_wait, self._wait_events = False, []
         self.stats = {"launched_in_backward": 0, "launched_after": 0, "wait_s": 0.0, "passes": 0}
         if self.overlap:
             for p in self.params:
@@ -136,6 +140,7 @@ class FlatGradSync:
         self._counts = [0] * len(self.buckets)
         self._expected = self._profiles.get(key)
         self._work = [None] * len(self.buckets)
+        self._next = len(self.buckets) - 1          # buckets are exchanged in ONE order on every rank: last bucket first
 
     def grad_ready(self, p):
         if self._counts is None:
@@ -145,19 +150,42 @@ class FlatGradSync:
             return
         self._counts[b] += 1
         if self._expected is not None:
-            if self._counts[b] == self._expected[b] and self._work[b] is None:
-                self._launch(b, True)
-            elif self._counts[b] > self._expected[b]:
+            if self._counts[b] > self._expected[b]:
                 raise RuntimeError(f"gradient bucket {b} of pass {self._key} received more gradient announcements than in "
                                    f"its recording step: the autograd graph changed under an unchanged pass key")
+            # Rank-invariant collective order: the recorded profile (and the pass key behind it) is rank-local state -- two
+            # ranks may disagree on it (e.g. a critic window that one rank's longest clip does not reach) -- so completion
+            # order must never decide which collective is issued next.  A complete bucket b is exchanged only once every
+            # bucket above it has been: every rank issues N-1, N-2, ..., 0, whatever it recorded; ranks that complete a
+            # bucket later simply issue the same sequence later (finish() flushes the rest in the same order).
+            while self._next >= 0 and self._counts[self._next] >= self._expected[self._next]:
+                self._launch(self._next, True)
+                self._next -= 1
 
     def _launch(self, b, in_backward):
         s, e = self.buckets[b]
-        self._work[b] = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.flat.is_cuda:
+            # The bucket's gradients were written by the compute stream (autograd) and by the weight-gradient side stream
+            # (kernels.WGRAD_STREAM): the collective is issued from a launch stream that has caught up with both, so
+            # neither of them waits for the other (or for RCCL) here.
+            from .. import kernels as _K
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(self.flat.device)
+            cs = self._comm_stream
+            cs.wait_stream(torch.cuda.current_stream(self.flat.device))
+            if _K.WGRAD_STREAM is not None:
+                cs.wait_stream(_K.WGRAD_STREAM)
+            with torch.cuda.stream(cs):
+                self._work[b] = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._work[b] = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.stats["launched_in_backward" if in_backward else "launched_after"] += 1
+        self.order.append(b)
+        if len(self.order) > 64:
+            del self.order[:-64]
 
     def finish(self):
-        """After backward: exchange the buckets that did not complete during it, wait for all, average."""
+        """After backward: exchange the buckets that did not complete during it (same descending order), wait, average."""
         if self.world_size <= 1:
             return
         if not self.overlap or self._counts is None:
@@ -166,17 +194,33 @@ class FlatGradSync:
             return
         if self._expected is None:
             self._profiles[self._key] = list(self._counts)
-        for b in range(len(self.buckets)):
-            if self._work[b] is None:
-                self._launch(b, False)
+        while self._next >= 0:
+            self._launch(self._next, False)
+            self._next -= 1
         import time as _t
+        cuda = self.flat.is_cuda
+        if cuda and self.measure_wait:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         t0 = _t.perf_counter()
         for w in self._work:
-            w.wait()
+            w.wait()                       # (device tensors: the CURRENT stream waits for RCCL's; the host does not block)
         self.stats["wait_s"] += _t.perf_counter() - t0
+        if cuda and self.measure_wait:
+            e1.record()
+            self._wait_events.append((e0, e1))
         self.stats["passes"] += 1
         self.flat.div_(self.world_size)
         self._counts = self._work = None
+
+    def exposed_wait_ms(self):
+        """Device time the compute stream spent waiting for RCCL in finish() since the last call (measure_wait = True)."""
+        if not self._wait_events:
+            return 0.0
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._wait_events)
+        self._wait_events = []
+        return ms
 
     def all_reduce(self):
         """Blocking exchange of the whole buffer (no overlap): kept for callers outside the Trainer's step."""
@@ -223,6 +267,7 @@ class Trainer:
                                       "bf16 matrix cores with an fp32-class operand split) instead of autocast")
         self.task, self.optimizers, self.grad_sync = None, [], []
         self._critic_stream, self._critic_busy = None, False
+        self._wgrad_stream = None            # side stream of the weight gradients; kernels.WGRAD_STREAM only while a step runs
         self._grad_enabled_for = None        # (task, optimizer index) whose parameters currently have requires_grad = True
         self._param_cache = None
         # hipGraph replay of each optimizer pass's forward+backward (fixed-shape batches; see _graphed_forward_backward)
@@ -492,21 +537,29 @@ class Trainer:
 
     def _run_training_batch(self, batch_idx, batch):
         from .. import functional as SF
+        from .. import kernels as _K
         SF.begin_weight_epoch()               # packed weight images may be reused inside this step (until the next update)
+        # The side stream of the weight gradients is routing state of THIS step only: whoever calls the kernels after the
+        # step returns (validation, user code, the next test) must get their results on the stream they launch from.
+        prev_side = _K.WGRAD_STREAM
+        graph_mode = self.hip_graph and self.on_gpu
+        want_side = self.on_gpu and not graph_mode and hparams.get("wgrad_side_stream", True)
+        if want_side and self._wgrad_stream is None:
+            self._wgrad_stream = torch.cuda.Stream(self.device)
+        _K.WGRAD_STREAM = self._wgrad_stream if want_side else None
         try:
             return self._run_training_batch_body(batch_idx, batch)
         finally:
+            side, _K.WGRAD_STREAM = _K.WGRAD_STREAM, prev_side
+            if side is not None:              # (every pass already joined it after its backward; an exception may not have)
+                torch.cuda.current_stream(self.device).wait_stream(side)
+            _K.abort_deferred_reduces()       # (a pass that raised inside backward leaves no recorded reduce behind)
+            SF.GRAD_READY = None
             SF.end_weight_epoch()             # outside a managed step trainable weights are never served from the cache
 
     def _run_training_batch_body(self, batch_idx, batch):
         task = self.task
         graph_mode = self.hip_graph and self.on_gpu
-        from .. import kernels as _K
-        want_side = (self.on_gpu and not graph_mode and self.world_size == 1 and hparams.get("wgrad_side_stream", True))
-        if want_side and _K.WGRAD_STREAM is None:
-            _K.WGRAD_STREAM = torch.cuda.Stream(self.device)
-        elif not want_side:
-            _K.WGRAD_STREAM = None
         if graph_mode:
             for g in self.grad_sync:
                 if g is not None and g.drop_autograd_grads:
@@ -527,7 +580,7 @@ class Trainer:
         # it runs on a second stream that starts once everything issued so far is done, and the compute stream only waits
         # for it where the generator pass first touches critic state (task.critic_barrier).  One process, eager launches.
         disc_idx = getattr(task, "independent_critic_pass", None)
-        overlap_disc = (disc_idx is not None and self.on_gpu and not graph_mode and self.world_size == 1
+        overlap_disc = (disc_idx is not None and self.on_gpu and not graph_mode
                         and self.accumulate_grad_batches == 1 and hparams.get("overlap_critic_pass", True))
         if overlap_disc and self._critic_stream is None:
             self._critic_stream = torch.cuda.Stream(self.device)

@@ -89,6 +89,28 @@ def _worker(rank, world, port, emu_lib, out):
             ((torch.nn.functional.linear(yr.mean(-1), ps[3], ps[4]) * df).sum() / 4).backward()
             res["ov_ref"].append(torch.cat([t.grad.flatten() for t in ps]).numpy())
     res["stats"] = dict(sync2.stats)
+    # (e) rank-divergent pass keys (the key holds rank-local state, e.g. which critic windows the rank's longest clip
+    # reaches): rank 0 replays a recorded profile (buckets go out from inside backward), rank 1 sees its key for the first
+    # time (everything goes out in finish()).  The collectives must still pair up: one bucket order on every rank.
+    gi = torch.Generator().manual_seed(77)
+    xf, df = torch.randn(4, 4, 20, generator=gi), torch.randn(4, 3, generator=gi)
+    sync2.zero()
+    sync2.order.clear()
+    sync2.begin_pass(("pass", 0) if rank == 0 else ("pass", "first seen on this rank"))
+    SF.GRAD_READY = sync2.grad_ready
+    y = SF.conv1d(xf[rank::world], conv_v, bias, 1, 1, weight_g=conv_g)
+    ((lin(y.mean(-1)) * df[rank::world]).sum() / 2).backward()
+    SF.GRAD_READY = None
+    res["div_in_backward"] = len(sync2.order)
+    sync2.finish()
+    res["div_order"] = list(sync2.order)
+    res["div_grad"] = torch.cat([p.grad.flatten() for p in params2]).numpy().copy()
+    if rank == 0:
+        ps = [p.detach().clone().requires_grad_(True) for p in params2]
+        w = ps[0] * (ps[1] / ps[0].flatten(1).norm(dim=1).view(-1, 1, 1))
+        yr = torch.nn.functional.conv1d(xf, w, ps[2], 1, 1)
+        ((torch.nn.functional.linear(yr.mean(-1), ps[3], ps[4]) * df).sum() / 4).backward()
+        res["div_ref"] = torch.cat([t.grad.flatten() for t in ps]).numpy()
     np.save(os.path.join(out, f"r{rank}.npy"), res, allow_pickle=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -111,6 +133,12 @@ def test_flat_grad_allreduce_two_ranks_gloo(tmp_path, _emu_lib):
     st = r0["stats"]
     assert st["passes"] == 3 and st["launched_after"] == r0["n_buckets"]           # recording pass: nothing overlapped
     assert st["launched_in_backward"] == 2 * r0["n_buckets"]                       # passes 2 and 3: every bucket overlapped
+    # rank-divergent keys: same (descending) bucket order on both ranks although one overlapped and the other did not
+    nb = r0["n_buckets"]
+    assert r0["div_order"] == r1["div_order"] == list(range(nb - 1, -1, -1))
+    assert r0["div_in_backward"] > 0 and r1["div_in_backward"] == 0
+    assert np.array_equal(r0["div_grad"], r1["div_grad"])
+    assert np.abs(r0["div_grad"] - r0["div_ref"]).max() < 2e-5 * max(1.0, np.abs(r0["div_ref"]).max())
 
 
 def test_batch_sharding_rule():

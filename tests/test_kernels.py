@@ -623,6 +623,7 @@ def test_deferred_wgrad_reduces_equal_immediate(dev):
         assert K._DEFERRED is None
         return sinks_all
     now, later = run(False), run(True)
+    _join(dev)
     for a_, b_ in zip(now, later):
         for t0, t1 in zip(a_, b_):
             if t0 is not None:
@@ -643,8 +644,18 @@ def test_deferred_wgrad_reduces_equal_immediate(dev):
             if deferred:
                 K.flush_deferred_reduces()
         return sk
-    for t0, t1 in zip(twice(False), twice(True)):
+    r0, r1 = twice(False), twice(True)
+    _join(dev)
+    for t0, t1 in zip(r0, r1):
         assert torch.equal(t0, t1)
+
+
+def _join(dev):
+    """Results that went into sinks may have been produced on kernels.WGRAD_STREAM: join before reading them."""
+    if dev.type == "cuda":
+        if K.WGRAD_STREAM is not None:
+            torch.cuda.current_stream().wait_stream(K.WGRAD_STREAM)
+        torch.cuda.synchronize()
 
 
 def _untimed_on_gpu(dev):

@@ -53,3 +53,53 @@ def test_stacked_critic_calls_equal_separate_calls(dev):
         assert (a - b["y"]).abs().max().item() < 5e-5 * max(1.0, a.abs().max().item())
     for a, b in zip(grads_sep, grads_many):
         assert (a - b).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item())
+
+
+def test_critic_general_shapes_match_stock_torch(dev):
+    """Reference-legal critic configurations outside the fast path (multi_window_disc.py:14-65): a number of mel bins whose
+    halvings turn odd (60 -> 30 -> 15 -> 8) and a 5x5 kernel.  Both used to raise inside SF.critic_block; they now take the
+    general conv + Dropout2d factor + stock norm.  Compared with the same towers applied through stock torch ops (eval)."""
+    from neuralsvb_amd.modules.mel_disc import Discriminator
+    for freq, kernel in ((60, (3, 3)), (80, (5, 5)), (60, (5, 5))):
+        torch.manual_seed(3)
+        disc = Discriminator(time_lengths=[32, 64], freq_length=freq, hidden_size=16, kernel=kernel, cond_size=0,
+                             norm_type="in", reduction="stack").eval()
+        g = torch.Generator().manual_seed(4)
+        x = torch.randn(2, 70, freq, generator=g)
+        starts = [[3, 3], [6, 6]]
+        ref_scores, ref_fmaps = [], []
+        with torch.no_grad():
+            for tower, wl, st in zip(disc.discriminator.conv_layers, [32, 64], starts):
+                h = x[:, None, st[0]:st[0] + wl]
+                for blk in tower.model:
+                    h = blk(h)
+                    ref_fmaps.append(h)
+                ref_scores.append(tower.adv_layer(h.flatten(1)))
+        ref_y = torch.stack(ref_scores, -1)
+        d2 = disc.to(dev)
+        xd = x.clone().to(dev).requires_grad_(True)
+        o = d2(xd, None, start_frames_wins=[list(s) for s in starts], longest=70)
+        assert (o["y"].detach().cpu() - ref_y).abs().max().item() < 5e-5 * max(1.0, ref_y.abs().max().item()), (freq, kernel)
+        for a, b in zip(o["h"], ref_fmaps):
+            assert a.shape == b.shape and (a.detach().cpu() - b).abs().max().item() < 5e-5 * max(1.0, b.abs().max().item())
+        many = d2.forward_many([(xd, [list(s) for s in starts], None, 70)], want_fmaps=False)
+        assert (many[0]["y"].detach().cpu() - ref_y).abs().max().item() < 5e-5 * max(1.0, ref_y.abs().max().item())
+        # gradients through the general path
+        xr = x.clone().requires_grad_(True)
+        disc_cpu = disc.cpu()
+        hs = []
+        for tower, wl, st in zip(disc_cpu.discriminator.conv_layers, [32, 64], starts):
+            h = xr[:, None, st[0]:st[0] + wl]
+            for blk in tower.model:
+                h = blk(h)
+            hs.append(tower.adv_layer(h.flatten(1)))
+        (torch.stack(hs, -1) ** 2).sum().backward()
+        gref = [p.grad.clone() for p in disc_cpu.parameters()]
+        for p in disc_cpu.parameters():
+            p.grad = None
+        d2 = disc_cpu.to(dev)
+        xd = x.clone().to(dev).requires_grad_(True)
+        (d2(xd, None, start_frames_wins=[list(s) for s in starts], longest=70)["y"] ** 2).sum().backward()
+        assert (xd.grad.cpu() - xr.grad).abs().max().item() < 1e-4 * max(1.0, xr.grad.abs().max().item())
+        for p, gr in zip(d2.parameters(), gref):
+            assert (p.grad.cpu() - gr).abs().max().item() < 2e-4 * max(1.0, gr.abs().max().item())
