@@ -238,16 +238,16 @@ def bench_vocoder(args, device):
     cpu = None
     if not args.no_cpu_baseline:
         from oracle.vocoder_step_ref import vocoder_train_step
-        nb = 4
+        nb = min(B, args.vocoder_cpu_batch)
         torch.set_num_threads(min(16, os.cpu_count() or 1))
         sd = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
-        a = (sd(task.model_gen), sd(task.model_disc["mpd"]), sd(task.model_disc["msd"]), mel[:nb].cpu(), wav[:nb, None], f0[:nb],
-             dict(hparams))
-        vocoder_train_step(*a)
-        tt = float(np.median([vocoder_train_step(*a) for _ in range(2)]))
+        models = (sd(task.model_gen), sd(task.model_disc["mpd"]), sd(task.model_disc["msd"]))
+        vocoder_train_step(*models, mel[:2].cpu(), wav[:2, None], f0[:2], dict(hparams))          # warm-up on 2 segments
+        tt = vocoder_train_step(*models, mel[:nb].cpu(), wav[:nb, None], f0[:nb], dict(hparams))
         cpu = {"value": nb * L / sr / tt, "unit": "audio-seconds/sec", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": f"oracle CPU port of the G+MPD+MSD step (forward + both backward passes, no optimizer update), "
-                         f"B={nb} x {L} samples, median of 2 after 1 warm-up, torch fp32", "s_per_step": tt}
+               "sample": f"oracle CPU port of the G+MPD+MSD step (forward + both backward passes + both AdamW updates), "
+                         f"B={nb} x {L} samples (the GPU line's batch is {B}), one step after a 2-segment warm-up, torch fp32",
+               "s_per_step": tt}
     return {"metric": "audio-seconds/sec per train step (NSF-HifiGAN vocoder-only, G+MPD+MSD)", "value": B * L / sr / dt,
             "unit": "audio-seconds/sec", "ms_per_step": dt * 1e3,
             "config": {"workload": f"configs[2]: NSF-HifiGAN vocoder-only training step (generator + MPD + MSD passes, AdamW), "
@@ -382,6 +382,10 @@ def main():
                          "residual epilogues, stacked-way split, deferred weight-gradient reduces) back on their element-wise forms")
     ap.add_argument("--extra-hparams", default="", help="A/B switch: appended to the task's hparams string (k=v,k=v)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--vocoder-cpu-batch", type=int, default=64, help="segments in the CPU leg of the vocoder workload (GPU: 64)")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="default N=1 line only: skip the short configs[2] (vocoder step) and configs[4] (inference RTF) runs that "
+                         "are reported under `extra_workloads`")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay each optimizer pass's forward+backward as a captured hipGraph instead of issuing the launches "
@@ -430,6 +434,9 @@ def main():
         if os.environ.get("SVB_BENCH_MARKERS"):      # rocprofv3 runs: a spin kernel brackets the timed region in the kernel trace
             torch.cuda._sleep(1000)
             torch.cuda.synchronize()
+        for gsync in trainer.grad_sync:
+            if gsync is not None and world > 1:
+                gsync.measure_wait = True           # two event records per pass: device time the compute stream waits for RCCL
         t0 = time.perf_counter()
         run_steps(trainer, task, batch, args.steps, 1 + args.warmup)
         t_host = time.perf_counter() - t0           # host side done issuing; the GPU may still be working
@@ -442,6 +449,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        t_rank = dt
+        exposed_ms = 0.0
+        for gsync in trainer.grad_sync:
+            if gsync is not None and world > 1:
+                exposed_ms += gsync.exposed_wait_ms()
+                gsync.measure_wait = False
         if world > 1:
             tt = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -495,7 +508,11 @@ def main():
                     "bucket_mb": hp.get("ddp_bucket_mb", 8),
                     "buckets_launched_in_backward": sum(x["launched_in_backward"] for x in st),
                     "buckets_launched_after_backward": sum(x["launched_after"] for x in st),
-                    "exposed_wait_ms_per_pass": 1e3 * sum(x["wait_s"] for x in st) / passes}
+                    "host_wait_ms_per_pass": 1e3 * sum(x["wait_s"] for x in st) / passes,
+                    "exposed_wait_ms_per_step": exposed_ms / args.steps,
+                    "ms_per_step_this_rank": t_rank / args.steps * 1e3,
+                    "side_stream_weight_gradients": hp.get("wgrad_side_stream", True) and not args.no_side_stream,
+                    "critic_pass_on_own_stream": hp.get("overlap_critic_pass", True)}
         roof = cpu = None
         if rank == 0 and not args.no_roofline:
             roof = conv_roofline(trainer, task, batch, 3, 1 + args.warmup + args.steps, args.precision) if world == 1 else None
@@ -505,6 +522,23 @@ def main():
             log("cpu baseline (oracle port)")
             cpu = cpu_baseline(task, batch, hp, args)
             log(f"cpu baseline done: {cpu['s_per_step']:.2f} s/step on {cpu['cores']} threads")
+        extra_w = None
+        if rank == 0 and world == 1 and not args.no_extra_workloads and not args.graph:
+            # BASELINE configs[2] and configs[4] ride on the default line (short runs, each with its own roofline and CPU leg)
+            # so that the driver's `bench.py --gpus 1` record holds them; the headline value above is already final.
+            del trainer, task, batch
+            torch.cuda.empty_cache()
+            extra_w = {}
+            for name, fn, st, wu in (("vocoder", bench_vocoder, 6, 3), ("infer", bench_infer, 12, 4)):
+                log(f"extra workload: {name}")
+                a2 = argparse.Namespace(**vars(args))
+                a2.steps, a2.warmup = st, wu
+                try:
+                    extra_w[name] = fn(a2, device)
+                    log(f"  {name}: {extra_w[name]['ms_per_step']:.1f} ms/step, {extra_w[name]['value']:.1f} audio-s/s")
+                except Exception as e:                 # the headline line must survive a failure of an extra
+                    extra_w[name] = {"error": repr(e)}
+                    log(f"  {name} failed: {e!r}")
         if rank == 0:
             print(json.dumps({
                 "metric": "audio-seconds/sec per train step (vae_global_mle_eng)", "value": value,
@@ -518,7 +552,8 @@ def main():
                                        f"hop 128, T={T}, 80-bin mel", "global_batch": args.batch * world,
                            "parallelism": f"dp{world}", "random_init_weights": True},
                 "value_with_h2d": args.batch * args.seconds * world / (ms_h2d * 1e-3), "ms_per_step_with_h2d": ms_h2d,
-                "comm": comm, "data_side": data_side, "roofline": roof, "cpu_baseline": cpu}))
+                "comm": comm, "data_side": data_side, "roofline": roof, "cpu_baseline": cpu,
+                "extra_workloads": extra_w}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define SVB_ABI_VERSION 3
+#define SVB_ABI_VERSION 4
 int svb_abi_version(void);
 
 /* ---- fused conv epilogue / prologue description ------------------------------------------------------
@@ -39,36 +39,6 @@ typedef struct SvbConvEpilogue {
     const unsigned short* x_q; /* bf16x3 entry points only: optional Q image of x (svb_split_q layout).  When given (and
                                 * in_gate is NULL) the kernel stages its input tiles from it with plain 16-byte copies
                                 * instead of splitting fp32 x again in every consuming workgroup; results are bit-identical. */
-    /* svb_conv1d_forward_bf16x3 only, groups = 1: the gated stack's res/skip update (reference fs2_vae.py:83-89) as the
-     * epilogue of the 1x1 conv that produces it.  With skip_out set, the conv's rows v = acc + bias go to two tensors:
-     *   rows [0, res_rows):    y[b][r][t]            = (residual[b][r][t] + v) * mask[b][t]     (y, residual: [B][res_rows][T])
-     *   rows [res_rows, Cout): skip_out[b][r-res_rows][t] = (skip_in ? skip_in[...] : 0) + v, times mask[b][t] if skip_mask
-     * (skip_out / skip_in: [B][Cout-res_rows][T]; skip_in may equal skip_out).  res_rows = 0 for the stack's last layer
-     * (y, residual unused).  out_act / out_gate / in_gate must be unset.                                                 */
-    float* skip_out;
-    const float* skip_in;
-    int res_rows;
-    int skip_mask;
-    /* svb_conv1d_forward_bf16x3 only, groups = 1, Cout = 2C: the gated stack's gate (reference fs2_vae.py:10-16,75-80) as the
-     * epilogue of the in-layer conv.  With gate_acts set, y [B][2C][T] receives the conv output as usual and
-     *   gate_acts[b][c][t] = tanh(y[b][c][t] + g[b][goff+c][t]) * sigmoid(y[b][C+c][t] + g[b][goff+C+c][t])
-     * with g = gate_g [B][gate_gch][T] (NULL: no conditioning term).  The kernel reads the weight rows of a tile interleaved
-     * (tanh row c, sigmoid row C+c, tanh row c+1, ...) so that both halves of a channel are adjacent accumulator registers
-     * of one lane; only the tile shapes that read their weight fragments straight from global memory implement it (another
-     * force_cfg is replaced by the 128x96 tile).  Exclusive with skip_out / out_act / out_gate / residual / mask.        */
-    float* gate_acts;
-    const float* gate_g;
-    int gate_gch;
-    int gate_goff;
-    /* svb_conv1d_transposed_bf16x3 only, groups = 1, k = 1, stride 1: the gate's backward as the epilogue of the res/skip conv's
-     * data gradient.  With gateb_xin set (xin [B][2C][T], the in-layer conv's output; C = Cout of this call) the accumulator
-     * d = d(acts)[b][c][t] is not stored; instead, with a = xin[b][c][t] + g[b][goff+c][t], s = xin[b][C+c][t] + g[b][goff+C+c][t]
-     * (g = gate_g / gate_gch / gate_goff as above, NULL: no term):
-     *   y[b][c][t]   = d * sigmoid(s) * (1 - tanh(a)^2)            (y is [B][2C][T] here: d(xin))
-     *   y[b][C+c][t] = d * tanh(a) * sigmoid(s) * (1 - sigmoid(s))
-     * and, if gateb_dg is set ([B][gate_gch][T], the gradient of g), the same two values at channels goff+c / goff+C+c.      */
-    const float* gateb_xin;
-    float* gateb_dg;
 } SvbConvEpilogue;
 
 /* Weight pack (+ WeightNorm forward  w = g * v / ||v||, norm over all dims but 0).

@@ -18,9 +18,6 @@ class SvbConvEpilogue(C.Structure):
         ("residual", C.c_void_p), ("mask", C.c_void_p),
         ("in_slope", C.c_float), ("out_slope", C.c_float), ("out_gate_slope", C.c_float),
         ("out_act", C.c_int), ("force_cfg", C.c_int), ("x_q", C.c_void_p),
-        ("skip_out", C.c_void_p), ("skip_in", C.c_void_p), ("res_rows", C.c_int), ("skip_mask", C.c_int),
-        ("gate_acts", C.c_void_p), ("gate_g", C.c_void_p), ("gate_gch", C.c_int), ("gate_goff", C.c_int),
-        ("gateb_xin", C.c_void_p), ("gateb_dg", C.c_void_p),
     ]
 
 

@@ -35,14 +35,6 @@ struct SvbConvQArgs {
     const float* out_gate;
     const float* mask;
     const float* residual;
-    float* skip_out;              // MODE 3 (res/skip epilogue, see SvbConvEpilogue)
-    const float* skip_in;
-    int res_rows, skip_mask;
-    float* gate_acts;             // MODE 4 (gate epilogue)
-    const float* gate_g;
-    int gate_gch, gate_goff;
-    const float* gateb_xin;       // MODE 5 (gate-backward epilogue)
-    float* gateb_dg;
     float in_slope, out_slope, out_gate_slope;
     int out_act;
     int B, Cin, Cout, G, Cin_g, Cout_g, Tin, Tout;
@@ -52,12 +44,15 @@ struct SvbConvQArgs {
     int fast;                          // direct-A tiles, every K phase has exactly SLB slabs: straight-line pipelined loop
     int w_floats16, x_floats16;   // LDS carve sizes in 16-byte units (one of hi/lo each)
     int force_cfg;
+    int prio;                          // experiment switch (env SVB_CONV_PRIO): wave priority of the MFMA stage (1) / of the staging stage (2)
     unsigned long long* dbg;      // optional per-phase cycle stamps (svb_debug_set_timing_buffer; tools/stage_timing.py)
     int dbg_block0;               // first launch-order workgroup id that is stamped (env SVB_DBG_BLOCK0)
 };
 
 static unsigned long long* g_svbq_dbg = nullptr;
 static const bool g_svbq_nofast = getenv("SVB_NO_FASTLOOP") != nullptr;     // A/B switch for benchmarking
+static const int g_svbq_lds_pad = getenv("SVB_LDS_PAD_KB") ? atoi(getenv("SVB_LDS_PAD_KB")) * 1024 : 0;   // experiment: extra LDS -> 1 workgroup per CU
+static const int g_svbq_prio = getenv("SVB_CONV_PRIO") ? atoi(getenv("SVB_CONV_PRIO")) : 0;
 static const bool g_svbq_wg_narrow = getenv("SVB_WGRAD_NARROW") != nullptr;     // A/B switch: 64x64 weight-gradient tiles only
 extern "C" void svb_debug_set_timing_buffer(void* p) { g_svbq_dbg = (unsigned long long*)p; }
 static const int g_svbq_dbg_block0 = getenv("SVB_DBG_BLOCK0") ? atoi(getenv("SVB_DBG_BLOCK0")) : 0;   // first sampled workgroup
@@ -87,10 +82,9 @@ __device__ __forceinline__ void svbq_split8(const float* v, uint4& hi, uint4& lo
 }
 
 // MODE 0: fp32 x, split while staging;  1: the same with the activation-derivative gate on the load;  2: x comes pre-split
-// (Q image): the tile is staged with 16-byte copies -- four consecutive lanes fetch the 64-byte row of one position;
-// 3: staging as 0, res/skip epilogue (its own instantiations: the code of the other modes does not move);
-// 4: staging as 0, gate epilogue over interleaved weight rows (direct-A tiles only);
-// 5: staging as 0, gate-backward epilogue (the accumulator is d(acts); d(xin) -- twice the rows -- is what gets stored).
+// (Q image): the tile is staged with 16-byte copies -- four consecutive lanes fetch the 64-byte row of one position.
+// (Round 3 measured the gate / res-skip / gate-backward epilogue variants of this kernel on the MI355X: fewer launches, but
+//  0.2-0.35 ms MORE kernel time per step than the streaming kernels they replaced -- profiles/r03_fused_epilogue_ab.log -- removed.)
 template <int WM, int WN, int NT, int SLB, int MODE>
 __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs a, SvbConvPlan p) {
     constexpr bool GATE = MODE == 1, QIN = MODE == 2;
@@ -308,14 +302,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     // phase s right after their last use (rolling prefetch), so they have a whole phase to arrive.
     uint4 wfh[SLB], wfl[SLB];
     const int wf_row = wm * 32 + l31;
-    int wf_lane16 = (wf_row < m_valid ? wf_row : 0) * 2 + kb;                       // 16-byte units inside a slab
-    if constexpr (MODE == 4) {
-        // gate epilogue: tile row i is weight row (i & 1 ? C : 0) + (m_base + i) / 2 -- tanh row c and sigmoid row C + c of a
-        // channel become accumulator rows 2j, 2j+1, i.e. adjacent registers of one lane (w_off0 already holds m_base)
-        const int chalf = a.Cout_g >> 1, pair = (m_base + wf_row) >> 1;
-        const int wrow = pair < chalf ? (wf_row & 1) * chalf + pair : m_base;
-        wf_lane16 = (wrow - m_base) * 2 + kb;
-    }
+    const int wf_lane16 = (wf_row < m_valid ? wf_row : 0) * 2 + kb;                       // 16-byte units inside a slab
     auto load_wf = [&](int i, int kc0, int tg0) {          // slab i = (tap i / kch, chunk i % kch) of phase (kc0, tg0)
         const int nt_here = min(a.tg, ntap - tg0);
         const int kch_here = min(a.kch, a.kchunks - kc0);
@@ -417,6 +404,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
             __builtin_amdgcn_s_waitcnt(0x0F70);          // this phase's weight fragments (requested a phase ago)
             if (fastn) { if (QIN) load_xq(nkc); else load_x(nkc); }
             SVBQ_STAMP(1)
+            if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
             uint4 bh_u[2][NT], bl_u[2][NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) { bh_u[0][n] = x_hi[xbase[n] + xoff[0]]; bl_u[0][n] = x_lo[xbase[n] + xoff[0]]; }
@@ -446,6 +434,8 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
                 load_wf_full(i, lkc, ltg);
             }
             SVBQ_STAMP(2)
+            if (a.prio == 1) __builtin_amdgcn_s_setprio(0);
+            else if (a.prio == 2) __builtin_amdgcn_s_setprio(1);
             if (!has_next) break;
             if (new_x) {
                 xw = xbuf - cur;
@@ -457,6 +447,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
             }
             kc0 = nkc; tg0 = ntg;
             ++dbg_stage;
+            if (a.prio == 2) __builtin_amdgcn_s_setprio(0);
         }
     } else if (DIRECT_A) {
         if (ntap > 0) {
@@ -534,122 +525,6 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     const int out_base = p.phase_out_base[ph];
     dbg_stage = SVBQ_DBG_STAGES - 1;
     SVBQ_STAMP(6)
-    if constexpr (MODE == 4) {
-        // gate of the gated stack (G = 1, Cout = 2C, interleaved rows): registers r, r+1 (r even) of a lane are the tanh and
-        // the sigmoid pre-activation of channel `pair`
-        const int chalf = a.Cout >> 1;
-        float* yb = a.y + (size_t)b * a.Cout * a.Tout;
-        float* ab = a.gate_acts + (size_t)b * chalf * a.Tout;
-        const float* gbase = a.gate_g ? a.gate_g + ((size_t)b * a.gate_gch + a.gate_goff) * a.Tout : nullptr;
-        int poff[8];
-        float ba[8], bb[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = 2 * j;
-            const int pair = (m_base + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb) >> 1;
-            const bool ok = pair < chalf;
-            poff[j] = ok ? pair * a.Tout : -1;
-            ba[j] = (a.bias && ok) ? a.bias[pair] : 0.f;
-            bb[j] = (a.bias && ok) ? a.bias[chalf + pair] : 0.f;
-        }
-        const int hoff = chalf * a.Tout;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int ql = q0 + (wn * NT + n) * 32 + l31;
-            const int pos = ql * a.out_stride + out_base;
-            if (ql < nq) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (poff[j] >= 0) {
-                        const int oi = poff[j] + pos;
-                        const float va = acc[n][2 * j] + ba[j], vb = acc[n][2 * j + 1] + bb[j];
-                        yb[oi] = va;
-                        yb[oi + hoff] = vb;
-                        const float ga = gbase ? gbase[oi] : 0.f, gs = gbase ? gbase[oi + hoff] : 0.f;
-                        ab[oi] = tanhf(va + ga) * svb_sigmoid(vb + gs);
-                    }
-                }
-            }
-        }
-    } else if constexpr (MODE == 5) {
-        // backward of the gate: the accumulator row c is d(acts)[c]; with the saved pre-activations (+ conditioning) it
-        // becomes the two rows c, C + c of d(xin) (and of d(g))
-        const int C = a.Cout;
-        const size_t xb_off = (size_t)b * 2 * C * a.Tout;
-        float* yb = a.y + xb_off;
-        const float* xin = a.gateb_xin + xb_off;
-        const size_t gb_off = ((size_t)b * a.gate_gch + a.gate_goff) * a.Tout;
-        const float* gbase = a.gate_g ? a.gate_g + gb_off : nullptr;
-        float* dgb = a.gateb_dg ? a.gateb_dg + gb_off : nullptr;
-        const int hoff = C * a.Tout;
-        int rowoff[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = m_base + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
-            rowoff[r] = co < C ? co * a.Tout : -1;
-        }
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int ql = q0 + (wn * NT + n) * 32 + l31;
-            const int pos = ql * a.out_stride + out_base;
-            if (ql < nq) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (rowoff[r] >= 0) {
-                        const int oi = rowoff[r] + pos;
-                        float av = xin[oi], sv = xin[oi + hoff];
-                        if (gbase) { av += gbase[oi]; sv += gbase[oi + hoff]; }
-                        const float d = acc[n][r];
-                        const float th = tanhf(av), sg = svb_sigmoid(sv);
-                        const float da = d * sg * (1.f - th * th);
-                        const float ds = d * th * sg * (1.f - sg);
-                        yb[oi] = da;
-                        yb[oi + hoff] = ds;
-                        if (dgb) { dgb[oi] = da; dgb[oi + hoff] = ds; }
-                    }
-                }
-            }
-        }
-    } else if constexpr (MODE == 3) {
-        // res/skip update of the gated stack (G = 1): rows below res_rows update x, the others accumulate the skip sum
-        const int cres = a.res_rows, cs = a.Cout - cres;
-        const size_t rb_off = (size_t)b * cres * a.Tout, sb_off = (size_t)b * cs * a.Tout;
-        float* xn = a.y + rb_off;
-        const float* xo = a.residual + rb_off;
-        float* so = a.skip_out + sb_off;
-        const float* si = a.skip_in ? a.skip_in + sb_off : nullptr;
-        const float* maskb = a.mask ? a.mask + (size_t)b * a.Tout : nullptr;
-        const bool smask = a.skip_mask != 0;
-        int rowoff[16], kind[16];
-        float bv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = m_base + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
-            const bool ok = co < a.Cout;
-            kind[r] = ok ? (co < cres ? 1 : 2) : 0;
-            rowoff[r] = (co < cres ? co : co - cres) * a.Tout;
-            bv[r] = (a.bias && ok) ? a.bias[co] : 0.f;
-        }
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int ql = q0 + (wn * NT + n) * 32 + l31;
-            const int pos = ql * a.out_stride + out_base;
-            if (ql < nq) {
-                const float mk = maskb ? maskb[pos] : 1.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = acc[n][r] + bv[r];
-                    const int oi = rowoff[r] + pos;
-                    if (kind[r] == 1) {
-                        xn[oi] = (xo[oi] + v) * mk;
-                    } else if (kind[r] == 2) {
-                        const float o = si ? si[oi] + v : v;
-                        so[oi] = smask ? o * mk : o;
-                    }
-                }
-            }
-        }
-    } else
     {
         const size_t yb_off = (size_t)b * a.Cout * a.Tout;
         float* yb = a.y + yb_off;
@@ -767,9 +642,11 @@ __global__ __launch_bounds__(256) void svb_weight_pack_bf16x3_multi_kernel(const
 
 // ==================================================================================================================
 struct QCfg { int BM, BN; };
-#define SVBQ_NCFG 10
+#define SVBQ_NCFG 12
 static const QCfg kQCfgs[SVBQ_NCFG] = {{64, 128}, {128, 96}, {128, 128}, {64, 64}, {32, 128}, {64, 192}, {64, 256},
-                                       {64, 128}, {64, 192}, {64, 256}};      // 7..9: the direct-A forms of 0, 5, 6
+                                       {64, 128}, {64, 192}, {64, 256},       // 7..9: the direct-A forms of 0, 5, 6
+                                       {128, 64}, {128, 32}};                 // 10, 11: narrow direct-A tiles for short sequences
+                                                                              // (T = 281: more, shorter workgroups per launch)
 
 static int q_pick(int cout_g, int nq_max, long nz) {
     long best_cost = -1;
@@ -794,7 +671,7 @@ static void q_launch_kernel(const SvbConvQArgs& a, const SvbConvPlan& p, dim3 gr
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((svb_conv1d_bf16x3_kernel<WM, WN, NT, SLB, MODE>), grid, dim3(256), lds, stream, a, p);
+    hipLaunchKernelGGL((svb_conv1d_bf16x3_kernel<WM, WN, NT, SLB, MODE>), grid, dim3(256), lds + g_svbq_lds_pad, stream, a, p);
 }
 
 template <int WM, int WN, int NT, int SLB>
@@ -811,7 +688,7 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     int kch = SLB / a.tg;
     // Q input: usable without an input gate, with whole 16-channel chunks per group, and when one chunk's span fits the
     // per-thread unit budget
-    const bool qin = a.xq && !a.in_gate && !a.skip_out && !a.gate_acts && !a.gateb_xin && (a.G == 1 || a.Cin_g % 16 == 0) && 4 * span_max <= SVBQ_QUNITS * 256;
+    const bool qin = a.xq && !a.in_gate && (a.G == 1 || a.Cin_g % 16 == 0) && 4 * span_max <= SVBQ_QUNITS * 256;
     const int kch_cap = qin ? (SVBQ_QUNITS * 256) / (4 * span_max) : (a.fast_x ? SVBQ_XUNITS / a.xit : 2);
     if (kch > kch_cap) kch = kch_cap;
     if (kch > a.kchunks) kch = a.kchunks;
@@ -841,12 +718,7 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     a.w_floats16 = SLB <= 5 ? 0 : a.tg * a.kch * BM * 3;
     a.x_floats16 = a.kch * a.xrows * 3;
     dim3 grid(a.G * svb_cdiv(a.Cout_g, BM), svb_cdiv(nq_max, BN), a.B * p.n_phase);
-    if (a.gate_acts) {
-        if constexpr (SLB <= 5) q_launch_kernel<WM, WN, NT, SLB, 4>(a, p, grid, lds_bytes(a.kch), stream);
-        else return SVB_ERR_UNSUPPORTED;
-    } else if (a.gateb_xin) q_launch_kernel<WM, WN, NT, SLB, 5>(a, p, grid, lds_bytes(a.kch), stream);
-    else if (a.skip_out) q_launch_kernel<WM, WN, NT, SLB, 3>(a, p, grid, lds_bytes(a.kch), stream);
-    else if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, 1>(a, p, grid, lds_bytes(a.kch), stream);
+    if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, 1>(a, p, grid, lds_bytes(a.kch), stream);
     else if (qin) q_launch_kernel<WM, WN, NT, SLB, 2>(a, p, grid, lds_bytes(a.kch), stream);
     else q_launch_kernel<WM, WN, NT, SLB, 0>(a, p, grid, lds_bytes(a.kch), stream);
     SVB_CHECK_LAUNCH();
@@ -875,7 +747,6 @@ static int q_dispatch(SvbConvQArgs& a, const SvbConvPlan& p, hipStream_t stream)
     if ((long)a.Cout * a.Tout > 0x7fffffffL) return SVB_ERR_UNSUPPORTED;      // the epilogue's per-clip offsets are 32-bit
     int cfg = q_pick(a.Cout_g, nq_max, (long)a.B * p.n_phase * a.G);
     if (a.force_cfg >= 0 && a.force_cfg < SVBQ_NCFG) cfg = a.force_cfg;
-    if (a.gate_acts && !(cfg == 1 || cfg == 2 || cfg >= 7)) cfg = 1;      // gate epilogue: direct-A tiles only
     for (int attempt = 0; attempt < 2; ++attempt) {
         int rc;
         switch (cfg) {
@@ -888,7 +759,9 @@ static int q_dispatch(SvbConvQArgs& a, const SvbConvPlan& p, hipStream_t stream)
             case 6: rc = q_launch<2, 2, 4, 8>(a, p, nq_max, span_off_max, ntap_max, stream); break;
             case 7: SVBQ_DIRECT(2, 2, 2) break;
             case 8: SVBQ_DIRECT(2, 2, 3) break;
-            default: SVBQ_DIRECT(2, 2, 4) break;
+            case 9: SVBQ_DIRECT(2, 2, 4) break;
+            case 10: SVBQ_DIRECT(4, 1, 2) break;
+            default: SVBQ_DIRECT(4, 1, 1) break;
         }
         if (rc != SVB_ERR_UNSUPPORTED || cfg == 3) return rc;
         cfg = 3;        // strided convs with very wide input spans: the narrowest tile has the smallest LDS footprint
@@ -908,11 +781,9 @@ static void q_fill(SvbConvQArgs& a, const SvbConvEpilogue* e) {
     a.mask = e ? e->mask : nullptr;
     a.force_cfg = e ? e->force_cfg - 1 : -1;
     a.xq = e ? e->x_q : nullptr;
-    a.skip_out = nullptr; a.skip_in = nullptr; a.res_rows = 0; a.skip_mask = 0;     // (svb_conv1d_forward_bf16x3 sets them)
-    a.gate_acts = nullptr; a.gate_g = nullptr; a.gate_gch = 0; a.gate_goff = 0;
-    a.gateb_xin = nullptr; a.gateb_dg = nullptr;        // (svb_conv1d_transposed_bf16x3 sets them)
     a.dbg = g_svbq_dbg;
     a.dbg_block0 = g_svbq_dbg_block0;
+    a.prio = g_svbq_prio;
 }
 
 extern "C" int svb_weight_pack_bf16x3(const float* v, const float* g, unsigned short* qa_hi, unsigned short* qa_lo,
@@ -946,18 +817,6 @@ extern "C" int svb_conv1d_forward_bf16x3(const float* x, const unsigned short* q
     memset(&p, 0, sizeof(p));
     a.x = x; a.wq_hi = qa_hi; a.wq_lo = qa_lo; a.y = y;
     q_fill(a, epi);
-    if (epi && epi->skip_out) {       // res/skip epilogue (MODE 3)
-        if (groups != 1 || epi->res_rows < 0 || epi->res_rows >= Cout || epi->out_act || epi->out_gate || epi->in_gate ||
-            (epi->res_rows > 0 && !epi->residual) || (epi->skip_mask && !epi->mask))
-            return SVB_ERR_ARG;
-        a.skip_out = epi->skip_out; a.skip_in = epi->skip_in; a.res_rows = epi->res_rows; a.skip_mask = epi->skip_mask;
-    }
-    if (epi && epi->gate_acts) {      // gate epilogue (MODE 4)
-        if (groups != 1 || (Cout & 1) || epi->skip_out || epi->out_act || epi->out_gate || epi->in_gate || epi->residual ||
-            epi->mask || (epi->gate_g && (epi->gate_goff < 0 || epi->gate_goff + Cout > epi->gate_gch)))
-            return SVB_ERR_ARG;
-        a.gate_acts = epi->gate_acts; a.gate_g = epi->gate_g; a.gate_gch = epi->gate_gch; a.gate_goff = epi->gate_goff;
-    }
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.G = groups; a.Cin_g = Cin / groups; a.Cout_g = Cout / groups;
     a.Tin = Tin; a.Tout = Tout; a.sx = stride; a.out_stride = 1;
     a.w_tap_slabs = svb_cdiv(a.Cin_g, 16); a.w_g_slabs = 0; a.w_slab_rows = Cout; a.w_goff_m = a.Cout_g;
@@ -1005,15 +864,6 @@ extern "C" int svb_conv1d_transposed_bf16x3(const float* x, const unsigned short
     memset(&p, 0, sizeof(p));
     a.x = x; a.wq_hi = qb_hi; a.wq_lo = qb_lo; a.y = y;
     q_fill(a, epi);
-    if (epi && epi->gateb_xin) {      // gate-backward epilogue (MODE 5)
-        if (groups != 1 || k != 1 || stride != 1 || pad != 0 || Tin != Tout || epi->bias || epi->out_act || epi->out_gate ||
-            epi->in_gate || epi->residual || epi->mask || epi->skip_out || epi->gate_acts ||
-            ((epi->gate_g || epi->gateb_dg) && (epi->gate_goff < 0 || epi->gate_goff + 2 * Cout > epi->gate_gch)) ||
-            (long)2 * Cout * Tout > 0x7fffffffL)
-            return SVB_ERR_ARG;
-        a.gateb_xin = epi->gateb_xin; a.gateb_dg = epi->gateb_dg;
-        a.gate_g = epi->gate_g; a.gate_gch = epi->gate_gch; a.gate_goff = epi->gate_goff;
-    }
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.G = groups; a.Cin_g = Cin / groups; a.Cout_g = Cout / groups;
     a.Tin = Tin; a.Tout = Tout; a.sx = 1; a.out_stride = stride;
     const int kchb = svb_cdiv(a.Cin_g, 16);

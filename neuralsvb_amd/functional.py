@@ -61,16 +61,6 @@ USE_Q = False            # bf16x3 mode, opt-in: producers inside the gated stack
                          # into the conv epilogues, where the Q image costs no extra pass.
 
 
-FUSE_RES_SKIP = False    # gated stack, bf16x3: the res/skip update (x = (x + rs[:C]) * mask, out += rs[C:]) as the epilogue of the
-                         # 1x1 conv that produces rs (its own kernel instantiations, svb_conv1d_bf16x3_kernel<..., 3>): one launch
-                         # and ~4C*B*T*4 bytes of traffic per layer less.  Landed after the round's last GPU minute: bit-exact
-                         # against the two-kernel form on the lane emulator, NOT yet timed on the MI355X -- off until it is.
-
-FUSE_GATE = False         # gated stack, bf16x3: tanh(a + g) * sigmoid(b + g) as the epilogue of the in-layer conv
-                         # (svb_conv1d_bf16x3_kernel<..., 4>: interleaved weight rows put both halves of a channel in adjacent
-                         # accumulator registers of one lane) and its backward as the epilogue of the res/skip conv's data
-                         # gradient (<..., 5>).  Same status as FUSE_RES_SKIP: bit-exact on the emulator, untimed.
-
 DIRECT_GRADS = True      # weight/bias gradients of leaf parameters that already own a `.grad` buffer are accumulated into
                          # it by the reduce kernel itself (autograd gets None and skips its `grad += new` pass)
 
@@ -78,9 +68,9 @@ DIRECT_GRADS = True      # weight/bias gradients of leaf parameters that already
 def reset_runtime_state():
     """Arithmetic mode, optional fusions and the Trainer-set routing state back to their import-time values (see
     kernels.reset_runtime_state)."""
-    global USE_Q, FUSE_RES_SKIP, FUSE_GATE, DIRECT_GRADS, GRAD_READY, CAPTURING, PACK_CACHE, PACK_REGISTRY, PACK_EPOCH
+    global USE_Q, DIRECT_GRADS, GRAD_READY, CAPTURING, PACK_CACHE, PACK_REGISTRY, PACK_EPOCH
     set_precision("fp32")
-    USE_Q = FUSE_RES_SKIP = FUSE_GATE = False
+    USE_Q = False
     DIRECT_GRADS = PACK_CACHE = PACK_REGISTRY = True
     GRAD_READY = PACK_EPOCH = None
     CAPTURING = False
@@ -410,33 +400,23 @@ class _WNStackFn(torch.autograd.Function):
         saved_x, saved_xin, saved_acts, packs_b = [], [], [], []
         out = None
         useq = USE_Q and PRECISION == "bf16x3" and C % 16 == 0
-        fuse_rs = FUSE_RES_SKIP and PRECISION == "bf16x3" and not useq and (C * T) < (1 << 31)
-        fuse_gate = FUSE_GATE and PRECISION == "bf16x3" and not useq
         xq = K.split_q(x) if useq else None
         for i, (in_v, in_g, in_b, rs_v, rs_g, rs_b) in enumerate(layers):
             dil = dilation_rate ** i
             pad = (kernel_size * dil - dil) // 2
             pa_in, pb_in = _pack(_c(in_v), _c(in_g))
             acts_q = None
-            if fuse_gate:        # the gate as the in-layer conv's own epilogue: no gate kernel, xin is not read back
-                xin, acts = K.conv1d_gate(x, pa_in, 2 * C, kernel_size, pad, dil, bias=_c(in_b), g=G, g_off=i * 2 * C)
+            xin = K.conv1d_forward(x, pa_in, 2 * C, kernel_size, 1, pad, dil, 1, bias=_c(in_b), x_q=xq)
+            if useq:
+                acts, acts_q = K.wn_gate_fwd(xin, G, i * 2 * C, want_q=True)
             else:
-                xin = K.conv1d_forward(x, pa_in, 2 * C, kernel_size, 1, pad, dil, 1, bias=_c(in_b), x_q=xq)
-                if useq:
-                    acts, acts_q = K.wn_gate_fwd(xin, G, i * 2 * C, want_q=True)
-                else:
-                    acts = K.wn_gate_fwd(xin, G, i * 2 * C)
+                acts = K.wn_gate_fwd(xin, G, i * 2 * C)
             pa_rs, pb_rs = _pack(_c(rs_v), _c(rs_g))
             last = i == n_layers - 1
             saved_x.append(x)
             saved_xin.append(xin)
             saved_acts.append(acts)
             packs_b.append((pb_in, pb_rs))
-            if fuse_rs:          # the res/skip update as the 1x1 conv's own epilogue: no `rs` tensor, no update kernel
-                x_new, out = K.conv1d_res_skip(acts, pa_rs, rs_v.shape[0], x, mask, out, last, bias=_c(rs_b))
-                if not last:
-                    x = x_new
-                continue
             rs = K.conv1d_forward(acts, pa_rs, rs_v.shape[0], 1, bias=_c(rs_b), x_q=acts_q)
             if useq:
                 x_new, out, xq = K.wn_res_skip(x, rs, mask, out, last, want_q=True)
@@ -444,7 +424,7 @@ class _WNStackFn(torch.autograd.Function):
                 x_new, out = K.wn_res_skip(x, rs, mask, out, last)
             if not last:
                 x = x_new
-        if mask is not None and not fuse_rs:       # (the fused last layer already applied it)
+        if mask is not None:
             out = out * mask[:, None, :]
         ctx.meta = (n_layers, kernel_size, dilation_rate, C)
         ctx.useq = useq
@@ -509,15 +489,11 @@ class _WNStackFn(torch.autograd.Function):
                 dx_next = None
                 continue
             dxin_q = None
-            if FUSE_GATE and not useq and isinstance(pb_rs, K.PackedQ):
-                # the gate's backward as the epilogue of the res/skip conv's data gradient: d(acts) is never written
-                dxin = K.conv1d_gate_bwd(drs, pb_rs, C, xin, G, i * 2 * C, dG)
+            dacts = K.conv1d_transposed(drs, pb_rs, C, acts.shape[2], 1, x_q=drs_q)
+            if useq and need_dx:
+                dxin, dxin_q = K.wn_gate_bwd(xin, G, dacts, i * 2 * C, dg=dG, want_q=True)
             else:
-                dacts = K.conv1d_transposed(drs, pb_rs, C, acts.shape[2], 1, x_q=drs_q)
-                if useq and need_dx:
-                    dxin, dxin_q = K.wn_gate_bwd(xin, G, dacts, i * 2 * C, dg=dG, want_q=True)
-                else:
-                    dxin = K.wn_gate_bwd(xin, G, dacts, i * 2 * C, dg=dG)
+                dxin = K.wn_gate_bwd(xin, G, dacts, i * 2 * C, dg=dG)
             if need_in_w:
                 sk = _sinks(in_v, in_g, in_b)
                 r = K.conv1d_wgrad(dxin, x_i, ks, 1, pad, dil, v=in_v if in_g is not None else None, g=in_g, want_bias=True,

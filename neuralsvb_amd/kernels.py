@@ -19,8 +19,9 @@ _CFG_NAMES = ["svb_conv1d_mfma_kernel<2,2,2,*,80> (64x128)", "svb_conv1d_mfma_ke
               "svb_conv1d_mfma_kernel<4,1,4,*,80> (128x128)", "svb_conv1d_mfma_kernel<2,2,1,*,80> (64x64)",
               "svb_conv1d_mfma_kernel<1,4,1,*,80> (32x128)", "svb_conv1d_mfma_kernel<2,2,3,*,80> (64x192)",
               "svb_conv1d_mfma_kernel<2,2,4,*,80> (64x256)", "svb_conv1d_mfma_kernel<2,2,2,direct> (64x128)",
-              "svb_conv1d_mfma_kernel<2,2,3,direct> (64x192)", "svb_conv1d_mfma_kernel<2,2,4,direct> (64x256)"]
-_NCFG_Q = 10     # tile configurations of the bf16x3 kernel (the fp32 kernel has the first 5)
+              "svb_conv1d_mfma_kernel<2,2,3,direct> (64x192)", "svb_conv1d_mfma_kernel<2,2,4,direct> (64x256)",
+              "svb_conv1d_mfma_kernel<4,1,2,direct> (128x64)", "svb_conv1d_mfma_kernel<4,1,1,direct> (128x32)"]
+_NCFG_Q = 12     # tile configurations of the bf16x3 kernel (the fp32 kernel has the first 5)
 
 
 # ---- per-shape tile autotuning ("measure, don't guess"): the first time a conv signature is seen on the GPU all five
@@ -110,17 +111,9 @@ def _f32(*ts):
 
 
 def make_epilogue(bias=None, in_gate=None, in_slope=0.0, out_act=ACT_NONE, out_slope=0.0, out_gate=None,
-                  out_gate_slope=0.0, residual=None, mask=None, force_cfg=0, x_q=None, skip_out=None, skip_in=None,
-                  res_rows=0, skip_mask=False, gate_acts=None, gate_g=None, gate_goff=0, gateb_xin=None, gateb_dg=None):
+                  out_gate_slope=0.0, residual=None, mask=None, force_cfg=0, x_q=None):
     e = L.SvbConvEpilogue()
     e.x_q = _ptr(x_q)
-    e.gateb_xin, e.gateb_dg = _ptr(gateb_xin), _ptr(gateb_dg)
-    if gate_g is None and gateb_dg is not None:
-        e.gate_gch = int(gateb_dg.shape[1])
-    e.gate_acts, e.gate_g, e.gate_goff = _ptr(gate_acts), _ptr(gate_g), int(gate_goff)
-    if gate_g is not None:
-        e.gate_gch = int(gate_g.shape[1])
-    e.skip_out, e.skip_in, e.res_rows, e.skip_mask = _ptr(skip_out), _ptr(skip_in), int(res_rows), int(bool(skip_mask))
     e.bias, e.in_gate, e.out_gate = _ptr(bias), _ptr(in_gate), _ptr(out_gate)
     e.residual, e.mask = _ptr(residual), _ptr(mask)
     e.in_slope, e.out_slope, e.out_gate_slope = float(in_slope), float(out_slope), float(out_gate_slope)
@@ -234,21 +227,12 @@ def conv1d_forward(x, pa, cout, k, stride=1, pad=0, dil=1, groups=1, out=None, *
     if q:
         y = out if out is not None else torch.empty((B, cout, tout), device=x.device, dtype=torch.float32)
         e = make_epilogue(**epi)
-        if x.is_cuda and not epi.get("force_cfg") and epi.get("gate_acts") is not None:
-            # gate epilogue: only the tiles that read their weight fragments from global memory implement it -- the one
-            # measured for the plain conv of this shape if it is such a tile, else 128x96
-            best = _TUNED.get(("qf", B, cin, cout, groups, tin, k, stride, pad, dil, False), 0)
-            e.force_cfg = best if best in (2, 3, 8, 9, 10) else 2
-        elif x.is_cuda and not epi.get("force_cfg") and epi.get("skip_out") is None:
+        if x.is_cuda and not epi.get("force_cfg"):
             def launch(cfg):
                 e.force_cfg = cfg
                 L.check(lib.svb_conv1d_forward_bf16x3(_ptr(x), _ptr(pa.hi), _ptr(pa.lo), _ptr(y), B, cin, cout, groups, tin,
                                                       tout, k, stride, pad, dil, C.byref(e), st), "svb_conv1d_forward_bf16x3")
             e.force_cfg = _tuned_cfg(("qf", B, cin, cout, groups, tin, k, stride, pad, dil, has_q), launch, _NCFG_Q)
-        elif x.is_cuda and not epi.get("force_cfg"):
-            # res/skip epilogue: it accumulates in place, so it is never launched for timing -- it takes the tile measured for
-            # the plain conv of the same shape (if that was seen), else the heuristic one
-            e.force_cfg = _TUNED.get(("qf", B, cin, cout, groups, tin, k, stride, pad, dil, False), 0)
         probe = _ConvProbe(lib, x, cout // groups, tout, 2.0 * B * cout * tout * (cin // groups) * k, B * groups, e.force_cfg,
                            "svb_conv1d_bf16x3_kernel", tag=("fwd", B, cin, cout, groups, tin, k, stride, dil))
         L.check(lib.svb_conv1d_forward_bf16x3(_ptr(x), _ptr(pa.hi), _ptr(pa.lo), _ptr(y), B, cin, cout, groups, tin, tout, k,
@@ -302,48 +286,6 @@ def conv1d_taps(x, packed, cout, offsets, tout=None, **epi):
     launch(cfg)
     probe.done()
     return y
-
-
-def conv1d_gate(x, pa, c2, k, pad, dil, bias=None, g=None, g_off=0, force_cfg=0):
-    """The gated stack's in-layer conv with the gate as its epilogue (bf16x3 only; reference fs2_vae.py:10-16,73-80):
-    xin = conv(x) [B,2C,T];  acts = tanh(xin[:, :C] + g[:, off:off+C]) * sigmoid(xin[:, C:] + g[:, off+C:off+2C]).
-    Returns (xin, acts) -- xin is what the backward pass reads."""
-    if not isinstance(pa, PackedQ):
-        raise TypeError("conv1d_gate: bf16x3 packed weights only")
-    B, cin, T = x.shape
-    acts = torch.empty((B, c2 // 2, T), device=x.device, dtype=torch.float32)
-    xin = conv1d_forward(x, pa, c2, k, 1, pad, dil, 1, bias=bias, gate_acts=acts, gate_g=g, gate_goff=g_off, force_cfg=force_cfg)
-    return xin, acts
-
-
-def conv1d_gate_bwd(drs, pb, c, xin, g=None, g_off=0, dg=None, force_cfg=0):
-    """The gate's backward as the epilogue of the res/skip conv's data gradient (bf16x3 only): d(acts) = conv1x1^T(drs) stays
-    in the accumulators; returns d(xin) [B,2C,T] (wn_gate_bwd's result) and writes the same values into dg's channels
-    [g_off, g_off+2C) when dg is given."""
-    if not isinstance(pb, PackedQ):
-        raise TypeError("conv1d_gate_bwd: bf16x3 packed weights only")
-    B, _, T = drs.shape
-    dxin = torch.empty((B, 2 * c, T), device=drs.device, dtype=torch.float32)
-    conv1d_transposed(drs, pb, c, T, 1, out=dxin, gateb_xin=xin, gateb_dg=dg, gate_g=g, gate_goff=g_off, force_cfg=force_cfg)
-    return dxin
-
-
-def conv1d_res_skip(acts, pa, cout, x, mask, out, last, bias=None, force_cfg=0):
-    """The gated stack's res/skip 1x1 conv with its update as the conv's epilogue (bf16x3 only; reference fs2_vae.py:83-89):
-    rs = conv1x1(acts);  x_new = (x + rs[:, :C]) * mask;  out (+)= rs[:, C:]   (last layer: out (+)= rs, then * mask).
-    `out`: the running skip sum, updated IN PLACE (None on the first layer: allocated).  Returns (x_new or None, out)."""
-    if not isinstance(pa, PackedQ):
-        raise TypeError("conv1d_res_skip: bf16x3 packed weights only")
-    B, cin, T = acts.shape
-    c = cout if last else cout // 2
-    first = out is None
-    if first:
-        out = torch.empty((B, c, T), device=acts.device, dtype=torch.float32)
-    x_new = None if last else torch.empty((B, c, T), device=acts.device, dtype=torch.float32)
-    conv1d_forward(acts, pa, cout, 1, out=out if last else x_new, bias=bias, residual=None if last else x, mask=mask,
-                   skip_out=out, skip_in=None if first else out, res_rows=0 if last else c, skip_mask=last and mask is not None,
-                   force_cfg=force_cfg)
-    return x_new, out
 
 
 def conv1d_transposed(x, pb, cout, tout, k, stride=1, pad=0, dil=1, groups=1, out=None, **epi):
@@ -466,7 +408,9 @@ def _side_ws(side, dev, slot, n):
 # stream the partials were produced on -- ~60 reduce launches per step become 3.
 _DEFERRED = None         # None: off;  else {"descs": [...], "keep": [...], "stream": raw handle, "side": Stream|None, "dev": device}
 _ARENA = {}              # (device index, raw stream handle) -> [tensor, used floats]: an arena is only ever touched by one stream
-ARENA_MIN_FLOATS = 64 << 20
+ARENA_MIN_FLOATS = 12 << 20     # 48 MB per stream: the pending partials of a few layers stay inside the memory-side cache (the
+                                # first version kept a whole pass -- ~0.9 GB -- and its one reduce streamed them back from HBM:
+                                # 15.71 vs 15.52 ms/step); a full arena finishes what is pending and starts over
 
 
 def begin_deferred_reduces():
@@ -489,7 +433,7 @@ def _arena_take(dev, st, n):
 def _arena_grow(dev, side, st, n):
     key = (dev.index, st)
     ent = _ARENA.get(key)
-    want = max(ARENA_MIN_FLOATS, 2 * (ent[0].numel() if ent is not None else 0), 2 * n)
+    want = max(ARENA_MIN_FLOATS, n)              # (grown only for a single request that is larger than the arena)
     if side is not None:
         with torch.cuda.stream(side):
             t = torch.empty((want,), device=dev, dtype=torch.float32)

@@ -17,6 +17,9 @@ from .vc_asr import VCASR
 
 
 SPLIT_STACKED = True     # stacked ways: per-way mel_out views through SF.split_stacked_ways (one gradient buffer for both)
+PPG_SIDE_STREAM = True   # prepare_condition: the frozen PPG encoder (no grad, T/2 frames: it under-fills the chip) runs on its own
+                         # stream beside the pitch encoder -- the two branches only meet at the conditioning projection
+_PPG_STREAMS = {}
 FUSED_GN = True          # ConvBlock: GroupNorm + ReLU + residual as one HIP pass per direction
 
 
@@ -96,8 +99,24 @@ class MleSVBVAE(nn.Module):
     def prepare_condition(self, mels_content, pitch, spk_ids, groups=1):
         T = pitch.shape[1]
         pe = self.pitch_embed          # nn.Embedding(300, H, padding_idx=0) + transpose, as one gather into [B,H,T]
+        side = None
+        if PPG_SIDE_STREAM and mels_content.is_cuda and not SF.CAPTURING:
+            # independent branches (svb_vae.py:66-72): PPG encoder on a side stream that first catches up with the producers of
+            # the mel, pitch encoder on the current one; the current stream waits where the content features are first read
+            cur = torch.cuda.current_stream(mels_content.device)
+            side = _PPG_STREAMS.get(mels_content.device.index)
+            if side is None:
+                side = _PPG_STREAMS[mels_content.device.index] = torch.cuda.Stream(mels_content.device)
+            side.wait_stream(cur)
+            mels_content.record_stream(side)
+            with torch.cuda.stream(side):
+                h = self.vc_asr(mels_content)["h_content"].detach()
         h_pitch = self.pitch_encoder(SF.embedding_nct(pitch, pe.weight, pe.padding_idx))
-        h = self.vc_asr(mels_content)["h_content"].detach()
+        if side is not None:
+            cur.wait_stream(side)
+            h.record_stream(cur)
+        else:
+            h = self.vc_asr(mels_content)["h_content"].detach()
         for m in self.upsample_layer:
             if isinstance(m, nn.Sequential):
                 h = F.interpolate(h, scale_factor=m[0].scale_factor, mode="nearest")

@@ -99,8 +99,8 @@ class SVBVAEMleTask(BaseTask):
 
     def build_model(self):
         SF.set_precision(hparams.get("conv_precision", "fp32"))
-        SF.FUSE_RES_SKIP = bool(hparams.get("wn_fuse_res_skip", False))
-        SF.FUSE_GATE = bool(hparams.get("wn_fuse_gate", False))
+        from ..modules import svb_vae as _svb
+        _svb.PPG_SIDE_STREAM = bool(hparams.get("overlap_ppg_encoder", True))
         self.build_tts_model()
         if hparams.get("pretrain_asr_ckpt"):
             ckpt_utils.load_ckpt(self.model.vc_asr, hparams["pretrain_asr_ckpt"], model_name="model",

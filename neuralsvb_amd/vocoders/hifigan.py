@@ -54,7 +54,9 @@ class HifiGAN(BaseVocoder):
 
     @torch.no_grad()
     def spec2wav(self, mel, **kwargs):
-        """mel [T,80] (or [B,T,80]), f0=[T] (or [B,T]) -> np.float32 wav [T*hop] (or [B, T*hop])."""
+        """mel [T,80] (or [B,T,80]), f0=[T] (or [B,T]) -> np.float32 wav [T*hop] (or [B, T*hop]).
+        Optional rand_ini [B,9] / noise [B,T*hop,9]: the NSF source's draws (SineGen's initial phases and additive noise,
+        source.py:84-86,125-127) supplied by the caller instead of drawn -- what a parity test injects."""
         mel = torch.as_tensor(np.asarray(mel) if not isinstance(mel, torch.Tensor) else mel, dtype=torch.float32)
         single = mel.dim() == 2
         c = (mel[None] if single else mel).transpose(2, 1).to(self.device)
@@ -62,7 +64,9 @@ class HifiGAN(BaseVocoder):
         if f0 is not None:
             f0 = torch.as_tensor(np.asarray(f0) if not isinstance(f0, torch.Tensor) else f0, dtype=torch.float32)
             f0 = (f0[None] if single else f0).to(self.device)
-            y = self.model(c, f0)
+            inj = {k: torch.as_tensor(kwargs[k], dtype=torch.float32).to(self.device) for k in ("rand_ini", "noise")
+                   if kwargs.get(k) is not None}
+            y = self.model(c, f0, **inj)
         else:
             y = self.model(c)
         y = y[:, 0].cpu().numpy()

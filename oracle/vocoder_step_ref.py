@@ -3,8 +3,7 @@
 
 vocoder_train_step: the composed NSF-HifiGAN GAN step of neuralsvb_amd/tasks/hifigan_task.py on the oracle's restatements
 of the reference modules (modules/hifigan/hifigan.py:105-169,202-325 and loss functions :328-365, mel_utils.py:45-79) --
-generator pass (mel L1 + adversarial terms, backward) + discriminator pass (backward); optimizer updates are left out (they
-are <1 % of the CPU time).  infer_clip: MleSVBVAE three ways + five generator passes on one clip, as tasks/infer.py does.
+generator pass (mel L1 + adversarial terms, backward, AdamW) + discriminator pass (backward, AdamW).  infer_clip: MleSVBVAE three ways + five generator passes on one clip, as tasks/infer.py does.
 """
 import time
 
@@ -15,8 +14,8 @@ from oracle import frontend as FE
 from oracle import modules_ref as R
 
 
-def vocoder_train_step(gen_sd, mpd_sd, msd_sd, mel, wav, f0, cfg, lambda_mel=5.0, lambda_adv=1.0):
-    """mel [B,80,frames], wav [B,1,L], f0 [B,frames].  Returns seconds spent."""
+def vocoder_train_step(gen_sd, mpd_sd, msd_sd, mel, wav, f0, cfg, lambda_mel=5.0, lambda_adv=1.0, with_optimizer=True):
+    """mel [B,80,frames], wav [B,1,L], f0 [B,frames].  Returns seconds spent (both passes incl. their AdamW updates)."""
     B, L = wav.shape[0], wav.shape[-1]
     t0 = time.perf_counter()
     def leafs(sd):
@@ -38,11 +37,20 @@ def vocoder_train_step(gen_sd, mpd_sd, msd_sd, mel, wav, f0, cfg, lambda_mel=5.0
     _, g2, _, _ = R.multi_scale_disc(ssd, wav, y_)
     loss = loss + (R.generator_loss(g1) + R.generator_loss(g2)) * lambda_adv
     loss.backward()
+    if with_optimizer:
+        torch.optim.AdamW([v for v in gsd.values() if v.requires_grad], lr=cfg.get("lr", 2e-4), betas=(0.8, 0.99)).step()
+        for sd_ in (psd, ssd):
+            for v in sd_.values():
+                if v.requires_grad:
+                    v.grad = None
     yd = y_.detach()
     r1, f1, _, _ = R.multi_period_disc(psd, wav, yd)
     r2, f2, _, _ = R.multi_scale_disc(ssd, wav, yd)
     ld = sum(R.discriminator_loss(r1, f1)) + sum(R.discriminator_loss(r2, f2))
     ld.backward()
+    if with_optimizer:
+        torch.optim.AdamW([v for sd_ in (psd, ssd) for v in sd_.values() if v.requires_grad], lr=cfg.get("lr", 2e-4),
+                          betas=(0.8, 0.99)).step()
     return time.perf_counter() - t0
 
 

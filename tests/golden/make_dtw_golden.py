@@ -53,7 +53,9 @@ def main():
                     f"p{p}.cost": cost, f"p{p}.dtw": dtw, f"p{p}.align": al, f"p{p}.aligned": np.asarray(out)})
         print(f"pair {p}: S={S} T={T} cost {cost.dtype} dtw[-1,-1]={dtw[-1, -1]:.6f}")
     res["n"] = np.array(len(pairs()))
-    np.savez_compressed(os.path.join(HERE, "dtw_ref.npz"), **res)
+    sys.path.insert(0, HERE)
+    from detnpz import savez_det
+    savez_det(os.path.join(HERE, "dtw_ref.npz"), **res)
     print("written", os.path.getsize(os.path.join(HERE, "dtw_ref.npz")), "bytes")
 
 

@@ -3,7 +3,8 @@
 Build-container only (the reference is not present on the GPU box).  Usage:  python tests/golden/make_golden.py
 Writes tests/golden/ref_state_keys.json (state_dict key/shape lists of the reference modules at the real
 hparams) and tests/golden/*.npz (inputs, injected randomness, reference outputs).  Weights are procedural
-(oracle/procedural.py), so no state_dict is stored.
+(oracle/procedural.py), so no state_dict is stored.  Every case that lets the reference draw random numbers seeds torch's global
+generator first (CASE_SEEDS), so a second run of this script on the unmodified reference writes byte-identical files.
 """
 import contextlib
 import json
@@ -18,6 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
 from oracle import procedural, ref_shims  # noqa: E402
+sys.path.insert(0, HERE)
+from detnpz import savez_det  # noqa: E402
 
 HIFIGAN_CFG = {  # hop-128 NSF configuration (working assumption, configurable)
     "resblock": "1", "upsample_rates": [8, 4, 2, 2], "upsample_kernel_sizes": [16, 8, 4, 4],
@@ -86,6 +89,9 @@ def make_vae_inputs(B=2, T=64, lens=(64, 52), seed=0):
     return out
 
 
+CASE_SEEDS = {"vae_mle": 4101, "vae_mle_b16": 4102, "vae_mle_b16_grad": 4103, "hifigan_gen": 4104, "spec2wav": 4105,
+              "hifigan_train": 4106}
+
 BENCH_LENS = (1124, 1124, 1100, 1124, 1056, 1124, 1003, 1124, 1124, 960, 1124, 1088, 1124, 1124, 912, 1124)
 BENCH_FRAME_STRIDE = 8
 
@@ -97,6 +103,7 @@ def vae_bench_shape(model):
     statistics and the scalar terms."""
     inp = make_vae_inputs(B=16, T=1124, lens=BENCH_LENS, seed=21)
     rec = []
+    torch.manual_seed(CASE_SEEDS["vae_mle_b16"])
     with record_rng(rec), torch.no_grad():
         out = model(amateur_mel=inp["mels"], prof_mel=inp["prof_mels"], amateur_pitch=inp["pitch"],
                     prof_pitch=inp["prof_pitch"], amateur_spk_id=inp["spk"], prof_spk_id=inp["spk"],
@@ -113,7 +120,89 @@ def vae_bench_shape(model):
         for k in ("kl", "m_q", "logs_q", "z_q", "mle"):
             if k in out[way] and isinstance(out[way][k], torch.Tensor):
                 save[f"{way}.{k}"] = out[way][k].numpy()
-    np.savez_compressed(os.path.join(HERE, "vae_mle_b16.npz"), **save)
+    save.update(vae_bench_shape_gradients(model, inp))
+    savez_det(os.path.join(HERE, "vae_mle_b16.npz"), **save)
+
+
+BENCH_GRAD_PARAMS = ["vae_model.decoder.wn.in_layers.0.weight_v", "vae_model.decoder.wn.in_layers.3.weight_g",
+                     "vae_model.decoder.wn.cond_layer.weight_v", "vae_model.decoder.wn.res_skip_layers.1.weight_v",
+                     "vae_model.encoder.pre_net.0.weight", "vae_model.encoder.wn.in_layers.7.weight_v",
+                     "vae_model.encoder.wn.cond_layer.weight_g", "vae_model.decoder.pre_net.0.weight",
+                     "vae_model.decoder.out_proj.bias", "vae_model.encoder.poolings.3.weight", "vae_model.g_pre_net.0.weight",
+                     "pitch_embed.weight", "pitch_encoder.conv.1.conv.conv.weight", "upsample_layer.0.1.weight",
+                     "encoded_embed_proj.weight", "spk_embed_proj.weight"]
+
+
+def vae_bench_shape_gradients(model, inp):
+    """Backward tile / split-K choices are made per shape, so gradients are pinned AT the bench shape too: the reference's
+    forward of the two training ways (a2a, p2p; phase 2) at B=16 x T=1124 in train mode, the scalar
+    sum_way [ mean |mel_out - target| over all elements + kl ], backward, and a digest (l2 norm + 24 samples) of the gradient
+    of a dozen parameters spread over the decoder / encoder gated stacks, their conditioning layers and the condition path."""
+    rec = []
+    torch.manual_seed(CASE_SEEDS["vae_mle_b16_grad"])
+    model.zero_grad()
+    with record_rng(rec):
+        out = model(amateur_mel=inp["mels"], prof_mel=inp["prof_mels"], amateur_pitch=inp["pitch"],
+                    prof_pitch=inp["prof_pitch"], amateur_spk_id=inp["spk"], prof_spk_id=inp["spk"],
+                    a2p_alignment=inp["a2p_alignment"], p2a_alignment=None, infer=False,
+                    concurrent_ways=["a2a", "p2p"], disable_map=True)
+    assert [k for k, _ in rec] == ["randn_like", "randn_like"]
+    tgt = {"a2a": inp["mels"], "p2p": inp["prof_mels"]}
+    terms = {}
+    loss = 0.0
+    for way in ("a2a", "p2p"):
+        terms[f"{way}.l1"] = (out[way]["mel_out"] - tgt[way]).abs().mean()
+        terms[f"{way}.kl"] = out[way]["kl"]
+        loss = loss + terms[f"{way}.l1"] + terms[f"{way}.kl"]
+    loss.backward()
+    params = dict(model.named_parameters())
+    save = {"grad.eps_a2a": rec[0][1].numpy(), "grad.eps_p2p": rec[1][1].numpy(),
+            "grad.terms": np.array([float(terms[k]) for k in ("a2a.l1", "a2a.kl", "p2p.l1", "p2p.kl")]),
+            "grad.params": np.array(BENCH_GRAD_PARAMS)}
+    for k in BENCH_GRAD_PARAMS:
+        save[f"grad.{k}"] = grad_digest(params[k].grad)
+    model.zero_grad()
+    return save
+
+
+def spec2wav_golden(gen):
+    """V6: the reference's vocoder PLUGIN (vocoders/hifigan.py:17-69) end to end -- a checkpoint directory in its own layout
+    (config.yaml + model_ckpt_steps_<N>.ckpt holding state_dict['model_gen']) is written with the procedural generator
+    weights, `HifiGAN()` loads it through load_model (strict load, weight norm folded, eval) and `spec2wav(mel[T,80], f0=f0[T])`
+    runs on one clip.  The three NSF draws are recorded for injection."""
+    import tempfile
+    import yaml
+    from utils.hparams import hparams as ref_hp
+    with tempfile.TemporaryDirectory() as d:
+        cfg = dict(HIFIGAN_CFG)
+        with open(os.path.join(d, "config.yaml"), "w") as f:
+            yaml.safe_dump(cfg, f)
+        torch.save({"state_dict": {"model_gen": gen.state_dict()}}, os.path.join(d, "model_ckpt_steps_7.ckpt"))
+        old = {k: ref_hp.get(k) for k in ("vocoder_ckpt", "profile_infer", "vocoder_denoise_c")}
+        ref_hp.update(vocoder_ckpt=d, profile_infer=False, vocoder_denoise_c=0.0)
+        try:
+            from vocoders.hifigan import HifiGAN
+            voc = HifiGAN()
+            g = torch.Generator().manual_seed(17)
+            T = 40
+            mel = (torch.randn(T, 80, generator=g) * 0.8 - 3.0).numpy()
+            f0 = (110 + 260 * torch.rand(T, generator=g)).numpy()
+            f0[5:9] = 0.0
+            f0[33:] = 0.0
+            rec = []
+            torch.manual_seed(CASE_SEEDS["spec2wav"])
+            with record_rng(rec):
+                wav = voc.spec2wav(mel, f0=f0)
+            assert [k for k, _ in rec] == ["rand", "randn_like", "randn_like"], [k for k, _ in rec]
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    ref_hp.pop(k, None)
+                else:
+                    ref_hp[k] = v
+    assert wav.shape == (T * HIFIGAN_CFG["hop_size"],) and wav.dtype == np.float32
+    savez_det(os.path.join(HERE, "spec2wav.npz"), mel=mel, f0=f0, rand_ini=rec[0][1].numpy(), noise=rec[1][1].numpy(),
+                        wav=wav)
 
 
 def grad_digest(t):
@@ -130,6 +219,7 @@ def hifigan_train_golden(mpd, msd, y, yh):
     converged with 10 train-mode forwards (procedural u, v start far from the dominant singular pair) and stored."""
     from modules.hifigan.hifigan import discriminator_loss, feature_loss, generator_loss
     mpd.train(); msd.train()
+    torch.manual_seed(CASE_SEEDS["hifigan_train"])
     with torch.no_grad():
         for _ in range(10):
             msd(y, yh)
@@ -154,7 +244,7 @@ def hifigan_train_golden(mpd, msd, y, yh):
     for k, v in msd.state_dict().items():
         if k.endswith("weight_u") or k.endswith("weight_v") and v.dim() == 1:
             save[f"msd.buf1.{k}"] = v.numpy().copy()
-    np.savez_compressed(os.path.join(HERE, "hifigan_train.npz"), **save)
+    savez_det(os.path.join(HERE, "hifigan_train.npz"), **save)
 
 
 def main():
@@ -170,7 +260,7 @@ def main():
     from utils.pitch_utils import f0_to_coarse
     rng = np.random.RandomState(0)
     f0 = np.concatenate([np.zeros(16), rng.uniform(30, 1400, 2000), [50.0, 1100.0, 700.0, 1e-3]])
-    np.savez_compressed(os.path.join(HERE, "f0_to_coarse.npz"), f0=f0, coarse_np=f0_to_coarse(f0.copy()),
+    savez_det(os.path.join(HERE, "f0_to_coarse.npz"), f0=f0, coarse_np=f0_to_coarse(f0.copy()),
                         coarse_torch=f0_to_coarse(torch.from_numpy(f0.astype(np.float32))).numpy())
 
     # ---------------- MleSVBVAE (M1-M8), real dims ----------------
@@ -181,6 +271,7 @@ def main():
     model.vc_asr.eval()
     inp = make_vae_inputs()
     rec = []
+    torch.manual_seed(CASE_SEEDS["vae_mle"])
     with record_rng(rec):
         out = model(amateur_mel=inp["mels"], prof_mel=inp["prof_mels"], amateur_pitch=inp["pitch"],
                     prof_pitch=inp["prof_pitch"], amateur_spk_id=inp["spk"], prof_spk_id=inp["spk"],
@@ -200,7 +291,7 @@ def main():
     from modules.commons.ssim import ssim
     mo, tg = out["a2a"]["mel_out"].detach(), inp["mels"]
     save["loss.ssim_map_a2a"] = ssim(mo[:, None] + 6.0, tg[:, None] + 6.0, size_average=False).numpy()
-    np.savez_compressed(os.path.join(HERE, "vae_mle.npz"), **save)
+    savez_det(os.path.join(HERE, "vae_mle.npz"), **save)
     vae_bench_shape(model)
 
     # ---------------- mel discriminator (G1), eval mode (Dropout2d off), fixed windows ----------------
@@ -214,7 +305,7 @@ def main():
     x[1, 131:] = 0.0
     starts = [[7, 7], [40, 40], [3, 3]]
     o = disc(x, None, start_frames_wins=[list(s) for s in starts])
-    np.savez_compressed(os.path.join(HERE, "mel_disc.npz"), x=x.numpy(), starts=np.array(starts), y=o["y"].detach().numpy(),
+    savez_det(os.path.join(HERE, "mel_disc.npz"), x=x.numpy(), starts=np.array(starts), y=o["y"].detach().numpy(),
                         h_stats=np.stack([fmap_stats(h) for h in o["h"]]))
 
     # ---------------- NSF-HifiGAN generator (V1, V2) ----------------
@@ -228,12 +319,15 @@ def main():
     f0[0, 3:5] = 0.0
     f0[1, 9:] = 0.0
     rec = []
+    torch.manual_seed(CASE_SEEDS["hifigan_gen"])
     with record_rng(rec), torch.no_grad():
         wav = gen(mel, f0)
     kinds = [k for k, _ in rec]
     assert kinds == ["rand", "randn_like", "randn_like"], kinds
-    np.savez_compressed(os.path.join(HERE, "hifigan_gen.npz"), mel=mel.numpy(), f0=f0.numpy(), rand_ini=rec[0][1].numpy(),
+    savez_det(os.path.join(HERE, "hifigan_gen.npz"), mel=mel.numpy(), f0=f0.numpy(), rand_ini=rec[0][1].numpy(),
                         noise=rec[1][1].numpy(), wav=wav.numpy())
+
+    spec2wav_golden(gen)
 
     # ---------------- MPD / MSD (V3, V4), eval mode (no spectral-norm power iteration) ----------------
     mpd, msd = MultiPeriodDiscriminator(), MultiScaleDiscriminator()
@@ -252,7 +346,7 @@ def main():
             save[f"{name}.fmap_r_stats"] = np.stack([fmap_stats(t) for fm in fmap_rs for t in fm])
             save[f"{name}.fmap_g_stats"] = np.stack([fmap_stats(t) for fm in fmap_gs for t in fm])
             save[f"{name}.fmap_shapes"] = np.array([list(t.shape) + [0] * (4 - t.dim()) for fm in fmap_rs for t in fm])
-    np.savez_compressed(os.path.join(HERE, "hifigan_disc.npz"), **save)
+    savez_det(os.path.join(HERE, "hifigan_disc.npz"), **save)
     hifigan_train_golden(mpd, msd, y, yh)
 
     with open(os.path.join(HERE, "ref_state_keys.json"), "w") as f:

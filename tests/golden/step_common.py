@@ -18,6 +18,7 @@ STEP_HPARAMS = ("audio_sample_rate=24000,fmax=12000,num_sanity_val_steps=0,max_u
 N_TRAIN, N_VALID = 8, 2
 SECONDS = (2.0, 1.7, 2.0, 1.5)          # ragged clips: T = 376 / 316 / 376 / 280 frames after the multiple-of-4 cut
 N_STEPS = 5                               # global_step 0 (gen only), 1-2 (phase 2: gen + disc), 3-4 (phase 3: map)
+STEP_SEED = 20260926                      # torch / numpy global streams of the golden run (make_step_golden.py seeds them)
 SAMPLE_PARAMS = 24                        # elements sampled per parameter for the gradient / weight probes
 
 
@@ -63,6 +64,13 @@ def weight_summary(named_tensors):
     return out
 
 
+# float32 fields computed through vectorised transcendentals: torch's CPU kernels evaluate the unaligned head / tail of a buffer
+# with scalar libm and the body with SIMD polynomials, so the reference's OWN `energy = (mel.exp() ** 2).sum(-1).sqrt()`
+# (tasks/tts/dataset_utils.py:141) moves by an ulp per element -- 1e-6 of the sum -- from run to run with the allocation's
+# alignment (seen between two runs of make_step_golden.py).  Their digests keep 5 significant digits; everything else is exact.
+ULP_NOISY = ("energy", "prof_energy")
+
+
 def batch_summary(batch):
     """Exact content digest of a collated batch: shapes, dtypes and float64 sums / position-weighted sums per tensor."""
     out = {}
@@ -72,6 +80,8 @@ def batch_summary(batch):
             f = v.double().flatten()
             w = torch.arange(1, f.numel() + 1, dtype=torch.float64) % 9973
             out[k] = {"shape": list(v.shape), "dtype": str(v.dtype), "sum": float(f.sum()), "wsum": float((f * w).sum())}
+            if k in ULP_NOISY:
+                out[k]["sum"], out[k]["wsum"] = float(f"{out[k]['sum']:.5g}"), float(f"{out[k]['wsum']:.5g}")
         elif isinstance(v, (list, tuple)) and all(isinstance(x, str) for x in v):
             out[k] = {"list": list(v)}
         elif isinstance(v, (int, float)):
@@ -113,7 +123,10 @@ def save_events(path, events_per_step):
                 flat[f"s{s}.e{i}"] = np.packbits(ev[1].numpy().astype(np.uint8), axis=-1)
                 flat[f"s{s}.e{i}.c"] = np.array(ev[1].shape[-1])
         flat[f"s{s}.kinds"] = np.array(kinds)
-    np.savez_compressed(path, **flat)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from detnpz import savez_det
+    savez_det(path, **flat)
 
 
 def load_events(path):

@@ -390,52 +390,6 @@ def test_wn_stack_bf16x3_mode(dev):
             assert rel_err(a.grad, b.grad) < 3e-4
 
 
-@pytest.mark.parametrize("masked", [True, False])
-@pytest.mark.parametrize("which", ["res_skip", "gate", "both"])
-def test_wn_stack_fused_res_skip_epilogue_is_bit_exact(dev, masked, which):
-    """SF.FUSE_RES_SKIP / SF.FUSE_GATE (bf16x3): the res/skip update as the epilogue of the 1x1 conv that produces it, the gate
-    as the epilogue of the in-layer conv (reference fs2_vae.py:10-16,73-89) must give bit-identical outputs and gradients to
-    the conv + svb_wn_gate_fwd / svb_wn_res_skip form -- three layers (first: no skip sum yet; middle; last: skip rows only,
-    mask folded in), ragged channel / time tails."""
-    from tests.test_kernels import _untimed_on_gpu
-    _untimed_on_gpu(dev)
-    g_ = torch.Generator().manual_seed(34)
-    B, C, T, gin, n, ks = 2, 24, 77, 12, 3, 3
-    x = torch.randn(B, C, T, generator=g_)
-    mask = torch.ones(B, T)
-    mask[1, 60:] = 0.0
-    gcond = torch.randn(B, gin, T, generator=g_)
-    cond = [torch.randn(2 * C * n, gin, 1, generator=g_) * 0.3, torch.rand(2 * C * n, 1, 1, generator=g_) + 0.5,
-            torch.randn(2 * C * n, generator=g_) * 0.1]
-    layers = []
-    for i in range(n):
-        rc = 2 * C if i < n - 1 else C
-        layers.append([torch.randn(2 * C, C, ks, generator=g_) * 0.3, torch.rand(2 * C, 1, 1, generator=g_) + 0.5,
-                       torch.randn(2 * C, generator=g_) * 0.1, torch.randn(rc, C, 1, generator=g_) * 0.3,
-                       torch.rand(rc, 1, 1, generator=g_) + 0.5, torch.randn(rc, generator=g_) * 0.1])
-    dy = torch.randn(B, C, T, generator=g_)
-    res = {}
-    SF.set_precision("bf16x3")
-    try:
-        for fused in (False, True):
-            SF.FUSE_RES_SKIP = fused and which in ("res_skip", "both")
-            SF.FUSE_GATE = fused and which in ("gate", "both")
-            xd = _leaf(x, dev)
-            cd = [_leaf(t, dev) for t in cond]
-            ld = [[_leaf(t, dev) for t in lp] for lp in layers]
-            y = SF.wn_stack(xd, mask.to(dev) if masked else None, gcond.to(dev), cd, ld, ks)
-            y.backward(dy.to(dev))
-            res[fused] = [y.detach(), xd.grad] + [t.grad for t in cd] + [t.grad for lp in ld for t in lp]
-    finally:
-        SF.FUSE_RES_SKIP = SF.FUSE_GATE = False
-        SF.set_precision("fp32")
-    for a, b in zip(res[False], res[True]):
-        if a.device.type == "cpu":
-            assert torch.equal(a, b)
-        else:               # (gradients: sums over thousands of terms of values that may differ in the last bit)
-            assert rel_err(a, b) < 1e-5
-
-
 def test_weight_pack_cache_semantics(dev):
     """Packed weight images: frozen weights are packed once; trainable weights are repacked on every call unless a
     Trainer-managed weight epoch is open, and an epoch bump (optimizer step) invalidates them."""

@@ -258,3 +258,50 @@ def test_conformer_block_residual_epilogues_equal_explicit_adds(dev):
         finally:
             vc_asr.FOLD_RESIDUALS = True
     assert (y_fused - y_plain).abs().max().item() < 1e-5 * y_plain.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_mle_svb_vae_bench_shape_gradients(gpu_only, precision):
+    """Backward tiles and split-K factors are chosen per shape, so the gradient is pinned at the bench's shape too (B = 16 x
+    T = 1124, the two phase-2 ways, train mode): the scalar  sum_way [ mean |mel_out - target| + kl ]  of the unmodified
+    reference (tests/golden/make_golden.py:vae_bench_shape_gradients) and the gradient digest (l2 norm + 24 samples) of 16
+    parameters across the decoder / encoder gated stacks, their conditioning layers and the condition path."""
+    import sys
+    sys.path.insert(0, G)
+    import make_golden as M
+    from neuralsvb_amd import functional as SF
+    dev = gpu_only
+    d, inp = _bench_shape_case()
+    model, _ = build_model(dev)
+    model.train()
+    SF.set_precision(precision)
+    try:
+        out = model(amateur_mel=inp["mels"].to(dev), prof_mel=inp["prof_mels"].to(dev), amateur_pitch=inp["pitch"].to(dev),
+                    prof_pitch=inp["prof_pitch"].to(dev), amateur_spk_id=inp["spk"].to(dev), prof_spk_id=inp["spk"].to(dev),
+                    a2p_alignment=inp["a2p_alignment"].to(dev), infer=False, concurrent_ways=["a2a", "p2p"], disable_map=True,
+                    eps_a2a=t(d["grad.eps_a2a"]).to(dev), eps_p2p=t(d["grad.eps_p2p"]).to(dev))
+        tgt = {"a2a": inp["mels"].to(dev), "p2p": inp["prof_mels"].to(dev)}
+        terms = []
+        loss = 0.0
+        for way in ("a2a", "p2p"):
+            l1 = (out[way]["mel_out"] - tgt[way]).abs().mean()
+            terms += [l1, out[way]["kl"]]
+            loss = loss + l1 + out[way]["kl"]
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        SF.set_precision("fp32")
+    got_terms = np.array([float(x) for x in terms])
+    assert np.allclose(got_terms, d["grad.terms"], rtol=2e-5 if precision == "fp32" else 1e-4, atol=1e-6), (got_terms, d["grad.terms"])
+    params = dict(model.named_parameters())
+    norm_tol, samp_tol = (1e-4, 5e-4) if precision == "fp32" else (3e-4, 1.5e-3)
+    worst = (0.0, 0.0)
+    for name in [str(x) for x in d["grad.params"]]:
+        ref = d[f"grad.{name}"]
+        got = M.grad_digest(params[name].grad.cpu())
+        rn = abs(got[0] - ref[0]) / max(abs(ref[0]), 1e-12)
+        rs = np.abs(got[1:] - ref[1:]).max() / max(np.abs(ref[1:]).max(), 1e-12)
+        worst = (max(worst[0], rn), max(worst[1], rs))
+        assert rn <= norm_tol and rs <= samp_tol, (precision, name, rn, rs)
+    print(precision, "worst gradient norm / sample relative error at the bench shape:", worst)

@@ -76,6 +76,16 @@ def test_hifigan_generator_matches_reference():
     close(wav, d["wav"], 2e-5, "wav")
 
 
+def test_spec2wav_plugin_golden_matches_oracle_generator():
+    """The reference's vocoder plugin run (vocoders/hifigan.py:17-69, tests/golden/spec2wav.npz) is the generator applied to
+    one clip with weight norm folded: the oracle's generator restatement reproduces it from the recorded draws."""
+    d = np.load(os.path.join(G, "spec2wav.npz"))
+    sd = procedural.state_dict_for(KEYS["HifiGanGenerator"], prefix="model_gen.")
+    with torch.no_grad():
+        wav = R.hifigan_generator(sd, t(d["mel"]).T[None], t(d["f0"])[None], t(d["rand_ini"]), t(d["noise"]), HIFIGAN_CFG)
+    close(wav.reshape(-1), d["wav"], 2e-5, "spec2wav")
+
+
 @pytest.mark.parametrize("name", ["mpd", "msd"])
 def test_hifigan_discriminators_match_reference(name):
     d = np.load(os.path.join(G, "hifigan_disc.npz"))

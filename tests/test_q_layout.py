@@ -91,7 +91,7 @@ def test_conv_from_q_image_is_bit_identical(dev, case):
     bias = torch.randn(cout, generator=g).to(dev)
     qa, qb = K.weight_pack_q(w, None, groups)
     xq = K.split_q(x)
-    for cfg in range(1, 11):
+    for cfg in range(1, 13):
         y0 = K.conv1d_forward(x, qa, cout, k, s, pad, dil, groups, bias=bias, force_cfg=cfg)
         y1 = K.conv1d_forward(x, qa, cout, k, s, pad, dil, groups, bias=bias, force_cfg=cfg, x_q=xq)
         assert torch.equal(y0, y1), (case, cfg, (y0 - y1).abs().max().item())

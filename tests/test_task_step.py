@@ -230,9 +230,6 @@ def test_fused_step_paths_equal_elementwise_paths(dev, tmp_path, phase):
                 o.load_state_dict(s)
         hp["fused_mel_loss"] = hp["defer_wgrad_reduce"] = fused
         fs2_vae.FUSED_HEAD = svb_vae.FUSED_GN = svb_vae.SPLIT_STACKED = mel_disc.FUSED_CROP = vc_asr.FOLD_RESIDUALS = fused
-        # (the gated stack's epilogue fusions -- opt-in, not yet timed on the MI355X -- ride along on the emulator, where they
-        #  are bit-exact; their MI355X status is reported by the kernel-level tests)
-        SF.FUSE_RES_SKIP = SF.FUSE_GATE = bool(fused) and dev.type == "cpu"
         from neuralsvb_amd import kernels as K
         n_deferred = [0]
         o_flush = K.flush_deferred_reduces
@@ -250,7 +247,6 @@ def test_fused_step_paths_equal_elementwise_paths(dev, tmp_path, phase):
             K.flush_deferred_reduces = o_flush
             hp["fused_mel_loss"], hp["defer_wgrad_reduce"] = True, False
             fs2_vae.FUSED_HEAD = svb_vae.FUSED_GN = svb_vae.SPLIT_STACKED = mel_disc.FUSED_CROP = vc_asr.FOLD_RESIDUALS = True
-            SF.FUSE_RES_SKIP = SF.FUSE_GATE = False
     try:
         t1, g1 = run(True)
         t0, g0 = run(False)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of train-step variants on ONE MI355X box, back to back (a gpurun call of this script costs ~10 s per variant):
-#   gpurun --timeout 200 -- 'bash tools/ab_bench.sh "" "wn_fuse_res_skip=True" "wn_fuse_gate=True" "wn_fuse_res_skip=True,wn_fuse_gate=True" "--legacy-paths"'
+#   gpurun --timeout 200 -- 'bash tools/ab_bench.sh "" "defer_wgrad_reduce=True" "--legacy-paths"'
 # Each argument is either an hparams override string (k=v,k=v) or a bench.py flag (starts with --); "" = defaults.
 # Prints ms/step (+ host issue time) per variant; the JSON lines land in gpurun_out/ab/.
 mkdir -p gpurun_out/ab
