@@ -397,11 +397,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py measures the HIP path: an MI355X is required"
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # ("nccl" = RCCL on ROCm.  SVB_DIST_BACKEND=gloo: the 2-ranks-on-one-GPU test of the N > 1 stream handling, where RCCL
+        #  refuses two ranks on one device)
+        dist.init_process_group(os.environ.get("SVB_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.workload != "train":
         assert world == 1, "the vocoder / inference workloads are single-GPU lines"

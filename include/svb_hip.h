@@ -168,6 +168,50 @@ int svb_wn_res_skip_bwd(const float* dx_new, const float* dout, const float* mas
  * Replaces the per-consumer fp32 -> bf16 split of the conv kernels (no reference counterpart: layout plumbing). */
 int svb_split_q(const float* x, const float* mask, unsigned short* xq, int B, int C, int T, void* stream);
 
+/* ---- The whole gated stack (`WN.forward`, reference modules/fastspeech/fs2_vae.py:61-91; p_dropout = 0) and its backward as
+ * ONE call each: a host-side loop over the entry points above (bf16x3 convs, gate, res/skip, weight gradients + their reduces),
+ * in the order the Python layer issues them -- bit-identical results, ~130 Python-issued launches per generator pass less.
+ * All tensors fp32 [B][channels][T] contiguous; layer i has dilation dil_rate^i and padding (k*d - d)/2.                        */
+#define SVB_WN_MAX_LAYERS 16
+typedef struct SvbWnLayer {
+    const unsigned short *in_a_hi, *in_a_lo;   /* in-layer conv C -> 2C, k taps: packed A image (forward) ...                */
+    const unsigned short *in_b_hi, *in_b_lo;   /* ... and B image (data gradient); svb_weight_pack_bf16x3 layouts            */
+    const unsigned short *rs_a_hi, *rs_a_lo;   /* res/skip 1x1 conv C -> rs_cout                                              */
+    const unsigned short *rs_b_hi, *rs_b_lo;
+    const float *in_bias, *rs_bias;            /* [2C], [rs_cout]                                                             */
+    const float *in_v, *in_g, *rs_v, *rs_g;    /* backward: the weights (v, and g when weight-normalised, else g = NULL)      */
+    float *d_in_v, *d_in_g, *d_in_b;           /* backward: gradient buffers ACCUMULATED into (d_in_v NULL: in-layer frozen)   */
+    float *d_rs_v, *d_rs_g, *d_rs_b;
+    int rs_cout;                               /* 2C; C for the last layer                                                    */
+    int cfg_in_fwd, cfg_rs_fwd, cfg_in_bwd, cfg_rs_bwd;   /* force_cfg of the four convs (0 = heuristic tile)                */
+} SvbWnLayer;
+typedef struct SvbWnStack {
+    int B, C, T, n_layers, k, dil_rate, g_channels;
+    const float* x0;      /* stack input [B][C][T]                                                                            */
+    const float* mask;    /* [B][T] or NULL                                                                                   */
+    const float* G;       /* conditioning [B][g_channels][T] (layer i reads channels i*2C .. (i+1)*2C) or NULL                */
+    float* xbuf;          /* [n_layers-1][B][C][T]: the inputs of layers 1.. (written forward, read backward)                 */
+    float* xin;           /* [n_layers][B][2C][T]: in-layer conv outputs (saved for the gate's backward)                      */
+    float* acts;          /* [n_layers][B][C][T]: gate outputs (saved for the res/skip conv's weight gradient)                */
+    SvbWnLayer layer[SVB_WN_MAX_LAYERS];
+} SvbWnStack;
+/* out [B][C][T] receives the skip sum WITHOUT the final mask (the caller multiplies); rs_scratch: [B][2C][T].               */
+int svb_wn_stack_forward(const SvbWnStack* s, float* rs_scratch, float* out, void* stream);
+typedef struct SvbWnBackward {
+    const float* dout;    /* gradient of the (masked) output, already multiplied by the mask: [B][C][T]                       */
+    float* dx;            /* [B][C][T]: on return the gradient of x0 (valid if need_dx0)                                       */
+    float* dG;            /* [B][g_channels][T] gradient of G (every slice written) or NULL                                   */
+    float *drs, *dxin;    /* [n_layers][B][2C][T] each: per layer, because the weight gradients read them on the side stream  */
+    float *dacts, *dxm;   /* [B][C][T] scratch                                                                                */
+    float* arena;         /* split-K partials of the pending weight gradients; a full arena is reduced and reused             */
+    size_t arena_floats;
+    int need_dx0;
+} SvbWnBackward;
+/* side_stream (optional): the weight gradients and their reduces are issued there after it has caught up with `stream`; the
+ * caller joins it.  Weight gradients whose d_*_v is NULL are skipped.  SVB_ERR_UNSUPPORTED: a weight gradient does not fit
+ * the bf16x3 kernel's envelope or the arena (nothing has been launched for that gradient; earlier launches stand).        */
+int svb_wn_stack_backward(const SvbWnStack* s, const SvbWnBackward* b, void* stream, void* side_stream);
+
 /* ---- LayerNorm over the channel (last) dim of [rows, C] (reference modules/fastspeech/conformer/layers.py:160-170,
  * conformer.py:30; torch.nn.LayerNorm eps 1e-5).                                                             */
 int svb_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

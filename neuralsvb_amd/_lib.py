@@ -21,6 +21,27 @@ class SvbConvEpilogue(C.Structure):
     ]
 
 
+SVB_WN_MAX_LAYERS = 16
+
+
+class SvbWnLayer(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("in_a_hi", "in_a_lo", "in_b_hi", "in_b_lo", "rs_a_hi", "rs_a_lo", "rs_b_hi", "rs_b_lo",
+                                           "in_bias", "rs_bias", "in_v", "in_g", "rs_v", "rs_g", "d_in_v", "d_in_g", "d_in_b",
+                                           "d_rs_v", "d_rs_g", "d_rs_b")] +
+                [(n, C.c_int) for n in ("rs_cout", "cfg_in_fwd", "cfg_rs_fwd", "cfg_in_bwd", "cfg_rs_bwd")])
+
+
+class SvbWnStack(C.Structure):
+    _fields_ = ([(n, C.c_int) for n in ("B", "C", "T", "n_layers", "k", "dil_rate", "g_channels")] +
+                [(n, C.c_void_p) for n in ("x0", "mask", "G", "xbuf", "xin", "acts")] +
+                [("layer", SvbWnLayer * SVB_WN_MAX_LAYERS)])
+
+
+class SvbWnBackward(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("dout", "dx", "dG", "drs", "dxin", "dacts", "dxm", "arena")] +
+                [("arena_floats", C.c_size_t), ("need_dx0", C.c_int)])
+
+
 class SvbPackDesc(C.Structure):
     _fields_ = [("v", C.c_void_p), ("g", C.c_void_p), ("qa_hi", C.c_void_p), ("qa_lo", C.c_void_p), ("qb_hi", C.c_void_p),
                 ("qb_lo", C.c_void_p), ("d0", C.c_int), ("d1", C.c_int), ("k", C.c_int), ("groups", C.c_int),
@@ -60,6 +81,8 @@ SIGNATURES = {
     "svb_wn_gate_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
     "svb_wn_res_skip_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
     "svb_wn_res_skip": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
+    "svb_wn_stack_forward": (I, [P, P, P, P]),
+    "svb_wn_stack_backward": (I, [P, P, P, P]),
     "svb_split_q": (I, [P, P, P, I, I, I, P]),
     "svb_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
     "svb_relpos_softmax": (I, [P, P, P, P, I, I, I, F, P]),

@@ -68,10 +68,10 @@ DIRECT_GRADS = True      # weight/bias gradients of leaf parameters that already
 def reset_runtime_state():
     """Arithmetic mode, optional fusions and the Trainer-set routing state back to their import-time values (see
     kernels.reset_runtime_state)."""
-    global USE_Q, DIRECT_GRADS, GRAD_READY, CAPTURING, PACK_CACHE, PACK_REGISTRY, PACK_EPOCH
+    global USE_Q, DIRECT_GRADS, GRAD_READY, CAPTURING, PACK_CACHE, PACK_REGISTRY, PACK_EPOCH, STACK_EXECUTOR
     set_precision("fp32")
     USE_Q = False
-    DIRECT_GRADS = PACK_CACHE = PACK_REGISTRY = True
+    DIRECT_GRADS = PACK_CACHE = PACK_REGISTRY = STACK_EXECUTOR = True
     GRAD_READY = PACK_EPOCH = None
     CAPTURING = False
 
@@ -380,6 +380,123 @@ def linear_nct(x, weight, bias=None):
     return conv1d(x, weight[:, :, None], bias)
 
 
+STACK_EXECUTOR = True    # bf16x3: the gated stack's launches are issued by ONE C-ABI call per direction (csrc/wn_stack.hip) instead of
+                         # ~11 Python-issued launches per layer -- same kernels, same order, bit-identical results; what changes
+                         # is the host time per step (the step is host-bound on hosts slower than the GPU)
+
+
+def _wn_exec_plan(x, layers, n_layers, ks, dr):
+    """Tile choices of the four convs of every layer as the per-launch path would make them, or None while one of them is still
+    to be measured (that call takes the per-launch path, which measures)."""
+    B, C, T = x.shape
+    gpu = x.is_cuda
+    plan = []
+    for i in range(n_layers):
+        dil = dr ** i
+        pad = (ks * dil - dil) // 2
+        rc = layers[i][3].shape[0]
+        c = (K.tuned_choice(("qf", B, C, 2 * C, 1, T, ks, 1, pad, dil, False), gpu),
+             K.tuned_choice(("qf", B, C, rc, 1, T, 1, 1, 0, 1, False), gpu),
+             K.tuned_choice(("qt", B, 2 * C, C, 1, T, T, ks, 1, pad, dil, False), gpu),
+             K.tuned_choice(("qt", B, rc, C, 1, T, T, 1, 1, 0, 1, False), gpu))
+        if None in c:
+            return None
+        plan.append(c)
+    return plan
+
+
+def _wn_exec_forward(ctx, plan, x, mask, gcond, G, cond_v, cond_g, cond_b, cond_pb, layers, n_layers, ks, dr, n_in):
+    B, C, T = x.shape
+    dev = x.device
+    XBUF = torch.empty((max(n_layers - 1, 1), B, C, T), device=dev, dtype=torch.float32)
+    XIN = torch.empty((n_layers, B, 2 * C, T), device=dev, dtype=torch.float32)
+    ACTS = torch.empty((n_layers, B, C, T), device=dev, dtype=torch.float32)
+    rs = torch.empty((B, 2 * C, T), device=dev, dtype=torch.float32)
+    out = torch.empty((B, C, T), device=dev, dtype=torch.float32)
+    d = K.wn_stack_desc(x, mask, G, n_layers, ks, dr)
+    d.xbuf, d.xin, d.acts = XBUF.data_ptr(), XIN.data_ptr(), ACTS.data_ptr()
+    packs_b, keep, flat = [], [], []
+    for i, (in_v, in_g, in_b, rs_v, rs_g, rs_b) in enumerate(layers):
+        in_v, in_g, in_b, rs_v, rs_g, rs_b = _c(in_v), _c(in_g), _c(in_b), _c(rs_v), _c(rs_g), _c(rs_b)
+        pa_in, pb_in = _pack(in_v, in_g)
+        pa_rs, pb_rs = _pack(rs_v, rs_g)
+        ly = d.layer[i]
+        ly.in_a_hi, ly.in_a_lo, ly.in_b_hi, ly.in_b_lo = (pa_in.hi.data_ptr(), pa_in.lo.data_ptr(), pb_in.hi.data_ptr(),
+                                                          pb_in.lo.data_ptr())
+        ly.rs_a_hi, ly.rs_a_lo, ly.rs_b_hi, ly.rs_b_lo = (pa_rs.hi.data_ptr(), pa_rs.lo.data_ptr(), pb_rs.hi.data_ptr(),
+                                                          pb_rs.lo.data_ptr())
+        ly.in_bias, ly.rs_bias = K._ptr(in_b), K._ptr(rs_b)
+        ly.rs_cout = rs_v.shape[0]
+        ly.cfg_in_fwd, ly.cfg_rs_fwd, ly.cfg_in_bwd, ly.cfg_rs_bwd = plan[i]
+        packs_b.append((pb_in, pb_rs))
+        keep.append((pa_in, pa_rs))
+        flat += [in_v, in_g, in_b, rs_v, rs_g, rs_b]
+    K.wn_stack_forward(d, x, rs, out)
+    if mask is not None:
+        out = out * mask[:, None, :]
+    ctx.cexec, ctx.desc, ctx.keep = True, d, keep
+    ctx.meta = (n_layers, ks, dr, C)
+    ctx.useq = False
+    ctx.n_in = n_in
+    ctx.packs = (cond_pb, packs_b)
+    ctx.cond_b = cond_b
+    ctx.save_for_backward(x, mask, gcond, G, _c(cond_v), _c(cond_g), XBUF, XIN, ACTS, *flat)
+    return out
+
+
+def _wn_exec_backward(ctx, dout, xs, mask, G, dG, params, grads, need, need_x):
+    """The stack's backward through the C executor.  Returns False (nothing launched) when a gradient this pass needs cannot be
+    accumulated in place by the reduce kernel -- the caller then runs the per-launch form on the same saved tensors."""
+    n_layers, ks, dr, C = ctx.meta
+    d = ctx.desc
+    x0 = xs[0]
+    B, _, T = x0.shape
+    dev = x0.device
+    sinks_all = []
+    for i, (in_v, in_g, in_b, rs_v, rs_g, rs_b) in enumerate(params):
+        p = 6 + 6 * i
+        need_in_w, need_rs_w = any(need[3 + p:6 + p]), any(need[6 + p:9 + p])
+        ly = d.layer[i]
+        row = []
+        for want, v, g, b_, kk, names in ((need_in_w, in_v, in_g, in_b, ks, ("in_v", "in_g", "d_in_v", "d_in_g", "d_in_b")),
+                                          (need_rs_w, rs_v, rs_g, rs_b, 1, ("rs_v", "rs_g", "d_rs_v", "d_rs_g", "d_rs_b"))):
+            sk = _sinks(v, g, b_) if want else (None, None, None)
+            if want:
+                rowlen = v.shape[1] * kk
+                ok = sk[0] is not None and sk[2] is not None and (g is None or sk[1] is not None)
+                if ok and g is not None:
+                    ok = rowlen % 4 == 0 and rowlen <= 4096 and sk[0].data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
+                if not ok:
+                    return False
+            setattr(ly, names[0], K._ptr(v))
+            setattr(ly, names[1], K._ptr(g))
+            setattr(ly, names[2], K._ptr(sk[0]))
+            setattr(ly, names[3], K._ptr(sk[1]))
+            setattr(ly, names[4], K._ptr(sk[2]))
+            row.append((sk, (v, g, b_), want))
+        sinks_all.append(row)
+    side = K.WGRAD_STREAM if dev.type == "cuda" else None
+    DRS = torch.empty((n_layers, B, 2 * C, T), device=dev, dtype=torch.float32)
+    DXIN = torch.empty((n_layers, B, 2 * C, T), device=dev, dtype=torch.float32)
+    scratch = torch.empty((3, B, C, T), device=dev, dtype=torch.float32)
+    bw = K.L.SvbWnBackward()
+    bw.dout, bw.dx, bw.dG = dout.data_ptr(), scratch[2].data_ptr(), K._ptr(dG)
+    bw.drs, bw.dxin, bw.dacts, bw.dxm = DRS.data_ptr(), DXIN.data_ptr(), scratch[0].data_ptr(), scratch[1].data_ptr()
+    arena = K.wn_arena(dev, side)
+    bw.arena, bw.arena_floats, bw.need_dx0 = arena.data_ptr(), arena.numel(), int(bool(need_x))
+    if side is not None:          # the weight gradients read these on the side stream after the caller has dropped them
+        for t in (dout, DRS, DXIN) + tuple(ctx.saved_tensors[6:9]) + (x0,):
+            t.record_stream(side)
+    K.wn_stack_backward(d, bw, x0, side)
+    for i, row in enumerate(sinks_all):
+        for sk, prm, want in row:
+            if want:
+                _notify(sk, prm, (None, None if prm[1] is not None else 0, None))
+    if need_x:
+        grads[0] = scratch[2]
+    return True
+
+
 class _WNStackFn(torch.autograd.Function):
     """WN.forward (reference modules/fastspeech/fs2_vae.py:61-91) with p_dropout = 0.
 
@@ -400,6 +517,15 @@ class _WNStackFn(torch.autograd.Function):
         saved_x, saved_xin, saved_acts, packs_b = [], [], [], []
         out = None
         useq = USE_Q and PRECISION == "bf16x3" and C % 16 == 0
+        plan = None
+        if (STACK_EXECUTOR and PRECISION == "bf16x3" and not useq and not CAPTURING and K.PROFILE is None
+                and n_layers <= K.L.SVB_WN_MAX_LAYERS and all(lp[3].shape[0] == (2 * C if i + 1 < n_layers else C)
+                                                              for i, lp in enumerate(layers))):
+            plan = _wn_exec_plan(x, layers, n_layers, kernel_size, dilation_rate)
+        if plan is not None:
+            return _wn_exec_forward(ctx, plan, x, mask, gcond, G, cond_v, cond_g, cond_b, cond_pb, layers, n_layers, kernel_size,
+                                    dilation_rate, len(tensors))
+        ctx.cexec = False
         xq = K.split_q(x) if useq else None
         for i, (in_v, in_g, in_b, rs_v, rs_g, rs_b) in enumerate(layers):
             dil = dilation_rate ** i
@@ -442,9 +568,19 @@ class _WNStackFn(torch.autograd.Function):
     def backward(ctx, dout):
         n_layers, ks, dr, C = ctx.meta
         sv = ctx.saved_tensors
-        mask, gcond, G, cond_v, cond_g = sv[:5]
         cond_b = ctx.cond_b
         cond_pb, packs_b = ctx.packs
+        if ctx.cexec:
+            # the forward ran through the C executor: stacked saved tensors
+            x0, mask, gcond, G, cond_v, cond_g, XBUF, XIN, ACTS = sv[:9]
+            params = [sv[9 + 6 * i:15 + 6 * i] for i in range(n_layers)]
+            xs = [x0] + [XBUF[i] for i in range(n_layers - 1)]
+            xins, actss = [XIN[i] for i in range(n_layers)], [ACTS[i] for i in range(n_layers)]
+        else:
+            mask, gcond, G, cond_v, cond_g = sv[:5]
+            xs = [sv[5 + 9 * i] for i in range(n_layers)]
+            xins, actss = [sv[6 + 9 * i] for i in range(n_layers)], [sv[7 + 9 * i] for i in range(n_layers)]
+            params = [sv[8 + 9 * i:14 + 9 * i] for i in range(n_layers)]
         dout = dout.contiguous()
         if mask is not None:
             dout = dout * mask[:, None, :]
@@ -456,11 +592,11 @@ class _WNStackFn(torch.autograd.Function):
         need_dG = G is not None and (need_cond_w or need_gcond)
         dG = torch.empty_like(G) if need_dG else None
         dx_next = None  # gradient flowing into x_{i+1}
-        for i in reversed(range(n_layers)):
-            base = 5 + 9 * i
-            x_i, xin, acts = sv[base:base + 3]
+        done = ctx.cexec and _wn_exec_backward(ctx, dout, xs, mask, G, dG, params, grads, need, need_x)
+        for i in (() if done else reversed(range(n_layers))):
+            x_i, xin, acts = xs[i], xins[i], actss[i]
             pb_in, pb_rs = packs_b[i]
-            in_v, in_g, in_b, rs_v, rs_g, rs_b = sv[base + 3:base + 9]
+            in_v, in_g, in_b, rs_v, rs_g, rs_b = params[i]
             dil = dr ** i
             pad = (ks * dil - dil) // 2
             last = i == n_layers - 1
@@ -507,7 +643,8 @@ class _WNStackFn(torch.autograd.Function):
                 dx_next = K.conv1d_transposed(dxin, pb_in, C, x_i.shape[2], ks, 1, pad, dil, residual=dxm, x_q=dxin_q)
             else:
                 dx_next = None
-        grads[0] = dx_next
+        if not done:
+            grads[0] = dx_next
         if need_dG:
             if need_cond_w:
                 sk = _sinks(cond_v, cond_g, cond_b)

@@ -21,7 +21,7 @@ _CFG_NAMES = ["svb_conv1d_mfma_kernel<2,2,2,*,80> (64x128)", "svb_conv1d_mfma_ke
               "svb_conv1d_mfma_kernel<2,2,4,*,80> (64x256)", "svb_conv1d_mfma_kernel<2,2,2,direct> (64x128)",
               "svb_conv1d_mfma_kernel<2,2,3,direct> (64x192)", "svb_conv1d_mfma_kernel<2,2,4,direct> (64x256)",
               "svb_conv1d_mfma_kernel<4,1,2,direct> (128x64)", "svb_conv1d_mfma_kernel<4,1,1,direct> (128x32)"]
-_NCFG_Q = 12     # tile configurations of the bf16x3 kernel (the fp32 kernel has the first 5)
+_NCFG_Q = int(os.environ.get("SVB_NCFG_Q", "12"))     # tile configurations of the bf16x3 kernel (the fp32 kernel has the first 5)
 
 
 # ---- per-shape tile autotuning ("measure, don't guess"): the first time a conv signature is seen on the GPU all five
@@ -84,24 +84,29 @@ def _ptr(t):
 
 
 def _prep(*tensors):
-    """Validate device/dtype/contiguity; return (lib, stream)."""
-    lib = L.get_lib()
-    dev = None
+    """Validate device/contiguity; return (lib, stream).  (On the issue path of every launch: one pass, no device objects.)"""
+    lib = L._LIB if L._LIB is not None else L.get_lib()
+    first = None
     for t in tensors:
         if t is None:
             continue
         if not t.is_contiguous():
             raise ValueError("svb kernels need contiguous tensors")
-        if dev is None:
-            dev = t.device
-        elif t.device != dev:
-            raise ValueError(f"tensors on different devices: {dev} vs {t.device}")
-    if dev is None:
+        if first is None:
+            first, idx = t, t.get_device()
+        elif t.get_device() != idx:
+            raise ValueError(f"tensors on different devices: {first.device} vs {t.device}")
+    if first is None:
         raise ValueError("no tensors")
-    if dev.type != L.device_type():
-        raise RuntimeError(f"neuralsvb_amd kernels run on the MI355X only (got {dev.type} tensors for a {L.device_type()} "
-                           f"library); there is no CPU fallback")
-    return lib, (_raw_stream(dev) if dev.type == "cuda" else None)
+    if first.is_cuda:
+        if L._LIB_IS_EMU:
+            raise RuntimeError("neuralsvb_amd kernels run on the MI355X only (got cuda tensors for a cpu library); there is no "
+                               "CPU fallback")
+        return lib, torch._C._cuda_getCurrentRawStream(idx)
+    if not L._LIB_IS_EMU:
+        raise RuntimeError("neuralsvb_amd kernels run on the MI355X only (got cpu tensors for a cuda library); there is no CPU "
+                           "fallback")
+    return lib, None
 
 
 def _f32(*ts):
@@ -328,6 +333,53 @@ def conv1d_transposed(x, pb, cout, tout, k, stride=1, pad=0, dil=1, groups=1, ou
     return y
 
 
+def tuned_choice(sig, on_gpu):
+    """Tile configuration the autotuner holds for `sig`; 0 (the library's heuristic) where nothing is ever tuned (CPU tensors,
+    autotuning off); None when the signature still has to be measured (the caller takes the per-launch path once)."""
+    best = _TUNED.get(sig)
+    if best is not None:
+        return best
+    return None if (AUTOTUNE and on_gpu and PROFILE is None) else 0
+
+
+# ---- the gated stack as one C-ABI call per direction (csrc/wn_stack.hip) ---------------------------------------------------
+_WN_ARENA = {}            # (device index, raw stream) -> fp32 arena for the split-K partials of the stack's weight gradients
+WN_ARENA_FLOATS = 12 << 20
+
+
+def wn_arena(dev, side):
+    key = (dev.index, side.cuda_stream if side is not None else 0)
+    a = _WN_ARENA.get(key)
+    if a is None:
+        if side is not None:
+            with torch.cuda.stream(side):
+                a = torch.empty((WN_ARENA_FLOATS,), device=dev, dtype=torch.float32)
+        else:
+            a = torch.empty((WN_ARENA_FLOATS,), device=dev, dtype=torch.float32)
+        _WN_ARENA[key] = a
+    return a
+
+
+def wn_stack_desc(x, mask, G, n_layers, k, dil_rate):
+    d = L.SvbWnStack()
+    B, Cc, T = x.shape
+    d.B, d.C, d.T, d.n_layers, d.k, d.dil_rate = B, Cc, T, n_layers, k, dil_rate
+    d.g_channels = int(G.shape[1]) if G is not None else 0
+    d.x0, d.mask, d.G = _ptr(x), _ptr(mask), _ptr(G)
+    return d
+
+
+def wn_stack_forward(desc, x, rs_scratch, out):
+    lib, st = _prep(x, rs_scratch, out)
+    L.check(lib.svb_wn_stack_forward(C.byref(desc), _ptr(rs_scratch), _ptr(out), st), "svb_wn_stack_forward")
+
+
+def wn_stack_backward(desc, bw, x, side):
+    lib, st = _prep(x)
+    L.check(lib.svb_wn_stack_backward(C.byref(desc), C.byref(bw), st, side.cuda_stream if side is not None else None),
+            "svb_wn_stack_backward")
+
+
 WGRAD_BF16X3 = False      # set by functional.set_precision: stride-1 weight gradients on the bf16x3 kernel
 
 
@@ -478,6 +530,7 @@ def reset_runtime_state():
     PROFILE = None
     _ARENA.clear()
     _SIDE_WS.clear()
+    _WN_ARENA.clear()
 
 
 def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0, b_gate=None, b_slope=0.0,

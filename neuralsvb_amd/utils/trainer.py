@@ -472,11 +472,10 @@ class Trainer:
             if loss.requires_grad:
                 from .. import functional as _SF
                 from .. import kernels as _K
-                # opt-in (one process, eager launches): the stage-2 reduces of this pass's weight gradients are finished by
-                # one multi-tensor launch at its end (with a gradient exchange they must be final when they are announced).
-                # Off by default: ~58 launches per step less, but the pass's ~0.9 GB of partials are then read back from
-                # HBM instead of the memory-side cache -- 15.71 vs 15.52 ms/step on a step that is GPU-bound by now.
-                defer = (hparams.get("defer_wgrad_reduce", False) and _SF.GRAD_READY is None and not _SF.CAPTURING
+                # one process, eager launches: the stage-2 reduces of this pass's weight gradients are batched -- partials collect
+                # in a 48 MB arena per stream and one multi-tensor launch finishes them when it is full and at the end of the
+                # pass (with a gradient exchange they must be final when they are announced: immediate reduces there)
+                defer = (hparams.get("defer_wgrad_reduce", True) and _SF.GRAD_READY is None and not _SF.CAPTURING
                          and self.world_size == 1 and not (self.hip_graph and self.on_gpu))
                 if defer:
                     _K.begin_deferred_reduces()

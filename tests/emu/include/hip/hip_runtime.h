@@ -218,3 +218,11 @@ static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+
+// ---- events / stream waits used by the host-side stack executor (wn_stack.hip): the emulator runs every launch to completion
+// in program order on one "stream", so these are no-ops
+typedef void* hipEvent_t;
+#define hipEventDisableTiming 0
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }

@@ -9,6 +9,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -194,3 +195,60 @@ def test_bench_multi_rank_path_two_ranks_gloo(tmp_path, _emu_lib):
     mp.spawn(_bench_worker, args=(2, port, EMU_LIB, str(tmp_path)), nprocs=2, join=True)
     w0, w1 = np.load(tmp_path / "b0.npy"), np.load(tmp_path / "b1.npy")
     assert np.isfinite(w0).all() and np.array_equal(w0, w1)
+
+
+def _gpu_pair_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import argparse
+    import sys
+    import tempfile
+    sys.path.insert(0, ROOT)
+    import bench
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = argparse.Namespace(batch=2, seconds=0.71, sample_rate=24000, bf16=False, precision="bf16x3", graph=False)
+    small = (",hidden_size=32,fvae_enc_dec_hidden=32,latent_size=16,fvae_enc_n_layers=2,fvae_dec_n_layers=2,"
+             "mel_disc_hidden_size=16,warmup_updates=4,ddp_bucket_mb=0.02")
+    from neuralsvb_amd import kernels as K
+    seen = {"side": 0, "critic": 0}
+    with tempfile.TemporaryDirectory() as tmp:
+        task, trainer, batch, hp = bench.build_task(args, rank, world, dev, tmp, extra_hparams=small)
+        assert trainer.use_ddp and trainer.world_size == world and trainer.on_gpu
+        orig = trainer._optimizer_pass
+
+        def spy(*a, **k):
+            seen["side"] += int(K.WGRAD_STREAM is not None)
+            seen["critic"] += int(torch.cuda.current_stream() == trainer._critic_stream)
+            return orig(*a, **k)
+        trainer._optimizer_pass = spy
+        bench.run_steps(trainer, task, batch, 3, 1)
+        trainer._join_critic_stream()
+        torch.cuda.synchronize()
+        assert K.WGRAD_STREAM is None                        # (the side stream is routing state of a step only)
+        w = torch.cat([p.detach().flatten() for p in task.gen_params + task.disc_params]).cpu()
+        st = [dict(g.stats) for g in trainer.grad_sync if g is not None]
+        order = [list(g.order) for g in trainer.grad_sync if g is not None]
+    np.save(os.path.join(out, f"g{rank}.npy"), {"w": w.numpy(), "stats": st, "seen": seen, "order": order}, allow_pickle=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu_same_step_as_one_rank(tmp_path, gpu_only):
+    """The N > 1 step is the N = 1 step: weight gradients on the side stream and the critic pass on its own stream stay on with a
+    gradient exchange (the bucket collectives are issued from a launch stream that has caught up with both producers).  Two
+    ranks on ONE MI355X over gloo (RCCL refuses two ranks per device; the 8-GPU run is the driver's): three phase-2 steps,
+    identical replicas afterwards, buckets exchanged from inside backward in descending order on both ranks."""
+    probe = torch.zeros(4, device="cuda")
+    port = _free_port()
+    mp.spawn(_gpu_pair_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "g0.npy", allow_pickle=True).item()
+    r1 = np.load(tmp_path / "g1.npy", allow_pickle=True).item()
+    assert np.isfinite(r0["w"]).all() and np.array_equal(r0["w"], r1["w"])
+    for r in (r0, r1):
+        assert r["seen"]["side"] >= 6 and r["seen"]["critic"] >= 3, r["seen"]        # gen + critic passes of 3 steps
+        assert sum(s["launched_in_backward"] for s in r["stats"]) > 0, r["stats"]
+    assert r0["order"] == r1["order"]
+    del probe

@@ -589,3 +589,57 @@ def test_vae_latent_head_matches_torch(dev, groups):
     zr, _, _, klr = ref_fn(xr)
     ((zr * cz).sum() + (klr * ck).sum()).backward()
     assert (xd2.grad.cpu() - xr.grad).abs().max() < 1e-5 * max(1.0, xr.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("masked", [True, False])
+@pytest.mark.parametrize("grad_buffers", ["all", "none", "frozen_in"])
+def test_wn_stack_c_executor_equals_per_launch_path(dev, masked, grad_buffers):
+    """SF.STACK_EXECUTOR (bf16x3): the gated stack issued by one C-ABI call per direction (csrc/wn_stack.hip) must give
+    bit-identical outputs and gradients to the per-launch Python sequence -- same kernels, same arguments, same order.
+    grad_buffers: 'all' = every parameter owns a `.grad` buffer (the Trainer's state: gradients are accumulated in place by the
+    reduce kernel, the backward runs in C too); 'none' = no buffers (the C backward declines, the per-launch backward runs on
+    the executor's stacked saved tensors); 'frozen_in' = buffers, but the in-layers do not train (their gradients are skipped)."""
+    g_ = torch.Generator().manual_seed(35)
+    B, C, T, gin, n, ks = 2, 16, 70, 12, 3, 3
+    x = torch.randn(B, C, T, generator=g_)
+    mask = torch.ones(B, T)
+    mask[1, 55:] = 0.0
+    gcond = torch.randn(B, gin, T, generator=g_)
+    cond = [torch.randn(2 * C * n, gin, 1, generator=g_) * 0.3, torch.rand(2 * C * n, 1, 1, generator=g_) + 0.5,
+            torch.randn(2 * C * n, generator=g_) * 0.1]
+    layers = []
+    for i in range(n):
+        rc = 2 * C if i < n - 1 else C
+        layers.append([torch.randn(2 * C, C, ks, generator=g_) * 0.3, torch.rand(2 * C, 1, 1, generator=g_) + 0.5,
+                       torch.randn(2 * C, generator=g_) * 0.1, torch.randn(rc, C, 1, generator=g_) * 0.3,
+                       torch.rand(rc, 1, 1, generator=g_) + 0.5, torch.randn(rc, generator=g_) * 0.1])
+    dy = torch.randn(B, C, T, generator=g_)
+    res = {}
+    SF.set_precision("bf16x3")
+    old = SF.STACK_EXECUTOR
+    try:
+        for cexec in (False, True):
+            SF.STACK_EXECUTOR = cexec
+            xd = _leaf(x, dev)
+            cd = [_leaf(t, dev) for t in cond]
+            ld = [[_leaf(t, dev) for t in lp] for lp in layers]
+            leaves = cd + [t for lp in ld for t in lp]
+            if grad_buffers != "none":
+                for t in leaves:
+                    t.grad = torch.full_like(t, 0.125)              # (accumulated into, not overwritten)
+            if grad_buffers == "frozen_in":
+                for lp in ld:
+                    for t in lp[:3]:
+                        t.requires_grad_(False)
+            y = SF.wn_stack(xd, mask.to(dev) if masked else None, gcond.to(dev), cd, ld, ks, dilation_rate=2)
+            y.backward(dy.to(dev))
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            res[cexec] = [y.detach(), xd.grad] + [t.grad for t in leaves]
+    finally:
+        SF.STACK_EXECUTOR = old
+        SF.set_precision("fp32")
+    for a, b in zip(res[False], res[True]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)

@@ -241,11 +241,12 @@ def test_fused_step_paths_equal_elementwise_paths(dev, tmp_path, phase):
         try:
             out = _grads_after_passes(task, trainer, batch, dev, gs, eps, 77)
             if phase == 2 and not no_critic:           # (bf16x3: the generator's weight gradients all go through the deferred reduce)
-                assert (n_deferred[0] > 20) == bool(fused), n_deferred
+                # (the gated stacks batch their own reduces inside the C executor; what is counted here are the other convs)
+                assert (n_deferred[0] > 10) == bool(fused), n_deferred
             return out
         finally:
             K.flush_deferred_reduces = o_flush
-            hp["fused_mel_loss"], hp["defer_wgrad_reduce"] = True, False
+            hp["fused_mel_loss"], hp["defer_wgrad_reduce"] = True, True
             fs2_vae.FUSED_HEAD = svb_vae.FUSED_GN = svb_vae.SPLIT_STACKED = mel_disc.FUSED_CROP = vc_asr.FOLD_RESIDUALS = True
     try:
         t1, g1 = run(True)

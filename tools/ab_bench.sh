@@ -8,6 +8,6 @@ i=0
 for v in "$@"; do
   i=$((i+1))
   if [[ "$v" == --* ]]; then extra="$v"; elif [[ -n "$v" ]]; then extra="--extra-hparams $v"; else extra=""; fi
-  timeout 120 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline $extra > gpurun_out/ab/v$i.json 2> gpurun_out/ab/v$i.err
+  timeout 120 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-extra-workloads $extra > gpurun_out/ab/v$i.json 2> gpurun_out/ab/v$i.err
   echo "variant $i [${v:-defaults}]: $(grep -h 'ms/step' gpurun_out/ab/v$i.err | sed 's/\[bench [0-9:]*\] //' | tr '\n' ';')"
 done

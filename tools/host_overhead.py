@@ -1,0 +1,97 @@
+"""Host-side cost of issuing a training step, measured WITHOUT a GPU: every kernel entry point of the C ABI is bound to a no-op C
+function with the same ctypes signature (size queries keep the real host functions of the library), tensors live on the CPU and
+are tiny, so what remains is exactly the Python / autograd / ctypes work per launch -- the quantity that bounds the step on a box
+whose host is slower than its GPU.  Numbers are garbage by construction; only time and call counts mean anything.
+
+  python tools/host_overhead.py [--profile] [--steps N]"""
+import argparse
+import cProfile
+import ctypes as C
+import os
+import pstats
+import subprocess
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def null_library():
+    from neuralsvb_amd import _lib
+    emu = os.path.join(ROOT, "tests", "emu", "libsvb_emu.so")
+    real = _lib.bind(emu)
+    d = tempfile.mkdtemp()
+    open(os.path.join(d, "n.c"), "w").write("int svb_noop() { return 0; }\n")
+    subprocess.run(["gcc", "-shared", "-fPIC", "-O2", "-o", os.path.join(d, "n.so"), os.path.join(d, "n.c")], check=True)
+    noop = C.CDLL(os.path.join(d, "n.so"))
+
+    class Lib:
+        pass
+    lib = Lib()
+    n_calls = {"n": 0}
+    for name, (res, args) in _lib.SIGNATURES.items():
+        if any(s in name for s in ("workspace", "abi_version", "pick_cfg", "_floats", "_bytes", "debug")):
+            setattr(lib, name, getattr(real, name))
+            continue
+        proto = C.CFUNCTYPE(res, *args)
+        setattr(lib, name, proto(("svb_noop", noop)))
+    return lib
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--extra-hparams", default="")
+    ap.add_argument("--no-stack-executor", action="store_true")
+    a = ap.parse_args()
+    from neuralsvb_amd import _lib
+    _lib._LIB, _lib._LIB_IS_EMU = null_library(), True
+    from neuralsvb_amd import kernels as K
+    K.AUTOTUNE = False
+    if a.no_stack_executor:
+        from neuralsvb_amd import functional as SF
+        SF.STACK_EXECUTOR = False
+    import bench
+    args = argparse.Namespace(batch=2, seconds=0.71, sample_rate=24000, bf16=False, precision="bf16x3", graph=False)
+    extra = ",ds_workers=0" + (("," + a.extra_hparams) if a.extra_hparams else "")
+    with tempfile.TemporaryDirectory() as tmp:
+        # the synthetic dataset needs a real mel front-end once: build it with the emulator library, then swap
+        null = _lib._LIB
+        _lib._LIB = _lib.bind(os.path.join(ROOT, "tests", "emu", "libsvb_emu.so"))
+        task, trainer, batch, hp = bench.build_task(args, 0, 1, torch.device("cpu"), tmp, extra_hparams=extra)
+        _lib._LIB = null
+        torch.set_num_threads(1)
+        # (on the GPU the optimizer is one fused launch per pass; torch's CPU AdamW is a per-tensor Python loop that would drown
+        #  everything else here: leave it, the flat-buffer memset and the clipping norm out of the measurement)
+        for o in trainer.optimizers:
+            if o is not None:
+                o.step = lambda *a, **k: None
+        for g in trainer.grad_sync:
+            if g is not None:
+                g.zero = lambda: None
+        torch.nn.utils.clip_grad_norm_ = lambda *a, **k: torch.zeros(())
+        import neuralsvb_amd.tasks.svb_vae_task as tk
+        if hasattr(tk, "clip_grad_norm_"):
+            tk.clip_grad_norm_ = lambda *a, **k: torch.zeros(())
+        bench.run_steps(trainer, task, batch, 3, 1)
+        t0 = time.perf_counter()
+        if a.profile:
+            pr = cProfile.Profile()
+            pr.enable()
+        bench.run_steps(trainer, task, batch, a.steps, 4)
+        if a.profile:
+            pr.disable()
+        dt = (time.perf_counter() - t0) / a.steps
+        print(f"host time per step with no-op kernels: {dt * 1e3:.2f} ms")
+        if a.profile:
+            st = pstats.Stats(pr)
+            st.sort_stats("tottime").print_stats(45)
+
+
+if __name__ == "__main__":
+    main()
