@@ -107,8 +107,9 @@ def main():
         return x * (keep.to(x.dtype) / (1.0 - p))[:, :, None, None]
 
     # conditioning probe: the critic's InstanceNorm2d planes (multi_window_disc.py:24-27).  A near-constant plane (variance close
-    # to eps = 1e-5) makes d(loss)/d(input) through that norm ill-conditioned: rounding noise of the arithmetic is amplified by
-    # ~1/(var + eps) there.  Recorded per step (smallest plane variance seen by any critic call of the step).
+    # to eps = 1e-5) would make d(loss)/d(input) through that norm ill-conditioned.  Recorded per step (smallest variance of a
+    # plane that Dropout2d kept, over the critic calls of the step): it stays >= 1e-3 for every seed tried, i.e. this is NOT
+    # where the draw-dependent sensitivity of the generator gradient comes from (profiles/r03_step_golden_seed_diagnosis.md).
     o_inorm = F.instance_norm
 
     def instance_norm(x, *a, **k):
@@ -119,32 +120,6 @@ def main():
                 state["cur"]["critic_min_plane_var"] = min(state["cur"].get("critic_min_plane_var", float("inf")), float(pv.min()))
         return o_inorm(x, *a, **k)
     F.instance_norm = instance_norm
-
-    # second conditioning probe: the train-mode BatchNorm1d layers of the encoder's pooling tail (vae_models.py:86-94).  The
-    # loss sees only the TIME MEAN of that tail, so the gradient entering each BatchNorm is (nearly) constant over time per clip,
-    # and BatchNorm's backward subtracts its batch mean: what survives is the DIFFERENCE between the (four) clips' gradients.
-    # When the clips' latent gradients nearly agree -- it depends on the draws -- the surviving part is orders of magnitude
-    # smaller than the incoming one and every relative rounding error upstream is amplified by that ratio in the gradients of
-    # everything below the tail (the whole encoder and the conditioning path).  Recorded per generator pass: the largest
-    # ||dy|| / ||dy - mean(dy)|| over the two BatchNorms.
-    bn_hooks = []
-
-    def _bn_probe(mod, grad_in, grad_out):
-        dy = grad_out[0].detach().double()
-        res = dy - dy.mean(dim=(0, 2), keepdim=True)
-        amp = float(dy.norm() / res.norm().clamp_min(1e-300))
-        if state["cur"] is not None:
-            state["cur"]["bn_common_mode_amp"] = max(state["cur"].get("bn_common_mode_amp", 0.0), amp)
-
-    orig_build2 = rtask.SVBVAEMleTask.build_model
-
-    def build_model2(self):
-        m = orig_build2(self)
-        for mod in self.model.vae_model.encoder.poolings:
-            if isinstance(mod, torch.nn.BatchNorm1d):
-                bn_hooks.append(mod.register_full_backward_hook(_bn_probe))
-        return m
-    rtask.SVBVAEMleTask.build_model = build_model2
 
     def run_training_batch(self, batch_idx, batch):
         task = self.get_task_ref()
@@ -189,7 +164,6 @@ def main():
         json.dump(rec, f)
     C.save_events(os.path.join(out_dir, "step_ref_draws.npz"), events_per_step)
     print("critic min plane variance per step:", [st.get("critic_min_plane_var") for st in rec["steps"]])
-    print("BatchNorm common-mode amplification per step:", [round(st.get("bn_common_mode_amp", 0.0), 1) for st in rec["steps"]])
     os.chdir(ROOT)
     shutil.rmtree(tmp, ignore_errors=True)
     print("step golden written:", os.path.getsize(os.path.join(HERE, "step_ref.json")), "bytes json")
