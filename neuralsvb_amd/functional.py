@@ -130,19 +130,14 @@ def begin_weight_epoch():
     PACK_EPOCH = _EPOCH_COUNTER
 
 
-FROZEN_EPOCH = 0         # bumped when weights that do not train may have changed (restore, load_state_dict announced through
-                         # note_weights_updated()): consumers that bake frozen weights into replayed graphs key on it
-
-
 def note_weights_updated(params=None):
     """Trainable weights were modified in place (optimizer step, restore, broadcast): start a fresh epoch if one is open.
     `params` (optional): exactly the tensors that changed -- only their persistent bf16x3 images are marked stale."""
-    global PACK_EPOCH, _EPOCH_COUNTER, FROZEN_EPOCH
+    global PACK_EPOCH, _EPOCH_COUNTER
     if PACK_EPOCH is not None:
         _EPOCH_COUNTER += 1
         PACK_EPOCH = _EPOCH_COUNTER
     if params is None:
-        FROZEN_EPOCH += 1
         for e in _REG.values():
             e.dirty = True
         for ent in _S2W.values():

@@ -21,8 +21,6 @@ from .. import kernels as K
 from .layers import Conv1d, LinearNCT, LayerNormNCT, attach_opaque
 
 
-GRAPH_REPLAY = True      # VCASR.forward (frozen, no grad): captured once per input shape, replayed afterwards (see VCASR._replayed)
-GRAPH_WARMUP, GRAPH_MAX_SHAPES = 2, 6
 FOLD_RESIDUALS = True    # EncoderLayer: residual adds / macaron 0.5 in the conv epilogues (False: explicit element-wise ops)
 
 
@@ -239,44 +237,6 @@ class VCASR(nn.Module):
         """mel_input [B,T,80] -> {'h_content': [B, H, T/2] (NCT)}  (vc_modules.py:75-80, encoder only)."""
         if prev_tokens is not None:
             raise NotImplementedError("the ASR decoder is not on the hot path")
-        if GRAPH_REPLAY and mel_input.is_cuda and not SF.CAPTURING and K.PROFILE is None:
-            return {"h_content": self._replayed(mel_input)}
-        return {"h_content": self._encode(mel_input)}
-
-    def _encode(self, mel_input):
         nonpad = (mel_input.abs().sum(-1) != 0).float()
         x, _ = self.mel_prenet(mel_input.transpose(1, 2).contiguous(), nonpad)
-        return self.content_encoder(x)
-
-    # ---- the frozen encoder as a replayed hipGraph ----------------------------------------------------------------------
-    # Forward-only, frozen weights, static shapes: ~60 launches per call whose only per-step variable is the input.  After two
-    # eager calls per (shape, arithmetic) -- kernel autotuning and lazy initialisation happen there -- the third is captured
-    # and from then on a call is: copy the mel into the graph's input buffer, replay, copy the result out.  Any change of the
-    # weights (load_state_dict, functional.note_weights_updated) drops the graphs: packed weight images are baked into them.
-    def _replayed(self, mel_input):
-        key = (tuple(mel_input.shape), mel_input.device.index, SF.PRECISION, SF.FROZEN_EPOCH)
-        st = self.__dict__.setdefault("_graphs", {})
-        ent = st.get(key)
-        if ent is None:
-            if len(st) >= GRAPH_MAX_SHAPES:
-                return self._encode(mel_input)
-            ent = st[key] = {"seen": 0, "graph": None}
-        if ent["graph"] is None:
-            ent["seen"] += 1
-            if ent["seen"] <= GRAPH_WARMUP or any(p.requires_grad for p in self.parameters()):
-                return self._encode(mel_input)
-            ent["x"] = torch.empty_like(mel_input)
-            ent["x"].copy_(mel_input)
-            torch.cuda.current_stream().synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                ent["y"] = self._encode(ent["x"])
-            ent["graph"] = g
-            ent["keep"] = [e.get("packs") for e in SF._PACKS.values()]      # packed (frozen) weight images the graph reads
-        ent["x"].copy_(mel_input)
-        ent["graph"].replay()
-        return ent["y"].clone()
-
-    def _load_from_state_dict(self, *a, **k):
-        self.__dict__.pop("_graphs", None)
-        return super()._load_from_state_dict(*a, **k)
+        return {"h_content": self.content_encoder(x)}

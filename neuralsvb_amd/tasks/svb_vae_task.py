@@ -100,8 +100,6 @@ class SVBVAEMleTask(BaseTask):
     def build_model(self):
         SF.set_precision(hparams.get("conv_precision", "fp32"))
         SF.STACK_EXECUTOR = bool(hparams.get("wn_stack_executor", True))
-        from ..modules import vc_asr as _vc
-        _vc.GRAPH_REPLAY = bool(hparams.get("ppg_graph_replay", True))
         from ..modules import svb_vae as _svb
         _svb.PPG_SIDE_STREAM = bool(hparams.get("overlap_ppg_encoder", True)) and os.environ.get("SVB_PPG_SIDE", "1") != "0"
         self.build_tts_model()

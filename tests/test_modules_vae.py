@@ -311,46 +311,3 @@ def test_mle_svb_vae_bench_shape_gradients(gpu_only, precision):
             bad.append((name, rn, rs))
     print(precision, "worst gradient norm / sample relative error at the bench shape:", worst)
     assert not bad, (precision, bad)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
-def test_frozen_ppg_encoder_graph_replay_equals_eager(gpu_only, precision):
-    """VCASR.forward (frozen, no grad) is captured as a hipGraph on its third call per input shape and replayed afterwards: the
-    replayed result must equal the eager one bit for bit, follow a new input, and be dropped when the weights change."""
-    from neuralsvb_amd import functional as SF
-    from neuralsvb_amd.modules import vc_asr as V
-    dev = gpu_only
-    model, _ = build_model(dev)
-    enc = model.vc_asr
-    g = torch.Generator().manual_seed(5)
-    mel_a = (torch.randn(3, 96, 80, generator=g) * 0.8 - 3).to(dev)
-    mel_a[2, 70:] = 0.0
-    mel_b = (torch.randn(3, 96, 80, generator=g) * 0.8 - 3).to(dev)
-    SF.set_precision(precision)
-    old = V.GRAPH_REPLAY
-    try:
-        V.GRAPH_REPLAY = False
-        ref_a, ref_b = enc(mel_a)["h_content"].clone(), enc(mel_b)["h_content"].clone()
-        V.GRAPH_REPLAY = True
-        outs = [enc(mel_a)["h_content"].clone() for _ in range(V.GRAPH_WARMUP + 2)]      # eager, eager, capture+replay, replay
-        key = [k for k in enc._graphs if k[0] == tuple(mel_a.shape)]
-        assert key and enc._graphs[key[0]]["graph"] is not None
-        for o in outs:
-            assert torch.equal(o, ref_a)
-        assert torch.equal(enc(mel_b)["h_content"], ref_b)                                  # replay follows its input
-        # a weight change drops the graphs (packed weight images are baked into them)
-        sd = {k: v.clone() for k, v in enc.state_dict().items()}
-        sd["mel_prenet.out_proj.weight"] = sd["mel_prenet.out_proj.weight"] * 1.5
-        enc.load_state_dict(sd)
-        SF.note_weights_updated()
-        assert not getattr(enc, "_graphs", {})
-        V.GRAPH_REPLAY = False
-        ref_c = enc(mel_a)["h_content"].clone()
-        V.GRAPH_REPLAY = True
-        assert not torch.equal(ref_c, ref_a)
-        for _ in range(V.GRAPH_WARMUP + 2):
-            assert torch.equal(enc(mel_a)["h_content"], ref_c)
-    finally:
-        V.GRAPH_REPLAY = old
-        SF.set_precision("fp32")
