@@ -408,30 +408,38 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
             uint4 bh_u[2][NT], bl_u[2][NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) { bh_u[0][n] = x_hi[xbase[n] + xoff[0]]; bl_u[0][n] = x_lo[xbase[n] + xoff[0]]; }
+            {
+                // The slab loop with every non-MFMA instruction placed BY HAND in the shadow of an MFMA -- after MFMA j of slab i: one
+                // LDS read of slab i+1's B fragments (j < 2 NT), or the reload of this slab's lo weight fragment for the next phase
+                // (its hi fragment follows the slab's last MFMA) -- and the order pinned per MFMA.  Left alone, the scheduler sinks
+                // every LDS read to just before its MFMA and waits lgkmcnt(0) in between; pinned in clumps (reads of slab i+1, the 9
+                // MFMAs of slab i, the reloads -- the r02 form) a wave leaves ~200 idle matrix-pipe cycles per slab whenever its
+                // SIMD partner is not in its own MFMA stage: 5.04k -> 4.35k cycles per K phase on 256->256 k5, 96.8 -> 88.8 us
+                // (profiles/r03_conv_dense_slab_loop.log).  Same MFMA order per accumulator: bit-identical results.
+                // (Tried on top and rejected, same log: the next x tile's 32 dword loads spread over the MFMA gaps instead of
+                // issued in one burst in front of the stage -- a VMEM issue holds the in-order wave far longer than an LDS read,
+                // the MFMA stage grew from 2.56k to 4.08k cycles and the kernel lost 15 %.)
+                constexpr int NM = 3 * NT;
 #pragma unroll
-            for (int i = 0; i < SLB; ++i) {
-                if (i + 1 < SLB) {
+                for (int i = 0; i < SLB; ++i) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&wfh[i]), al = *reinterpret_cast<const bf16x8*>(&wfl[i]);
+                    const size_t base16 = (w_off0 + ((size_t)(ltg + sl_t[i]) * tap_step * a.w_tap_slabs + (size_t)(lkc + sl_c[i])) * slab_elems) / 8;
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        bh_u[(i + 1) & 1][n] = x_hi[xbase[n] + xoff[i + 1]];
-                        bl_u[(i + 1) & 1][n] = x_lo[xbase[n] + xoff[i + 1]];
+                    for (int j = 0; j < NM; ++j) {
+                        const int n = j % NT, prod = j / NT;            // products: lo*hi, hi*lo, hi*hi
+                        if (prod == 0) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, *reinterpret_cast<const bf16x8*>(&bh_u[i & 1][n]), acc[n], 0, 0, 0);
+                        else if (prod == 1) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, *reinterpret_cast<const bf16x8*>(&bl_u[i & 1][n]), acc[n], 0, 0, 0);
+                        else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, *reinterpret_cast<const bf16x8*>(&bh_u[i & 1][n]), acc[n], 0, 0, 0);
+                        if (i + 1 < SLB && j < 2 * NT) {               // fillers 0 .. 2NT-1: next slab's B fragments
+                            const int nn = j >> 1;
+                            if (j & 1) bl_u[(i + 1) & 1][nn] = x_lo[xbase[nn] + xoff[i + 1]];
+                            else bh_u[(i + 1) & 1][nn] = x_hi[xbase[nn] + xoff[i + 1]];
+                        }
+                        if (j == NT) wfl[i] = (reinterpret_cast<const uint4*>(a.wq_lo) + base16)[wf_lane16];   // `al` is dead after product 0
+                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    wfh[i] = (reinterpret_cast<const uint4*>(a.wq_hi) + base16)[wf_lane16];                     // `ah` after the slab's last MFMA
                 }
-                // pin the order: left alone, the scheduler sinks every LDS read to just before its MFMA (to save registers) and
-                // waits lgkmcnt(0) between consecutive MFMAs -- the LDS latency of each read is then exposed
-                __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&wfh[i]), al = *reinterpret_cast<const bf16x8*>(&wfl[i]);
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, *reinterpret_cast<const bf16x8*>(&bh_u[i & 1][n]), acc[n], 0, 0, 0);
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, *reinterpret_cast<const bf16x8*>(&bl_u[i & 1][n]), acc[n], 0, 0, 0);
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, *reinterpret_cast<const bf16x8*>(&bh_u[i & 1][n]), acc[n], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                load_wf_full(i, lkc, ltg);
             }
             SVBQ_STAMP(2)
             if (a.prio == 1) __builtin_amdgcn_s_setprio(0);
