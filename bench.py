@@ -137,12 +137,12 @@ def conv_alg_bytes(tag):
 
 
 def pmc_traffic(tag_counts):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r02_pmc_traffic.json, written by
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r03_pmc_traffic.json -- r02's if absent --, written by
     tools/pmc_traffic.py on the MI355X: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, each calibrated
     on a launch of known traffic with the same access pattern).  Launch-weighted over the shapes the kernel ran in this
     step; (None, why) when the file does not cover at least 70 % of its launches."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (3, 2)) if os.path.exists(q)), None)
+    if path is None:
         return None, "no PMC file"
     db = json.load(open(path)).get("shapes", {})
     tot = n = 0
@@ -154,7 +154,7 @@ def pmc_traffic(tag_counts):
     allc = sum(tag_counts.values())
     if n == 0 or n < 0.7 * allc:
         return None, f"PMC file covers {n}/{allc} launches"
-    return tot / n, f"profiles/r02_pmc_traffic.json, {n}/{allc} launches covered"
+    return tot / n, f"profiles/{os.path.basename(path)}, {n}/{allc} launches covered"
 
 
 def cpu_baseline(task, batch, hp, args):

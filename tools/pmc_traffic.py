@@ -1,4 +1,4 @@
-"""HBM-side traffic (rocprofv3 PMC) of the step's dominant conv kernel, per shape -> profiles/r02_pmc_traffic.json (GPU box).
+"""HBM-side traffic (rocprofv3 PMC) of the step's dominant conv kernel, per shape -> profiles/r03_pmc_traffic.json (GPU box).
 
 As MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (they do not fit one pass), nothing but
 --pmc on the rocprofv3 command line, units of KB, and -- because the gfx950 counters are only calibrated for 16-byte streaming
@@ -78,7 +78,7 @@ def main():
         cal[counter] = {"raw_bytes": raw, "known_bytes": known, "factor": known / raw}
         print("calibration", counter, cal[counter], flush=True)
     out = {"kernel": dom, "cfg": cfg, "calibration": cal, "method": __doc__.split("\n\n")[1], "shapes": {}}
-    for tag, cnt in tags[:16]:
+    for tag, cnt in tags[:int(os.environ.get("SVB_PMC_SHAPES", "16"))]:
         op, B, ca, cb_, G, T, k, s, dil = tag
         if G != 1 or s != 1 or dil != 1 or op == "taps":
             continue
@@ -95,7 +95,7 @@ def main():
         out["shapes"][json.dumps(list(tag))] = ent
         print(tag, ent, flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    for path in (os.path.join(ROOT, "gpurun_out", "r02_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")):
+    for path in (os.path.join(ROOT, "gpurun_out", "r03_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")):
         with open(path, "w") as f:
             json.dump(out, f, indent=1)
 
