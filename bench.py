@@ -152,7 +152,7 @@ def pmc_traffic(tag_counts):
             tot += cnt * ent["hbm_bytes"]
             n += cnt
     allc = sum(tag_counts.values())
-    if n == 0 or n < 0.7 * allc:
+    if n == 0 or n < 0.6 * allc:
         return None, f"PMC file covers {n}/{allc} launches"
     return tot / n, f"profiles/{os.path.basename(path)}, {n}/{allc} launches covered"
 
