@@ -83,6 +83,10 @@ __device__ __forceinline__ void svbq_split8(const float* v, uint4& hi, uint4& lo
 
 // MODE 0: fp32 x, split while staging;  1: the same with the activation-derivative gate on the load;  2: x comes pre-split
 // (Q image): the tile is staged with 16-byte copies -- four consecutive lanes fetch the 64-byte row of one position.
+// (Round 3 also measured MODE 0 / 1 tiles read with 16-byte loads ALONG time -- one thread = 4 positions of a channel pair, a
+//  quarter of the VMEM instructions, the tile written to LDS as 8 ds_write_b32 per unit instead of 2 ds_write_b128: every conv
+//  shape of the step got 15-30 % SLOWER (profiles/r03_conv_quad_staging_ab.log), so the VMEM instruction count of the x tile
+//  is not what bounds the kernel -- removed.)
 // (Round 3 measured the gate / res-skip / gate-backward epilogue variants of this kernel on the MI355X: fewer launches, but
 //  0.2-0.35 ms MORE kernel time per step than the streaming kernels they replaced -- profiles/r03_fused_epilogue_ab.log -- removed.)
 template <int WM, int WN, int NT, int SLB, int MODE>
@@ -418,7 +422,10 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
                 // (profiles/r03_conv_dense_slab_loop.log).  Same MFMA order per accumulator: bit-identical results.
                 // (Tried on top and rejected, same log: the next x tile's 32 dword loads spread over the MFMA gaps instead of
                 // issued in one burst in front of the stage -- a VMEM issue holds the in-order wave far longer than an LDS read,
-                // the MFMA stage grew from 2.56k to 4.08k cycles and the kernel lost 15 %.)
+                // the MFMA stage grew from 2.56k to 4.08k cycles and the kernel lost 15 %.  Ablations of this loop, same log: without
+                // its LDS reads the stage is as long (they are free); without the 10 weight-fragment reloads it is 1.74k instead of
+                // 2.56k cycles -- each global_load_dwordx4 holds the wave ~80 cycles -- but issuing them behind the stage instead
+                // costs more in the store stage than it saves here.)
                 constexpr int NM = 3 * NT;
 #pragma unroll
                 for (int i = 0; i < SLB; ++i) {
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
                         if (j == NT) wfl[i] = (reinterpret_cast<const uint4*>(a.wq_lo) + base16)[wf_lane16];   // `al` is dead after product 0
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    wfh[i] = (reinterpret_cast<const uint4*>(a.wq_hi) + base16)[wf_lane16];                     // `ah` after the slab's last MFMA
+                    wfh[i] = (reinterpret_cast<const uint4*>(a.wq_hi) + base16)[wf_lane16];   // `ah` after the slab's last MFMA
                 }
             }
             SVBQ_STAMP(2)

@@ -524,6 +524,27 @@ def test_conv1d_bf16x3_wide_tiles_three_position_groups(dev, cfg):
     assert rel_err(dx, dref) < 6e-5
 
 
+@pytest.mark.parametrize("cfg", [1, 2, 4, 11])
+@pytest.mark.parametrize("T,k,pad,dil", [(4, 3, 1, 1), (5, 5, 2, 1), (7, 3, 9, 9), (129, 3, 3, 3), (131, 5, 2, 1), (260, 3, 27, 27),
+                                         (66, 3, 5, 1)])
+def test_conv1d_bf16x3_clip_edges(dev, cfg, T, k, pad, dil):
+    """Tiles that straddle the clip's first or last position: padding wider than the clip, clips of 4..7 positions, T not a
+    multiple of 4, over-wide padding that lengthens the output -- plain and with the LeakyReLU-derivative gate on the input,
+    against the oracle."""
+    g = torch.Generator().manual_seed(1000 * cfg + T + k)
+    B, Cin, Cout = 2, 32, 40
+    x = torch.randn(B, Cin, T, generator=g)
+    gate = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) * 0.2
+    qa, _ = K.weight_pack_q(w.to(dev), None, 1)
+    ref = oops.conv1d(x, w, None, 1, pad, dil)
+    y = K.conv1d_forward(x.to(dev), qa, Cout, k, 1, pad, dil, 1, force_cfg=cfg)
+    assert y.shape == ref.shape and rel_err(y, ref) < 6e-5
+    refg = oops.conv1d(x * torch.where(gate > 0, 1.0, 0.2), w, None, 1, pad, dil)
+    yg = K.conv1d_forward(x.to(dev), qa, Cout, k, 1, pad, dil, 1, in_gate=gate.to(dev), in_slope=0.2, force_cfg=cfg)
+    assert rel_err(yg, refg) < 6e-5
+
+
 @pytest.mark.parametrize("T", [37, 64, 130])
 def test_relpos_attention_fused_matches_espnet(dev, T):
     """svb_relpos_attn_fwd (content scores + rel-shifted position scores + scale + key mask + softmax + value product in one
