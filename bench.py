@@ -140,7 +140,7 @@ def pmc_traffic(tag_counts):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r03_pmc_traffic.json -- r02's if absent --, written by
     tools/pmc_traffic.py on the MI355X: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, each calibrated
     on a launch of known traffic with the same access pattern).  Launch-weighted over the shapes the kernel ran in this
-    step; (None, why) when the file does not cover at least 70 % of its launches."""
+    step; (None, why) when the file does not cover at least 60 % of its launches."""
     path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (3, 2)) if os.path.exists(q)), None)
     if path is None:
         return None, "no PMC file"
@@ -226,10 +226,17 @@ def bench_vocoder(args, device):
             trainer.run_training_batch(i, batch)
     steps(args.warmup, 1)
     torch.cuda.synchronize()
+    markers = bool(os.environ.get("SVB_BENCH_MARKERS"))      # rocprofv3 runs: a spin kernel brackets the timed region in the trace
+    if markers:
+        torch.cuda._sleep(1000)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     steps(args.steps, 1 + args.warmup)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    if markers:
+        torch.cuda._sleep(1000)
+        torch.cuda.synchronize()
     K.PROFILE = []
     steps(2, 1 + args.warmup + args.steps)
     torch.cuda.synchronize()
@@ -340,6 +347,16 @@ def _roofline_from_records(rec, steps, precision):
         d[2] += 1
     if not by:
         return None
+    if os.environ.get("SVB_BENCH_SHAPES"):
+        by_shape = {}
+        for name, flops, e0, e1, tag in rec:
+            d = by_shape.setdefault((tag, name.split("<")[-1].split(">")[0] if "<" in name else name), [0.0, 0.0, 0])
+            d[0] += flops
+            d[1] += e0.elapsed_time(e1) * 1e-3
+            d[2] += 1
+        log("per-shape conv time (op, B, C_a, C_b, groups, T, k, stride, dil): calls/step, ms/step, us/call, TFLOP/s")
+        for tag, (fl, sec, cnt) in sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('SVB_BENCH_SHAPES_TOP', '70'))]:
+            log(f"  {str(tag[0]):56s} {tag[1]:14s} {cnt / steps:6.1f} {sec / steps * 1e3:8.3f} {sec / cnt * 1e6:8.1f} us {fl / sec / 1e12:8.1f}")
     name, (fl, sec, cnt) = max(by.items(), key=lambda kv: kv[1][1])
     tot_fl, tot_s = sum(v[0] for v in by.values()), sum(v[1] for v in by.values())
     return {"bound": "mfma", "kernel": name, "achieved": fl / sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",

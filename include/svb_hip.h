@@ -409,6 +409,13 @@ int svb_embed_nct_fwd(const int64_t* idx, const float* w, float* out, int B, int
 int svb_embed_nct_bwd(const int64_t* idx, const float* dy, float* part, float* dw, int B, int H, int T, int V, int padding_idx,
                       int accumulate, void* stream);
 
+/* ---- Multi-period discriminator plumbing (reference modules/hifigan/hifigan.py:171-223: `x.view(b, c, t // period, period)` +
+ * Conv2d((k,1), (stride,1)) layers).  Feature maps stay in the reference's [B][C][H][p] layout; a (k,1) conv is a 1-D conv with
+ * dilation p over the flattened [H*p] axis, and a stride-s layer runs at stride 1 on the row space-to-depth image
+ *   img[plane][r][row][w] = x[plane][s*(row - lead) + r][w]   (zero outside the plane; `lead` zero rows in front, R rows in all)
+ * (inverse != 0: the gather back, x[plane][h][w] = img[plane][h % s][lead + h / s][w] -- its gradient).  planes = B*C.        */
+int svb_period_s2d(const float* src, float* dst, long planes, int H, int p, int s, int lead, int R, int inverse, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

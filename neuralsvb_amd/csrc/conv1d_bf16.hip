@@ -930,6 +930,9 @@ struct SvbWgradQArgs {
     int k, off0, dil, sx;
     int n_tg, a_tiles, b_tiles, chunks_per_b, total_chunks, nsplit;
     int at, bt;   // 32x32 accumulator tiles per wave along A / B rows (workgroup tile 64*at x 64*bt)
+    int gp_ca, gp_cb;   // group packing: G / CA_g / CB_g above describe `gp` real groups merged into one (their channels are
+                        // contiguous), so that a 64x64 tile holds gp diagonal blocks of gp_ca x gp_cb REAL per-group channels instead
+                        // of one (MSD's grouped k41 convs: 16 x 8 channels per group); only those blocks are stored.  0 = off.
     int pa, pb;   // LDS row pitches in dwords (2 * odd)
     // tap groups.  Stride 1: group i = taps [i*TGW, ...), Bt position of tile index t: q0 + off0 + j0*dil + t.
     // Stride s > 1 (dil 1): taps are grouped by phase r = (j - pad) mod s; within a phase the strided gather
@@ -1207,7 +1210,8 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
         }
     }
 
-    float* part = a.part + (size_t)blockIdx.y * a.CA * a.CB_g * a.k;
+    const int cb_real = a.gp_cb ? a.gp_cb : a.CB_g;         // row pitch of the gradient: REAL input channels per group
+    float* part = a.part + (size_t)blockIdx.y * a.CA * cb_real * a.k;
 #pragma unroll
     for (int ia = 0; ia < AT; ++ia)
 #pragma unroll
@@ -1215,13 +1219,16 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
 #pragma unroll
             for (int t = 0; t < TGW; ++t) {
                 if (t < ntap) {
+                    const int bl = b0 + (wn + 2 * ib) * 32 + l31;
+                    const int bgrp = a.gp_cb ? bl / a.gp_cb : 0;
+                    const int bcol = a.gp_cb ? bl - bgrp * a.gp_cb : bl;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
                         const int al = a0 + (wm + 2 * ia) * 32 + row;
-                        const int bl = b0 + (wn + 2 * ib) * 32 + l31;
-                        if (al < a.CA_g && bl < a.CB_g)
-                            part[((size_t)(g * a.CA_g + al) * a.CB_g + bl) * a.k + (j0 + t * a.sx)] = acc[ia][ib][t][r];
+                        const bool diag = !a.gp_ca || al / a.gp_ca == bgrp;        // packed groups: only the diagonal blocks exist
+                        if (al < a.CA_g && bl < a.CB_g && diag)
+                            part[((size_t)(g * a.CA_g + al) * cb_real + bcol) * a.k + (j0 + t * a.sx)] = acc[ia][ib][t][r];
                     }
                 }
             }
@@ -1237,6 +1244,10 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
     }
 }
 
+// Tap-group width cap of dilated weight gradients: the general shifted-operand path reads 5 + 5 dwords per tap and MFMA step, and
+// with 5 accumulator sets per wave it runs at 70 TF on the period discriminators' 1024 -> 1024 layers where 3 + 2 taps reach 125
+// (vocoder step 134.3 -> 130.5 ms with 3, 137.0 with 2; profiles/r03_vocoder_period_layout.log).
+static const int g_svbq_wg_dil_tgw = getenv("SVB_WG_DIL_TGW") ? atoi(getenv("SVB_WG_DIL_TGW")) : 3;
 static int wgq_tgw(int k) { return k <= 5 ? k : (k % 5 == 0 ? 5 : (svb_cdiv(k, 4) <= svb_cdiv(k, 5) ? 4 : 5)); }
 
 // Tap groups of a weight gradient (see SvbWgradQArgs).  Returns the number of groups (0 = outside the envelope) and the
@@ -1245,8 +1256,11 @@ static int wgq_groups(int k, int sx, int pad, int dil, int* tgw_out, short* j0, 
     if (sx > 1 && dil != 1) return 0;
     int n = 0;
     if (sx == 1) {
-        const int tgw = wgq_tgw(k);
-        if (((tgw - 1) * dil + 1) / 2 > 4 * SVBQ_WG_NXIT) return 0;
+        int tgw = wgq_tgw(k);
+        // a tap group's Bt window is 64 + (tgw - 1) * dil positions, at most 24 beyond the chunk: wide dilations (the period
+        // discriminators' (5,1) convs run as dilation-p convs over [H, p] planes) get narrower groups, not the fp32 kernel
+        while (tgw > 1 && ((tgw - 1) * dil + 1) / 2 > 4 * SVBQ_WG_NXIT) --tgw;
+        if (dil > 1 && g_svbq_wg_dil_tgw > 0 && tgw > g_svbq_wg_dil_tgw) tgw = g_svbq_wg_dil_tgw;
         for (int j = 0; j < k; j += tgw, ++n) {
             if (j0) { j0[n] = (short)j; ntap[n] = (short)(k - j < tgw ? k - j : tgw); r[n] = 0; o0[n] = (short)(j * dil - pad); }
         }
@@ -1284,6 +1298,15 @@ static void wgq_tile(int CA_g, int CB_g, int tgw, bool gated, int* at, int* bt) 
     else if (b2) *bt = 2;
 }
 
+// Group packing factor (see SvbWgradQArgs::gp_ca): the largest power of two m dividing `groups` with m*CA_g <= 64 and m*CB_g <= 64.
+static const bool g_svbq_wg_nopack = getenv("SVB_WG_NO_GROUP_PACK") != nullptr;      // A/B switch
+static int wgq_pack(int groups, int CA_g, int CB_g) {
+    int m = 1;
+    if (g_svbq_wg_nopack) return 1;
+    while (groups % (2 * m) == 0 && 2 * m * CA_g <= 64 && 2 * m * CB_g <= 64) m *= 2;
+    return m;
+}
+
 // 0 floats (and *nsplit = 0) when the shape is outside this kernel's envelope: the caller uses svb_conv1d_wgrad.
 extern "C" size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB, int groups, int TA, int k, int sx, int pad,
                                                            int dil, int* nsplit_out) {
@@ -1293,12 +1316,14 @@ extern "C" size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB
     int tgw = 0;
     const int n_tg = wgq_groups(k, sx, pad, dil, &tgw, nullptr, nullptr, nullptr, nullptr);
     if (n_tg <= 0) return 0;
+    const int gp = wgq_pack(groups, CA / groups, CB / groups);
+    const long slab = (long)CA * (CB / groups) * k;
+    groups /= gp;
     const int CA_g = CA / groups, CB_g = CB / groups;
     int at = 1, bt = 1;
     wgq_tile(CA_g, CB_g, tgw, false, &at, &bt);
     const long tiles = (long)groups * svb_cdiv(CA_g, 64 * at) * svb_cdiv(CB_g, 64 * bt) * n_tg;
     const long chunks = (long)B * svb_cdiv(TA, SVBQ_WG_QC);
-    const long slab = (long)CA * CB_g * k;
     long ns_cap = 512 / tiles;                                   // one resident wave of blocks at 2 per CU
     if (ns_cap < 1) ns_cap = 1;
     if (ns_cap > chunks) ns_cap = chunks;
@@ -1350,6 +1375,9 @@ extern "C" int svb_conv1d_wgrad_bf16x3(const float* a_t, const float* b_t, float
     SvbWgradQArgs a;
     a.a = a_t; a.b = b_t; a.part = part; a.a_gate = a_gate; a.b_gate = b_gate; a.a_slope = a_slope; a.b_slope = b_slope;
     a.bias_part = bias_part;
+    const int gp = wgq_pack(groups, CA / groups, CB / groups);
+    a.gp_ca = gp > 1 ? CA / groups : 0; a.gp_cb = gp > 1 ? CB / groups : 0;
+    groups /= gp;
     a.B = B; a.CA = CA; a.CB = CB; a.G = groups; a.CA_g = CA / groups; a.CB_g = CB / groups; a.TA = TA; a.TB = TB;
     a.k = k; a.off0 = -pad; a.dil = dil; a.sx = sx;
     int tgw = 0;

@@ -1,0 +1,47 @@
+// period_ops.hip -- layout plumbing of the multi-period discriminator (reference modules/hifigan/hifigan.py:171-223,
+// DiscriminatorP: x.view(b, c, t // period, period) followed by Conv2d((k,1), (stride,1), padding=(pad,0)) layers).
+//
+// The product keeps every feature map in the reference's own [B][C][H][p] layout and runs a (k,1) conv as a 1-D conv over the
+// flattened [H*p] axis with dilation p (a tap moves by one ROW = p elements): clips are p times longer than in a period-major
+// [B*p][C][H] layout, which is what the 64-wide tiles of the conv and weight-gradient kernels need (H is 10..50 in the deep
+// layers).  A stride-s layer becomes stride 1 through a space-to-depth of the ROWS: channel (c, r) of the image holds rows
+// s*h + r, so that  out[h] = sum_j W_j x[s*h + j - pad]  is a conv with ceil-many taps over s*C channels (tap q, phase r <->
+// j = s*q + r + pad; slots without a tap carry zero weights).  This file holds that row space-to-depth and its inverse.
+// HBM-bound copies: every element is read once and written once, runs of p contiguous floats on both sides.
+#include "svb_common.h"
+#include "../../include/svb_hip.h"
+
+// forward  (inverse = 0): img[pl][r][row][w] = x[pl][s*(row - lead) + r][w]   (0 where the source row is outside [0, H))
+// inverse  (inverse = 1): x[pl][hh][w]       = img[pl][hh % s][lead + hh / s][w]
+__global__ __launch_bounds__(256) void svb_period_s2d_kernel(const float* src, float* dst, long planes, int H, int p, int s,
+                                                             int lead, int R, int inverse) {
+    const long total = inverse ? planes * H * p : planes * s * R * p;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int w = (int)(i % p);
+        long rest = i / p;
+        if (inverse) {
+            const int hh = (int)(rest % H);
+            const long pl = rest / H;
+            const int r = hh % s, row = lead + hh / s;
+            dst[i] = row < R ? src[((pl * s + r) * R + row) * p + w] : 0.f;
+        } else {
+            const int row = (int)(rest % R);
+            rest /= R;
+            const int r = (int)(rest % s);
+            const long pl = rest / s;
+            const int hh = s * (row - lead) + r;
+            dst[i] = (row >= lead && hh < H) ? src[(pl * H + hh) * p + w] : 0.f;
+        }
+    }
+}
+
+extern "C" int svb_period_s2d(const float* src, float* dst, long planes, int H, int p, int s, int lead, int R, int inverse,
+                              void* stream) {
+    if (!src || !dst || planes <= 0 || H <= 0 || p <= 0 || s <= 0 || lead < 0 || R <= lead) return SVB_ERR_ARG;
+    const long total = inverse ? planes * H * p : planes * s * R * p;
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(svb_period_s2d_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream,
+                       src, dst, planes, H, p, s, lead, R, inverse);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}

@@ -1059,6 +1059,47 @@ class _EmbedNCTFn(torch.autograd.Function):
         return None, dw, None
 
 
+class _PeriodS2DFn(torch.autograd.Function):
+    """Row space-to-depth of the period discriminators' [B,C,H,p] planes (kernels.period_s2d); backward = the gather back."""
+
+    @staticmethod
+    def forward(ctx, x, cfg):
+        H, p, s, lead, R = cfg
+        ctx.cfg = cfg
+        return K.period_s2d(x.contiguous(), H, p, s, lead, R)
+
+    @staticmethod
+    def backward(ctx, dimg):
+        H, p, s, lead, R = ctx.cfg
+        return K.period_s2d(dimg.contiguous(), H, p, s, lead, R, inverse=True), None
+
+
+def period_strided_conv(x, H, p, weight_v, weight_g, bias, stride, padding, out_act=ACT_NONE, out_slope=0.0):
+    """weight_norm(Conv2d(cin, cout, (k,1), (stride,1), padding=(padding,0))) on x [B, Cin, H*p] = the reference's [B,Cin,H,p]
+    planes (modules/hifigan/hifigan.py:202-221) -> ([B, Cout, H_out*p], H_out).  Stride 1: a dilation-p conv.  Stride s: a
+    stride-1 dilation-p conv over the row space-to-depth image (s*Cin channels, tap q / phase r <-> j = s*q + r + padding; the
+    slots no tap falls on carry zero weights, which WeightNorm's row norm does not see)."""
+    v = weight_v.squeeze(-1) if weight_v.dim() == 4 else weight_v
+    cout, cin, k = v.shape
+    g = None if weight_g is None else weight_g.view(-1, 1, 1)
+    if stride == 1:
+        y = conv1d(x, v, bias, 1, padding * p, p, weight_g=g, out_act=out_act, out_slope=out_slope)
+        return y, y.shape[-1] // p
+    s = int(stride)
+    h_out = (H + 2 * padding - k) // s + 1
+    q_min, q_max = (0 - padding) // s, (k - 1 - padding) // s           # floor division: tap j sits at row offset q = floor((j - padding) / s)
+    if q_min > 0 or q_max < 0:
+        raise NotImplementedError("taps that all sit on one side of the output row")
+    lead, taps = -q_min, q_max - q_min + 1
+    img = _PeriodS2DFn.apply(x, (H, p, s, lead, lead + h_out + q_max))      # rows [-lead, h_out + q_max) of the phase planes
+    # weights: slot (q, r) <- tap j = s*q + r + padding  (F.pad supplies the empty slots in front / behind)
+    front = padding + s * q_min                                           # j of slot (q_min, r = 0); <= 0
+    v2 = torch.nn.functional.pad(v, (-front, s * taps + front - k))                         # [cout, cin, taps * s]
+    v2 = v2.view(cout, cin, taps, s).permute(0, 1, 3, 2).reshape(cout, cin * s, taps)
+    y = conv1d(img, v2, bias, 1, 0, p, weight_g=g, out_act=out_act, out_slope=out_slope)
+    return y, h_out
+
+
 def embedding_nct(idx, weight, padding_idx=None):
     """embedding(idx).transpose(1, 2) as one kernel: idx int64 [B,T], weight [V,H] -> [B,H,T]."""
     return _EmbedNCTFn.apply(idx, weight, padding_idx)

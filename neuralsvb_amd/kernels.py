@@ -1213,6 +1213,22 @@ def embed_nct_bwd(idx, dy, V, padding_idx=-1, into=None):
     return None if into is not None else dw
 
 
+def period_s2d(x, H, p, s, lead, R, inverse=False):
+    """Row space-to-depth of [B,C,H*p] planes (forward -> [B, C*s, R*p]) or the gather back (inverse, x is the image ->
+    [B, C/s, H*p]); see include/svb_hip.h svb_period_s2d."""
+    _f32(x)
+    lib, st = _prep(x)
+    B, c = x.shape[0], x.shape[1]
+    if inverse:
+        out = torch.empty((B, c // s, H * p), device=x.device, dtype=torch.float32)
+        planes = B * (c // s)
+    else:
+        out = torch.empty((B, c * s, R * p), device=x.device, dtype=torch.float32)
+        planes = B * c
+    L.check(lib.svb_period_s2d(_ptr(x), _ptr(out), planes, H, p, s, lead, R, int(inverse), st), "svb_period_s2d")
+    return out
+
+
 def f0_to_coarse(f0):
     """float64 tensor -> numpy semantics (rint); float32 tensor -> torch semantics ((x+0.5).long())."""
     lib, st = _prep(f0)

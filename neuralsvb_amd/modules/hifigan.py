@@ -152,8 +152,9 @@ class HifiGanGenerator(nn.Module):
 
 
 class _ConvK1(nn.Module):
-    """weight_norm(Conv2d(cin, cout, (k,1), (s,1), padding=(p,0))) parameters (4-D, reference layout); computed as a 1-D
-    conv over a period-major [B*p, C, H] tensor."""
+    """weight_norm(Conv2d(cin, cout, (k,1), (s,1), padding=(p,0))) parameters (4-D, reference layout); computed on the
+    reference's own [B, C, H, period] planes as a dilation-`period` 1-D conv over the flattened [H*period] axis -- strided
+    layers through a row space-to-depth (functional.period_strided_conv)."""
 
     def __init__(self, cin, cout, k, stride, padding):
         super().__init__()
@@ -163,9 +164,10 @@ class _ConvK1(nn.Module):
         self.weight_v = nn.Parameter(ref.weight.data.clone())
         self.bias = ref.bias
 
-    def forward(self, x, out_act=SF.ACT_NONE):
-        return SF.conv1d(x, self.weight_v.squeeze(-1), self.bias, self.stride, self.padding,
-                         weight_g=self.weight_g.view(-1, 1, 1), out_act=out_act, out_slope=LRELU_SLOPE)
+    def forward(self, x, H, period, out_act=SF.ACT_NONE):
+        """x [B, Cin, H*period] -> ([B, Cout, H_out*period], H_out)."""
+        return SF.period_strided_conv(x, H, period, self.weight_v, self.weight_g, self.bias, self.stride, self.padding,
+                                      out_act=out_act, out_slope=LRELU_SLOPE)
 
 
 class DiscriminatorP(nn.Module):
@@ -180,20 +182,21 @@ class DiscriminatorP(nn.Module):
         self.conv_post = _ConvK1(1024, 1, 3, 1, 1)
 
     def forward(self, x, mel=None):
-        """x [B,1,T] -> (flattened logits [B, H'*p], fmaps as [B,C,H,p] views)  (hifigan.py:202-223)."""
+        """x [B,1,T] -> (flattened logits [B, H'*p], fmaps [B,C,H,p])  (hifigan.py:202-223).  Every feature map lives in the
+        reference's layout: no period-major copy, and a clip is H*p positions long for the conv tiles instead of H."""
         b, c, t = x.shape
         p = self.period
         if t % p != 0:
             x = F.pad(x, (0, p - (t % p)), "reflect")
             t = x.shape[-1]
-        h = x.view(b, c, t // p, p).permute(0, 3, 1, 2).reshape(b * p, c, t // p)        # period-major
+        h, H = x, t // p
         fmap = []
         for l in self.convs:
-            h = l(h, out_act=SF.ACT_LRELU)
-            fmap.append(h.view(b, p, h.shape[1], h.shape[2]).permute(0, 2, 3, 1))
-        h = self.conv_post(h)
-        fmap.append(h.view(b, p, 1, h.shape[2]).permute(0, 2, 3, 1))
-        return fmap[-1].reshape(b, -1), fmap
+            h, H = l(h, H, p, out_act=SF.ACT_LRELU)
+            fmap.append(h.view(b, h.shape[1], H, p))
+        h, H = self.conv_post(h, H, p)
+        fmap.append(h.view(b, 1, H, p))
+        return h.reshape(b, -1), fmap
 
 
 class MultiPeriodDiscriminator(nn.Module):

@@ -643,3 +643,41 @@ def test_wn_stack_c_executor_equals_per_launch_path(dev, masked, grad_buffers):
         assert (a is None) == (b is None)
         if a is not None:
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("case", [
+    # period, H, Cin, Cout, k, stride, pad
+    (2, 17, 3, 8, 5, 3, 2),       # MPD strided layer (hifigan.py:178), H % 3 == 2
+    (3, 12, 4, 6, 5, 3, 2),       # H % 3 == 0
+    (11, 10, 16, 24, 5, 3, 2),    # the deep layers' shape family: 10 rows of 11
+    (5, 7, 1, 32, 5, 3, 2),       # first layer (one input channel), H % 3 == 1
+    (7, 9, 20, 20, 5, 1, 2),      # stride-1 layer (hifigan.py:179) = dilation-p conv
+    (11, 6, 24, 1, 3, 1, 1),      # conv_post (hifigan.py:180)
+    (3, 20, 4, 8, 7, 2, 3),       # another (k, stride, pad) family: taps over 4 row offsets, 2 phases
+])
+def test_period_strided_conv_matches_conv2d(dev, case, precision):
+    """The period discriminators' weight_norm(Conv2d((k,1), (stride,1), padding=(pad,0))) + LeakyReLU on [B,C,H,p] planes
+    (reference modules/hifigan/hifigan.py:171-223), computed as a dilation-p 1-D conv -- strided layers over the row
+    space-to-depth image (csrc/period_ops.hip) -- against torch's conv2d: output and all four gradients."""
+    p, H, cin, cout, k, stride, pad = case
+    g_ = torch.Generator().manual_seed(p * 100 + H)
+    B = 2
+    x = torch.randn(B, cin, H, p, generator=g_)
+    v = torch.randn(cout, cin, k, 1, generator=g_) * 0.3
+    gn = torch.rand(cout, 1, 1, 1, generator=g_) + 0.5
+    b = torch.randn(cout, generator=g_)
+    rl = [t.clone().requires_grad_(True) for t in (x, v, gn, b)]
+    w = rl[2] * rl[1] / rl[1].flatten(1).norm(dim=1).view(-1, 1, 1, 1)
+    yr = F.leaky_relu(F.conv2d(rl[0], w, rl[3], (stride, 1), (pad, 0)), 0.1)
+    dy = torch.randn(yr.shape, generator=g_)
+    yr.backward(dy)
+    xd, vd, gd, bd = (_leaf(t, dev) for t in (x, v, gn, b))
+    with SF.precision_scope(precision):
+        y, h_out = SF.period_strided_conv(xd.view(B, cin, H * p), H, p, vd, gd, bd, stride, pad, out_act=SF.ACT_LRELU, out_slope=0.1)
+        assert h_out == yr.shape[2] and y.shape == (B, cout, h_out * p)
+        y.backward(dy.reshape(B, cout, -1).to(dev))
+    tol = 2e-5 if precision == "fp32" else 6e-5
+    assert rel_err(y.view(yr.shape), yr) < tol
+    for got, ref in ((xd.grad, rl[0].grad), (vd.grad, rl[1].grad), (gd.grad, rl[2].grad), (bd.grad, rl[3].grad)):
+        assert rel_err(got, ref) < 5 * tol

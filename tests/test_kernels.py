@@ -429,6 +429,11 @@ WGQ_CASES = [
     (2, 40, 200, 1, 70, 1, 0, 1),        # 1x1, Cout (A rows) >= 128: 128x64 workgroup tile, ragged second tile
     (2, 130, 70, 1, 90, 1, 0, 1),        # 1x1, Cin (B rows) >= 128 only: 64x128 workgroup tile
     (1, 256, 384, 1, 130, 1, 0, 1),      # both sides wide: the A side is doubled
+    (2, 24, 40, 1, 110, 5, 22, 11),      # MPD (5,1) stride-1 conv as a dilation-p conv over [H, p] planes: tap groups narrowed to 3
+    (2, 20, 12, 1, 150, 2, 7, 7),        # ... and its space-to-depth form of the strided layers: 2 taps, dilation p
+    (2, 32, 64, 4, 140, 9, 4, 1),        # grouped, 16 x 8 channels per group: all 4 groups packed into one tile
+    (1, 48, 96, 6, 100, 3, 1, 1),        # 6 groups of 16 x 8: packed in pairs (largest power of two dividing 6)
+    (2, 128, 64, 2, 90, 3, 1, 1),        # 32 x 64 per group: nothing to pack
 ]
 
 
