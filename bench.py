@@ -536,6 +536,30 @@ def main():
         roof = cpu = None
         if rank == 0 and not args.no_roofline:
             roof = conv_roofline(trainer, task, batch, 3, 1 + args.warmup + args.steps, args.precision) if world == 1 else None
+            if roof is not None:
+                # the same launches with nothing beside them: in the benchmarked configuration weight gradients, the critic pass
+                # and the PPG encoder run on their own streams, and a conv's HIP events then include the time it shared the CUs
+                from neuralsvb_amd.modules import svb_vae as _svb
+                keys = ("wgrad_side_stream", "overlap_critic_pass")
+                saved, ppg = {k: hp.get(k) for k in keys}, _svb.PPG_SIDE_STREAM
+                try:
+                    for k in keys:
+                        hp[k] = False
+                    _svb.PPG_SIDE_STREAM = False
+                    ser = conv_roofline(trainer, task, batch, 3, 4 + args.warmup + args.steps, args.precision)
+                finally:
+                    for k in keys:
+                        if saved[k] is None:
+                            hp.pop(k, None)
+                        else:
+                            hp[k] = saved[k]
+                    _svb.PPG_SIDE_STREAM = ppg
+                if ser is not None:
+                    roof["serial_streams"] = {
+                        "note": "same step with weight gradients, critic pass and PPG encoder on the compute stream: the kernel's own duration",
+                        "kernel": ser["kernel"], "achieved": ser["achieved"], "frac": ser["frac"], "avg_launch_us": ser["avg_launch_us"],
+                        "frac_executed": ser["frac_executed"], "all_conv_kernels": ser["all_conv_kernels"]}
+                    log(f"conv roofline with serial streams: {ser['achieved']:.1f} TFLOP/s = {ser['frac']:.4f} of bf16 peak")
         if world > 1:
             dist.barrier()
         if rank == 0 and world == 1 and not args.no_cpu_baseline:

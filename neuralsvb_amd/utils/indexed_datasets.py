@@ -1,5 +1,6 @@
 """On-disk dataset of the reference, byte-compatible (utils/indexed_datasets.py:7-54):
 `<prefix>.data` = concatenated pickles, `<prefix>.idx` = np.save({'offsets': [...]})."""
+import os
 import pickle
 
 import numpy as np
@@ -21,8 +22,17 @@ class IndexedDataset:
             raise IndexError("index out of range")
         if i in self._cache:
             return self._cache[i]
-        self._fh.seek(self.offsets[i])
-        item = pickle.loads(self._fh.read(self.offsets[i + 1] - self.offsets[i]))
+        # positional read: DataLoader workers forked AFTER the file was opened share this descriptor -- and with seek + read its
+        # file offset -- with their parent and with each other (the reference opens lazily per process and has the same hazard
+        # once an item was read before the fork; round 3's multi-worker soak of the device collater hit it as UnpicklingError)
+        n, off = self.offsets[i + 1] - self.offsets[i], self.offsets[i]
+        buf = os.pread(self._fh.fileno(), n, off)
+        while len(buf) < n:
+            more = os.pread(self._fh.fileno(), n - len(buf), off + len(buf))
+            if not more:
+                raise EOFError(f"{self.path}.data ends inside item {i}")
+            buf += more
+        item = pickle.loads(buf)
         if self._cache_cap:
             if len(self._cache) >= self._cache_cap:
                 self._cache.pop(next(iter(self._cache)))

@@ -86,12 +86,14 @@ def test_build_dataloader_with_device_collate(ds, gpu_only):
     from neuralsvb_amd.tasks.svb_vae_task import SVBVAEMleTask
     from neuralsvb_amd.utils.trainer import move_to_device
     task = SVBVAEMleTask()
-    host = list(task.build_dataloader(ds, False, hparams["max_tokens"], 4))
-    hparams["device_collate"] = True
+    prev = hparams.get("device_collate", False)
     try:
+        hparams["device_collate"] = False
+        host = list(task.build_dataloader(ds, False, hparams["max_tokens"], 4))
+        hparams["device_collate"] = True
         devl = list(task.build_dataloader(ds, False, hparams["max_tokens"], 4))
     finally:
-        hparams["device_collate"] = False
+        hparams["device_collate"] = prev
     assert len(devl) == len(host) == 2
     for hb, db in zip(host, devl):
         hb = move_to_device(hb, gpu_only)
@@ -99,3 +101,36 @@ def test_build_dataloader_with_device_collate(ds, gpu_only):
         for k in ("mels", "prof_mels", "pitch", "prof_pitch", "a2p_f0_alignment", "uv", "prof_uv", "multi_spk_emb"):
             assert torch.equal(db[k], hb[k]), k
         assert int(_ulp_diff(db["f0"].cpu(), hb["f0"].cpu()).max()) <= 1
+
+
+@pytest.mark.gpu
+def test_device_collate_multi_worker_soak(ds, gpu_only, monkeypatch):
+    """The loader as a training run uses it: two worker processes decode items, batches of changing size and length arrive
+    back to back for several epochs (the pinned staging buffers and the H2D copies of batch n+1 are reused / issued while
+    batch n's kernels may still run), every batch compared with the host collater's.  This is the soak behind
+    `device_collate: true` being the YAML default."""
+    from neuralsvb_amd.tasks.device_collate import DeviceCollateLoader
+    from neuralsvb_amd.utils.trainer import move_to_device
+    rng = np.random.RandomState(3)
+    batches = []
+    for _ in range(6):                               # 6 epochs of ragged batches (1..5 items), shuffled
+        order = rng.permutation(C.N_TRAIN).tolist()
+        while order:
+            n = int(rng.randint(1, 6))
+            batches.append(order[:n])
+            order = order[n:]
+    loader = DeviceCollateLoader(ds, batches, gpu_only, num_workers=2)
+    seen = 0
+    kept = []
+    for idx, db in zip(batches, loader):
+        hb = move_to_device(ds.collater([ds[i] for i in idx]), gpu_only)
+        assert db["item_name"] == hb["item_name"]
+        for k in ("mels", "prof_mels", "pitch", "prof_pitch", "a2p_f0_alignment", "uv", "prof_uv", "multi_spk_emb"):
+            assert torch.equal(db[k], hb[k]), (seen, k)
+        assert int(_ulp_diff(db["f0"].cpu(), hb["f0"].cpu()).max()) <= 1
+        kept.append((db["mels"], hb["mels"]))        # earlier batches must survive the staging buffers' reuse
+        seen += 1
+    assert seen == len(batches) >= 12
+    torch.cuda.synchronize()
+    for a, b in kept:
+        assert torch.equal(a, b)

@@ -48,6 +48,22 @@ wall = t1 - t0
 print(f"{len(rows)} dispatches {note}; span {wall / 1e6:.2f} ms = {wall / 1e6 / steps:.2f} ms/step over {steps:g} steps; "
       f"sum of kernel durations {busy / 1e6 / steps:.2f} ms/step ({100.0 * busy / wall:.1f} % of the span); "
       f"{len(rows) / steps:.0f} launches/step")
+# time with at least one kernel running (union of the dispatch intervals): span - union = the device sat idle (host-bound gaps,
+# launch latency); union < sum = kernels of different streams overlapped
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows)
+union, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+gaps = []
+for s_, e_ in iv[1:]:
+    if s_ > cur_e:
+        union += cur_e - cur_s
+        gaps.append(s_ - cur_e)
+        cur_s, cur_e = s_, e_
+    else:
+        cur_e = max(cur_e, e_)
+union += cur_e - cur_s
+big = sum(g_ for g_ in gaps if g_ > 20000)
+print(f"device busy (union of kernel intervals) {union / 1e6 / steps:.2f} ms/step, idle {(wall - union) / 1e6 / steps:.2f} ms/step in "
+      f"{len(gaps) / steps:.0f} gaps/step (of which gaps > 20 us: {big / 1e6 / steps:.2f} ms/step)")
 for g, (d, c) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
     print(f"  {g:26s} {d / 1e6 / steps:7.3f} ms/step {c / steps:7.1f} launches/step")
 print(f"{'ms/step':>9} {'calls/step':>10} {'avg us':>8}  kernel")
