@@ -537,6 +537,9 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     // 32-bit offset and bias, per column block n the position; the store is `uniform base + 32-bit lane offset`.  (Written
     // naively -- 64-bit index products and the activation switch per element -- this block cost ~45 VALU instructions per
     // element, a fifth of the workgroup's time.)  The feature switches are kernel arguments, i.e. scalar branches.
+    // (Round 3 tried the stores as 16-byte quads through a per-wave LDS transpose -- 4 VMEM instructions per 32x32 tile and lane
+    // instead of 16, gate / residual / mask as 16-byte loads: the epilogue went from 7.1-8.0k to 11-14k cycles, every shape got
+    // 2-8 % slower, profiles/r03_conv_vector_epilogue_ab.log.  The epilogue is not bound by its store-instruction count.)
     const int out_base = p.phase_out_base[ph];
     dbg_stage = SVBQ_DBG_STAGES - 1;
     SVBQ_STAMP(6)

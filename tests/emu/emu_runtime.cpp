@@ -81,6 +81,8 @@ void wave_sync() {
 
 int emu_lane_id() { return g_blk->fibers[g_blk->cur].linear & 63; }
 
+void emu_wave_sync() { wave_sync(); }
+
 void emu_syncthreads() {
     Block* b = g_blk;
     const unsigned gen = b->bar_gen;

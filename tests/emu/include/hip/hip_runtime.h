@@ -75,6 +75,8 @@ static inline void __builtin_amdgcn_s_barrier_emu() { emu_syncthreads(); }
 #define __builtin_amdgcn_s_barrier() emu_syncthreads()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+void emu_wave_sync();                                             // all lanes of the calling wave arrive before any continues
+#define __builtin_amdgcn_wave_barrier() emu_wave_sync()
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 // LDS-DMA (global_load_lds_dwordx4): lane L copies its 16 bytes to wave_base + 16*L; completes immediately here
 #define SVB_GLDS16(g, lds_wave_base) memcpy((char*)(lds_wave_base) + 16 * emu_lane_id(), (const void*)(g), 16)
