@@ -191,11 +191,149 @@ __global__ __launch_bounds__(256) void svb_gn_relu_bwd_kernel(const float* gy, c
     }
 }
 
+// Row-resident forms (round 3): one WAVE per channel of the group, the channel's row held in registers as KR 16-byte quads per
+// lane -- h (and gy) are read from HBM exactly once, every load of a row is in flight at once, the channel's gamma / beta are
+// wave-uniform scalars.  The streaming kernels above (scalar dependent-latency loops over a 72 KB slab, 2 workgroups per CU)
+// ran at 0.7-1.2 TB/s: 88 / 91 us per call at [32, 256, 1124], G = 16 (tools/ewbench.py).  Need cg <= 16, T % 4 == 0,
+// T / 4 <= 64 * KR and 16-byte aligned tensors; other shapes keep the kernels above.
+template <int KR>
+__global__ __launch_bounds__(1024) void svb_gn_relu_fwd_rows_kernel(const float* h, const float* res, const float* gamma,
+                                                                   const float* beta, float* y, float* stats, int C, int T,
+                                                                   int G, float eps) {
+    __shared__ float red[16];
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int cg = C / G, n = cg * T, T4 = T >> 2;
+    const int lane = threadIdx.x & 63, cl = threadIdx.x >> 6;          // blockDim = 64 * cg
+    const int c = g * cg + cl;
+    const size_t row = ((size_t)b * C + c) * T;
+    const float4* hp = reinterpret_cast<const float4*>(h + row);
+    float4 v[KR];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        const int i = lane + 64 * k;
+        v[k] = i < T4 ? hp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    s = svb_wave_sum(s);
+    if (lane == 0) red[cl] = s;
+    __syncthreads();
+    float tot = 0.f;
+    for (int w = 0; w < cg; ++w) tot += red[w];
+    const float mean = tot / (float)n;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        if (lane + 64 * k < T4) {
+            const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    }
+    q = svb_wave_sum(q);
+    __syncthreads();
+    if (lane == 0) red[cl] = q;
+    __syncthreads();
+    tot = 0.f;
+    for (int w = 0; w < cg; ++w) tot += red[w];
+    const float rstd = 1.f / sqrtf(tot / (float)n + eps);
+    if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
+    const float gm = gamma[c], bt = beta[c];
+    const float4* rp = res ? reinterpret_cast<const float4*>(res + row) : nullptr;
+    float4* yp = reinterpret_cast<float4*>(y + row);
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        const int i = lane + 64 * k;
+        if (i < T4) {
+            float4 o;
+            o.x = fmaxf((v[k].x - mean) * rstd * gm + bt, 0.f);
+            o.y = fmaxf((v[k].y - mean) * rstd * gm + bt, 0.f);
+            o.z = fmaxf((v[k].z - mean) * rstd * gm + bt, 0.f);
+            o.w = fmaxf((v[k].w - mean) * rstd * gm + bt, 0.f);
+            if (rp) { const float4 r = rp[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+            yp[i] = o;
+        }
+    }
+}
+
+template <int KR>
+__global__ __launch_bounds__(1024) void svb_gn_relu_bwd_rows_kernel(const float* gy, const float* h, const float* gamma,
+                                                                   const float* beta, const float* stats, float* dh, float* dgb,
+                                                                   int B, int C, int T, int G) {
+    __shared__ float ch_a[16], ch_b[16];
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int cg = C / G, n = cg * T, T4 = T >> 2;
+    const int lane = threadIdx.x & 63, cl = threadIdx.x >> 6;
+    const int c = g * cg + cl;
+    const size_t row = ((size_t)b * C + c) * T;
+    const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
+    const float gm = gamma[c], bt = beta[c];
+    const float4* hp = reinterpret_cast<const float4*>(h + row);
+    const float4* gp = reinterpret_cast<const float4*>(gy + row);
+    float4 xh[KR], gg[KR];                     // xhat and the ReLU-gated gradient of this lane's quads
+    float a = 0.f, bb = 0.f;
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        const int i = lane + 64 * k;
+        const bool ok = i < T4;
+        const float4 hv = ok ? hp[i] : make_float4(mean, mean, mean, mean);
+        const float4 gv = ok ? gp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        xh[k] = make_float4((hv.x - mean) * rstd, (hv.y - mean) * rstd, (hv.z - mean) * rstd, (hv.w - mean) * rstd);
+        gg[k].x = (xh[k].x * gm + bt) > 0.f ? gv.x : 0.f;
+        gg[k].y = (xh[k].y * gm + bt) > 0.f ? gv.y : 0.f;
+        gg[k].z = (xh[k].z * gm + bt) > 0.f ? gv.z : 0.f;
+        gg[k].w = (xh[k].w * gm + bt) > 0.f ? gv.w : 0.f;
+        a += (gg[k].x * xh[k].x + gg[k].y * xh[k].y) + (gg[k].z * xh[k].z + gg[k].w * xh[k].w);
+        bb += (gg[k].x + gg[k].y) + (gg[k].z + gg[k].w);
+    }
+    a = svb_wave_sum(a);
+    bb = svb_wave_sum(bb);
+    if (lane == 0) {
+        ch_a[cl] = a; ch_b[cl] = bb;
+        dgb[(size_t)b * C + c] = a;
+        dgb[(size_t)B * C + (size_t)b * C + c] = bb;
+    }
+    __syncthreads();
+    float s1 = 0.f, s2 = 0.f;
+    for (int w = 0; w < cg; ++w) { const float gw = gamma[g * cg + w]; s1 += gw * ch_b[w]; s2 += gw * ch_a[w]; }
+    const float inv_n = 1.f / (float)n;
+    float4* dp = reinterpret_cast<float4*>(dh + row);
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        const int i = lane + 64 * k;
+        if (i < T4) {
+            float4 o;
+            o.x = rstd * (gg[k].x * gm - inv_n * (s1 + xh[k].x * s2));
+            o.y = rstd * (gg[k].y * gm - inv_n * (s1 + xh[k].y * s2));
+            o.z = rstd * (gg[k].z * gm - inv_n * (s1 + xh[k].z * s2));
+            o.w = rstd * (gg[k].w * gm - inv_n * (s1 + xh[k].w * s2));
+            dp[i] = o;
+        }
+    }
+}
+
+static const bool g_svb_gn_rows_off = getenv("SVB_GN_NO_ROWS") != nullptr;       // A/B switch
+// KR of the row-resident kernels for this shape, 0 = not eligible
+static int svb_gn_rows_kr(int C, int T, int G, const void* p0, const void* p1, const void* p2) {
+    if (g_svb_gn_rows_off || C / G > 16 || (T & 3)) return 0;
+    if ((((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 15) != 0) return 0;
+    const int need = ((T >> 2) + 63) / 64;
+    return need <= 2 ? 2 : (need <= 5 ? 5 : (need <= 8 ? 8 : 0));
+}
+
 extern "C" int svb_gn_relu_fwd(const float* h, const float* res, const float* gamma, const float* beta, float* y, float* stats,
                                int B, int C, int T, int G, float eps, void* stream) {
     if (!h || !gamma || !beta || !y || !stats || B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G || C / G > 64) return SVB_ERR_ARG;
-    hipLaunchKernelGGL(svb_gn_relu_fwd_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, h, res, gamma, beta, y, stats, C, T,
-                       G, eps);
+    const int kr = svb_gn_rows_kr(C, T, G, h, res, y);
+    const dim3 rows_block(64 * (C / G));
+    if (kr == 2)
+        hipLaunchKernelGGL(svb_gn_relu_fwd_rows_kernel<2>, dim3(B * G), rows_block, 0, (hipStream_t)stream, h, res, gamma, beta, y, stats, C, T, G, eps);
+    else if (kr == 5)
+        hipLaunchKernelGGL(svb_gn_relu_fwd_rows_kernel<5>, dim3(B * G), rows_block, 0, (hipStream_t)stream, h, res, gamma, beta, y, stats, C, T, G, eps);
+    else if (kr == 8)
+        hipLaunchKernelGGL(svb_gn_relu_fwd_rows_kernel<8>, dim3(B * G), rows_block, 0, (hipStream_t)stream, h, res, gamma, beta, y, stats, C, T, G, eps);
+    else
+        hipLaunchKernelGGL(svb_gn_relu_fwd_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, h, res, gamma, beta, y, stats, C, T,
+                           G, eps);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
@@ -204,8 +342,17 @@ extern "C" int svb_gn_relu_bwd(const float* gy, const float* h, const float* gam
                                float* dh, float* dgb, int B, int C, int T, int G, void* stream) {
     if (!gy || !h || !gamma || !beta || !stats || !dh || !dgb || B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G || C / G > 64)
         return SVB_ERR_ARG;
-    hipLaunchKernelGGL(svb_gn_relu_bwd_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, gy, h, gamma, beta, stats, dh, dgb,
-                       B, C, T, G);
+    const int kr = svb_gn_rows_kr(C, T, G, gy, h, dh);
+    const dim3 rows_block(64 * (C / G));
+    if (kr == 2)
+        hipLaunchKernelGGL(svb_gn_relu_bwd_rows_kernel<2>, dim3(B * G), rows_block, 0, (hipStream_t)stream, gy, h, gamma, beta, stats, dh, dgb, B, C, T, G);
+    else if (kr == 5)
+        hipLaunchKernelGGL(svb_gn_relu_bwd_rows_kernel<5>, dim3(B * G), rows_block, 0, (hipStream_t)stream, gy, h, gamma, beta, stats, dh, dgb, B, C, T, G);
+    else if (kr == 8)
+        hipLaunchKernelGGL(svb_gn_relu_bwd_rows_kernel<8>, dim3(B * G), rows_block, 0, (hipStream_t)stream, gy, h, gamma, beta, stats, dh, dgb, B, C, T, G);
+    else
+        hipLaunchKernelGGL(svb_gn_relu_bwd_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, gy, h, gamma, beta, stats, dh, dgb,
+                           B, C, T, G);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }

@@ -525,12 +525,18 @@ def test_persistent_weight_images_and_multi_tensor_repack(dev):
         SF.set_precision("fp32")
 
 
-def test_group_norm_relu_residual_matches_torch(dev):
+@pytest.mark.parametrize("shape", [(3, 48, 37, 3),        # T % 4 != 0: the streaming kernels
+                                   (2, 32, 40, 2),        # row-resident kernels (one wave per channel), 2 quads per lane
+                                   (2, 64, 1124, 4),      # the step's row length: 5 quads per lane
+                                   (1, 16, 2000, 1),      # 8 quads per lane
+                                   (2, 24, 64, 3),        # 8 channels per group: 512-thread workgroups
+                                   (1, 128, 48, 2)])      # 64 channels per group: streaming kernels
+def test_group_norm_relu_residual_matches_torch(dev, shape):
     """ConvBlock's GroupNorm(C/16) + ReLU and ConvStacks' residual (common_layers.py:688-707,739-773): values and all
     gradients against stock torch fp32."""
     import torch.nn.functional as F
     g_ = torch.Generator().manual_seed(21)
-    B, Cc, T, G = 3, 48, 37, 3
+    B, Cc, T, G = shape
     h = (torch.randn(B, Cc, T, generator=g_) * 1.7 + 0.3).requires_grad_(True)
     res = torch.randn(B, Cc, T, generator=g_).requires_grad_(True)
     gm = (torch.rand(Cc, generator=g_) + 0.5).requires_grad_(True)
