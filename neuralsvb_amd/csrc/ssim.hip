@@ -3,8 +3,8 @@
 // reference's mel loss (modules/commons/ssim.py:331-351, called by tasks/tts/fs2.py:166-175 on [B,1,T,80]+6).
 //
 // One workgroup owns a tile of TT frames x all F bins; x=pred+bias and y=target+bias are staged once into LDS with the
-// 5-wide zero halo that F.conv2d(padding=5) implies, and every thread evaluates full 11x11 windows from LDS
-// (121 taps x 5 moments per pixel: ~1.7 GFLOP at B=16 -- VALU work that hides under the HBM stream).
+// 5-wide zero halo that F.conv2d(padding=5) implies; the separable window is applied along the bins into LDS planes, then
+// along the frames per pixel (see ssim_hpass5 / ssim_vpass5).
 // Algorithmic bytes: forward reads 2 and writes 1 value per pixel (12 B/pixel); backward reads 3, writes 1 (+3 maps
 // of workspace written and re-read).  Strided inputs are accepted so the [B,80,T] decoder output is read in place.
 #include "svb_common.h"
@@ -14,61 +14,136 @@
 #define SSIM_R 5
 #define SSIM_TT 16
 #define SSIM_FMAX 128
+#define SSIM_ROWS_ (SSIM_TT + 2 * SSIM_R)
 
 struct SsimWin { float g[SSIM_W]; };
 
 struct SsimStats { float mu1, mu2, e11, e22, e12; };
 
-__device__ __forceinline__ SsimStats ssim_window(const float* xs, const float* ys, int row, int col, int ld, const SsimWin& w) {
-    SsimStats s = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < SSIM_W; ++i) {
-        const float gi = w.g[i];
-        const float* xr = xs + (row + i) * ld + col;
-        const float* yr = ys + (row + i) * ld + col;
+// The gaussian window is separable: the five moment images are filtered along the bins first (every staged row, into `hm`:
+// 5 planes of rows x F), then along the frames per output pixel -- 11 + 11 taps per moment instead of 121.  (Round 3: the
+// full 2-D windows made these kernels VALU/LDS-bound -- ~1.2 k VALU ops and 242 LDS reads per pixel, 70 us per call at
+// [32, 1124, 80] for 23 MB of input -- the separable form needs ~150 and ~90.)
+__device__ __forceinline__ void ssim_hpass5(const float* xs, const float* ys, int ld, int F, int rows, const SsimWin& w, float* hm) {
+    const int n = rows * F;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int r = i / F, c = i - r * F;
+        const float* xr = xs + r * ld + c;
+        const float* yr = ys + r * ld + c;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
 #pragma unroll
         for (int j = 0; j < SSIM_W; ++j) {
-            const float wij = gi * w.g[j];
-            const float x = xr[j], y = yr[j];
-            s.mu1 = fmaf(wij, x, s.mu1);
-            s.mu2 = fmaf(wij, y, s.mu2);
-            s.e11 = fmaf(wij, x * x, s.e11);
-            s.e22 = fmaf(wij, y * y, s.e22);
-            s.e12 = fmaf(wij, x * y, s.e12);
+            const float g = w.g[j], x = xr[j], y = yr[j];
+            a0 = fmaf(g, x, a0);
+            a1 = fmaf(g, y, a1);
+            a2 = fmaf(g, x * x, a2);
+            a3 = fmaf(g, y * y, a3);
+            a4 = fmaf(g, x * y, a4);
         }
+        hm[i] = a0; hm[n + i] = a1; hm[2 * n + i] = a2; hm[3 * n + i] = a3; hm[4 * n + i] = a4;
+    }
+}
+
+__device__ __forceinline__ SsimStats ssim_vpass5(const float* hm, int n, int row, int col, int F, const SsimWin& w) {
+    SsimStats s = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* p = hm + row * F + col;
+#pragma unroll
+    for (int i = 0; i < SSIM_W; ++i) {
+        const float g = w.g[i];
+        s.mu1 = fmaf(g, p[i * F], s.mu1);
+        s.mu2 = fmaf(g, p[n + i * F], s.mu2);
+        s.e11 = fmaf(g, p[2 * n + i * F], s.e11);
+        s.e22 = fmaf(g, p[3 * n + i * F], s.e22);
+        s.e12 = fmaf(g, p[4 * n + i * F], s.e12);
     }
     return s;
 }
 
-// stage x,y rows [t0-halo, t0+TT+halo) x cols [-5, F+5) into LDS (zero outside the image)
+// the same for the three cotangent maps of the backward's second stage
+__device__ __forceinline__ void ssim_hpass3(const float* ga, const float* gb, const float* gc, int ld, int F, int rows,
+                                            const SsimWin& w, float* hm) {
+    const int n = rows * F;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int r = i / F, c = i - r * F;
+        const int base = r * ld + c;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < SSIM_W; ++j) {
+            const float g = w.g[j];
+            a0 = fmaf(g, ga[base + j], a0);
+            a1 = fmaf(g, gb[base + j], a1);
+            a2 = fmaf(g, gc[base + j], a2);
+        }
+        hm[i] = a0; hm[n + i] = a1; hm[2 * n + i] = a2;
+    }
+}
+
+__device__ __forceinline__ void ssim_vpass3(const float* hm, int n, int row, int col, int F, const SsimWin& w, float& fa, float& fb,
+                                            float& fc) {
+    const float* p = hm + row * F + col;
+    fa = fb = fc = 0.f;
+#pragma unroll
+    for (int i = 0; i < SSIM_W; ++i) {
+        const float g = w.g[i];
+        fa = fmaf(g, p[i * F], fa);
+        fb = fmaf(g, p[n + i * F], fb);
+        fc = fmaf(g, p[2 * n + i * F], fc);
+    }
+}
+
+// dynamic LDS of the stencil kernels: `tiles` staged images of rows x (F + 10) followed by `planes` filtered planes of rows x F
+#define SSIM_ROWS (SSIM_TT + 2 * SSIM_R)
+static size_t ssim_lds_bytes(int F, int tiles, int planes) {
+    return sizeof(float) * (size_t)SSIM_ROWS * ((size_t)tiles * (F + 2 * SSIM_R) + (size_t)planes * F);
+}
+
+// stage x,y rows [t0-halo, t0+TT+halo) x cols [-5, F+5) into LDS (zero outside the image).  The thread -> element map follows the
+// source's contiguous axis: the decoder's mel is read in place as [B,80,T] (frames contiguous, st < sf), where a bins-fastest
+// map makes every lane of a load touch its own cache line.  All loads of a tile are issued before the first LDS store.
+#define SSIM_STAGE_IT ((SSIM_ROWS_ * (SSIM_FMAX + 2 * SSIM_R) + 255) / 256)
 __device__ __forceinline__ void ssim_stage(const float* p, long sb, long st, long sf, int b, int T, int F, int t_first, int rows,
                                            float bias, float* dst, int ld) {
     const int n = rows * ld;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int r = i / ld, c = i - r * ld;
+    const bool tmaj = st < sf;                    // wave-uniform
+    const float* pb = p + (long)b * sb;
+    float v[SSIM_STAGE_IT];
+    int di[SSIM_STAGE_IT];
+#pragma unroll
+    for (int k = 0; k < SSIM_STAGE_IT; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        int r, c;
+        if (tmaj) { c = i / rows; r = i - c * rows; } else { r = i / ld; c = i - r * ld; }
         const int t = t_first + r, f = c - SSIM_R;
-        float v = 0.f;
-        if (t >= 0 && t < T && f >= 0 && f < F) v = p[(long)b * sb + (long)t * st + (long)f * sf] + bias;
-        dst[i] = v;
+        const bool ok = i < n && t >= 0 && t < T && f >= 0 && f < F;
+        di[k] = i < n ? r * ld + c : -1;
+        v[k] = ok ? pb[(long)t * st + (long)f * sf] + bias : 0.f;
     }
+#pragma unroll
+    for (int k = 0; k < SSIM_STAGE_IT; ++k)
+        if (di[k] >= 0) dst[di[k]] = v[k];
 }
 
 __global__ __launch_bounds__(256) void svb_ssim_fwd_kernel(const float* pred, long psb, long pst, long psf, const float* tgt,
                                                            long tsb, long tst, long tsf, float* out, int B, int T, int F,
                                                            float bias, SsimWin w) {
-    __shared__ float xs[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
-    __shared__ float ys[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    HIP_DYNAMIC_SHARED(float, ssim_smem)
+    float* xs = ssim_smem;
+    float* ys = xs + SSIM_ROWS * (F + 2 * SSIM_R);
+    float* hm = ys + SSIM_ROWS * (F + 2 * SSIM_R);
+    const int hn = SSIM_ROWS * F;
     const int b = blockIdx.y, t0 = blockIdx.x * SSIM_TT;
     const int ld = F + 2 * SSIM_R, rows = SSIM_TT + 2 * SSIM_R;
     ssim_stage(pred, psb, pst, psf, b, T, F, t0 - SSIM_R, rows, bias, xs, ld);
     ssim_stage(tgt, tsb, tst, tsf, b, T, F, t0 - SSIM_R, rows, bias, ys, ld);
+    __syncthreads();
+    ssim_hpass5(xs, ys, ld, F, rows, w, hm);
     __syncthreads();
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
         const int r = i / F, c = i - r * F;
         const int t = t0 + r;
         if (t >= T) continue;
-        const SsimStats s = ssim_window(xs, ys, r, c, ld, w);
+        const SsimStats s = ssim_vpass5(hm, hn, r, c, F, w);
         const float mu1_sq = s.mu1 * s.mu1, mu2_sq = s.mu2 * s.mu2, mu12 = s.mu1 * s.mu2;
         const float s1 = s.e11 - mu1_sq, s2 = s.e22 - mu2_sq, s12 = s.e12 - mu12;
         out[((long)b * T + t) * F + c] = ((2.f * mu12 + C1) * (2.f * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2));
@@ -79,12 +154,17 @@ __global__ __launch_bounds__(256) void svb_ssim_fwd_kernel(const float* pred, lo
 __global__ __launch_bounds__(256) void svb_ssim_bwd1_kernel(const float* pred, long psb, long pst, long psf, const float* tgt,
                                                             long tsb, long tst, long tsf, const float* dmap, float* gws, int B,
                                                             int T, int F, float bias, SsimWin w) {
-    __shared__ float xs[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
-    __shared__ float ys[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    HIP_DYNAMIC_SHARED(float, ssim_smem)
+    float* xs = ssim_smem;
+    float* ys = xs + SSIM_ROWS * (F + 2 * SSIM_R);
+    float* hm = ys + SSIM_ROWS * (F + 2 * SSIM_R);
+    const int hn = SSIM_ROWS * F;
     const int b = blockIdx.y, t0 = blockIdx.x * SSIM_TT;
     const int ld = F + 2 * SSIM_R, rows = SSIM_TT + 2 * SSIM_R;
     ssim_stage(pred, psb, pst, psf, b, T, F, t0 - SSIM_R, rows, bias, xs, ld);
     ssim_stage(tgt, tsb, tst, tsf, b, T, F, t0 - SSIM_R, rows, bias, ys, ld);
+    __syncthreads();
+    ssim_hpass5(xs, ys, ld, F, rows, w, hm);
     __syncthreads();
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     const long plane = (long)B * T * F;
@@ -92,7 +172,7 @@ __global__ __launch_bounds__(256) void svb_ssim_bwd1_kernel(const float* pred, l
         const int r = i / F, c = i - r * F;
         const int t = t0 + r;
         if (t >= T) continue;
-        const SsimStats s = ssim_window(xs, ys, r, c, ld, w);
+        const SsimStats s = ssim_vpass5(hm, hn, r, c, F, w);
         const float mu1_sq = s.mu1 * s.mu1, mu2_sq = s.mu2 * s.mu2, mu12 = s.mu1 * s.mu2;
         const float s1 = s.e11 - mu1_sq, s2 = s.e22 - mu2_sq, s12 = s.e12 - mu12;
         const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s1 + s2 + C2;
@@ -111,9 +191,12 @@ __global__ __launch_bounds__(256) void svb_ssim_bwd1_kernel(const float* pred, l
 __global__ __launch_bounds__(256) void svb_ssim_bwd2_kernel(const float* pred, long psb, long pst, long psf, const float* tgt,
                                                             long tsb, long tst, long tsf, const float* gws, float* dpred, int B,
                                                             int T, int F, float bias, SsimWin w) {
-    __shared__ float ga[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
-    __shared__ float gb[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
-    __shared__ float gc[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    HIP_DYNAMIC_SHARED(float, ssim_smem)
+    float* ga = ssim_smem;
+    float* gb = ga + SSIM_ROWS * (F + 2 * SSIM_R);
+    float* gc = gb + SSIM_ROWS * (F + 2 * SSIM_R);
+    float* hm = gc + SSIM_ROWS * (F + 2 * SSIM_R);
+    const int hn = SSIM_ROWS * F;
     const int b = blockIdx.y, t0 = blockIdx.x * SSIM_TT;
     const int ld = F + 2 * SSIM_R, rows = SSIM_TT + 2 * SSIM_R;
     const long plane = (long)B * T * F;
@@ -122,23 +205,14 @@ __global__ __launch_bounds__(256) void svb_ssim_bwd2_kernel(const float* pred, l
     ssim_stage(gws + plane, sb, F, 1, b, T, F, t0 - SSIM_R, rows, 0.f, gb, ld);
     ssim_stage(gws + 2 * plane, sb, F, 1, b, T, F, t0 - SSIM_R, rows, 0.f, gc, ld);
     __syncthreads();
+    ssim_hpass3(ga, gb, gc, ld, F, rows, w, hm);
+    __syncthreads();
     for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
         const int r = i / F, c = i - r * F;
         const int t = t0 + r;
         if (t >= T) continue;
-        float fa = 0.f, fb = 0.f, fc = 0.f;
-#pragma unroll
-        for (int ii = 0; ii < SSIM_W; ++ii) {
-            const float gi = w.g[ii];
-            const int base = (r + ii) * ld + c;
-#pragma unroll
-            for (int j = 0; j < SSIM_W; ++j) {
-                const float wij = gi * w.g[j];
-                fa = fmaf(wij, ga[base + j], fa);
-                fb = fmaf(wij, gb[base + j], fb);
-                fc = fmaf(wij, gc[base + j], fc);
-            }
-        }
+        float fa, fb, fc;
+        ssim_vpass3(hm, hn, r, c, F, w, fa, fb, fc);
         const float x = pred[(long)b * psb + (long)t * pst + (long)c * psf] + bias;
         const float y = tgt[(long)b * tsb + (long)t * tst + (long)c * tsf] + bias;
         dpred[((long)b * T + t) * F + c] = fa + 2.f * x * fb + y * fc;
@@ -170,8 +244,11 @@ __device__ __forceinline__ void mel_speech_rows(const float* tgt, long tsb, long
 __global__ __launch_bounds__(256) void svb_mel_loss_fwd_kernel(const float* pred, long psb, long pst, long psf, const float* tgt,
                                                                long tsb, long tst, long tsf, float* part, int B, int T, int F,
                                                                float bias, int terms, SsimWin w) {
-    __shared__ float xs[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
-    __shared__ float ys[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    HIP_DYNAMIC_SHARED(float, ssim_smem)
+    float* xs = ssim_smem;
+    float* ys = xs + SSIM_ROWS * (F + 2 * SSIM_R);
+    float* hm = ys + SSIM_ROWS * (F + 2 * SSIM_R);
+    const int hn = SSIM_ROWS * F;
     __shared__ float wrow[SSIM_TT];
     __shared__ float red[4];
     const int b = blockIdx.y, t0 = blockIdx.x * SSIM_TT;
@@ -181,6 +258,10 @@ __global__ __launch_bounds__(256) void svb_mel_loss_fwd_kernel(const float* pred
         ssim_stage(tgt, tsb, tst, tsf, b, T, F, t0 - SSIM_R, rows, bias, ys, ld);
     }
     mel_speech_rows(tgt, tsb, tst, tsf, b, t0, T, F, wrow);
+    if (terms & 2) {
+        ssim_hpass5(xs, ys, ld, F, rows, w, hm);
+        __syncthreads();
+    }
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     float a_l1 = 0.f, a_ss = 0.f, a_w = 0.f;
     for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
@@ -195,7 +276,7 @@ __global__ __launch_bounds__(256) void svb_mel_loss_fwd_kernel(const float* pred
             a_l1 += fabsf(p - y) * wt;
         }
         if (terms & 2) {
-            const SsimStats s = ssim_window(xs, ys, r, c, ld, w);
+            const SsimStats s = ssim_vpass5(hm, hn, r, c, F, w);
             const float mu1_sq = s.mu1 * s.mu1, mu2_sq = s.mu2 * s.mu2, mu12 = s.mu1 * s.mu2;
             const float s1 = s.e11 - mu1_sq, s2 = s.e22 - mu2_sq, s12 = s.e12 - mu12;
             const float m = ((2.f * mu12 + C1) * (2.f * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2));
@@ -226,14 +307,19 @@ __global__ __launch_bounds__(256) void svb_mel_loss_bwd1_kernel(const float* pre
                                                                 long tsb, long tst, long tsf, const float* gout,
                                                                 const float* sums, float* gws, int B, int T, int F, float bias,
                                                                 SsimWin w) {
-    __shared__ float xs[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
-    __shared__ float ys[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    HIP_DYNAMIC_SHARED(float, ssim_smem)
+    float* xs = ssim_smem;
+    float* ys = xs + SSIM_ROWS * (F + 2 * SSIM_R);
+    float* hm = ys + SSIM_ROWS * (F + 2 * SSIM_R);
+    const int hn = SSIM_ROWS * F;
     __shared__ float wrow[SSIM_TT];
     const int b = blockIdx.y, t0 = blockIdx.x * SSIM_TT;
     const int ld = F + 2 * SSIM_R, rows = SSIM_TT + 2 * SSIM_R;
     ssim_stage(pred, psb, pst, psf, b, T, F, t0 - SSIM_R, rows, bias, xs, ld);
     ssim_stage(tgt, tsb, tst, tsf, b, T, F, t0 - SSIM_R, rows, bias, ys, ld);
     mel_speech_rows(tgt, tsb, tst, tsf, b, t0, T, F, wrow);
+    ssim_hpass5(xs, ys, ld, F, rows, w, hm);
+    __syncthreads();
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     const long plane = (long)B * T * F;
     const float gs = -gout[1] / sums[2];
@@ -241,7 +327,7 @@ __global__ __launch_bounds__(256) void svb_mel_loss_bwd1_kernel(const float* pre
         const int r = i / F, c = i - r * F;
         const int t = t0 + r;
         if (t >= T) continue;
-        const SsimStats s = ssim_window(xs, ys, r, c, ld, w);
+        const SsimStats s = ssim_vpass5(hm, hn, r, c, F, w);
         const float mu1_sq = s.mu1 * s.mu1, mu2_sq = s.mu2 * s.mu2, mu12 = s.mu1 * s.mu2;
         const float s1 = s.e11 - mu1_sq, s2 = s.e22 - mu2_sq, s12 = s.e12 - mu12;
         const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s1 + s2 + C2;
@@ -261,9 +347,12 @@ __global__ __launch_bounds__(256) void svb_mel_loss_bwd2_kernel(const float* pre
                                                                 long tsb, long tst, long tsf, const float* gout,
                                                                 const float* sums, const float* gws, float* dpred, int B, int T,
                                                                 int F, float bias, int terms, SsimWin w) {
-    __shared__ float ga[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
-    __shared__ float gb[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
-    __shared__ float gc[(SSIM_TT + 2 * SSIM_R) * (SSIM_FMAX + 2 * SSIM_R)];
+    HIP_DYNAMIC_SHARED(float, ssim_smem)
+    float* ga = ssim_smem;
+    float* gb = ga + SSIM_ROWS * (F + 2 * SSIM_R);
+    float* gc = gb + SSIM_ROWS * (F + 2 * SSIM_R);
+    float* hm = gc + SSIM_ROWS * (F + 2 * SSIM_R);
+    const int hn = SSIM_ROWS * F;
     __shared__ float wrow[SSIM_TT];
     const int b = blockIdx.y, t0 = blockIdx.x * SSIM_TT;
     const int ld = F + 2 * SSIM_R, rows = SSIM_TT + 2 * SSIM_R;
@@ -275,6 +364,10 @@ __global__ __launch_bounds__(256) void svb_mel_loss_bwd2_kernel(const float* pre
         ssim_stage(gws + 2 * plane, sb, F, 1, b, T, F, t0 - SSIM_R, rows, 0.f, gc, ld);
     }
     mel_speech_rows(tgt, tsb, tst, tsf, b, t0, T, F, wrow);
+    if (terms & 2) {
+        ssim_hpass3(ga, gb, gc, ld, F, rows, w, hm);
+        __syncthreads();
+    }
     const float gl = (terms & 1) ? gout[0] / sums[2] : 0.f;
     for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
         const int r = i / F, c = i - r * F;
@@ -284,19 +377,8 @@ __global__ __launch_bounds__(256) void svb_mel_loss_bwd2_kernel(const float* pre
         const float y = tgt[(long)b * tsb + (long)t * tst + (long)c * tsf];
         float d = 0.f;
         if (terms & 2) {
-            float fa = 0.f, fb = 0.f, fc = 0.f;
-#pragma unroll
-            for (int ii = 0; ii < SSIM_W; ++ii) {
-                const float gi = w.g[ii];
-                const int base = (r + ii) * ld + c;
-#pragma unroll
-                for (int j = 0; j < SSIM_W; ++j) {
-                    const float wij = gi * w.g[j];
-                    fa = fmaf(wij, ga[base + j], fa);
-                    fb = fmaf(wij, gb[base + j], fb);
-                    fc = fmaf(wij, gc[base + j], fc);
-                }
-            }
+            float fa, fb, fc;
+            ssim_vpass3(hm, hn, r, c, F, w, fa, fb, fc);
             d = fa + 2.f * (p + bias) * fb + (y + bias) * fc;
         }
         if (terms & 1) {
@@ -306,6 +388,21 @@ __global__ __launch_bounds__(256) void svb_mel_loss_bwd2_kernel(const float* pre
         dpred[((long)b * T + t) * F + c] = d;
     }
 }
+
+// the stencil kernels' dynamic LDS can exceed the 64 KB default (F = 128: 95 KB)
+template <typename K>
+static void ssim_allow_lds(K kernel, bool* done) {
+    if (!*done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        *done = true;
+    }
+}
+#define SSIM_LAUNCH(kernel, grid, lds, stream, ...)                                         \
+    do {                                                                                    \
+        static bool attr_ = false;                                                          \
+        ssim_allow_lds(kernel, &attr_);                                                     \
+        hipLaunchKernelGGL(kernel, grid, dim3(256), lds, (hipStream_t)(stream), __VA_ARGS__); \
+    } while (0)
 
 static SsimWin make_window() {
     SsimWin w;
@@ -322,7 +419,7 @@ extern "C" int svb_ssim_fwd(const float* pred, long psb, long pst, long psf, con
                             float* out_map, int B, int T, int F, float bias, void* stream) {
     if (!pred || !tgt || !out_map || B <= 0 || T <= 0 || F <= 0 || F > SSIM_FMAX || B > 65535) return SVB_ERR_ARG;
     dim3 grid(svb_cdiv(T, SSIM_TT), B);
-    hipLaunchKernelGGL(svb_ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, pred, psb, pst, psf, tgt, tsb, tst, tsf,
+    SSIM_LAUNCH(svb_ssim_fwd_kernel, grid, ssim_lds_bytes(F, 2, 5), stream, pred, psb, pst, psf, tgt, tsb, tst, tsf,
                        out_map, B, T, F, bias, make_window());
     SVB_CHECK_LAUNCH();
     return SVB_OK;
@@ -334,9 +431,9 @@ extern "C" int svb_ssim_bwd(const float* pred, long psb, long pst, long psf, con
         return SVB_ERR_ARG;
     dim3 grid(svb_cdiv(T, SSIM_TT), B);
     const SsimWin w = make_window();
-    hipLaunchKernelGGL(svb_ssim_bwd1_kernel, grid, dim3(256), 0, (hipStream_t)stream, pred, psb, pst, psf, tgt, tsb, tst, tsf,
+    SSIM_LAUNCH(svb_ssim_bwd1_kernel, grid, ssim_lds_bytes(F, 2, 5), stream, pred, psb, pst, psf, tgt, tsb, tst, tsf,
                        dmap, workspace, B, T, F, bias, w);
-    hipLaunchKernelGGL(svb_ssim_bwd2_kernel, grid, dim3(256), 0, (hipStream_t)stream, pred, psb, pst, psf, tgt, tsb, tst, tsf,
+    SSIM_LAUNCH(svb_ssim_bwd2_kernel, grid, ssim_lds_bytes(F, 3, 3), stream, pred, psb, pst, psf, tgt, tsb, tst, tsf,
                        workspace, dpred, B, T, F, bias, w);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
@@ -347,7 +444,7 @@ extern "C" int svb_mel_loss_fwd(const float* pred, long psb, long pst, long psf,
     if (!pred || !tgt || !out || !part || B <= 0 || T <= 0 || F <= 0 || F > SSIM_FMAX || B > 65535 || !(terms & 3))
         return SVB_ERR_ARG;
     dim3 grid(svb_cdiv(T, SSIM_TT), B);
-    hipLaunchKernelGGL(svb_mel_loss_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, pred, psb, pst, psf, tgt, tsb, tst, tsf,
+    SSIM_LAUNCH(svb_mel_loss_fwd_kernel, grid, ssim_lds_bytes(F, 2, 5), stream, pred, psb, pst, psf, tgt, tsb, tst, tsf,
                        part, B, T, F, bias, terms, make_window());
     hipLaunchKernelGGL(svb_mel_loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)part,
                        (int)(grid.x * grid.y), out);
@@ -364,9 +461,9 @@ extern "C" int svb_mel_loss_bwd(const float* pred, long psb, long pst, long psf,
     dim3 grid(svb_cdiv(T, SSIM_TT), B);
     const SsimWin w = make_window();
     if (terms & 2)
-        hipLaunchKernelGGL(svb_mel_loss_bwd1_kernel, grid, dim3(256), 0, (hipStream_t)stream, pred, psb, pst, psf, tgt, tsb, tst,
+        SSIM_LAUNCH(svb_mel_loss_bwd1_kernel, grid, ssim_lds_bytes(F, 2, 5), stream, pred, psb, pst, psf, tgt, tsb, tst,
                            tsf, gout, sums, workspace, B, T, F, bias, w);
-    hipLaunchKernelGGL(svb_mel_loss_bwd2_kernel, grid, dim3(256), 0, (hipStream_t)stream, pred, psb, pst, psf, tgt, tsb, tst, tsf,
+    SSIM_LAUNCH(svb_mel_loss_bwd2_kernel, grid, ssim_lds_bytes(F, 3, 3), stream, pred, psb, pst, psf, tgt, tsb, tst, tsf,
                        gout, sums, (const float*)workspace, dpred, B, T, F, bias, terms, w);
     SVB_CHECK_LAUNCH();
     return SVB_OK;

@@ -313,7 +313,9 @@ def test_ssim_map_forward_backward(dev):
     ref.backward(dm)
     p = pred_nct.detach().to(dev).transpose(1, 2)            # non-contiguous view, as in the model
     out = K.ssim_fwd(p, tgt.to(dev), 6.0)
-    assert (out.cpu() - ref.detach()).abs().max() < 2e-5
+    # the fp32 oracle is itself 3.0e-5 away from the same map in fp64 on this input (E[xy] - mu_x mu_y cancels to ~1e-6 of its
+    # operands where the target is silent); the separable kernel sits at 1.3e-5 from fp64 and 2.9e-5 from the fp32 oracle
+    assert (out.cpu() - ref.detach()).abs().max() < 5e-5
     dp = K.ssim_bwd(p, tgt.to(dev), dm.to(dev), 6.0)
     assert rel_err(dp, pred_nct.grad.transpose(1, 2)) < 1e-4
 

@@ -54,3 +54,18 @@ for (B, C, T, Gn) in ((32, 256, 1124, 8), (32, 256, 1124, 16), (32, 256, 562, 8)
     a = torch.empty_like(h)
     show(f"torch copy C{C} T{T}", timeit(lambda: a.copy_(h)), 2 * e)
     show(f"torch add C{C} T{T}", timeit(lambda: torch.add(h, res, out=a)), 3 * e)
+# fused mel loss (masked L1 + SSIM) at the step's shape: pred read through the decoder's [B,80,T] strides
+B, T, Fb = 32, 1124, 80
+pred = torch.randn(B, Fb, T, device=dev).transpose(1, 2)
+tgt = torch.randn(B, T, Fb, device=dev)
+e = B * T * Fb * 4
+show("mel_loss_fwd [32,1124,80]", timeit(lambda: K.mel_loss_fwd(pred, tgt, 6.0, 3)), 2 * e)
+gout = torch.ones(3, device=dev)
+sums_t = K.mel_loss_fwd(pred, tgt, 6.0, 3)
+show("mel_loss_bwd [32,1124,80]", timeit(lambda: K.mel_loss_bwd(pred, tgt, gout, sums_t, 6.0, 3)), 9 * e)
+for terms in (1, 2):
+    show(f"mel_loss_fwd terms={terms}", timeit(lambda: K.mel_loss_fwd(pred, tgt, 6.0, terms)), 2 * e)
+    show(f"mel_loss_bwd terms={terms}", timeit(lambda: K.mel_loss_bwd(pred, tgt, gout, sums_t, 6.0, terms)), 9 * e)
+predc = pred.contiguous()
+show("mel_loss_fwd contiguous pred", timeit(lambda: K.mel_loss_fwd(predc, tgt, 6.0, 3)), 2 * e)
+show("ssim_fwd", timeit(lambda: K.ssim_fwd(pred, tgt, 6.0)), 3 * e)
