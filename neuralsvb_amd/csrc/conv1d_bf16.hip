@@ -1301,6 +1301,7 @@ static void wgq_tile(int CA_g, int CB_g, int tgw, bool gated, int* at, int* bt) 
     else if (b2) *bt = 2;
 }
 
+static const long g_svbq_wg_blocks = getenv("SVB_WG_BLOCKS") ? atol(getenv("SVB_WG_BLOCKS")) : 512;   // split-K target: workgroups per launch
 // Group packing factor (see SvbWgradQArgs::gp_ca): the largest power of two m dividing `groups` with m*CA_g <= 64 and m*CB_g <= 64.
 static const bool g_svbq_wg_nopack = getenv("SVB_WG_NO_GROUP_PACK") != nullptr;      // A/B switch
 static int wgq_pack(int groups, int CA_g, int CB_g) {
@@ -1327,7 +1328,7 @@ extern "C" size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB
     wgq_tile(CA_g, CB_g, tgw, false, &at, &bt);
     const long tiles = (long)groups * svb_cdiv(CA_g, 64 * at) * svb_cdiv(CB_g, 64 * bt) * n_tg;
     const long chunks = (long)B * svb_cdiv(TA, SVBQ_WG_QC);
-    long ns_cap = 512 / tiles;                                   // one resident wave of blocks at 2 per CU
+    long ns_cap = g_svbq_wg_blocks / tiles;                      // one resident wave of blocks at 2 per CU
     if (ns_cap < 1) ns_cap = 1;
     if (ns_cap > chunks) ns_cap = chunks;
     while (ns_cap > 1 && ns_cap * slab > (16L << 20)) --ns_cap;  // <= 64 MB of partials

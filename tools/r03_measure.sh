@@ -21,6 +21,11 @@ for v in default noside; do
   python $R/tools/trace_summary.py /tmp/prof_$v/r03_kernel_trace.csv 20 80 > $R/$O/kernel_summary_$v.txt
   cp /tmp/prof_$v/r03_kernel_stats.csv $R/$O/kernel_stats_$v.csv 2>/dev/null
 done
+rm -rf /tmp/prof_voc
+SVB_BENCH_MARKERS=1 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_voc -o r03 --output-format csv -- \
+   python $R/bench.py --workload vocoder --steps 4 --warmup 3 --no-cpu-baseline > $R/$O/bench_under_rocprof_vocoder.json 2> $R/$O/bench_under_rocprof_vocoder.err
+python $R/tools/trace_summary.py /tmp/prof_voc/r03_kernel_trace.csv 4 60 > $R/$O/kernel_summary_vocoder.txt
+(cd $R && timeout 100 python tools/ewbench.py > $O/streaming_kernels.log 2>&1)
 C="SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 for shp in "32 192 384 1124 5" "32 192 384 281 5"; do
   nm=$(echo $shp | tr ' ' '_')
