@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 3, GPU call 1: (1) full gpu suite at HEAD, (2) the epilogue variants (MODE 3/4/5) on the MI355X, (3) A/B of their switches,
 # (4) kernel trace of the default (benchmarked) configuration + one without the side stream.
-#   gpurun --timeout 900 -- 'bash tools/r03_gpu1.sh'
+#   gpurun --timeout 900 -- 'bash tools/r03_runs/r03_gpu1.sh'
 set -x
 O=gpurun_out/r03a
 mkdir -p $O
