@@ -1247,6 +1247,231 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
     }
 }
 
+// ==================================================================================================================
+// Weight gradient of GROUPED convs with few channels per group (round 3; the multi-scale discriminator's k41 convs have 16 x 8,
+// 32 x 16, 32 x 32, 64 x 32 channels per group -- reference modules/hifigan/hifigan.py:259-268).  The kernel above tiles
+// (output channels) x (input channels) in 32 x 32 MFMA blocks and walks the taps as shifted operands; with 8 input channels per
+// group 3-12 % of its MFMA work lands on the block diagonal that exists.  Here the GEMM is turned: a 16 x 16 MFMA tile is
+// 16 output channels of ONE group x 16 TAPS of one input channel (v_mfma_f32_16x16x32_bf16, K = 32 positions), so every
+// product is one the gradient needs (k = 41: 41 of 48 columns).
+//   workgroup = (group, 16-row block of its output channels); wave w owns input channels [w*CPW, (w+1)*CPW) of the group
+//   A operand  = dy rows [16][64 positions] of the chunk, bf16 hi / lo pairs in LDS (16-byte fragment reads)
+//   B operand  = x row of one input channel, stored per stride phase (position P0 + s*q + r -> phase r, index q): tap j = s*u + r
+//                of output position t reads phase r at q = t + u, i.e. 8 consecutive halfwords at an arbitrary halfword offset,
+//                assembled from 5 dwords with a funnel shift (as the general path above)
+//   part[split][ca][cb][j] as above; bias partials = row sums of the (gated) dy rows this workgroup stages.
+// Envelope (host): groups > 1, CA_g % 16 == 0, CB_g in {4, 8, 16, 32}, dil == 1, stride in {1, 2, 4}, k <= 48.
+// ==================================================================================================================
+struct SvbWgradG16Args {
+    const float* a;
+    const float* b;
+    float* part;
+    float* bias_part;
+    const float* a_gate;
+    const float* b_gate;
+    float a_slope, b_slope;
+    int B, CA, CB, G, CA_g, CB_g, TA, TB, k, pad, sx, sxs;       // sxs = log2(sx)
+    int a_tiles, chunks_per_b, total_chunks, nsplit;
+    int q_len;            // positions per phase row (even)
+    int px;               // phase-row pitch in dwords
+    int cb_blocks;        // workgroups per (group, 16-row block): CB_g / (4 * CPW)
+};
+#define SVBQ_G16_PA 36    // dy row pitch in dwords (16-byte aligned rows)
+
+template <int CPW, int NJT>
+__global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_g16_kernel(SvbWgradG16Args a) {
+    constexpr int XE = 5 * CPW;                  // staged x elements per thread and chunk (bound; see the envelope)
+    constexpr int TPC = 64 / CPW;                // threads per input-channel row (256 / CB_g)
+    HIP_DYNAMIC_SHARED(unsigned, g16_smem)
+    unsigned* A_hi = g16_smem;
+    unsigned* A_lo = A_hi + 16 * SVBQ_G16_PA;
+    unsigned* X_hi = A_lo + 16 * SVBQ_G16_PA;
+    const int x_rows = 4 * CPW * a.sx;
+    unsigned* X_lo = X_hi + x_rows * a.px;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kg = lane >> 4, l15 = lane & 15;
+    int bidx = blockIdx.x;
+    const int cbb = bidx % a.cb_blocks; bidx /= a.cb_blocks;      // input channels are split over cb_blocks workgroups of 4*CPW
+    const int at = bidx % a.a_tiles, g = bidx / a.a_tiles;
+    const int ca0 = g * a.CA_g + at * 16;        // first output channel of this workgroup
+    const int cbl0 = cbb * 4 * CPW;              // first input channel of this workgroup, within the group
+    const int cb0 = g * a.CB_g + cbl0;
+
+    f32x4 acc[CPW][NJT];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[c][jt][r] = 0.f;
+
+    // staging roles
+    const int arow = tid >> 4, at4 = (tid & 15) * 4;                 // dy: row, first of 4 consecutive positions
+    const int xcb = tid / TPC, xl = tid - xcb * TPC;                  // x: input channel row, first offset
+    const int span = a.sx * a.q_len;                                 // staged positions per row: P0 .. P0 + span
+    const unsigned a_roff = 4u * (unsigned)((ca0 + arow) * a.TA);
+    const unsigned x_roff = 4u * (unsigned)((cb0 + xcb) * a.TB);
+    float ar[4], xr[XE];
+    float bsum = 0.f;
+    const bool do_bias = a.bias_part != nullptr && cbb == 0;
+    // B-fragment constants per tap tile: phase row offset and position shift of this lane's tap
+    int b_row[NJT], b_u[NJT];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) {
+        const int j = 16 * jt + l15;
+        b_row[jt] = (j & (a.sx - 1)) * a.px;
+        b_u[jt] = j >> a.sxs;
+    }
+
+    auto load_tiles = [&](int chunk) {
+        const int bb = chunk / a.chunks_per_b;
+        const int t0 = (chunk - bb * a.chunks_per_b) * 64;
+        const float* ab = a.a + (size_t)bb * a.CA * a.TA;
+        const float* bbp = a.b + (size_t)bb * a.CB * a.TB;
+        const int P0 = t0 * a.sx - a.pad;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = t0 + at4 + e;
+            float v = svbq_ld(ab, a_roff + 4u * (unsigned)min(t, a.TA - 1));
+            if (a.a_gate) v *= svb_gate(svbq_ld(a.a_gate + (size_t)bb * a.CA * a.TA, a_roff + 4u * (unsigned)min(t, a.TA - 1)), a.a_slope);
+            ar[e] = t < a.TA ? v : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < XE; ++e) {
+            const int i = xl + TPC * e;
+            const int p = P0 + i;
+            const bool ok = i < span && p >= 0 && p < a.TB;
+            const unsigned off = x_roff + 4u * (unsigned)min(max(p, 0), a.TB - 1);
+            float v = svbq_ld(bbp, off);
+            if (a.b_gate) v *= svb_gate(svbq_ld(a.b_gate + (size_t)bb * a.CB * a.TB, off), a.b_slope);
+            xr[e] = ok ? v : 0.f;
+        }
+    };
+    auto store_tiles = [&]() {
+        unsigned h0, l0, h1, l1;
+        svbq_split2(ar[0], ar[1], h0, l0);
+        svbq_split2(ar[2], ar[3], h1, l1);
+        bsum += (ar[0] + ar[1]) + (ar[2] + ar[3]);
+        const int d = arow * SVBQ_G16_PA + (at4 >> 1);
+        A_hi[d] = h0; A_hi[d + 1] = h1;
+        A_lo[d] = l0; A_lo[d + 1] = l1;
+        unsigned short* xh = reinterpret_cast<unsigned short*>(X_hi);
+        unsigned short* xl16 = reinterpret_cast<unsigned short*>(X_lo);
+#pragma unroll
+        for (int e = 0; e < XE; ++e) {
+            const int i = xl + TPC * e;
+            if (i < span) {
+                unsigned hi, lo;
+                svbq_split2(xr[e], 0.f, hi, lo);
+                const int idx = ((xcb * a.sx + (i & (a.sx - 1))) * a.px) * 2 + (i >> a.sxs);
+                xh[idx] = (unsigned short)(hi & 0xFFFFu);
+                xl16[idx] = (unsigned short)(lo & 0xFFFFu);
+            }
+        }
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 ahu = *reinterpret_cast<const uint4*>(A_hi + l15 * SVBQ_G16_PA + 16 * ks + 4 * kg);
+            const uint4 alu = *reinterpret_cast<const uint4*>(A_lo + l15 * SVBQ_G16_PA + 16 * ks + 4 * kg);
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&ahu), al = *reinterpret_cast<const bf16x8*>(&alu);
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                const int rowbase = (wave * CPW + c) * a.sx * a.px;
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    const int q0 = 32 * ks + 8 * kg + b_u[jt];
+                    const unsigned* hp = X_hi + rowbase + b_row[jt] + (q0 >> 1);
+                    const unsigned* lp = X_lo + rowbase + b_row[jt] + (q0 >> 1);
+                    const unsigned sh = (unsigned)(q0 & 1) * 16u;
+                    unsigned uh[5], ul[5];
+#pragma unroll
+                    for (int d = 0; d < 5; ++d) { uh[d] = hp[d]; ul[d] = lp[d]; }
+                    const uint4 bhu = make_uint4(svbq_funnel(uh[1], uh[0], sh), svbq_funnel(uh[2], uh[1], sh),
+                                                 svbq_funnel(uh[3], uh[2], sh), svbq_funnel(uh[4], uh[3], sh));
+                    const uint4 blu = make_uint4(svbq_funnel(ul[1], ul[0], sh), svbq_funnel(ul[2], ul[1], sh),
+                                                 svbq_funnel(ul[3], ul[2], sh), svbq_funnel(ul[4], ul[3], sh));
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&bhu), bl = *reinterpret_cast<const bf16x8*>(&blu);
+                    acc[c][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[c][jt], 0, 0, 0);
+                    acc[c][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[c][jt], 0, 0, 0);
+                    acc[c][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[c][jt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);       // (without it hipcc hoists every fragment read of the k-step: spills)
+            }
+        }
+    };
+
+    int chunk = blockIdx.y;
+    if (chunk < a.total_chunks) {
+        load_tiles(chunk);
+        store_tiles();
+        __syncthreads();
+        while (true) {
+            const int next = chunk + a.nsplit;
+            const bool has_next = next < a.total_chunks;
+            if (has_next) load_tiles(next);
+            compute();
+            if (!has_next) break;
+            __syncthreads();
+            store_tiles();
+            __syncthreads();
+            chunk = next;
+        }
+    }
+
+    float* part = a.part + (size_t)blockIdx.y * a.CA * a.CB_g * a.k;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int cb = cbl0 + wave * CPW + c;
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            const int j = 16 * jt + l15;
+            if (j < a.k) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    part[((size_t)(ca0 + 4 * kg + r) * a.CB_g + cb) * a.k + j] = acc[c][jt][r];
+            }
+        }
+    }
+    if (do_bias) {            // the 16 lanes that staged one dy row hold its partial sums
+        float v = bsum;
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+        if ((tid & 15) == 0) a.bias_part[(size_t)blockIdx.y * a.CA + ca0 + arow] = v;
+    }
+}
+
+static const bool g_svbq_g16_off = getenv("SVB_WG_NO_G16") != nullptr;          // A/B switch
+// the grouped 16-row kernel's envelope; returns the tap tiles (0 = not eligible)
+static int wgq_g16_njt(int groups, int CA_g, int CB_g, int k, int sx, int dil) {
+    if (g_svbq_g16_off || groups <= 1 || CA_g % 16 || dil != 1 || k > 48) return 0;
+    if (!(CB_g == 4 || CB_g == 8 || CB_g == 16 || CB_g == 32)) return 0;
+    if (!(sx == 1 || sx == 2 || sx == 4)) return 0;
+    return svb_cdiv(k, 16);
+}
+static int wgq_g16_qlen(int njt, int sx) {
+    int q = 64 + ((16 * njt - 1) / sx) + 2;          // positions per phase row: 64 outputs + the furthest tap + the fragment's reach
+    return q + (q & 1);
+}
+
+template <int CPW, int NJT>
+static void wgq_g16_launch_k(const SvbWgradG16Args& a, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_wgrad_g16_kernel<CPW, NJT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((svb_conv1d_wgrad_g16_kernel<CPW, NJT>), grid, dim3(256), lds, st, a);
+}
+template <int CPW>
+static void wgq_g16_launch(const SvbWgradG16Args& a, int njt, dim3 grid, size_t lds, hipStream_t st) {
+    if (njt == 1) wgq_g16_launch_k<CPW, 1>(a, grid, lds, st);
+    else if (njt == 2) wgq_g16_launch_k<CPW, 2>(a, grid, lds, st);
+    else wgq_g16_launch_k<CPW, 3>(a, grid, lds, st);
+}
+
 // Tap-group width cap of dilated weight gradients: the general shifted-operand path reads 5 + 5 dwords per tap and MFMA step, and
 // with 5 accumulator sets per wave it runs at 70 TF on the period discriminators' 1024 -> 1024 layers where 3 + 2 taps reach 125
 // (vocoder step 134.3 -> 130.5 ms with 3, 137.0 with 2; profiles/r03_vocoder_period_layout.log).
@@ -1320,8 +1545,20 @@ extern "C" size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB
     int tgw = 0;
     const int n_tg = wgq_groups(k, sx, pad, dil, &tgw, nullptr, nullptr, nullptr, nullptr);
     if (n_tg <= 0) return 0;
-    const int gp = wgq_pack(groups, CA / groups, CB / groups);
     const long slab = (long)CA * (CB / groups) * k;
+    if (wgq_g16_njt(groups, CA / groups, CB / groups, k, sx, dil)) {       // grouped 16-row kernel: one workgroup per 16 output channels
+        const long tiles16 = ((long)CA / 16) * (CB / groups > 16 ? 2 : 1);
+        const long chunks16 = (long)B * svb_cdiv(TA, 64);
+        long cap = g_svbq_wg_blocks / tiles16;
+        if (cap < 1) cap = 1;
+        if (cap > chunks16) cap = chunks16;
+        while (cap > 1 && cap * slab > (16L << 20)) --cap;
+        const long per16 = svb_cdiv(chunks16, cap);
+        const long ns16 = svb_cdiv(chunks16, per16);
+        if (nsplit_out) *nsplit_out = (int)ns16;
+        return (size_t)ns16 * slab;
+    }
+    const int gp = wgq_pack(groups, CA / groups, CB / groups);
     groups /= gp;
     const int CA_g = CA / groups, CB_g = CB / groups;
     int at = 1, bt = 1;
@@ -1376,6 +1613,31 @@ extern "C" int svb_conv1d_wgrad_bf16x3(const float* a_t, const float* b_t, float
     if (!a_t || !b_t || !part || B <= 0 || groups <= 0 || CA % groups || CB % groups || k <= 0 || k > SVB_MAX_TAPS ||
         dil <= 0 || nsplit <= 0 || sx <= 0)
         return SVB_ERR_ARG;
+    if (const int njt = wgq_g16_njt(groups, CA / groups, CB / groups, k, sx, dil)) {
+        SvbWgradG16Args q;
+        q.a = a_t; q.b = b_t; q.part = part; q.bias_part = bias_part; q.a_gate = a_gate; q.b_gate = b_gate;
+        q.a_slope = a_slope; q.b_slope = b_slope;
+        q.B = B; q.CA = CA; q.CB = CB; q.G = groups; q.CA_g = CA / groups; q.CB_g = CB / groups; q.TA = TA; q.TB = TB;
+        q.k = k; q.pad = pad; q.sx = sx; q.sxs = sx == 1 ? 0 : (sx == 2 ? 1 : 2);
+        q.a_tiles = q.CA_g / 16;
+        q.chunks_per_b = svb_cdiv(TA, 64); q.total_chunks = B * q.chunks_per_b;
+        if (nsplit > q.total_chunks) return SVB_ERR_ARG;
+        q.nsplit = nsplit;
+        q.q_len = wgq_g16_qlen(njt, sx);
+        q.px = (q.q_len / 2) | 1;
+        const int cb_wg = q.CB_g > 16 ? 16 : q.CB_g;            // input channels per workgroup (32 per group: two workgroups)
+        q.cb_blocks = q.CB_g / cb_wg;
+        const size_t lds16 = sizeof(unsigned) * ((size_t)2 * 16 * SVBQ_G16_PA + (size_t)2 * cb_wg * sx * q.px);
+        dim3 grid16(groups * q.a_tiles * q.cb_blocks, nsplit);
+        hipStream_t st16 = (hipStream_t)stream;
+        switch (cb_wg) {
+            case 4: wgq_g16_launch<1>(q, njt, grid16, lds16, st16); break;
+            case 8: wgq_g16_launch<2>(q, njt, grid16, lds16, st16); break;
+            default: wgq_g16_launch<4>(q, njt, grid16, lds16, st16); break;
+        }
+        SVB_CHECK_LAUNCH();
+        return SVB_OK;
+    }
     SvbWgradQArgs a;
     a.a = a_t; a.b = b_t; a.part = part; a.a_gate = a_gate; a.b_gate = b_gate; a.a_slope = a_slope; a.b_slope = b_slope;
     a.bias_part = bias_part;

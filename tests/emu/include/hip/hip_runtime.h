@@ -150,6 +150,30 @@ static inline emu_f32x16 emu_mfma_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_
     emu_wave_exchange_end();
     return d;
 }
+// v_mfma_f32_16x16x32_bf16: lane l supplies A[i=l&15][k=8*(l>>4)+e] and B[k=8*(l>>4)+e][j=l&15], e=0..7; D: col = l&15,
+// row = 4*(l>>4) + reg (cdna_hip_programming.md, fragment layout).
+static inline emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c, int, int, int) {
+    unsigned short ab[16];
+    memcpy(ab, &a, 16);
+    memcpy(ab + 8, &b, 16);
+    emu_wave_exchange_begin(ab, sizeof(ab));
+    const int l = emu_lane_id();
+    const int col = l & 15;
+    emu_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = (l >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            const unsigned short* pa = (const unsigned short*)emu_wave_slot(row + 16 * (k >> 3));
+            const unsigned short* pb = (const unsigned short*)emu_wave_slot(col + 16 * (k >> 3));
+            acc = fmaf(emu_bf16_to_f32(pa[k & 7]), emu_bf16_to_f32(pb[8 + (k & 7)]), acc);
+        }
+        d[r] = acc;
+    }
+    emu_wave_exchange_end();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_16x16x32_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu_mfma_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_16x16x4f32

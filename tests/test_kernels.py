@@ -403,6 +403,40 @@ WGQ_STRIDED = [
 ]
 
 
+WGQ_GROUPED16 = [
+    # B, Cin, Cout, G, T, k, s, pad     (per group: Cout/G output x Cin/G input channels)
+    (2, 32, 64, 4, 300, 41, 2, 20),      # MSD family (hifigan.py:259-268): 16 x 8 channels per group, 3 tap tiles, stride 2
+    (1, 64, 128, 4, 260, 41, 4, 20),     # 32 x 16 per group (two 16-row blocks per group), stride 4
+    (2, 64, 64, 2, 150, 41, 1, 20),      # 32 x 32 per group, stride 1
+    (1, 128, 256, 4, 90, 41, 4, 20),     # 64 x 32 per group
+    (2, 16, 64, 4, 200, 9, 1, 4),        # 16 x 4 per group, one tap tile
+    (1, 32, 32, 2, 130, 20, 2, 3),       # two tap tiles, odd padding / stride phase
+]
+
+
+@pytest.mark.parametrize("gated", [False, True])
+@pytest.mark.parametrize("case", WGQ_GROUPED16)
+def test_conv1d_wgrad_bf16x3_grouped_16row_kernel(dev, case, gated):
+    """Grouped weight gradients with 16 | (output channels per group) and 4..32 input channels per group run on the turned
+    GEMM (16 output channels x 16 taps per MFMA tile, csrc/conv1d_bf16.hip svb_conv1d_wgrad_g16_kernel): weight and bias
+    gradients against torch autograd, plain and with both activation-derivative gates."""
+    B, Cin, Cout, G, T, k, s, pad = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, Cin, T, generator=g)
+    w = (torch.randn(Cout, Cin // G, k, generator=g) * 0.2).requires_grad_(True)
+    bias = torch.randn(Cout, generator=g).requires_grad_(True)
+    xin = F.leaky_relu(x, 0.1) if gated else x
+    pre = oops.conv1d(xin, w, bias, s, pad, 1, G)
+    y = F.leaky_relu(pre, 0.2) if gated else pre
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    kw = dict(a_gate=y.detach().to(dev), a_slope=0.2, b_gate=x.to(dev), b_slope=0.1) if gated else {}
+    dw, db = K.conv1d_wgrad(dy.to(dev), x.to(dev), k, s, pad, 1, G, bf16x3=True, want_bias=True, **kw)
+    assert dw.shape == w.shape
+    assert rel_err(dw, w.grad) < 6e-5
+    assert rel_err(db, bias.grad) < 1e-5
+
+
 @pytest.mark.parametrize("case", WGQ_STRIDED)
 def test_conv1d_wgrad_bf16x3_strided(dev, case):
     """Strided weight gradient = `stride` stride-1 problems over the phase subsequences of the input."""
