@@ -103,3 +103,30 @@ def test_hifigan_discriminators_match_reference(name):
         close(b, d[f"{name}.y_d_g.{i}"], 3e-5 * max(1.0, np.abs(d[f"{name}.y_d_g.{i}"]).max()), f"{name}.g{i}")
     st = np.stack([fmap_stats(x) for fm in fr for x in fm])
     np.testing.assert_allclose(st, d[f"{name}.fmap_r_stats"], atol=3e-5, rtol=2e-4)
+
+
+def test_frontend_restatement_against_independent_implementations():
+    """The librosa-0.8.0 front-end (`librosa.stft`, `librosa.filters.mel`; pinned by the reference's Requirements.txt:41, not
+    vendored, no vectors in the reference) is restated in oracle/frontend.py from the published algorithm.  Two independent
+    anchors exist in this image: torch.stft with librosa's conventions (centred, reflect padding, periodic Hann) for the STFT,
+    and the example of librosa's own documentation for the Slaney filterbank (`librosa.filters.mel(22050, 2048)` prints
+    `[[0., 0.016, ...` and with `fmax=8000` `[[0., 0.02, ...`) -- the latter only to the printed precision."""
+    import torch
+    from oracle import frontend as ofe
+    rng = np.random.RandomState(0)
+    for n_fft, hop, n in ((512, 128, 5000), (2048, 512, 9000), (1024, 256, 1024)):
+        y = rng.randn(n).astype(np.float32)
+        mine = ofe.librosa_stft(y, n_fft, hop, n_fft)
+        ref = torch.stft(torch.from_numpy(y), n_fft, hop, n_fft, window=torch.hann_window(n_fft, periodic=True), center=True,
+                         pad_mode="reflect", return_complex=True).numpy()
+        assert mine.shape == ref.shape == (1 + n_fft // 2, 1 + n // hop)
+        assert np.abs(mine - ref).max() <= 2e-6 * np.abs(ref).max()
+    fb = ofe.librosa_mel_filterbank(22050, 2048)
+    assert fb.shape == (128, 1025) and fb.dtype == np.float32
+    assert round(float(fb[0, 1]), 3) == 0.016 and fb[0, 0] == 0 and fb[1, 0] == 0 and fb[-1, 0] == 0
+    assert round(float(ofe.librosa_mel_filterbank(22050, 2048, fmax=8000)[0, 1]), 2) == 0.02
+    # Slaney normalisation: every triangle has (continuous) area 1 in Hz, i.e. height 2 / (f_hi - f_lo); adjacent triangles
+    # cross at their feet, so the columns between the first and last centre carry one or two filters only
+    fb80 = ofe.librosa_mel_filterbank(24000, 512, 80, 50, 12000)
+    nz = (fb80 > 0).sum(0)
+    assert nz.max() <= 2 and fb80.min() >= 0 and (fb80.sum(1) > 0).all()
