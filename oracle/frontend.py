@@ -7,7 +7,10 @@ PARITY UNPINNED for the librosa arithmetic: the reference calls librosa 0.8.0
 (Requirements.txt:41), which is not vendored under /root/reference and is not
 installed here, and the reference ships no golden vectors.  `librosa_stft` and
 `librosa_mel_filterbank` restate the *published* librosa-0.8.0 algorithm
-(SURVEY.md Appendix C); everything downstream of them (log10/ln, eps, trimming,
+ and are cross-checked against torch.stft (librosa's conventions) and
+the filterbank example of librosa's own documentation by
+tests/test_oracle_golden.py::test_frontend_restatement_against_independent_implementations
+-- anchors, not librosa's source: the header stays "unpinned"; everything downstream of them (log10/ln, eps, trimming,
 pitch-bin quantisation) follows in-tree reference code and is pinned by reading, with
 `f0_to_coarse` additionally pinned against the imported reference function
 (tests/golden/make_golden.py).
