@@ -1526,6 +1526,10 @@ static void wgq_tile(int CA_g, int CB_g, int tgw, bool gated, int* at, int* bt) 
     else if (b2) *bt = 2;
 }
 
+// split-K target of SHORT problems (fewer than 8 chunks per workgroup at the target above: the T = 281 layers of the step).
+// Measured on the train step: 16.0 ms with 512 for all, 15.8 with 384, 15.7-15.8 with 256, 15.9 with 192, 16.15 with 128,
+// 17.6 with 64; the vocoder step does not move (tools/r03_runs/r03_gpu45.sh, r03_gpu46.sh).  0 = off.
+static const long g_svbq_wg_small_blocks = getenv("SVB_WG_SMALL_BLOCKS") ? atol(getenv("SVB_WG_SMALL_BLOCKS")) : 256;
 static const long g_svbq_wg_blocks = getenv("SVB_WG_BLOCKS") ? atol(getenv("SVB_WG_BLOCKS")) : 512;   // split-K target: workgroups per launch
 // Group packing factor (see SvbWgradQArgs::gp_ca): the largest power of two m dividing `groups` with m*CA_g <= 64 and m*CB_g <= 64.
 static const bool g_svbq_wg_nopack = getenv("SVB_WG_NO_GROUP_PACK") != nullptr;      // A/B switch
@@ -1567,6 +1571,12 @@ extern "C" size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB
     const long chunks = (long)B * svb_cdiv(TA, SVBQ_WG_QC);
     long ns_cap = g_svbq_wg_blocks / tiles;                      // one resident wave of blocks at 2 per CU
     if (ns_cap < 1) ns_cap = 1;
+    // short problems: a workgroup that would see fewer than 8 chunks spends most of its life writing its 82 KB partial tile;
+    // fewer, longer workgroups then (the other streams fill the CUs)
+    if (g_svbq_wg_small_blocks > 0 && chunks < 8 * ns_cap) {
+        ns_cap = g_svbq_wg_small_blocks / tiles;
+        if (ns_cap < 1) ns_cap = 1;
+    }
     if (ns_cap > chunks) ns_cap = chunks;
     while (ns_cap > 1 && ns_cap * slab > (16L << 20)) --ns_cap;  // <= 64 MB of partials
     const long per = svb_cdiv(chunks, ns_cap);
