@@ -1528,7 +1528,9 @@ static void wgq_tile(int CA_g, int CB_g, int tgw, bool gated, int* at, int* bt) 
 
 // split-K target of SHORT problems (fewer than 8 chunks per workgroup at the target above: the T = 281 layers of the step).
 // Measured on the train step: 16.0 ms with 512 for all, 15.8 with 384, 15.7-15.8 with 256, 15.9 with 192, 16.15 with 128,
-// 17.6 with 64; the vocoder step does not move (tools/r03_runs/r03_gpu45.sh, r03_gpu46.sh).  0 = off.
+// 17.6 with 64; the vocoder step does not move (tools/r03_runs/r03_gpu45.sh, r03_gpu46.sh); on a third box 16.00 / 16.06 / 16.04
+// without the rule against 15.84 / 15.81 / 15.82 with it (r03_gpu49.sh); the chunk threshold is flat between 6 and 16.  0 = off.
+static const long g_svbq_wg_small_chunks = getenv("SVB_WG_SMALL_CHUNKS") ? atol(getenv("SVB_WG_SMALL_CHUNKS")) : 8;
 static const long g_svbq_wg_small_blocks = getenv("SVB_WG_SMALL_BLOCKS") ? atol(getenv("SVB_WG_SMALL_BLOCKS")) : 256;
 static const long g_svbq_wg_blocks = getenv("SVB_WG_BLOCKS") ? atol(getenv("SVB_WG_BLOCKS")) : 512;   // split-K target: workgroups per launch
 // Group packing factor (see SvbWgradQArgs::gp_ca): the largest power of two m dividing `groups` with m*CA_g <= 64 and m*CB_g <= 64.
@@ -1573,7 +1575,7 @@ extern "C" size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB
     if (ns_cap < 1) ns_cap = 1;
     // short problems: a workgroup that would see fewer than 8 chunks spends most of its life writing its 82 KB partial tile;
     // fewer, longer workgroups then (the other streams fill the CUs)
-    if (g_svbq_wg_small_blocks > 0 && chunks < 8 * ns_cap) {
+    if (g_svbq_wg_small_blocks > 0 && chunks < g_svbq_wg_small_chunks * ns_cap) {
         ns_cap = g_svbq_wg_small_blocks / tiles;
         if (ns_cap < 1) ns_cap = 1;
     }
