@@ -104,7 +104,7 @@ def test_build_dataloader_with_device_collate(ds, gpu_only):
 
 
 @pytest.mark.gpu
-def test_device_collate_multi_worker_soak(ds, gpu_only, monkeypatch):
+def test_device_collate_multi_worker_soak(ds, gpu_only):
     """The loader as a training run uses it: two worker processes decode items, batches of changing size and length arrive
     back to back for several epochs (the pinned staging buffers and the H2D copies of batch n+1 are reused / issued while
     batch n's kernels may still run), every batch compared with the host collater's.  This is the soak behind
