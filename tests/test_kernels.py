@@ -5,7 +5,6 @@ container) and `gpu` (the product: libsvb_hip.so on an MI355X, marked `gpu`).
 Tolerances: fp32 conv/GEMM results differ from the oracle only by summation order -> rtol 2e-5 of the
 output scale (stated per test); integer outputs are compared exactly.
 """
-import math
 
 import os
 
