@@ -530,7 +530,8 @@ def test_persistent_weight_images_and_multi_tensor_repack(dev):
                                    (2, 64, 1124, 4),      # the step's row length: 5 quads per lane
                                    (1, 16, 2000, 1),      # 8 quads per lane
                                    (2, 24, 64, 3),        # 8 channels per group: 512-thread workgroups
-                                   (1, 128, 48, 2)])      # 64 channels per group: streaming kernels
+                                   (1, 128, 48, 2),       # 64 channels per group: streaming kernels
+                                   (2, 16, 4, 1)])        # one quad per row
 def test_group_norm_relu_residual_matches_torch(dev, shape):
     """ConvBlock's GroupNorm(C/16) + ReLU and ConvStacks' residual (common_layers.py:688-707,739-773): values and all
     gradients against stock torch fp32."""
@@ -661,6 +662,8 @@ def test_wn_stack_c_executor_equals_per_launch_path(dev, masked, grad_buffers):
     (7, 9, 20, 20, 5, 1, 2),      # stride-1 layer (hifigan.py:179) = dilation-p conv
     (11, 6, 24, 1, 3, 1, 1),      # conv_post (hifigan.py:180)
     (3, 20, 4, 8, 7, 2, 3),       # another (k, stride, pad) family: taps over 4 row offsets, 2 phases
+    (2, 3, 2, 4, 5, 3, 2),        # fewer rows than taps (one output row)
+    (13, 1, 2, 4, 5, 1, 2),       # a single row
 ])
 def test_period_strided_conv_matches_conv2d(dev, case, precision):
     """The period discriminators' weight_norm(Conv2d((k,1), (stride,1), padding=(pad,0))) + LeakyReLU on [B,C,H,p] planes

@@ -319,6 +319,23 @@ def test_ssim_map_forward_backward(dev):
     assert rel_err(dp, pred_nct.grad.transpose(1, 2)) < 1e-4
 
 
+@pytest.mark.parametrize("shape", [(1, 5, 128), (2, 16, 8), (1, 33, 1)])
+def test_ssim_map_shape_corners(dev, shape):
+    """The widest image the stencil kernels take (128 bins: 95 KB of dynamic LDS), clips shorter than one 16-frame tile, one bin."""
+    from oracle import modules_ref as R
+    B, T, Fb = shape
+    g_ = torch.Generator().manual_seed(B * 1000 + T + Fb)
+    pred = (torch.randn(B, T, Fb, generator=g_) * 0.8 - 3).requires_grad_(True)
+    tgt = torch.randn(B, T, Fb, generator=g_) * 0.8 - 3
+    ref = R.ssim_map(pred[:, None] + 6.0, tgt[:, None] + 6.0)
+    dm = torch.randn(ref.shape, generator=g_)
+    ref.backward(dm)
+    out = K.ssim_fwd(pred.detach().to(dev), tgt.to(dev), 6.0)
+    assert (out.cpu() - ref.detach()).abs().max() < 5e-5
+    dp = K.ssim_bwd(pred.detach().to(dev), tgt.to(dev), dm.to(dev), 6.0)
+    assert rel_err(dp, pred.grad) < 1e-4
+
+
 @pytest.mark.parametrize("terms", [(True, True), (True, False), (False, True)])
 def test_mel_loss_fused_forward_backward(dev, terms):
     """l1_loss + ssim_loss with weights_nonzero_speech (tasks/tts/fs2.py:143-175) as one pass: values and d/d pred vs the
@@ -410,6 +427,9 @@ WGQ_GROUPED16 = [
     (1, 128, 256, 4, 90, 41, 4, 20),     # 64 x 32 per group
     (2, 16, 64, 4, 200, 9, 1, 4),        # 16 x 4 per group, one tap tile
     (1, 32, 32, 2, 130, 20, 2, 3),       # two tap tiles, odd padding / stride phase
+    (1, 8, 32, 2, 5, 3, 1, 1),           # a clip shorter than one 64-position chunk, 4 input channels per group
+    (1, 64, 32, 2, 70, 48, 4, 24),       # the envelope's corners: k = 48, stride 4, 32 input channels per group (two workgroups)
+    (3, 16, 16, 1, 40, 5, 1, 2),         # groups == 1: NOT this kernel (dispatch check: same result through the 32x32 path)
 ]
 
 
