@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define SVB_ABI_VERSION 4
+#define SVB_ABI_VERSION 5
 int svb_abi_version(void);
 
 /* ---- fused conv epilogue / prologue description ------------------------------------------------------
@@ -103,9 +103,13 @@ int svb_conv1d_transposed_bf16x3(const float* x, const unsigned short* qb_hi, co
                                  int Cin, int Cout, int groups, int Tin, int Tout, int k, int stride, int pad, int dil,
                                  const SvbConvEpilogue* epi, void* stream);
 
-/* Debug hook (tools/stage_timing.py): when set to a device buffer of 64*32*8 uint64, the bf16x3 conv kernel's first 64
- * workgroups record shader-clock stamps around the phases of their K loop.  NULL (default) disables it.          */
+/* Instrumentation build only (`make -C neuralsvb_amd/csrc instr` -> libsvb_hip_instr.so, -DSVB_INSTRUMENT; tools/ load it, the
+ * product never does): cycle stamps of the conv kernels' stages and experiment switches.  svb_debug_set_timing_buffer: a device
+ * buffer of 64*32*8 uint64 for the first 64 workgroups; svb_debug_set_tw: stamp buffer + ablation mask of conv1d_tw.hip.       */
+#ifdef SVB_INSTRUMENT
 void svb_debug_set_timing_buffer(void* buf);
+void svb_debug_set_tw(void* buf, int ablate, int issue_slab_late);
+#endif
 
 /* Weight gradient, stage 1 (split-K partials): part[s][a][b][j] += A[n,a,q] * Bt[n,b,q*sx + j*dil - pad].
  * Conv1d: A = dy (CA=Cout), Bt = x (CB=Cin); ConvTranspose1d: A = x (CA=Cin), Bt = dy (CB=Cout).

@@ -73,7 +73,6 @@ SIGNATURES = {
     "svb_conv1d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, P, F, P, F, I, P]),
     "svb_conv1d_wgrad_bf16x3_workspace_floats": (SZ, [I, I, I, I, I, I, I, I, I, C.POINTER(I)]),
     "svb_conv1d_wgrad_bf16x3": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, P, F, P, F, I, P, P]),
-    "svb_debug_set_timing_buffer": (None, [P]),
     "svb_wgrad_reduce": (I, [P, I, P, P, P, P, I, I, I, I, P, P, P]),
     "svb_wgrad_reduce_multi": (I, [P, I, P]),
     "svb_bias_grad": (I, [P, P, F, P, I, I, I, P]),
@@ -134,12 +133,24 @@ class SvbLibraryMissing(RuntimeError):
     pass
 
 
+# instrumentation build only (libsvb_hip_instr.so, loaded by tools/): bound when present
+INSTR_SIGNATURES = {
+    "svb_debug_set_timing_buffer": (None, [P]),
+    "svb_debug_set_tw": (None, [P, I, I]),
+}
+
+
 def bind(path):
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in INSTR_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     return lib
 
 

@@ -13,10 +13,10 @@
 //                    a thread loads 8 channels of one position with 8 coalesced dword loads and issues two 16-byte
 //                    LDS stores, hi and lo)
 // 48-byte rows put the 16 lanes of every ds_read_b128 service group on 16 disjoint 4-bank windows.
-#include <stdlib.h>
 #include "svb_common.h"
 #include "svb_q.h"
 #include "conv1d.h"
+#include "conv1d_q.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -24,43 +24,29 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define SVBQ_XUNITS 4          /* register-staged x units per thread: (16-channel chunks per phase) x (128-position groups) */
 #define SVBQ_QUNITS 8          /* Q-input staging: 16-byte units per thread and phase */
 
-struct SvbConvQArgs {
-    const float* x;
-    const unsigned short* xq;     // optional Q image of x (svb_q.h): staged with plain 16-byte copies
-    const unsigned short* wq_hi;
-    const unsigned short* wq_lo;
-    const float* bias;
-    float* y;
-    const float* in_gate;
-    const float* out_gate;
-    const float* mask;
-    const float* residual;
-    float in_slope, out_slope, out_gate_slope;
-    int out_act;
-    int B, Cin, Cout, G, Cin_g, Cout_g, Tin, Tout;
-    int sx, out_stride;
-    int w_tap_slabs, w_g_slabs, w_slab_rows, w_goff_m, kchunks;
-    int tg, kch, xrows, fast_x, xit;   // xit: 128-position groups per chunk on the register-staged path (1..3)
-    int fast;                          // direct-A tiles, every K phase has exactly SLB slabs: straight-line pipelined loop
-    int w_floats16, x_floats16;   // LDS carve sizes in 16-byte units (one of hi/lo each)
-    int force_cfg;
-    int prio;                          // experiment switch (env SVB_CONV_PRIO): wave priority of the MFMA stage (1) / of the staging stage (2)
-    unsigned long long* dbg;      // optional per-phase cycle stamps (svb_debug_set_timing_buffer; tools/stage_timing.py)
-    int dbg_block0;               // first launch-order workgroup id that is stamped (env SVB_DBG_BLOCK0)
-};
 
+static const bool g_svbq_nofast = SVB_ENV_FLAG("SVB_NO_FASTLOOP");          // A/B switches of the instrumentation build
+static const int g_svbq_lds_pad = SVB_ENV_INT("SVB_LDS_PAD_KB", 0) * 1024;    // extra LDS -> 1 workgroup per CU
+static const bool g_svbq_wg_narrow = SVB_ENV_FLAG("SVB_WGRAD_NARROW");        // 64x64 weight-gradient tiles only
+#ifdef SVB_INSTRUMENT
 static unsigned long long* g_svbq_dbg = nullptr;
-static const bool g_svbq_nofast = getenv("SVB_NO_FASTLOOP") != nullptr;     // A/B switch for benchmarking
-static const int g_svbq_lds_pad = getenv("SVB_LDS_PAD_KB") ? atoi(getenv("SVB_LDS_PAD_KB")) * 1024 : 0;   // experiment: extra LDS -> 1 workgroup per CU
-static const int g_svbq_prio = getenv("SVB_CONV_PRIO") ? atoi(getenv("SVB_CONV_PRIO")) : 0;
-static const bool g_svbq_wg_narrow = getenv("SVB_WGRAD_NARROW") != nullptr;     // A/B switch: 64x64 weight-gradient tiles only
+static const int g_svbq_prio = SVB_ENV_INT("SVB_CONV_PRIO", 0);
 extern "C" void svb_debug_set_timing_buffer(void* p) { g_svbq_dbg = (unsigned long long*)p; }
-static const int g_svbq_dbg_block0 = getenv("SVB_DBG_BLOCK0") ? atoi(getenv("SVB_DBG_BLOCK0")) : 0;   // first sampled workgroup
+static const int g_svbq_dbg_block0 = SVB_ENV_INT("SVB_DBG_BLOCK0", 0);        // first sampled workgroup
 #define SVBQ_DBG_BLOCKS 64
 #define SVBQ_DBG_STAGES 32
 #define SVBQ_STAMP(slot)                                                                                            \
     if (a.dbg && tid == 0 && dbg_id >= 0 && dbg_id < SVBQ_DBG_BLOCKS && dbg_stage < SVBQ_DBG_STAGES)                 \
         a.dbg[((size_t)dbg_id * SVBQ_DBG_STAGES + dbg_stage) * 8 + (slot)] = __builtin_readcyclecounter();
+#define SVBQ_PRIO(cond, level) if (cond) __builtin_amdgcn_s_setprio(level);
+#define SVBQ_NEXT_STAGE ++dbg_stage;
+#define SVBQ_LAST_STAGE dbg_stage = SVBQ_DBG_STAGES - 1;
+#else
+#define SVBQ_NEXT_STAGE
+#define SVBQ_LAST_STAGE
+#define SVBQ_STAMP(slot)
+#define SVBQ_PRIO(cond, level)
+#endif
 
 // load base[byte_off]: `base` wave-uniform, byte_off a 32-bit per-lane offset (scalar-base + vector-offset addressing)
 __device__ __forceinline__ float svbq_ld(const float* base, unsigned byte_off) {
@@ -116,7 +102,10 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     const int qd = nwg >> 3, rd = nwg & 7, xcd = orig & 7;
     const int wgid = (xcd < rd ? xcd * (qd + 1) : rd * (qd + 1) + (xcd - rd) * qd) + (orig >> 3);
     const int mt = wgid % gridDim.x, qt = wgid / gridDim.x;
+#ifdef SVB_INSTRUMENT
     const int dbg_id = a.dbg ? (int)blockIdx.z * nwg + orig - a.dbg_block0 : -1;      // launch order, for the stage stamps
+    int dbg_stage = 0;
+#endif
     const int m_tiles_g = gridDim.x / a.G;
     const int g = mt / m_tiles_g, mtile = mt % m_tiles_g;
     const int b = blockIdx.z / p.n_phase, ph = blockIdx.z % p.n_phase;
@@ -369,7 +358,6 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     };
 
     int kc0 = 0, tg0 = 0;
-    int dbg_stage = 0;
     if (DIRECT_A && a.fast) {
         // ---- every K phase has exactly SLB slabs (tg * kch == SLB, tg | ntap, kch | kchunks): the phase body is ONE basic
         // block.  The per-slab tap offsets are fetched before the first LDS read (a scalar load in the slab loop drains the
@@ -408,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
             __builtin_amdgcn_s_waitcnt(0x0F70);          // this phase's weight fragments (requested a phase ago)
             if (fastn) { if (QIN) load_xq(nkc); else load_x(nkc); }
             SVBQ_STAMP(1)
-            if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+            SVBQ_PRIO(a.prio == 1, 1)
             uint4 bh_u[2][NT], bl_u[2][NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) { bh_u[0][n] = x_hi[xbase[n] + xoff[0]]; bl_u[0][n] = x_lo[xbase[n] + xoff[0]]; }
@@ -449,8 +437,8 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
                 }
             }
             SVBQ_STAMP(2)
-            if (a.prio == 1) __builtin_amdgcn_s_setprio(0);
-            else if (a.prio == 2) __builtin_amdgcn_s_setprio(1);
+            SVBQ_PRIO(a.prio == 1, 0)
+            SVBQ_PRIO(a.prio == 2, 1)
             if (!has_next) break;
             if (new_x) {
                 xw = xbuf - cur;
@@ -461,8 +449,8 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
                 cur = xw;
             }
             kc0 = nkc; tg0 = ntg;
-            ++dbg_stage;
-            if (a.prio == 2) __builtin_amdgcn_s_setprio(0);
+            SVBQ_NEXT_STAGE
+            SVBQ_PRIO(a.prio == 2, 0)
         }
     } else if (DIRECT_A) {
         if (ntap > 0) {
@@ -496,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
                     SVBQ_STAMP(5)
                 }
                 kc0 = nkc; tg0 = ntg;
-                ++dbg_stage;
+                SVBQ_NEXT_STAGE
             }
         }
     } else if (ntap > 0) {
@@ -529,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
             __syncthreads();
             SVBQ_STAMP(5)
             kc0 = nkc; tg0 = ntg;
-            ++dbg_stage;
+            SVBQ_NEXT_STAGE
         }
     }
 
@@ -541,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
     // instead of 16, gate / residual / mask as 16-byte loads: the epilogue went from 7.1-8.0k to 11-14k cycles, every shape got
     // 2-8 % slower, profiles/r03_conv_vector_epilogue_ab.log.  The epilogue is not bound by its store-instruction count.)
     const int out_base = p.phase_out_base[ph];
-    dbg_stage = SVBQ_DBG_STAGES - 1;
+    SVBQ_LAST_STAGE
     SVBQ_STAMP(6)
     {
         const size_t yb_off = (size_t)b * a.Cout * a.Tout;
@@ -764,6 +752,11 @@ static int q_dispatch(SvbConvQArgs& a, const SvbConvPlan& p, hipStream_t stream)
     if ((long)a.B * p.n_phase > 65535) return SVB_ERR_UNSUPPORTED;
     if ((long)a.Cout * a.Tout > 0x7fffffffL) return SVB_ERR_UNSUPPORTED;      // the epilogue's per-clip offsets are 32-bit
     int cfg = q_pick(a.Cout_g, nq_max, (long)a.B * p.n_phase * a.G);
+    if (a.force_cfg >= SVBQ_NCFG && a.force_cfg < SVBQ_NCFG + SVB_TW_NVARIANTS) {
+        // configurations 12 .. 17: the 8-wave tile-walking kernel (conv1d_tw.hip); outside its domain the heuristic tile runs
+        const int rc = svb_tw_launch(a, p, a.force_cfg - SVBQ_NCFG, stream);
+        if (rc != SVB_ERR_UNSUPPORTED) return rc;
+    }
     if (a.force_cfg >= 0 && a.force_cfg < SVBQ_NCFG) cfg = a.force_cfg;
     for (int attempt = 0; attempt < 2; ++attempt) {
         int rc;
@@ -799,9 +792,11 @@ static void q_fill(SvbConvQArgs& a, const SvbConvEpilogue* e) {
     a.mask = e ? e->mask : nullptr;
     a.force_cfg = e ? e->force_cfg - 1 : -1;
     a.xq = e ? e->x_q : nullptr;
+#ifdef SVB_INSTRUMENT
     a.dbg = g_svbq_dbg;
     a.dbg_block0 = g_svbq_dbg_block0;
     a.prio = g_svbq_prio;
+#endif
 }
 
 extern "C" int svb_weight_pack_bf16x3(const float* v, const float* g, unsigned short* qa_hi, unsigned short* qa_lo,
@@ -1442,7 +1437,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_g16_kernel(SvbWgradG1
     }
 }
 
-static const bool g_svbq_g16_off = getenv("SVB_WG_NO_G16") != nullptr;          // A/B switch
+static const bool g_svbq_g16_off = SVB_ENV_FLAG("SVB_WG_NO_G16");          // A/B switch
 // the grouped 16-row kernel's envelope; returns the tap tiles (0 = not eligible)
 static int wgq_g16_njt(int groups, int CA_g, int CB_g, int k, int sx, int dil) {
     if (g_svbq_g16_off || groups <= 1 || CA_g % 16 || dil != 1 || k > 48) return 0;
@@ -1475,7 +1470,7 @@ static void wgq_g16_launch(const SvbWgradG16Args& a, int njt, dim3 grid, size_t 
 // Tap-group width cap of dilated weight gradients: the general shifted-operand path reads 5 + 5 dwords per tap and MFMA step, and
 // with 5 accumulator sets per wave it runs at 70 TF on the period discriminators' 1024 -> 1024 layers where 3 + 2 taps reach 125
 // (vocoder step 134.3 -> 130.5 ms with 3, 137.0 with 2; profiles/r03_vocoder_period_layout.log).
-static const int g_svbq_wg_dil_tgw = getenv("SVB_WG_DIL_TGW") ? atoi(getenv("SVB_WG_DIL_TGW")) : 3;
+static const int g_svbq_wg_dil_tgw = SVB_ENV_INT("SVB_WG_DIL_TGW", 3);
 static int wgq_tgw(int k) { return k <= 5 ? k : (k % 5 == 0 ? 5 : (svb_cdiv(k, 4) <= svb_cdiv(k, 5) ? 4 : 5)); }
 
 // Tap groups of a weight gradient (see SvbWgradQArgs).  Returns the number of groups (0 = outside the envelope) and the
@@ -1530,11 +1525,11 @@ static void wgq_tile(int CA_g, int CB_g, int tgw, bool gated, int* at, int* bt) 
 // Measured on the train step: 16.0 ms with 512 for all, 15.8 with 384, 15.7-15.8 with 256, 15.9 with 192, 16.15 with 128,
 // 17.6 with 64; the vocoder step does not move (tools/r03_runs/r03_gpu45.sh, r03_gpu46.sh); on a third box 16.00 / 16.06 / 16.04
 // without the rule against 15.84 / 15.81 / 15.82 with it (r03_gpu49.sh); the chunk threshold is flat between 6 and 16.  0 = off.
-static const long g_svbq_wg_small_chunks = getenv("SVB_WG_SMALL_CHUNKS") ? atol(getenv("SVB_WG_SMALL_CHUNKS")) : 8;
-static const long g_svbq_wg_small_blocks = getenv("SVB_WG_SMALL_BLOCKS") ? atol(getenv("SVB_WG_SMALL_BLOCKS")) : 256;
-static const long g_svbq_wg_blocks = getenv("SVB_WG_BLOCKS") ? atol(getenv("SVB_WG_BLOCKS")) : 512;   // split-K target: workgroups per launch
+static const long g_svbq_wg_small_chunks = SVB_ENV_LONG("SVB_WG_SMALL_CHUNKS", 8);
+static const long g_svbq_wg_small_blocks = SVB_ENV_LONG("SVB_WG_SMALL_BLOCKS", 256);
+static const long g_svbq_wg_blocks = SVB_ENV_LONG("SVB_WG_BLOCKS", 512);   // split-K target: workgroups per launch
 // Group packing factor (see SvbWgradQArgs::gp_ca): the largest power of two m dividing `groups` with m*CA_g <= 64 and m*CB_g <= 64.
-static const bool g_svbq_wg_nopack = getenv("SVB_WG_NO_GROUP_PACK") != nullptr;      // A/B switch
+static const bool g_svbq_wg_nopack = SVB_ENV_FLAG("SVB_WG_NO_GROUP_PACK");      // A/B switch
 static int wgq_pack(int groups, int CA_g, int CB_g) {
     int m = 1;
     if (g_svbq_wg_nopack) return 1;

@@ -1,0 +1,500 @@
+// conv1d_tw.hip -- the "tile-walking" member of the bf16x3 implicit-GEMM conv family (round 4).
+//
+// Same arithmetic as conv1d_bf16.hip (operands split v = hi + lo into bf16, products hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_bf16, fp32 accumulate), a different machine mapping for the stride-1, ungrouped convs and data
+// gradients that carry most of the train step's FLOPs (reference: F.conv1d / F.conv_transpose1d of
+// modules/fastspeech/fs2_vae.py:73,83, modules/commons/common_layers.py:739-773, modules/voice_conversion/vae_models.py:86-127):
+//
+//   * ONE 512-thread workgroup (8 waves, 2 per SIMD) per CU walks several output tiles (persistent, static round-robin over
+//     an XCD-aware id): the x / weight tiles of the NEXT tile's first K phase are requested before the epilogue of the
+//     current tile, so only the first tile of a workgroup pays a prologue and the epilogue's stores drain behind the next
+//     tile's MFMAs.
+//   * weights go through LDS: a K phase's (tap, 16-channel chunk) slabs are copied global -> LDS by LDS-DMA
+//     (global_load_lds_dwordx4, no VGPRs, no ds_write) ONCE per workgroup and shared by the four waves that own the same
+//     rows -- the direct-A tiles of conv1d_bf16.hip re-read them per wave through the texture path (80 KB per phase and CU
+//     against 40 here, and 4.5 MFMAs per weight VMEM instruction against 12..18).
+//   * a wave owns (32*AF) x (32*BF) outputs (AF x BF accumulators): per slab 2AF + 2BF 16-byte LDS reads feed 3*AF*BF MFMAs.
+//   * the column space is FLATTENED over the batch: column n <-> (clip n / Tp, position n % Tp) with Tp = Tout + (tap span),
+//     so a tile's columns run across clip boundaries (the gap columns between two clips see exactly the conv's zero
+//     padding and are not stored) -- tiles do not have to divide T, whatever the sequence length.
+//   * LDS images are planar: plane = (hi|lo, 8-channel half kb), one 16-byte element per (row | position); every
+//     ds_read_b128 / ds_write_b128 of a 32-lane half touches 32 consecutive elements: bank-conflict free for any tap shift.
+//
+// Domain: sx == 1, out_stride == 1, one output phase, groups == 1, Cin % 16 == 0, <= TW_MAX_TAPS taps.  Everything else
+// stays on conv1d_bf16.hip (svb_tw_launch returns SVB_ERR_UNSUPPORTED).
+#include "svb_common.h"
+#include "svb_q.h"
+#include "conv1d_q.h"
+#include <svb_glds.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define TW_MAX_TAPS 8
+#define TW_SMAX 8          /* slabs (tap x chunk) per K phase */
+#define TW_XU 3            /* x staging units (8 channels of one position) per thread and phase */
+#define TW_LDS_BUDGET (158 * 1024)
+
+struct SvbTwArgs {
+    const float* x;
+    const unsigned short* wq_hi;
+    const unsigned short* wq_lo;
+    const float* bias;
+    float* y;
+    const float* in_gate;
+    const float* out_gate;
+    const float* mask;
+    const float* residual;
+    float in_slope, out_slope, out_gate_slope;
+    int out_act;
+    int B, Cin, Cout, Tin, Tout;
+    int Tp, ncols;          // clip pitch of the flattened column space, B * Tp
+    int min_off, span;      // smallest tap offset; x-tile rows per chunk (BN + tap span)
+    int ntap, kch, nphase, S;   // taps, chunks per K phase, K phases per tile, slabs per phase (kch * ntap)
+    int m_tiles, ntiles;
+    int w_rows, w_chunk16;  // rows per weight slab; 16-byte units between the slabs of consecutive chunks
+    int xunits;             // ceil(kch * span / 256)
+    int issue_slab_late;    // slab in front of which waves 4..7 issue the next phase's loads (waves 0..3: slab 0)
+    unsigned slx[TW_SMAX / 2];  // slab s -> row offset inside an x plane (chunk * span + tap_off - min_off), 16 bits each
+    int w_tap16;                // 16-byte units between the slabs of consecutive taps (weight slab of tap t = t)
+#ifdef SVB_INSTRUMENT
+    unsigned long long* dbg;    // stage stamps [workgroup < 4][wave][phase < 32][8] (tools/tw_stage_timing.py)
+    int ablate;                 // timing-only ablations: 1 no x loads, 2 no weight DMA, 4 no MFMAs, 8 no epilogue stores,
+                                // 16 no x split / LDS store, 32 no fragment reads
+#endif
+};
+
+#ifdef SVB_INSTRUMENT
+static unsigned long long* g_tw_dbg = nullptr;
+static int g_tw_ablate = 0, g_tw_issue_late = -1;
+extern "C" void svb_debug_set_tw(void* buf, int ablate, int issue_slab_late) {
+    g_tw_dbg = (unsigned long long*)buf; g_tw_ablate = ablate; g_tw_issue_late = issue_slab_late;
+}
+#define TW_ABL(bit) ((arg.ablate & (bit)) != 0)
+#define TW_STAMP(slot)                                                                                          \
+    if (arg.dbg && vid < 4 && lane == 0 && dbg_ph < 32)                                                          \
+        arg.dbg[(((size_t)vid * 8 + wave) * 32 + dbg_ph) * 8 + (slot)] = __builtin_readcyclecounter();
+#define TW_NEXT_PHASE ++dbg_ph;
+#else
+#define TW_ABL(bit) false
+#define TW_STAMP(slot)
+#define TW_NEXT_PHASE
+#endif
+
+template <int AF, int BF, bool GATE>
+__global__ __launch_bounds__(512, 2) void svb_conv1d_tw_kernel(SvbTwArgs arg) {
+    constexpr int BM = 64 * AF, BN = 128 * BF;
+    constexpr int NR = 2 * AF + 2 * BF, NM = 3 * AF * BF, NAB = AF * BF;
+    constexpr int WSLOTS = (4 * AF + 7) / 8;          // weight DMA instructions per wave and slab
+    HIP_DYNAMIC_SHARED(uint4, smem)
+    // kernel arguments as plain locals (a by-value struct that lambdas capture by reference can end up in scratch)
+    const int p_B = arg.B, p_Cin = arg.Cin, p_Cout = arg.Cout, p_Tin = arg.Tin, p_Tout = arg.Tout;
+    const int p_Tp = arg.Tp, p_ncols = arg.ncols, p_min_off = arg.min_off, p_span = arg.span;
+    const int p_ntap = arg.ntap, p_kch = arg.kch, p_nphase = arg.nphase, p_S = arg.S;
+    const int p_m_tiles = arg.m_tiles, p_ntiles = arg.ntiles, p_w_rows = arg.w_rows;
+    const unsigned p_w_chunk16 = (unsigned)arg.w_chunk16, p_w_tap16 = (unsigned)arg.w_tap16;
+    const int p_xunits = arg.xunits;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int kb = lane >> 5, l31 = lane & 31;
+    const int xh = wave >> 2;                         // x staging: waves 0..3 channel half 0, waves 4..7 half 1
+    const int XR = p_kch * p_span;                    // rows per x plane
+    const int WU = p_S * 4 * BM;                      // 16-byte units per weight buffer
+    const int XU16 = 4 * XR;                          // ... per x buffer
+    const int xbuf0 = 2 * WU;                         // LDS (16-byte units): W0 | W1 | X0 | X1
+
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int qd = nwg >> 3, rd = nwg & 7, xcd = orig & 7;
+    const int vid = (xcd < rd ? xcd * (qd + 1) : rd * (qd + 1) + (xcd - rd) * qd) + (orig >> 3);
+    if (vid >= p_ntiles) return;
+
+    // ---- per-kernel constants -------------------------------------------------------------------------------------------
+    // weight DMA roles: unit v = wave + 8 j of a slab's 4*AF (plane, 64-row block) units (BM = 64: waves 0..3, one plane each)
+    int w_pl[WSLOTS], w_rb[WSLOTS];
+    const uint4* w_arr[WSLOTS];            // hi or lo array, advanced to the plane's 8-channel half
+    {
+        const uint4* const w_hi16 = reinterpret_cast<const uint4*>(arg.wq_hi);
+        const uint4* const w_lo16 = reinterpret_cast<const uint4*>(arg.wq_lo);
+#pragma unroll
+        for (int j = 0; j < WSLOTS; ++j) {
+            const int v = AF == 1 ? (wave & 3) : wave + 8 * j;
+            w_pl[j] = v / AF;
+            w_rb[j] = v - w_pl[j] * AF;
+            w_arr[j] = ((w_pl[j] & 2) ? w_lo16 : w_hi16) + (w_pl[j] & 1);
+        }
+    }
+    // x staging: unit u of a thread = 8 channels (half xh of a 16-channel chunk) of plane row u * 256 + (tid & 255);
+    // loads go through a buffer descriptor: one per-lane 32-bit offset per unit and tile, the channel part is a scalar offset
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(arg.x), 0, 4u * (unsigned)(p_B * p_Cin * p_Tin), 0x00020000);
+    const __amdgpu_buffer_rsrc_t g_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GATE ? arg.in_gate : arg.x), 0, 4u * (unsigned)(p_B * p_Cin * p_Tin), 0x00020000);
+    const int x_row0 = tid & 255;
+    const int a_lane = kb * BM + wm * 32 * AF + l31;           // A fragment: plane kb, this wave's rows
+    const int b_lane = kb * XR + wn * 32 * BF + l31;           // B fragment: plane kb, this wave's columns
+
+    // ---- per-tile state -------------------------------------------------------------------------------------------------
+    int m_base = 0, n0 = 0;
+    unsigned x_off[TW_XU];
+    unsigned x_okmask = 0;                  // bit u: the unit's position is inside a clip (else the row is zero)
+    unsigned w_row16[WSLOTS];
+    auto setup_tile = [&](int tile) {
+        const int mt = tile % p_m_tiles, nt = tile / p_m_tiles;
+        m_base = mt * BM;
+        n0 = nt * BN;
+        x_okmask = 0;
+#pragma unroll
+        for (int u = 0; u < TW_XU; ++u) {
+            const int idx = u * 256 + x_row0;
+            const int c = idx / p_span, i = idx - c * p_span;
+            const int f = n0 + i;
+            const int bf = f / p_Tp, uf = f - bf * p_Tp;
+            const int pos = uf + p_min_off;
+            const bool ok = idx < XR && bf < p_B && pos >= 0 && pos < p_Tin;
+            x_okmask |= (ok ? 1u : 0u) << u;
+            x_off[u] = ok ? 4u * (unsigned)((bf * p_Cin + c * 16 + xh * 8) * p_Tin + pos) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < WSLOTS; ++j)
+            w_row16[j] = 2u * (unsigned)min(m_base + w_rb[j] * 64 + lane, p_w_rows - 1);
+    };
+
+    float xr[TW_XU][8];
+    float gr[GATE ? TW_XU : 1][8];
+    // all loads of a phase are requested at once; a unit outside the tile (or its clip) reads element 0 of the channel row
+    auto issue_x = [&](int ph) {
+        if (TW_ABL(1)) return;
+        const unsigned ch0 = (unsigned)(ph * p_kch * 16);
+#pragma unroll
+        for (int u = 0; u < TW_XU; ++u)
+            if (u < p_xunits) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    xr[u][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, x_off[u], 4u * (ch0 + e) * (unsigned)p_Tin, 0));
+                if (GATE) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        gr[u][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, x_off[u], 4u * (ch0 + e) * (unsigned)p_Tin, 0));
+                }
+            }
+    };
+    auto finish_x = [&](int xb16) {           // split + store into the x buffer that starts at 16-byte unit xb16
+        if (TW_ABL(16)) return;
+        const float in_slope = arg.in_slope;
+#pragma unroll
+        for (int u = 0; u < TW_XU; ++u)
+            if (u < p_xunits && u * 256 + x_row0 < XR) {
+                if (GATE) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xr[u][e] *= svb_gate(gr[u][e], in_slope);
+                }
+                unsigned h[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) svbq_split2(xr[u][2 * e], xr[u][2 * e + 1], h[e], l[e]);
+                uint4 hi = make_uint4(h[0], h[1], h[2], h[3]), lo = make_uint4(l[0], l[1], l[2], l[3]);
+                if (!((x_okmask >> u) & 1u)) { hi = make_uint4(0u, 0u, 0u, 0u); lo = hi; }
+                smem[xb16 + xh * XR + u * 256 + x_row0] = hi;
+                smem[xb16 + (2 + xh) * XR + u * 256 + x_row0] = lo;
+            }
+    };
+    // weight slabs of K phase ph -> the weight buffer that starts at 16-byte unit wb16 (LDS-DMA: lane L of an instruction
+    // fetches row (64-row block) + L of one plane, the 64 x 16 bytes land consecutively)
+    auto issue_w = [&](int ph, int wb16) {
+        if (TW_ABL(2)) return;
+        unsigned cb16 = (unsigned)(ph * p_kch) * p_w_chunk16;
+        int dst = wb16;
+        for (int c = 0; c < p_kch; ++c, cb16 += p_w_chunk16) {
+            unsigned sb16 = cb16;
+            for (int t = 0; t < p_ntap; ++t, sb16 += p_w_tap16, dst += 4 * BM) {
+#pragma unroll
+                for (int j = 0; j < WSLOTS; ++j) {
+                    const bool mine = AF == 1 ? wave < 4 : (AF == 2 || wave + 8 * j < 4 * AF);      // (BM = 64: 4 units per slab)
+                    if (mine) {
+                        const uint4* src = w_arr[j] + (size_t)sb16 + w_row16[j];
+                        svb_glds16(src, smem, 16u * (unsigned)(dst + w_pl[j] * BM + w_rb[j] * 64));
+                    }
+                }
+            }
+        }
+    };
+
+    f32x16 acc[AF][BF];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < AF; ++i)
+#pragma unroll
+            for (int n = 0; n < BF; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+    };
+
+    // ---- epilogue of the tile (m_base_e, n0_e): bias, activation, gate, residual, mask; column -> (clip, position).
+    // Stores / operand loads go through buffer descriptors: per (accumulator, column block) one per-lane offset, the 16 rows
+    // of an accumulator as scalar offsets.
+    const unsigned y_bytes = 4u * (unsigned)(p_B * p_Cout * p_Tout);
+    auto epilogue = [&](int m_base_e, int n0_e) {
+        const float* const e_bias = arg.bias;
+        const float* const e_mask = arg.mask;
+        const bool has_gate = arg.out_gate != nullptr, has_res = arg.residual != nullptr;
+        const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(arg.y, 0, y_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t og_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_gate ? arg.out_gate : arg.y), 0, y_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_res ? arg.residual : arg.y), 0, y_bytes, 0x00020000);
+        const bool plain = !has_gate && !has_res && !e_mask;
+        const int act = arg.out_act;
+        const float slope = arg.out_slope, gslope = arg.out_gate_slope;
+        const float neg = act == SVB_ACT_RELU ? 0.f : (act == SVB_ACT_LRELU ? slope : 1.f);      // v > 0 ? v : v * neg
+        const bool full_m = m_base_e + BM <= p_Cout;
+        int colbase[BF];            // (clip * Cout) * Tout + position, or -1
+        float mk[BF];
+#pragma unroll
+        for (int n = 0; n < BF; ++n) {
+            const int f = n0_e + wn * 32 * BF + 32 * n + l31;
+            const int bf = f / p_Tp, uf = f - bf * p_Tp;
+            const bool ok = f < p_ncols && uf < p_Tout;
+            colbase[n] = ok ? bf * p_Cout * p_Tout + uf : -1;
+            mk[n] = (ok && e_mask) ? e_mask[bf * p_Tout + uf] : 1.f;
+        }
+#pragma unroll
+        for (int i = 0; i < AF; ++i) {
+            const int ml0 = m_base_e + wm * 32 * AF + 32 * i + 4 * kb;          // row of accumulator element r: ml0 + (r&3) + 8 (r>>2)
+            float bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[r] = e_bias ? e_bias[min(ml0 + (r & 3) + 8 * (r >> 2), p_Cout - 1)] : 0.f;
+#pragma unroll
+            for (int n = 0; n < BF; ++n)
+                if (colbase[n] >= 0) {
+                    const unsigned voff = 4u * (unsigned)(ml0 * p_Tout + colbase[n]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        const unsigned soff = 4u * (unsigned)(dr * p_Tout);
+                        if (full_m || ml0 + dr < p_Cout) {
+                            float v = acc[i][n][r] + bv[r];
+                            if (plain && act != SVB_ACT_TANH) {
+                                v = v > 0.f ? v : v * neg;
+                            } else {
+                                v = svb_apply_act(v, act, slope);
+                                if (has_gate) v *= svb_gate(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(og_rsrc, voff, soff, 0)), gslope);
+                                if (has_res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rsrc, voff, soff, 0));
+                                v *= mk[n];
+                            }
+                            if (!TW_ABL(8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, voff, soff, 0);
+                        }
+                    }
+                }
+        }
+    };
+
+    // ---- one K phase of MFMAs.  Fragments are double-buffered in registers by slab parity; every LDS read of slab s+1
+    // sits, placed by hand and pinned, behind one MFMA of slab s.  LDS addresses: one per-lane byte address per operand
+    // plus wave-uniform offsets.
+    uint4 fa[2][2 * AF], fb[2][2 * BF];
+    const unsigned x_lo16 = 32u * (unsigned)XR;                  // byte distance hi plane -> lo plane of the x image
+    const char* const lds = reinterpret_cast<const char*>(smem);
+    const unsigned a_lane16 = 16u * (unsigned)a_lane, b_lane16 = 16u * (unsigned)b_lane;
+    auto read_frag = [&](int par, int r, unsigned wofs, unsigned xofs) {   // r: 0 .. NR-1 = A hi[AF], A lo[AF], B hi[BF], B lo[BF]
+        if (r < 2 * AF) {
+            const int arr = r / AF, i = r - arr * AF;
+            fa[par][r] = *reinterpret_cast<const uint4*>(lds + (a_lane16 + wofs) + 16u * (unsigned)(arr * 2 * BM + i * 32));
+        } else {
+            const int q = r - 2 * AF, arr = q / BF, n = q - arr * BF;
+            fb[par][q] = *reinterpret_cast<const uint4*>(lds + (b_lane16 + xofs + (arr ? x_lo16 : 0u)) + 16u * (unsigned)(n * 32));
+        }
+    };
+    auto mfma_step = [&](int par, int j) {
+        const int prod = j / NAB, idx = j - prod * NAB;
+        const int i = idx / BF, n = idx - i * BF;
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&fa[par][i]), al = *reinterpret_cast<const bf16x8*>(&fa[par][AF + i]);
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&fb[par][n]), bl = *reinterpret_cast<const bf16x8*>(&fb[par][BF + n]);
+        if (prod == 0) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][n], 0, 0, 0);
+        else if (prod == 1) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][n], 0, 0, 0);
+        else acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][n], 0, 0, 0);
+    };
+    // slab -> row offset inside an x plane (chunk * span + tap row), two 16-bit fields per word (host-packed)
+    const unsigned long long slx_lo = (unsigned long long)arg.slx[0] | ((unsigned long long)arg.slx[1] << 32);
+    const unsigned long long slx_hi = (unsigned long long)arg.slx[2] | ((unsigned long long)arg.slx[3] << 32);
+    auto slab_row = [&](int s) -> unsigned {       // (shifts, not a select chain: that becomes a lookup table in scratch)
+        const unsigned long long w = (s & 4) ? slx_hi : slx_lo;
+        return (unsigned)(w >> (16 * (s & 3))) & 0xFFFFu;
+    };
+    // the MFMAs of the slab held in fragment set `par`, the fragments of slab `sn` read into the other set meanwhile (past
+    // the phase's last slab `sn` is clamped: a harmless re-read instead of a second copy of the body)
+    auto slab_body = [&](int par, unsigned wb, unsigned xb, int sn) {
+        const unsigned wofs = wb + (unsigned)sn * (64u * BM), xofs = xb + 16u * slab_row(sn);
+#pragma unroll
+        for (int j = 0; j < NM; ++j) {
+            if (!TW_ABL(4)) mfma_step(par, j);
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (r >= j * NR / NM && r < (j + 1) * NR / NM && !TW_ABL(32)) read_frag(par ^ 1, r, wofs, xofs);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- main: the (tile, phase) sequence of this workgroup as ONE pipelined stream -------------------------------------------
+    int tile = vid;
+    setup_tile(tile);
+    zero_acc();
+    issue_x(0);
+    issue_w(0, 0);
+    finish_x(xbuf0);
+    __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0) lgkmcnt(0): DMA landed, LDS stores done
+    __builtin_amdgcn_s_barrier();
+    int ph = 0, buf = 0;
+#ifdef SVB_INSTRUMENT
+    int dbg_ph = 0;
+#endif
+    const int issue_at = xh ? arg.issue_slab_late : 0;
+    const int s_last = p_S - 1;
+    while (true) {
+        const bool last_ph = ph + 1 == p_nphase;
+        const int ntile = last_ph ? tile + nwg : tile;
+        const bool has_next = ntile < p_ntiles;
+        const int nph = last_ph ? 0 : ph + 1;
+        const int m_base_e = m_base, n0_e = n0;
+        const unsigned wb = 16u * (unsigned)(buf * WU), xb = 16u * (unsigned)(xbuf0 + buf * XU16);
+        const int nwb16 = (buf ^ 1) * WU, nxb16 = xbuf0 + (buf ^ 1) * XU16;
+
+        TW_STAMP(0)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) read_frag(0, r, wb, xb + 16u * slab_row(0));
+        for (int s = 0; s < p_S; s += 2) {
+            if (has_next && s == issue_at) {
+                TW_STAMP(1)
+                if (last_ph) setup_tile(ntile);
+                issue_x(nph);
+                issue_w(nph, nwb16);
+                TW_STAMP(2)
+            }
+            slab_body(0, wb, xb, min(s + 1, s_last));
+            if (s + 1 < p_S) slab_body(1, wb, xb, min(s + 2, s_last));
+        }
+        TW_STAMP(3)
+        if (has_next) finish_x(nxb16);
+        TW_STAMP(4)
+        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): next phase's weight slabs have landed (x loads were consumed above)
+        TW_STAMP(5)
+        if (last_ph) {
+            epilogue(m_base_e, n0_e);
+            zero_acc();
+        }
+        TW_STAMP(6)
+        __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): this wave's LDS stores are done; the epilogue's global stores stay in flight
+        __builtin_amdgcn_s_barrier();
+        TW_STAMP(7)
+        TW_NEXT_PHASE
+        if (!has_next) break;
+        buf ^= 1;
+        ph = nph;
+        tile = ntile;
+    }
+}
+
+// ==================================================================================================================
+struct TwCfg { int AF, BF; };
+static const TwCfg kTwCfgs[SVB_TW_NVARIANTS] = {{2, 2}, {2, 1}, {1, 2}, {3, 2}, {1, 1}, {3, 1}};
+
+template <int AF, int BF, bool GATE>
+static void tw_launch_kernel(const SvbTwArgs& a, int grid, size_t lds, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_tw_kernel<AF, BF, GATE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((svb_conv1d_tw_kernel<AF, BF, GATE>), dim3(grid), dim3(512), lds, stream, a);
+}
+
+template <int AF, int BF>
+static void tw_launch_gate(const SvbTwArgs& a, int grid, size_t lds, hipStream_t stream) {
+    if (a.in_gate) tw_launch_kernel<AF, BF, true>(a, grid, lds, stream);
+    else tw_launch_kernel<AF, BF, false>(a, grid, lds, stream);
+}
+
+static int g_tw_cus = 0;
+
+int svb_tw_launch(const SvbConvQArgs& q, const SvbConvPlan& p, int variant, hipStream_t stream) {
+    if (variant < 0 || variant >= SVB_TW_NVARIANTS) return SVB_ERR_UNSUPPORTED;
+    if (p.n_phase != 1 || q.sx != 1 || q.out_stride != 1 || q.G != 1 || q.Cin % 16 || q.xq) return SVB_ERR_UNSUPPORTED;
+    const int ntap = p.phase_start[1] - p.phase_start[0];
+    if (ntap < 1 || ntap > TW_MAX_TAPS || p.phase_out_base[0] != 0 || p.phase_nq[0] != q.Tout) return SVB_ERR_UNSUPPORTED;
+    const int AF = kTwCfgs[variant].AF, BF = kTwCfgs[variant].BF;
+    const int BM = 64 * AF, BN = 128 * BF;
+    if (q.Cout < 32) return SVB_ERR_UNSUPPORTED;
+    // 32-bit offsets inside the kernel
+    if ((long)q.B * q.Cin * q.Tin >= (1L << 30) || (long)q.B * q.Cout * q.Tout >= (1L << 30)) return SVB_ERR_UNSUPPORTED;
+
+    SvbTwArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = q.x; a.wq_hi = q.wq_hi; a.wq_lo = q.wq_lo; a.bias = q.bias; a.y = q.y;
+    a.in_gate = q.in_gate; a.out_gate = q.out_gate; a.mask = q.mask; a.residual = q.residual;
+    a.in_slope = q.in_slope; a.out_slope = q.out_slope; a.out_gate_slope = q.out_gate_slope; a.out_act = q.out_act;
+    a.B = q.B; a.Cin = q.Cin; a.Cout = q.Cout; a.Tin = q.Tin; a.Tout = q.Tout;
+    const int span_off = p.phase_span_off[0];
+    a.min_off = p.phase_min_off[0];
+    a.Tp = q.Tout + span_off;
+    if ((long)q.B * a.Tp >= (1L << 30)) return SVB_ERR_UNSUPPORTED;
+    a.ncols = q.B * a.Tp;
+    a.span = BN + span_off;
+    a.ntap = ntap;
+    const int kchunks = q.Cin / 16;
+    a.w_rows = q.w_slab_rows;
+    a.w_chunk16 = q.w_slab_rows * 2;
+    if ((long)q.w_tap_slabs * q.w_slab_rows * 2 * (SVB_MAX_TAPS + 1) >= (1L << 31)) return SVB_ERR_UNSUPPORTED;
+    for (int t = 0; t < ntap; ++t)
+        if (p.tap_w[p.phase_start[0] + t] != t) return SVB_ERR_UNSUPPORTED;
+    a.w_tap16 = q.w_tap_slabs * q.w_slab_rows * 2;
+    // chunks per phase: as many as divide the K extent, fit the slab / staging-unit caps and the LDS budget
+    int kch = 0;
+    for (int k = TW_SMAX / ntap; k >= 1; --k) {
+        if (kchunks % k) continue;
+        if ((k * a.span + 255) / 256 > TW_XU) continue;
+        const size_t lds = (size_t)2 * ((size_t)k * ntap * 4 * BM + (size_t)4 * k * a.span) * 16;
+        if (lds > TW_LDS_BUDGET) continue;
+        kch = k;
+        break;
+    }
+    if (!kch) return SVB_ERR_UNSUPPORTED;
+    a.kch = kch;
+    a.S = kch * ntap;
+    a.nphase = kchunks / kch;
+    a.xunits = (kch * a.span + 255) / 256;
+    a.issue_slab_late = a.S >= 4 ? 2 : 0;
+#ifdef SVB_INSTRUMENT
+    a.dbg = g_tw_dbg;
+    a.ablate = g_tw_ablate;
+    if (g_tw_issue_late >= 0) a.issue_slab_late = g_tw_issue_late;
+#endif
+    if (kch * a.span + span_off >= 65536) return SVB_ERR_UNSUPPORTED;
+    for (int s = 0; s < a.S; ++s) {
+        const unsigned row = (unsigned)((s / ntap) * a.span + p.tap_off[p.phase_start[0] + s % ntap] - a.min_off);
+        a.slx[s >> 1] |= row << (16 * (s & 1));
+    }
+    a.m_tiles = svb_cdiv(q.Cout, BM);
+    const long n_tiles = ((long)a.ncols + BN - 1) / BN;
+    if (a.m_tiles * n_tiles >= (1L << 30)) return SVB_ERR_UNSUPPORTED;
+    a.ntiles = (int)(a.m_tiles * n_tiles);
+    size_t lds = (size_t)2 * ((size_t)a.S * 4 * BM + (size_t)4 * kch * a.span) * 16;
+    if (lds < 82 * 1024) lds = 82 * 1024;          // one workgroup per CU whatever the tile needs (grid = CUs)
+    if (!g_tw_cus) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            g_tw_cus = cus;
+        else
+            g_tw_cus = 256;
+    }
+    const int grid = a.ntiles < g_tw_cus ? a.ntiles : g_tw_cus;
+    switch (variant) {
+        case 0: tw_launch_gate<2, 2>(a, grid, lds, stream); break;
+        case 1: tw_launch_gate<2, 1>(a, grid, lds, stream); break;
+        case 2: tw_launch_gate<1, 2>(a, grid, lds, stream); break;
+        case 3: tw_launch_gate<3, 2>(a, grid, lds, stream); break;
+        case 4: tw_launch_gate<1, 1>(a, grid, lds, stream); break;
+        default: tw_launch_gate<3, 1>(a, grid, lds, stream); break;
+    }
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}

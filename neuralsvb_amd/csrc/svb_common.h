@@ -54,6 +54,19 @@ __device__ __forceinline__ float svb_block_sum(float v, float* red) {
 
 static inline int svb_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Experiment switches and cycle stamps exist only in the instrumentation build (`make instr` -> libsvb_hip_instr.so,
+// compiled with -DSVB_INSTRUMENT, loaded by tools/ only); in the product library every switch is its default, a constant.
+#ifdef SVB_INSTRUMENT
+#include <stdlib.h>
+#define SVB_ENV_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define SVB_ENV_LONG(name, dflt) (getenv(name) ? atol(getenv(name)) : (long)(dflt))
+#define SVB_ENV_FLAG(name) (getenv(name) != nullptr)
+#else
+#define SVB_ENV_INT(name, dflt) (dflt)
+#define SVB_ENV_LONG(name, dflt) ((long)(dflt))
+#define SVB_ENV_FLAG(name) false
+#endif
+
 #define SVB_CHECK_LAUNCH()                                   \
     do {                                                     \
         if (hipGetLastError() != hipSuccess) return SVB_ERR_LAUNCH; \

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(1024) void svb_gn_relu_bwd_rows_kernel(const float*
     }
 }
 
-static const bool g_svb_gn_rows_off = getenv("SVB_GN_NO_ROWS") != nullptr;       // A/B switch
+static const bool g_svb_gn_rows_off = SVB_ENV_FLAG("SVB_GN_NO_ROWS");       // A/B switch
 // KR of the row-resident kernels for this shape, 0 = not eligible
 static int svb_gn_rows_kr(int C, int T, int G, const void* p0, const void* p1, const void* p2) {
     if (g_svb_gn_rows_off || C / G > 16 || (T & 3)) return 0;

@@ -12,7 +12,7 @@ mkdir -p "$HERE/build"
 for s in $SRCS; do
   o="$HERE/build/$(basename "$s" .hip).o"
   if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ -n "$(find "$ROOT/neuralsvb_amd/csrc" "$ROOT/include" "$HERE/include" -name '*.h' -newer "$o")" ]; then
-    "$CXX" -x c++ -std=c++17 -O2 -fPIC -I"$HERE/include" -I"$ROOT/include" -Wno-unknown-attributes -c "$s" -o "$o" &
+    "$CXX" -x c++ -std=c++17 -O2 -fPIC -I"$HERE/include" -I"$ROOT/include" -I"$ROOT/neuralsvb_amd/csrc" -Wno-unknown-attributes -c "$s" -o "$o" &
   fi
   OBJS="$OBJS $o"
 done

@@ -33,6 +33,9 @@ typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+#define hipDeviceAttributeMultiprocessorCount 0
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 4; return hipSuccess; }   // a 4-CU "device": persistent kernels walk several tiles
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 
@@ -78,9 +81,18 @@ static inline void __builtin_amdgcn_s_barrier_emu() { emu_syncthreads(); }
 void emu_wave_sync();                                             // all lanes of the calling wave arrive before any continues
 #define __builtin_amdgcn_wave_barrier() emu_wave_sync()
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
-// LDS-DMA (global_load_lds_dwordx4): lane L copies its 16 bytes to wave_base + 16*L; completes immediately here
-#define SVB_GLDS16(g, lds_wave_base) memcpy((char*)(lds_wave_base) + 16 * emu_lane_id(), (const void*)(g), 16)
-#define SVB_WAIT_VMCNT0() ((void)0)
+// buffer descriptors: (base, bytes); loads outside the range return 0, stores outside are dropped
+struct emu_buffer_rsrc { char* base; unsigned bytes; };
+typedef emu_buffer_rsrc __amdgpu_buffer_rsrc_t;
+static inline emu_buffer_rsrc __builtin_amdgcn_make_buffer_rsrc(void* p, short, unsigned bytes, int) { return emu_buffer_rsrc{(char*)p, bytes}; }
+static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(emu_buffer_rsrc r, unsigned voff, unsigned soff, int) {
+    unsigned v = 0;
+    if ((unsigned long long)voff + soff + 4 <= r.bytes) memcpy(&v, r.base + voff + soff, 4);
+    return v;
+}
+static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, emu_buffer_rsrc r, unsigned voff, unsigned soff, int) {
+    if ((unsigned long long)voff + soff + 4 <= r.bytes) memcpy(r.base + voff + soff, &v, 4);
+}
 #define __builtin_readcyclecounter() 0ull
 
 typedef float emu_f32x16 __attribute__((ext_vector_type(16)));

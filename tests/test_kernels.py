@@ -567,6 +567,57 @@ def test_conv1d_bf16x3_direct_tiles_whole_phase_loops(dev, cfg, shape):
     assert rel_err(dx, dref) < 6e-5
 
 
+@pytest.mark.parametrize("cfg", [13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("shape", [(64, 1, 1), (32, 3, 1), (48, 5, 1), (32, 3, 3), (96, 1, 1)])
+def test_conv1d_bf16x3_tile_walking_kernel(dev, cfg, shape):
+    """The 8-wave tile-walking kernel (csrc/conv1d_tw.hip, configurations 13..18): weights through LDS by LDS-DMA, columns
+    flattened over the batch (tiles straddle clip boundaries: 3 clips x 150 positions in 128- / 256-column tiles), several
+    tiles per workgroup (the emulator's device has 4 CUs), 1 / 2 / 4 chunks per K phase, a ragged last row tile (72 outputs);
+    forward with bias + LeakyReLU, the transposed form with residual + mask, and the input gate, against the oracle."""
+    Cin, k, dil = shape
+    g = torch.Generator().manual_seed(cfg * 100 + Cin + k)
+    B, Cout, T = 3, 72, 150
+    pad = dil * (k - 1) // 2
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) * 0.2
+    bias = torch.randn(Cout, generator=g)
+    ref = F.leaky_relu(oops.conv1d(x, w, bias, 1, pad, dil), 0.2)
+    qa, qb = K.weight_pack_q(w.to(dev), None, 1)
+    y = K.conv1d_forward(x.to(dev), qa, Cout, k, 1, pad, dil, 1, bias=bias.to(dev), out_act=K.ACT_LRELU, out_slope=0.2,
+                         force_cfg=cfg)
+    assert rel_err(y, ref) < 6e-5
+    dy = torch.randn(ref.shape, generator=g)
+    res = torch.randn(B, Cin, T, generator=g)
+    mask = (torch.rand(B, T, generator=g) > 0.2).float()
+    dref = (torch.autograd.grad(oops.conv1d(x.requires_grad_(True), w, None, 1, pad, dil), x, dy)[0] + res) * mask[:, None]
+    dx = K.conv1d_transposed(dy.to(dev), qb, Cin, T, k, 1, pad, dil, 1, residual=res.to(dev), mask=mask.to(dev), force_cfg=cfg)
+    assert rel_err(dx, dref) < 6e-5
+    gate = torch.randn(B, Cin, T, generator=g)
+    refg = oops.conv1d(x.detach() * torch.where(gate > 0, 1.0, 0.2), w, None, 1, pad, dil)
+    yg = K.conv1d_forward(x.detach().to(dev), qa, Cout, k, 1, pad, dil, 1, in_gate=gate.to(dev), in_slope=0.2, force_cfg=cfg)
+    assert rel_err(yg, refg) < 6e-5
+
+
+@pytest.mark.parametrize("cfg", [13, 17])
+@pytest.mark.parametrize("T,k,pad,dil", [(4, 3, 1, 1), (7, 3, 9, 9), (131, 5, 2, 1), (260, 3, 27, 27), (66, 3, 5, 1)])
+def test_conv1d_bf16x3_tile_walking_clip_edges(dev, cfg, T, k, pad, dil):
+    """Clips shorter than the tap span, padding wider than the clip, over-wide padding that lengthens the output, dilation 27:
+    the flattened column space (pitch = Tout + tap span) against the oracle; plus a strided conv, which is outside the
+    kernel's domain and must come out of the heuristic tile unchanged."""
+    g = torch.Generator().manual_seed(1000 * cfg + T + k)
+    B, Cin, Cout = 2, 32, 40
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) * 0.2
+    qa, _ = K.weight_pack_q(w.to(dev), None, 1)
+    ref = oops.conv1d(x, w, None, 1, pad, dil)
+    y = K.conv1d_forward(x.to(dev), qa, Cout, k, 1, pad, dil, 1, force_cfg=cfg)
+    assert y.shape == ref.shape and rel_err(y, ref) < 6e-5
+    if T > 60:
+        refs = oops.conv1d(x, w, None, 2, pad, dil)
+        ys = K.conv1d_forward(x.to(dev), qa, Cout, k, 2, pad, dil, 1, force_cfg=cfg)
+        assert ys.shape == refs.shape and rel_err(ys, refs) < 6e-5
+
+
 @pytest.mark.parametrize("cfg", [6, 7, 9, 10])
 def test_conv1d_bf16x3_wide_tiles_three_position_groups(dev, cfg):
     """64x192 / 64x256 tiles on a long sequence: the register-staged x path with up to 3 groups of 128 positions."""
