@@ -108,7 +108,7 @@ int svb_conv1d_transposed_bf16x3(const float* x, const unsigned short* qb_hi, co
  * buffer of 64*32*8 uint64 for the first 64 workgroups; svb_debug_set_tw: stamp buffer + ablation mask of conv1d_tw.hip.       */
 #ifdef SVB_INSTRUMENT
 void svb_debug_set_timing_buffer(void* buf);
-void svb_debug_set_tw(void* buf, int ablate, int issue_slab_late);
+void svb_debug_set_tw(void* buf, int ablate, int drain_per_pair);
 #endif
 
 /* Weight gradient, stage 1 (split-K partials): part[s][a][b][j] += A[n,a,q] * Bt[n,b,q*sx + j*dil - pad].

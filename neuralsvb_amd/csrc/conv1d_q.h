@@ -32,5 +32,5 @@ struct SvbConvQArgs {
 // conv1d_tw.hip: the 8-wave tile-walking kernel.  variant = 0 .. SVB_TW_NVARIANTS-1; returns SVB_ERR_UNSUPPORTED when the
 // conv is outside its domain (strided / grouped / ragged channel chunks / too many taps) -- the caller then takes a
 // tile of conv1d_bf16.hip.
-#define SVB_TW_NVARIANTS 6
+#define SVB_TW_NVARIANTS 3
 int svb_tw_launch(const SvbConvQArgs& a, const SvbConvPlan& p, int variant, hipStream_t stream);

@@ -31,7 +31,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define TW_MAX_TAPS 8
 #define TW_SMAX 8          /* slabs (tap x chunk) per K phase */
-#define TW_XU 3            /* x staging units (8 channels of one position) per thread and phase */
+#define TW_XU 5            /* x staging units (8 channels of one position) per producer thread and phase */
 #define TW_LDS_BUDGET (158 * 1024)
 
 struct SvbTwArgs {
@@ -52,24 +52,27 @@ struct SvbTwArgs {
     int ntap, kch, nphase, S;   // taps, chunks per K phase, K phases per tile, slabs per phase (kch * ntap)
     int m_tiles, ntiles;
     int w_rows, w_chunk16;  // rows per weight slab; 16-byte units between the slabs of consecutive chunks
-    int xunits;             // ceil(kch * span / 256)
-    int issue_slab_late;    // slab in front of which waves 4..7 issue the next phase's loads (waves 0..3: slab 0)
+    int xunits;             // ceil(kch * span / 128): x staging units per producer thread and phase
+    int drain_per_pair;     // deferred-store groups (4 stores each, 16 per tile) a consumer issues behind each pair of slabs
     unsigned slx[TW_SMAX / 2];  // slab s -> row offset inside an x plane (chunk * span + tap_off - min_off), 16 bits each
     int w_tap16;                // 16-byte units between the slabs of consecutive taps (weight slab of tap t = t)
 #ifdef SVB_INSTRUMENT
     unsigned long long* dbg;    // stage stamps [workgroup < 4][wave][phase < 32][8] (tools/tw_stage_timing.py)
-    int ablate;                 // timing-only ablations: 1 no x loads, 2 no weight DMA, 4 no MFMAs, 8 no epilogue stores,
-                                // 16 no x split / LDS store, 32 no fragment reads
+    int ablate;                 // (unused: the timing-only ablations are compile-time, SVB_TW_ABLATE: 1 no x loads, 2 no weight DMA,
+                                // 4 no MFMAs, 8 no stores, 16 no x split / LDS store, 32 no fragment reads)
 #endif
 };
 
 #ifdef SVB_INSTRUMENT
 static unsigned long long* g_tw_dbg = nullptr;
-static int g_tw_ablate = 0, g_tw_issue_late = -1;
-extern "C" void svb_debug_set_tw(void* buf, int ablate, int issue_slab_late) {
-    g_tw_dbg = (unsigned long long*)buf; g_tw_ablate = ablate; g_tw_issue_late = issue_slab_late;
+static int g_tw_ablate = 0, g_tw_drain = 0;
+extern "C" void svb_debug_set_tw(void* buf, int ablate, int drain_per_pair) {
+    g_tw_dbg = (unsigned long long*)buf; g_tw_ablate = ablate; g_tw_drain = drain_per_pair;
 }
-#define TW_ABL(bit) ((arg.ablate & (bit)) != 0)
+#ifndef SVB_TW_ABLATE
+#define SVB_TW_ABLATE 0
+#endif
+#define TW_ABL(bit) (((SVB_TW_ABLATE) & (bit)) != 0)      /* compile-time: `make abl` builds one library per mask */
 #define TW_STAMP(slot)                                                                                          \
     if (arg.dbg && vid < 4 && lane == 0 && dbg_ph < 32)                                                          \
         arg.dbg[(((size_t)vid * 8 + wave) * 32 + dbg_ph) * 8 + (slot)] = __builtin_readcyclecounter();
@@ -80,11 +83,23 @@ extern "C" void svb_debug_set_tw(void* buf, int ablate, int issue_slab_late) {
 #define TW_NEXT_PHASE
 #endif
 
-template <int AF, int BF, bool GATE>
+// Roles: waves 0..3 (one per SIMD) are CONSUMERS -- each owns a 64 x 64 block of the workgroup's (64 CM) x (64 CN) tile as four
+// 32x32 accumulators and does nothing but LDS fragment reads and MFMAs; waves 4..7 are PRODUCERS -- they stage the next K
+// phase (x: buffer loads -> split -> ds_write, weights: LDS-DMA) into the other LDS buffer.  One barrier per K phase.
+// (Round 4 measured the symmetric form first -- every wave staging AND multiplying: a wave's serial non-MFMA work per phase
+//  was ~4k cycles against 1.9k cycles of MFMA issue, phases took 8.6k cycles where the matrix pipe needs 3.8k --
+//  profiles/r04_tw_symmetric_stages.log.)
+// The epilogue of the plain form (bias + ReLU / LeakyReLU / none) is DEFERRED: at the end of a tile the consumer applies bias +
+// activation into a second register set and drains it with a few stores per slab of the NEXT tile, behind its MFMAs -- the
+// 25-32 MB write burst of 256 workgroups reaching their epilogue together (20k cycles per tile, measured) becomes a steady
+// ~3 B/clk/CU stream.  Epilogues with gate / residual / mask / tanh run at the end of their tile.
+template <int CM, int CN, bool GATE>
 __global__ __launch_bounds__(512, 2) void svb_conv1d_tw_kernel(SvbTwArgs arg) {
-    constexpr int BM = 64 * AF, BN = 128 * BF;
+    constexpr int AF = 2, BF = 2;
+    constexpr int BM = 64 * CM, BN = 64 * CN;
     constexpr int NR = 2 * AF + 2 * BF, NM = 3 * AF * BF, NAB = AF * BF;
-    constexpr int WSLOTS = (4 * AF + 7) / 8;          // weight DMA instructions per wave and slab
+    constexpr int NGRP = NAB * 4;                     // deferred-store groups: 4 consecutive accumulator rows each
+    static_assert(CM * CN == 4, "four consumer waves");
     HIP_DYNAMIC_SHARED(uint4, smem)
     // kernel arguments as plain locals (a by-value struct that lambdas capture by reference can end up in scratch)
     const int p_B = arg.B, p_Cin = arg.Cin, p_Cout = arg.Cout, p_Tin = arg.Tin, p_Tout = arg.Tout;
@@ -96,9 +111,7 @@ __global__ __launch_bounds__(512, 2) void svb_conv1d_tw_kernel(SvbTwArgs arg) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;
     const int kb = lane >> 5, l31 = lane & 31;
-    const int xh = wave >> 2;                         // x staging: waves 0..3 channel half 0, waves 4..7 half 1
     const int XR = p_kch * p_span;                    // rows per x plane
     const int WU = p_S * 4 * BM;                      // 16-byte units per weight buffer
     const int XU16 = 4 * XR;                          // ... per x buffer
@@ -108,189 +121,281 @@ __global__ __launch_bounds__(512, 2) void svb_conv1d_tw_kernel(SvbTwArgs arg) {
     const int qd = nwg >> 3, rd = nwg & 7, xcd = orig & 7;
     const int vid = (xcd < rd ? xcd * (qd + 1) : rd * (qd + 1) + (xcd - rd) * qd) + (orig >> 3);
     if (vid >= p_ntiles) return;
+#ifdef SVB_INSTRUMENT
+    int dbg_ph = 0;
+#endif
 
-    // ---- per-kernel constants -------------------------------------------------------------------------------------------
-    // weight DMA roles: unit v = wave + 8 j of a slab's 4*AF (plane, 64-row block) units (BM = 64: waves 0..3, one plane each)
-    int w_pl[WSLOTS], w_rb[WSLOTS];
-    const uint4* w_arr[WSLOTS];            // hi or lo array, advanced to the plane's 8-channel half
-    {
-        const uint4* const w_hi16 = reinterpret_cast<const uint4*>(arg.wq_hi);
-        const uint4* const w_lo16 = reinterpret_cast<const uint4*>(arg.wq_lo);
+    if (wave >= 4) {
+        // =============================================== PRODUCERS ===============================================================
+        const int pw = wave - 4;
+        const int ptid = tid - 256;
+        const int xh = pw >> 1;                           // waves 4,5: channel half 0 of a chunk; waves 6,7: half 1
+        const int x_row0 = ptid & 127;
+        // weight DMA roles: unit v = pw + 4 j of a slab's 4*CM (plane, 64-row block) units
+        int w_pl[CM], w_rb[CM];
+        const uint4* w_arr[CM];            // hi or lo array, advanced to the plane's 8-channel half
+        {
+            const uint4* const w_hi16 = reinterpret_cast<const uint4*>(arg.wq_hi);
+            const uint4* const w_lo16 = reinterpret_cast<const uint4*>(arg.wq_lo);
 #pragma unroll
-        for (int j = 0; j < WSLOTS; ++j) {
-            const int v = AF == 1 ? (wave & 3) : wave + 8 * j;
-            w_pl[j] = v / AF;
-            w_rb[j] = v - w_pl[j] * AF;
-            w_arr[j] = ((w_pl[j] & 2) ? w_lo16 : w_hi16) + (w_pl[j] & 1);
+            for (int j = 0; j < CM; ++j) {
+                const int v = pw + 4 * j;
+                w_pl[j] = v / CM;
+                w_rb[j] = v - w_pl[j] * CM;
+                w_arr[j] = ((w_pl[j] & 2) ? w_lo16 : w_hi16) + (w_pl[j] & 1);
+            }
         }
-    }
-    // x staging: unit u of a thread = 8 channels (half xh of a 16-channel chunk) of plane row u * 256 + (tid & 255);
-    // loads go through a buffer descriptor: one per-lane 32-bit offset per unit and tile, the channel part is a scalar offset
-    const __amdgpu_buffer_rsrc_t x_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(arg.x), 0, 4u * (unsigned)(p_B * p_Cin * p_Tin), 0x00020000);
-    const __amdgpu_buffer_rsrc_t g_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GATE ? arg.in_gate : arg.x), 0, 4u * (unsigned)(p_B * p_Cin * p_Tin), 0x00020000);
-    const int x_row0 = tid & 255;
-    const int a_lane = kb * BM + wm * 32 * AF + l31;           // A fragment: plane kb, this wave's rows
-    const int b_lane = kb * XR + wn * 32 * BF + l31;           // B fragment: plane kb, this wave's columns
-
-    // ---- per-tile state -------------------------------------------------------------------------------------------------
-    int m_base = 0, n0 = 0;
-    unsigned x_off[TW_XU];
-    unsigned x_okmask = 0;                  // bit u: the unit's position is inside a clip (else the row is zero)
-    unsigned w_row16[WSLOTS];
-    auto setup_tile = [&](int tile) {
-        const int mt = tile % p_m_tiles, nt = tile / p_m_tiles;
-        m_base = mt * BM;
-        n0 = nt * BN;
-        x_okmask = 0;
+        // x staging: unit u of a thread = 8 channels (half xh of a 16-channel chunk) of plane row u * 128 + x_row0; loads go
+        // through a buffer descriptor: one per-lane 32-bit offset per unit and tile, the channel part is a scalar offset
+        const __amdgpu_buffer_rsrc_t x_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(arg.x), 0, 4u * (unsigned)(p_B * p_Cin * p_Tin), 0x00020000);
+        const __amdgpu_buffer_rsrc_t g_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GATE ? arg.in_gate : arg.x), 0, 4u * (unsigned)(p_B * p_Cin * p_Tin), 0x00020000);
+        unsigned x_off[TW_XU];
+        unsigned x_okmask = 0;                  // bit u: the unit's position is inside a clip (else the row is zero)
+        unsigned w_row16[CM];
+        auto setup_tile = [&](int tile) {
+            const int mt = tile % p_m_tiles, nt = tile / p_m_tiles;
+            const int m_base = mt * BM, n0 = nt * BN;
+            x_okmask = 0;
 #pragma unroll
-        for (int u = 0; u < TW_XU; ++u) {
-            const int idx = u * 256 + x_row0;
-            const int c = idx / p_span, i = idx - c * p_span;
-            const int f = n0 + i;
-            const int bf = f / p_Tp, uf = f - bf * p_Tp;
-            const int pos = uf + p_min_off;
-            const bool ok = idx < XR && bf < p_B && pos >= 0 && pos < p_Tin;
-            x_okmask |= (ok ? 1u : 0u) << u;
-            x_off[u] = ok ? 4u * (unsigned)((bf * p_Cin + c * 16 + xh * 8) * p_Tin + pos) : 0u;
-        }
+            for (int u = 0; u < TW_XU; ++u) {
+                const int idx = u * 128 + x_row0;
+                const int c = idx / p_span, i = idx - c * p_span;
+                const int f = n0 + i;
+                const int bf = f / p_Tp, uf = f - bf * p_Tp;
+                const int pos = uf + p_min_off;
+                const bool ok = idx < XR && bf < p_B && pos >= 0 && pos < p_Tin;
+                x_okmask |= (ok ? 1u : 0u) << u;
+                x_off[u] = ok ? 4u * (unsigned)((bf * p_Cin + c * 16 + xh * 8) * p_Tin + pos) : 0u;
+            }
 #pragma unroll
-        for (int j = 0; j < WSLOTS; ++j)
-            w_row16[j] = 2u * (unsigned)min(m_base + w_rb[j] * 64 + lane, p_w_rows - 1);
-    };
-
-    float xr[TW_XU][8];
-    float gr[GATE ? TW_XU : 1][8];
-    // all loads of a phase are requested at once; a unit outside the tile (or its clip) reads element 0 of the channel row
-    auto issue_x = [&](int ph) {
-        if (TW_ABL(1)) return;
-        const unsigned ch0 = (unsigned)(ph * p_kch * 16);
+            for (int j = 0; j < CM; ++j)
+                w_row16[j] = 2u * (unsigned)min(m_base + w_rb[j] * 64 + lane, p_w_rows - 1);
+        };
+        float xr[TW_XU][8];
+        float gr[GATE ? TW_XU : 1][8];
+        // all loads of a phase are requested at once; a unit outside the tile (or its clip) reads element 0 of the channel row
+        auto issue_x = [&](int ph) {
+            if (TW_ABL(1)) return;
+            const unsigned ch0 = (unsigned)(ph * p_kch * 16);
 #pragma unroll
-        for (int u = 0; u < TW_XU; ++u)
-            if (u < p_xunits) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    xr[u][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, x_off[u], 4u * (ch0 + e) * (unsigned)p_Tin, 0));
-                if (GATE) {
+            for (int u = 0; u < TW_XU; ++u)
+                if (u < p_xunits) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        gr[u][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, x_off[u], 4u * (ch0 + e) * (unsigned)p_Tin, 0));
-                }
-            }
-    };
-    auto finish_x = [&](int xb16) {           // split + store into the x buffer that starts at 16-byte unit xb16
-        if (TW_ABL(16)) return;
-        const float in_slope = arg.in_slope;
+                        xr[u][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, x_off[u], 4u * (ch0 + e) * (unsigned)p_Tin, 0));
+                    if (GATE) {
 #pragma unroll
-        for (int u = 0; u < TW_XU; ++u)
-            if (u < p_xunits && u * 256 + x_row0 < XR) {
-                if (GATE) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) xr[u][e] *= svb_gate(gr[u][e], in_slope);
-                }
-                unsigned h[4], l[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) svbq_split2(xr[u][2 * e], xr[u][2 * e + 1], h[e], l[e]);
-                uint4 hi = make_uint4(h[0], h[1], h[2], h[3]), lo = make_uint4(l[0], l[1], l[2], l[3]);
-                if (!((x_okmask >> u) & 1u)) { hi = make_uint4(0u, 0u, 0u, 0u); lo = hi; }
-                smem[xb16 + xh * XR + u * 256 + x_row0] = hi;
-                smem[xb16 + (2 + xh) * XR + u * 256 + x_row0] = lo;
-            }
-    };
-    // weight slabs of K phase ph -> the weight buffer that starts at 16-byte unit wb16 (LDS-DMA: lane L of an instruction
-    // fetches row (64-row block) + L of one plane, the 64 x 16 bytes land consecutively)
-    auto issue_w = [&](int ph, int wb16) {
-        if (TW_ABL(2)) return;
-        unsigned cb16 = (unsigned)(ph * p_kch) * p_w_chunk16;
-        int dst = wb16;
-        for (int c = 0; c < p_kch; ++c, cb16 += p_w_chunk16) {
-            unsigned sb16 = cb16;
-            for (int t = 0; t < p_ntap; ++t, sb16 += p_w_tap16, dst += 4 * BM) {
-#pragma unroll
-                for (int j = 0; j < WSLOTS; ++j) {
-                    const bool mine = AF == 1 ? wave < 4 : (AF == 2 || wave + 8 * j < 4 * AF);      // (BM = 64: 4 units per slab)
-                    if (mine) {
-                        const uint4* src = w_arr[j] + (size_t)sb16 + w_row16[j];
-                        svb_glds16(src, smem, 16u * (unsigned)(dst + w_pl[j] * BM + w_rb[j] * 64));
+                        for (int e = 0; e < 8; ++e)
+                            gr[u][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, x_off[u], 4u * (ch0 + e) * (unsigned)p_Tin, 0));
                     }
                 }
+        };
+        auto finish_x = [&](int xb16) {           // split + store into the x buffer that starts at 16-byte unit xb16
+            if (TW_ABL(16)) return;
+            const float in_slope = arg.in_slope;
+#pragma unroll
+            for (int u = 0; u < TW_XU; ++u)
+                if (u < p_xunits && u * 128 + x_row0 < XR) {
+                    if (GATE) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) xr[u][e] *= svb_gate(gr[u][e], in_slope);
+                    }
+                    unsigned h[4], l[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) svbq_split2(xr[u][2 * e], xr[u][2 * e + 1], h[e], l[e]);
+                    uint4 hi = make_uint4(h[0], h[1], h[2], h[3]), lo = make_uint4(l[0], l[1], l[2], l[3]);
+                    if (!((x_okmask >> u) & 1u)) { hi = make_uint4(0u, 0u, 0u, 0u); lo = hi; }
+                    smem[xb16 + xh * XR + u * 128 + x_row0] = hi;
+                    smem[xb16 + (2 + xh) * XR + u * 128 + x_row0] = lo;
+                }
+        };
+        // weight slabs of K phase ph -> the weight buffer that starts at 16-byte unit wb16 (LDS-DMA: lane L of an instruction
+        // fetches row (64-row block) + L of one plane, the 64 x 16 bytes land consecutively)
+        auto issue_w = [&](int ph, int wb16) {
+            if (TW_ABL(2)) return;
+            unsigned cb16 = (unsigned)(ph * p_kch) * p_w_chunk16;
+            int dst = wb16;
+            for (int c = 0; c < p_kch; ++c, cb16 += p_w_chunk16) {
+                unsigned sb16 = cb16;
+                for (int t = 0; t < p_ntap; ++t, sb16 += p_w_tap16, dst += 4 * BM) {
+#pragma unroll
+                    for (int j = 0; j < CM; ++j)
+                        svb_glds16(w_arr[j] + (size_t)sb16 + w_row16[j], smem, 16u * (unsigned)(dst + w_pl[j] * BM + w_rb[j] * 64));
+                }
             }
+        };
+
+        int tile = vid, ph = 0, buf = 0;
+        setup_tile(tile);
+        issue_w(0, 0);
+        issue_x(0);
+        finish_x(xbuf0);
+        __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0) lgkmcnt(0): DMA landed, LDS stores done
+        __builtin_amdgcn_s_barrier();
+        while (true) {
+            const bool last_ph = ph + 1 == p_nphase;
+            const int ntile = last_ph ? tile + nwg : tile;
+            const bool has_next = ntile < p_ntiles;
+            const int nph = last_ph ? 0 : ph + 1;
+            TW_STAMP(0)
+            if (has_next) {
+                if (last_ph) setup_tile(ntile);
+                issue_w(nph, (buf ^ 1) * WU);
+                issue_x(nph);
+                TW_STAMP(1)
+                finish_x(xbuf0 + (buf ^ 1) * XU16);
+                TW_STAMP(2)
+            }
+            __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0) lgkmcnt(0)
+            TW_STAMP(3)
+            __builtin_amdgcn_s_barrier();
+            TW_STAMP(4)
+            TW_NEXT_PHASE
+            if (!has_next) break;
+            buf ^= 1;
+            ph = nph;
+            tile = ntile;
+        }
+        return;
+    }
+
+    // ================================================= CONSUMERS =================================================================
+    const int cm = wave % CM, cn = wave / CM;
+    const int a_lane = kb * BM + cm * 32 * AF + l31;           // A fragment: plane kb, this wave's rows
+    const int b_lane = kb * XR + cn * 32 * BF + l31;           // B fragment: plane kb, this wave's columns
+    f32x16 acc[AF][BF], pend[AF][BF];
+#pragma unroll
+    for (int i = 0; i < AF; ++i)
+#pragma unroll
+        for (int n = 0; n < BF; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][n][r] = 0.f; pend[i][n][r] = 0.f; }
+    // (opaque to the optimiser: with `pend` a known constant the whole tile loop is peeled once -- twice the code -- for a first
+    // tile that never stores it)
+#pragma unroll
+    for (int i = 0; i < AF; ++i)
+#pragma unroll
+        for (int n = 0; n < BF; ++n) svb_opaque16(pend[i][n]);
+
+    const unsigned y_bytes = 4u * (unsigned)(p_B * p_Cout * p_Tout);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(arg.y, 0, y_bytes, 0x00020000);
+    const float* const e_bias = arg.bias;
+    const int e_act = arg.out_act;
+    const float e_slope = arg.out_slope;
+    const bool e_plain = !arg.out_gate && !arg.residual && !arg.mask && e_act != SVB_ACT_TANH;
+    const float e_neg = e_act == SVB_ACT_RELU ? 0.f : (e_act == SVB_ACT_LRELU ? e_slope : 1.f);      // v > 0 ? v : v * neg
+
+    // per-lane store offsets of a tile: voff[i][n] = 4 ((first row of accumulator i) * Tout + clip * Cout * Tout + position), or
+    // an offset beyond the buffer for columns outside the tensor (a buffer store there is dropped by the bounds check)
+    auto tile_offsets = [&](int m_base, int n0, unsigned (&voff)[AF][BF], int& ml0) {
+        ml0 = m_base + cm * 32 * AF + 4 * kb;
+#pragma unroll
+        for (int n = 0; n < BF; ++n) {
+            const int f = n0 + cn * 32 * BF + 32 * n + l31;
+            const int bf = f / p_Tp, uf = f - bf * p_Tp;
+            const bool ok = f < p_ncols && uf < p_Tout;
+#pragma unroll
+            for (int i = 0; i < AF; ++i)
+                voff[i][n] = ok ? 4u * (unsigned)((ml0 + 32 * i) * p_Tout + bf * p_Cout * p_Tout + uf) : 0x80000000u;
         }
     };
-
-    f32x16 acc[AF][BF];
-    auto zero_acc = [&]() {
+    // deferred stores: straight-line code, validity folded into the offset (a buffer store at an offset >= 2^31 is dropped by the
+    // bounds check: columns outside the tensor, rows beyond Cout in a ragged last row tile)
+    unsigned p_voff[AF][BF];
+    int p_lim = 0;                          // rows of the pending tile inside the tensor, counted from this lane's first row
+    int p_next = NGRP;                      // next group to store (NGRP: nothing pending)
+    const unsigned t4 = 4u * (unsigned)p_Tout;
+    auto store_group = [&](int g) {         // rows 8 (g & 3) + 4 kb + {0..3} of accumulator (g >> 2)
 #pragma unroll
-        for (int i = 0; i < AF; ++i)
+        for (int ab = 0; ab < NAB; ++ab)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                if (g == ab * 4 + r4) {
+                    const int i = ab / BF, n = ab - i * BF;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int dr = 8 * r4 + e;
+                        const unsigned off = (32 * i + dr < p_lim) ? p_voff[i][n] + (unsigned)dr * t4 : 0x80000000u;
+                        const float v = pend[i][n][4 * r4 + e];      // (a scalar first: bit_cast of a vector element reads element 0)
+                        if (!TW_ABL(8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, off, 0, 0);
+                    }
+                }
+    };
+    // end of a tile, plain form: pend = act(acc + bias), offsets kept, acc = 0.  (The previous tile's stores have all been
+    // issued: drain_per_pair covers the 16 groups within one tile's slabs.)
+    auto retire_tile = [&](int m_base, int n0) {
+        int ml0;
+        tile_offsets(m_base, n0, p_voff, ml0);
+        p_lim = p_Cout - ml0;
+#pragma unroll
+        for (int i = 0; i < AF; ++i) {
+            float bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[r] = e_bias ? e_bias[min(ml0 + 32 * i + (r & 3) + 8 * (r >> 2), p_Cout - 1)] : 0.f;
 #pragma unroll
             for (int n = 0; n < BF; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][n][r] + bv[r];
+                    pend[i][n][r] = v > 0.f ? v : v * e_neg;
+                    acc[i][n][r] = 0.f;
+                }
+        }
+        p_next = 0;
     };
-
-    // ---- epilogue of the tile (m_base_e, n0_e): bias, activation, gate, residual, mask; column -> (clip, position).
-    // Stores / operand loads go through buffer descriptors: per (accumulator, column block) one per-lane offset, the 16 rows
-    // of an accumulator as scalar offsets.
-    const unsigned y_bytes = 4u * (unsigned)(p_B * p_Cout * p_Tout);
-    auto epilogue = [&](int m_base_e, int n0_e) {
-        const float* const e_bias = arg.bias;
+    // end of a tile, general form (gate / residual / mask / tanh): stored at once
+    auto epilogue_now = [&](int m_base, int n0) {
         const float* const e_mask = arg.mask;
         const bool has_gate = arg.out_gate != nullptr, has_res = arg.residual != nullptr;
-        const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(arg.y, 0, y_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t og_rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_gate ? arg.out_gate : arg.y), 0, y_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_res ? arg.residual : arg.y), 0, y_bytes, 0x00020000);
-        const bool plain = !has_gate && !has_res && !e_mask;
-        const int act = arg.out_act;
-        const float slope = arg.out_slope, gslope = arg.out_gate_slope;
-        const float neg = act == SVB_ACT_RELU ? 0.f : (act == SVB_ACT_LRELU ? slope : 1.f);      // v > 0 ? v : v * neg
-        const bool full_m = m_base_e + BM <= p_Cout;
-        int colbase[BF];            // (clip * Cout) * Tout + position, or -1
+        const float gslope = arg.out_gate_slope;
+        unsigned voff[AF][BF];
+        int ml0;
+        tile_offsets(m_base, n0, voff, ml0);
+        const bool full_m = m_base + BM <= p_Cout;
         float mk[BF];
 #pragma unroll
         for (int n = 0; n < BF; ++n) {
-            const int f = n0_e + wn * 32 * BF + 32 * n + l31;
+            const int f = n0 + cn * 32 * BF + 32 * n + l31;
             const int bf = f / p_Tp, uf = f - bf * p_Tp;
-            const bool ok = f < p_ncols && uf < p_Tout;
-            colbase[n] = ok ? bf * p_Cout * p_Tout + uf : -1;
-            mk[n] = (ok && e_mask) ? e_mask[bf * p_Tout + uf] : 1.f;
+            mk[n] = (e_mask && f < p_ncols && uf < p_Tout) ? e_mask[bf * p_Tout + uf] : 1.f;
         }
 #pragma unroll
         for (int i = 0; i < AF; ++i) {
-            const int ml0 = m_base_e + wm * 32 * AF + 32 * i + 4 * kb;          // row of accumulator element r: ml0 + (r&3) + 8 (r>>2)
             float bv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bv[r] = e_bias ? e_bias[min(ml0 + (r & 3) + 8 * (r >> 2), p_Cout - 1)] : 0.f;
+            for (int r = 0; r < 16; ++r) bv[r] = e_bias ? e_bias[min(ml0 + 32 * i + (r & 3) + 8 * (r >> 2), p_Cout - 1)] : 0.f;
 #pragma unroll
             for (int n = 0; n < BF; ++n)
-                if (colbase[n] >= 0) {
-                    const unsigned voff = 4u * (unsigned)(ml0 * p_Tout + colbase[n]);
+                if (voff[i][n] < 0x80000000u) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int dr = (r & 3) + 8 * (r >> 2);
                         const unsigned soff = 4u * (unsigned)(dr * p_Tout);
-                        if (full_m || ml0 + dr < p_Cout) {
-                            float v = acc[i][n][r] + bv[r];
-                            if (plain && act != SVB_ACT_TANH) {
-                                v = v > 0.f ? v : v * neg;
-                            } else {
-                                v = svb_apply_act(v, act, slope);
-                                if (has_gate) v *= svb_gate(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(og_rsrc, voff, soff, 0)), gslope);
-                                if (has_res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rsrc, voff, soff, 0));
-                                v *= mk[n];
-                            }
-                            if (!TW_ABL(8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, voff, soff, 0);
+                        if (full_m || ml0 + 32 * i + dr < p_Cout) {
+                            float v = svb_apply_act(acc[i][n][r] + bv[r], e_act, e_slope);
+                            if (has_gate) v *= svb_gate(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(og_rsrc, voff[i][n], soff, 0)), gslope);
+                            if (has_res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rsrc, voff[i][n], soff, 0));
+                            v *= mk[n];
+                            if (!TW_ABL(8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, voff[i][n], soff, 0);
                         }
+                        acc[i][n][r] = 0.f;
                     }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
                 }
         }
     };
 
-    // ---- one K phase of MFMAs.  Fragments are double-buffered in registers by slab parity; every LDS read of slab s+1
-    // sits, placed by hand and pinned, behind one MFMA of slab s.  LDS addresses: one per-lane byte address per operand
-    // plus wave-uniform offsets.
+    // ---- one K phase of MFMAs.  Fragments are double-buffered in registers by slab parity; every LDS read of slab s+1 sits,
+    // placed by hand and pinned, behind one MFMA of slab s.  LDS addresses: one per-lane byte address per operand plus
+    // wave-uniform offsets.
     uint4 fa[2][2 * AF], fb[2][2 * BF];
     const unsigned x_lo16 = 32u * (unsigned)XR;                  // byte distance hi plane -> lo plane of the x image
     const char* const lds = reinterpret_cast<const char*>(smem);
@@ -313,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void svb_conv1d_tw_kernel(SvbTwArgs arg) {
         else if (prod == 1) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][n], 0, 0, 0);
         else acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][n], 0, 0, 0);
     };
-    // slab -> row offset inside an x plane (chunk * span + tap row), two 16-bit fields per word (host-packed)
+    // slab -> row offset inside an x plane (chunk * span + tap row), four 16-bit fields per word (host-packed)
     const unsigned long long slx_lo = (unsigned long long)arg.slx[0] | ((unsigned long long)arg.slx[1] << 32);
     const unsigned long long slx_hi = (unsigned long long)arg.slx[2] | ((unsigned long long)arg.slx[3] << 32);
     auto slab_row = [&](int s) -> unsigned {       // (shifts, not a select chain: that becomes a lookup table in scratch)
@@ -334,84 +439,54 @@ __global__ __launch_bounds__(512, 2) void svb_conv1d_tw_kernel(SvbTwArgs arg) {
         }
     };
 
-    // ---- main: the (tile, phase) sequence of this workgroup as ONE pipelined stream -------------------------------------------
-    int tile = vid;
-    setup_tile(tile);
-    zero_acc();
-    issue_x(0);
-    issue_w(0, 0);
-    finish_x(xbuf0);
-    __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0) lgkmcnt(0): DMA landed, LDS stores done
-    __builtin_amdgcn_s_barrier();
-    int ph = 0, buf = 0;
-#ifdef SVB_INSTRUMENT
-    int dbg_ph = 0;
-#endif
-    const int issue_at = xh ? arg.issue_slab_late : 0;
     const int s_last = p_S - 1;
-    while (true) {
-        const bool last_ph = ph + 1 == p_nphase;
-        const int ntile = last_ph ? tile + nwg : tile;
-        const bool has_next = ntile < p_ntiles;
-        const int nph = last_ph ? 0 : ph + 1;
-        const int m_base_e = m_base, n0_e = n0;
-        const unsigned wb = 16u * (unsigned)(buf * WU), xb = 16u * (unsigned)(xbuf0 + buf * XU16);
-        const int nwb16 = (buf ^ 1) * WU, nxb16 = xbuf0 + (buf ^ 1) * XU16;
-
-        TW_STAMP(0)
+    const int drain = arg.drain_per_pair;           // deferred-store groups issued behind each pair of slabs
+    int buf = 0;
+    __builtin_amdgcn_s_barrier();                   // the first K phase is staged
+    for (int tile = vid; tile < p_ntiles; tile += nwg) {
+        const int mt = tile % p_m_tiles, nt = tile / p_m_tiles;
+        for (int ph = 0; ph < p_nphase; ++ph) {
+            const unsigned wb = 16u * (unsigned)(buf * WU), xb = 16u * (unsigned)(xbuf0 + buf * XU16);
+            TW_STAMP(0)
 #pragma unroll
-        for (int r = 0; r < NR; ++r) read_frag(0, r, wb, xb + 16u * slab_row(0));
-        for (int s = 0; s < p_S; s += 2) {
-            if (has_next && s == issue_at) {
-                TW_STAMP(1)
-                if (last_ph) setup_tile(ntile);
-                issue_x(nph);
-                issue_w(nph, nwb16);
-                TW_STAMP(2)
+            for (int r = 0; r < NR; ++r) read_frag(0, r, wb, xb + 16u * slab_row(0));
+            for (int s = 0; s < p_S; s += 2) {
+                slab_body(0, wb, xb, min(s + 1, s_last));
+                if (s + 1 < p_S) slab_body(1, wb, xb, min(s + 2, s_last));
+                for (int d = 0; d < drain && p_next < NGRP; ++d, ++p_next) store_group(p_next);
             }
-            slab_body(0, wb, xb, min(s + 1, s_last));
-            if (s + 1 < p_S) slab_body(1, wb, xb, min(s + 2, s_last));
+            TW_STAMP(1)
+            __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0): the clamped re-reads of the last slab are done with this buffer
+            __builtin_amdgcn_s_barrier();
+            TW_STAMP(2)
+            TW_NEXT_PHASE
+            buf ^= 1;
         }
-        TW_STAMP(3)
-        if (has_next) finish_x(nxb16);
-        TW_STAMP(4)
-        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): next phase's weight slabs have landed (x loads were consumed above)
-        TW_STAMP(5)
-        if (last_ph) {
-            epilogue(m_base_e, n0_e);
-            zero_acc();
-        }
-        TW_STAMP(6)
-        __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): this wave's LDS stores are done; the epilogue's global stores stay in flight
-        __builtin_amdgcn_s_barrier();
-        TW_STAMP(7)
-        TW_NEXT_PHASE
-        if (!has_next) break;
-        buf ^= 1;
-        ph = nph;
-        tile = ntile;
+        if (e_plain) retire_tile(mt * BM, nt * BN);
+        else epilogue_now(mt * BM, nt * BN);
     }
+    for (; p_next < NGRP; ++p_next) store_group(p_next);
 }
 
 // ==================================================================================================================
-struct TwCfg { int AF, BF; };
-static const TwCfg kTwCfgs[SVB_TW_NVARIANTS] = {{2, 2}, {2, 1}, {1, 2}, {3, 2}, {1, 1}, {3, 1}};
+struct TwCfg { int CM, CN; };
+static const TwCfg kTwCfgs[SVB_TW_NVARIANTS] = {{2, 2}, {1, 4}, {4, 1}};      // 128x128, 64x256, 256x64
 
-template <int AF, int BF, bool GATE>
+template <int CM, int CN, bool GATE>
 static void tw_launch_kernel(const SvbTwArgs& a, int grid, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_tw_kernel<AF, BF, GATE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_tw_kernel<CM, CN, GATE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((svb_conv1d_tw_kernel<AF, BF, GATE>), dim3(grid), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((svb_conv1d_tw_kernel<CM, CN, GATE>), dim3(grid), dim3(512), lds, stream, a);
 }
 
-template <int AF, int BF>
+template <int CM, int CN>
 static void tw_launch_gate(const SvbTwArgs& a, int grid, size_t lds, hipStream_t stream) {
-    if (a.in_gate) tw_launch_kernel<AF, BF, true>(a, grid, lds, stream);
-    else tw_launch_kernel<AF, BF, false>(a, grid, lds, stream);
+    if (a.in_gate) tw_launch_kernel<CM, CN, true>(a, grid, lds, stream);
+    else tw_launch_kernel<CM, CN, false>(a, grid, lds, stream);
 }
 
 static int g_tw_cus = 0;
@@ -421,11 +496,10 @@ int svb_tw_launch(const SvbConvQArgs& q, const SvbConvPlan& p, int variant, hipS
     if (p.n_phase != 1 || q.sx != 1 || q.out_stride != 1 || q.G != 1 || q.Cin % 16 || q.xq) return SVB_ERR_UNSUPPORTED;
     const int ntap = p.phase_start[1] - p.phase_start[0];
     if (ntap < 1 || ntap > TW_MAX_TAPS || p.phase_out_base[0] != 0 || p.phase_nq[0] != q.Tout) return SVB_ERR_UNSUPPORTED;
-    const int AF = kTwCfgs[variant].AF, BF = kTwCfgs[variant].BF;
-    const int BM = 64 * AF, BN = 128 * BF;
+    const int BM = 64 * kTwCfgs[variant].CM, BN = 64 * kTwCfgs[variant].CN;
     if (q.Cout < 32) return SVB_ERR_UNSUPPORTED;
-    // 32-bit offsets inside the kernel
-    if ((long)q.B * q.Cin * q.Tin >= (1L << 30) || (long)q.B * q.Cout * q.Tout >= (1L << 30)) return SVB_ERR_UNSUPPORTED;
+    // 32-bit byte offsets inside the kernel; an offset >= 2^31 marks a column outside the tensor
+    if ((long)q.B * q.Cin * q.Tin >= (1L << 30) || (long)q.B * q.Cout * q.Tout >= (1L << 29)) return SVB_ERR_UNSUPPORTED;
 
     SvbTwArgs a;
     memset(&a, 0, sizeof(a));
@@ -451,7 +525,7 @@ int svb_tw_launch(const SvbConvQArgs& q, const SvbConvPlan& p, int variant, hipS
     int kch = 0;
     for (int k = TW_SMAX / ntap; k >= 1; --k) {
         if (kchunks % k) continue;
-        if ((k * a.span + 255) / 256 > TW_XU) continue;
+        if ((k * a.span + 127) / 128 > TW_XU) continue;
         const size_t lds = (size_t)2 * ((size_t)k * ntap * 4 * BM + (size_t)4 * k * a.span) * 16;
         if (lds > TW_LDS_BUDGET) continue;
         kch = k;
@@ -461,12 +535,14 @@ int svb_tw_launch(const SvbConvQArgs& q, const SvbConvPlan& p, int variant, hipS
     a.kch = kch;
     a.S = kch * ntap;
     a.nphase = kchunks / kch;
-    a.xunits = (kch * a.span + 255) / 256;
-    a.issue_slab_late = a.S >= 4 ? 2 : 0;
+    a.xunits = (kch * a.span + 127) / 128;
+    // the 16 deferred-store groups of a tile drain behind the slab pairs of the next one: all of them within one tile
+    const int pairs = a.nphase * ((a.S + 1) / 2);
+    a.drain_per_pair = (16 + pairs - 1) / pairs;
 #ifdef SVB_INSTRUMENT
     a.dbg = g_tw_dbg;
     a.ablate = g_tw_ablate;
-    if (g_tw_issue_late >= 0) a.issue_slab_late = g_tw_issue_late;
+    if (g_tw_drain > a.drain_per_pair) a.drain_per_pair = g_tw_drain;
 #endif
     if (kch * a.span + span_off >= 65536) return SVB_ERR_UNSUPPORTED;
     for (int s = 0; s < a.S; ++s) {
@@ -489,11 +565,8 @@ int svb_tw_launch(const SvbConvQArgs& q, const SvbConvPlan& p, int variant, hipS
     const int grid = a.ntiles < g_tw_cus ? a.ntiles : g_tw_cus;
     switch (variant) {
         case 0: tw_launch_gate<2, 2>(a, grid, lds, stream); break;
-        case 1: tw_launch_gate<2, 1>(a, grid, lds, stream); break;
-        case 2: tw_launch_gate<1, 2>(a, grid, lds, stream); break;
-        case 3: tw_launch_gate<3, 2>(a, grid, lds, stream); break;
-        case 4: tw_launch_gate<1, 1>(a, grid, lds, stream); break;
-        default: tw_launch_gate<3, 1>(a, grid, lds, stream); break;
+        case 1: tw_launch_gate<1, 4>(a, grid, lds, stream); break;
+        default: tw_launch_gate<4, 1>(a, grid, lds, stream); break;
     }
     SVB_CHECK_LAUNCH();
     return SVB_OK;

@@ -19,3 +19,7 @@ __device__ __forceinline__ void svb_glds16(const void* gsrc, void* lds, unsigned
                  : "v"(gsrc), "s"(dst)
                  : "memory");
 }
+
+// makes the 16 registers of an accumulator opaque to the optimiser at this point (no instruction is emitted)
+typedef float svb_glds_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void svb_opaque16(svb_glds_f32x16& v) { asm volatile("" : "+v"(v)); }

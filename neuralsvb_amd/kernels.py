@@ -21,10 +21,10 @@ _CFG_NAMES = ["svb_conv1d_mfma_kernel<2,2,2,*,80> (64x128)", "svb_conv1d_mfma_ke
               "svb_conv1d_mfma_kernel<2,2,4,*,80> (64x256)", "svb_conv1d_mfma_kernel<2,2,2,direct> (64x128)",
               "svb_conv1d_mfma_kernel<2,2,3,direct> (64x192)", "svb_conv1d_mfma_kernel<2,2,4,direct> (64x256)",
               "svb_conv1d_mfma_kernel<4,1,2,direct> (128x64)", "svb_conv1d_mfma_kernel<4,1,1,direct> (128x32)",
-              # 13..18: the 8-wave tile-walking kernel of csrc/conv1d_tw.hip (stride-1, ungrouped convs; elsewhere the heuristic tile)
-              "svb_conv1d_tw_kernel<2,2> (128x256)", "svb_conv1d_tw_kernel<2,1> (128x128)", "svb_conv1d_tw_kernel<1,2> (64x256)",
-              "svb_conv1d_tw_kernel<3,2> (192x256)", "svb_conv1d_tw_kernel<1,1> (64x128)", "svb_conv1d_tw_kernel<3,1> (192x128)"]
-_NCFG_Q = int(os.environ.get("SVB_NCFG_Q", "18"))     # tile configurations of the bf16x3 kernels (the fp32 kernel has the first 5)
+              # 13..15: the producer / consumer tile-walking kernel of csrc/conv1d_tw.hip (stride-1, ungrouped convs; elsewhere
+              # the heuristic tile runs)
+              "svb_conv1d_tw_kernel<2,2> (128x128)", "svb_conv1d_tw_kernel<1,4> (64x256)", "svb_conv1d_tw_kernel<4,1> (256x64)"]
+_NCFG_Q = int(os.environ.get("SVB_NCFG_Q", "15"))     # tile configurations of the bf16x3 kernels (the fp32 kernel has the first 5)
 
 
 # ---- per-shape tile autotuning ("measure, don't guess"): the first time a conv signature is seen on the GPU all five

@@ -5,3 +5,5 @@
 static inline void svb_glds16(const void* gsrc, void* lds, unsigned byte_off) {
     memcpy((char*)lds + byte_off + 16 * emu_lane_id(), gsrc, 16);
 }
+typedef float svb_glds_f32x16 __attribute__((ext_vector_type(16)));
+static inline void svb_opaque16(svb_glds_f32x16&) {}

@@ -567,13 +567,15 @@ def test_conv1d_bf16x3_direct_tiles_whole_phase_loops(dev, cfg, shape):
     assert rel_err(dx, dref) < 6e-5
 
 
-@pytest.mark.parametrize("cfg", [13, 14, 15, 16, 17, 18])
-@pytest.mark.parametrize("shape", [(64, 1, 1), (32, 3, 1), (48, 5, 1), (32, 3, 3), (96, 1, 1)])
+@pytest.mark.parametrize("cfg", [13, 14, 15])
+@pytest.mark.parametrize("shape", [(64, 1, 1), (32, 3, 1), (48, 5, 1), (32, 3, 3), (96, 1, 1), (192, 5, 1)])
 def test_conv1d_bf16x3_tile_walking_kernel(dev, cfg, shape):
-    """The 8-wave tile-walking kernel (csrc/conv1d_tw.hip, configurations 13..18): weights through LDS by LDS-DMA, columns
-    flattened over the batch (tiles straddle clip boundaries: 3 clips x 150 positions in 128- / 256-column tiles), several
-    tiles per workgroup (the emulator's device has 4 CUs), 1 / 2 / 4 chunks per K phase, a ragged last row tile (72 outputs);
-    forward with bias + LeakyReLU, the transposed form with residual + mask, and the input gate, against the oracle."""
+    """The producer / consumer tile-walking kernel (csrc/conv1d_tw.hip, configurations 13..15): weights through LDS by LDS-DMA,
+    columns flattened over the batch (tiles straddle clip boundaries: 3 clips x 150 positions in 64- / 128- / 256-column tiles),
+    several tiles per workgroup (the emulator's device has 4 CUs: deferred stores drained behind the next tile, or flushed when
+    the K extent is short), 1 / 2 / 4 chunks per K phase, a ragged last row tile (72 outputs); forward with bias + LeakyReLU
+    (the deferred epilogue), the transposed form with residual + mask (the immediate one), and the input gate, against the
+    oracle."""
     Cin, k, dil = shape
     g = torch.Generator().manual_seed(cfg * 100 + Cin + k)
     B, Cout, T = 3, 72, 150
@@ -598,7 +600,7 @@ def test_conv1d_bf16x3_tile_walking_kernel(dev, cfg, shape):
     assert rel_err(yg, refg) < 6e-5
 
 
-@pytest.mark.parametrize("cfg", [13, 17])
+@pytest.mark.parametrize("cfg", [13, 14])
 @pytest.mark.parametrize("T,k,pad,dil", [(4, 3, 1, 1), (7, 3, 9, 9), (131, 5, 2, 1), (260, 3, 27, 27), (66, 3, 5, 1)])
 def test_conv1d_bf16x3_tile_walking_clip_edges(dev, cfg, T, k, pad, dil):
     """Clips shorter than the tap span, padding wider than the clip, over-wide padding that lengthens the output, dilation 27:

@@ -10,11 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from neuralsvb_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "neuralsvb_amd", "libsvb_hip_instr.so")
+_ABL = os.environ.get("SVB_TW_ABL", "")          # "" = stamps only; N = the library compiled with -DSVB_TW_ABLATE=N (`make abl`)
+_lib.LIB_PATH = os.path.join(ROOT, "neuralsvb_amd", f"libsvb_hip_instr_a{_ABL}.so" if _ABL else "libsvb_hip_instr.so")
 from neuralsvb_amd import kernels as K  # noqa: E402
 
-STAGES = ["t0>t1 pre-issue", "t1>t2 VMEM issue", "t2>t3 to loop end", "t3>t4 split+store", "t4>t5 vmcnt(0)", "t5>t6 epilogue",
-          "t6>t7 barrier", "phase"]
+CONS = ["t0>t1 reads+MFMAs(+drain)", "t1>t2 lgkm+barrier", "phase"]
+PROD = ["t0>t1 setup+issue", "t1>t2 wait+split+store", "t2>t3 vmcnt/lgkm(0)", "t3>t4 barrier", "phase"]
 
 
 def timeit(fn, iters=10):
@@ -33,7 +34,7 @@ def timeit(fn, iters=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="32,192,384,1124,5")
-    ap.add_argument("--cfgs", default="13,16,14")
+    ap.add_argument("--cfgs", default="13,14")
     a = ap.parse_args()
     B, ca, cb, T, k = [int(v) for v in a.shape.split(",")]
     dev = torch.device("cuda:0")
@@ -45,34 +46,31 @@ def main():
     for cfg in [int(c) for c in a.cfgs.split(",")]:
         fn = lambda: K.conv1d_forward(x, pk, cb, k, 1, (k - 1) // 2, 1, 1, force_cfg=cfg)
         print(f"== cfg {cfg}: {K._CFG_NAMES[cfg - 1]}  shape B{B} {ca}->{cb} k{k} T{T}")
-        for late in (-1, 0):
-            for abl, what in [(0, "full"), (1, "no x loads"), (2, "no weight DMA"), (16, "no x split/store"), (1 | 16, "no x path"),
-                              (1 | 2 | 16, "no staging at all"), (8, "no epilogue stores"), (4, "no MFMAs"), (32, "no fragment reads"),
-                              (4 | 32, "staging only"), (1 | 2 | 16 | 8 | 32, "MFMAs only")]:
-                lib.svb_debug_set_tw(None, abl, late)
-                us = timeit(fn)
-                print(f"   issue_late={late:2d} ablate={abl:2d} {what:22s} {us:8.1f} us  {flops / us / 1e6:6.0f} TF", flush=True)
+        for drain in (0, 2, 4, 16):
+            lib.svb_debug_set_tw(None, 0, drain)
+            us = timeit(fn)
+            print(f"   ablate={_ABL or 0} drain>={drain:2d}  {us:8.1f} us  {flops / us / 1e6:6.0f} TF", flush=True)
         buf = torch.zeros(4 * 8 * 32 * 8, dtype=torch.int64, device=dev)
-        lib.svb_debug_set_tw(buf.data_ptr(), 0, -1)
+        lib.svb_debug_set_tw(buf.data_ptr(), 0, 0)
         fn()
         torch.cuda.synchronize()
-        lib.svb_debug_set_tw(None, 0, -1)
+        lib.svb_debug_set_tw(None, 0, 0)
         st = buf.cpu().view(4, 8, 32, 8)
         for wg in (0, 1):
-            for wave in (0, 4):
+            for wave, names in ((0, CONS), (4, PROD)):
                 s = st[wg, wave]
                 nph = int((s[:, 0] > 0).sum())
                 if nph < 3:
                     continue
                 rows = []
                 for ph in range(1, nph - 1):
-                    d = [int(s[ph, i + 1] - s[ph, i]) if s[ph, i + 1] > 0 and s[ph, i] > 0 else 0 for i in range(7)]
+                    d = [int(s[ph, i + 1] - s[ph, i]) if s[ph, i + 1] > 0 and s[ph, i] > 0 else 0 for i in range(len(names) - 1)]
                     d.append(int(s[ph + 1, 0] - s[ph, 0]))
                     rows.append(d)
-                print(f"   wg {wg} wave {wave}: {nph} phases stamped; per phase cycles (phases 1..{nph - 2}):")
-                for i, name in enumerate(STAGES):
+                print(f"   wg {wg} wave {wave} ({'consumer' if wave < 4 else 'producer'}): {nph} phases stamped; cycles per phase:")
+                for i, name in enumerate(names):
                     vals = [r[i] for r in rows]
-                    print(f"      {name:18s} mean {sum(vals) / len(vals):8.0f}   " + " ".join(f"{v:6d}" for v in vals[:14]))
+                    print(f"      {name:28s} mean {sum(vals) / len(vals):8.0f}   " + " ".join(f"{v:6d}" for v in vals[:14]))
 
 
 if __name__ == "__main__":
