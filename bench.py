@@ -70,7 +70,8 @@ def build_task(args, rank, world, device, tmp, extra_hparams=""):
 def run_steps(trainer, task, batch, n, start_step):
     for i in range(n):
         task.global_step = trainer.global_step = start_step + i      # phase 2, disc active (global_step >= 1)
-        trainer.run_training_batch(i, batch)
+        # (the training loop hands every step the batch that follows it, utils/trainer.py _with_lookahead: here the same clips)
+        trainer.run_training_batch(i, batch, next_batch=batch)
 
 
 def conv_roofline(trainer, task, batch, steps, start_step, precision="fp32"):

@@ -420,6 +420,17 @@ int svb_embed_nct_bwd(const int64_t* idx, const float* dy, float* part, float* d
  * (inverse != 0: the gather back, x[plane][h][w] = img[plane][h % s][lead + h / s][w] -- its gradient).  planes = B*C.        */
 int svb_period_s2d(const float* src, float* dst, long planes, int H, int p, int s, int lead, int R, int inverse, void* stream);
 
+/* ---- gradient clipping + AdamW of one optimizer over flat buffers (reference tasks/singing/svb_vae_task.py:84-118 torch.optim.AdamW,
+ * :390-404 clip_grad_norm_): p, g, m, v are flat fp32 arrays of n elements (n % 4 == 0; parameters, gradients, first and second
+ * moments at the same offsets).  coef = min(1, max_norm / (||g|| + 1e-6)) (max_norm <= 0: no clipping); g' = coef g;
+ * p *= 1 - lr wd;  m = lerp(m, g', 1 - beta1);  v = beta2 v + (1 - beta2) g'^2;
+ * p -= (lr / bias_correction1) m / (sqrt(v) / bias_correction2_sqrt + eps).  workspace: svb_adamw_flat_workspace_floats()
+ * floats (needed when max_norm > 0 or norm_out != NULL); norm_out: optional, receives ||g||.  Two launches.                    */
+int svb_adamw_flat_workspace_floats(void);
+int svb_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, float bias_correction1, float bias_correction2_sqrt, float max_norm, float* workspace,
+                   float* norm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,8 @@ I, F, P, SZ, I64 = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_int64
 # name -> (restype, argtypes)   -- must mirror include/svb_hip.h exactly
 SIGNATURES = {
     "svb_abi_version": (I, []),
+    "svb_adamw_flat_workspace_floats": (I, []),
+    "svb_adamw_flat": (I, [P, P, P, P, SZ, F, F, F, F, F, F, F, F, P, P, P]),
     "svb_weight_pack": (I, [P, P, P, P, I, I, I, I, P]),
     "svb_conv1d_forward": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),
     "svb_conv1d_transposed": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(SvbConvEpilogue), P]),

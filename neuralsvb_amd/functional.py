@@ -320,6 +320,20 @@ class _Conv1dFn(torch.autograd.Function):
 def conv1d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, weight_g=None, in_slope=None,
            out_act=ACT_NONE, out_slope=0.0, residual=None, mask=None):
     """x [B,Cin,T]; weight [Cout,Cin/groups,k] (or weight_v with weight_g [Cout,1,1]); mask [B,Tout]."""
+    if not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)
+                                         or (weight_g is not None and weight_g.requires_grad)
+                                         or (residual is not None and residual.requires_grad))):
+        # nothing to differentiate (the frozen PPG encoder, validation, inference): the kernel wrapper directly -- a custom
+        # autograd Function costs 20-40 us of host time per call before it has launched anything, on a step the host bounds
+        if out_act == ACT_TANH:
+            raise ValueError("fuse tanh outside (its backward is not a sign gate)")
+        if out_act != ACT_NONE and (residual is not None or mask is not None):
+            raise ValueError("activation cannot be combined with residual/mask in one node")
+        x, v, g = _c(x), _c(weight), _c(weight_g)
+        pa, _ = _pack(v, g, int(groups), want_a=True, want_b=False)
+        return K.conv1d_forward(x, pa, v.shape[0], v.shape[2], int(stride), int(padding), int(dilation), int(groups), bias=_c(bias),
+                                in_gate=x if in_slope is not None else None, in_slope=in_slope if in_slope is not None else 0.0,
+                                out_act=int(out_act), out_slope=float(out_slope), residual=_c(residual), mask=_c(mask))
     cfg = (int(stride), int(padding), int(dilation), int(groups), in_slope, int(out_act), float(out_slope))
     return _Conv1dFn.apply(x, weight, weight_g, bias, residual, mask, cfg)
 
@@ -371,6 +385,15 @@ class _ConvT1dFn(torch.autograd.Function):
 def conv_transpose1d(x, weight, bias=None, stride=1, padding=0, dilation=1, output_padding=0, weight_g=None,
                      in_slope=None, mask=None):
     """x [B,Cin,T]; weight [Cin,Cout,k] (weight_g [Cin,1,1] for weight_norm dim 0)."""
+    if not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)
+                                         or (weight_g is not None and weight_g.requires_grad))):
+        x, v, g = _c(x), _c(weight), _c(weight_g)          # (no autograd node: see conv1d)
+        k = v.shape[2]
+        tout = (x.shape[2] - 1) * int(stride) - 2 * int(padding) + int(dilation) * (k - 1) + int(output_padding) + 1
+        _, pb = _pack(v, g, 1, want_a=False, want_b=True)
+        return K.conv1d_transposed(x, pb, v.shape[1], tout, k, int(stride), int(padding), int(dilation), 1, bias=_c(bias),
+                                   in_gate=x if in_slope is not None else None,
+                                   in_slope=in_slope if in_slope is not None else 0.0, mask=_c(mask))
     cfg = (int(stride), int(padding), int(dilation), int(output_padding), in_slope)
     return _ConvT1dFn.apply(x, weight, weight_g, bias, mask, cfg)
 
@@ -1125,6 +1148,85 @@ def critic_block(x, weight, bias, lrelu_slope, drop_p, gamma, beta, eps=1e-5, pl
     keep = dropout2d_keep(N, cout, drop_p, y4.device) if drop_p else None
     h = _CropDropNormFn.apply(y4, keep, gamma, beta, (N, cout, H // 2, W // 2, eps, bool(s2d_out)))
     return (h, (N, cout, H // 2, W // 2)) if s2d_out else h
+
+
+class _OpCtx:
+    """Stand-in for the autograd ctx of one per-op Function inside a fused node: the per-op forward / backward static methods
+    only use `needs_input_grad`, `save_for_backward` / `saved_tensors` and plain attributes."""
+
+    def __init__(self, needs):
+        self.needs_input_grad = needs
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+FUSE_CRITIC_TOWER = True     # a whole critic tower (3 blocks + score layer) as ONE autograd node
+
+
+class _CriticTowerFn(torch.autograd.Function):
+    """One window's tower of the mel critic -- three [Conv2d 3x3 s2 + LeakyReLU -> Dropout2d -> InstanceNorm2d] blocks chained
+    through the conv's space-to-depth layout, then the score layer (reference multi_window_disc.py:14-64) -- as ONE autograd
+    node: the forward / backward bodies of the per-op Functions above run in sequence on a private tape.  torch charges
+    20-40 us of host time per custom Function call and again per backward node; a tower is 7 of each, the step runs 6 towers,
+    and the step is bound by the host's launch rate, not by the GPU.  Results are those of the per-op path bit for bit
+    (same kernels, same order; the Dropout2d factors are drawn in the same order).
+    args: x4, cfg, then per block (conv weight, conv bias, gamma|None, beta|None), then (score weight, score bias)."""
+
+    @staticmethod
+    def forward(ctx, x4, cfg, *params):
+        (N, C, H, W), slope, drops, epss = cfg
+        nb = len(drops)
+        need = ctx.needs_input_grad
+        tape = []
+        h, planes = x4, (N, C, H, W)
+        x_need = need[0]
+        for b in range(nb):
+            w, bias, gamma, beta = params[4 * b:4 * b + 4]
+            nw = need[2 + 4 * b:6 + 4 * b]
+            n_, c_, h_, w_ = planes
+            cout = w.shape[0]
+            c1 = _OpCtx((x_need, nw[0], nw[1], False))
+            y4 = _Conv2dS2Fn.forward(c1, h, w, bias, (n_, c_, h_, w_, slope))
+            keep = dropout2d_keep(n_, cout, drops[b], y4.device) if drops[b] else None
+            last = b + 1 == nb
+            c2 = _OpCtx((True, False, nw[2], nw[3], False))
+            h = _CropDropNormFn.forward(c2, y4, keep, gamma, beta, (n_, cout, h_ // 2, w_ // 2, epss[b], not last))
+            planes = (n_, cout, h_ // 2, w_ // 2)
+            tape.append((c1, c2))
+            x_need = True
+        sw, sb = params[4 * nb], params[4 * nb + 1]
+        if h.stride(3) != 1 or h.stride(2) != h.shape[3]:
+            h = h.contiguous()
+        c3 = _OpCtx((True, need[2 + 4 * nb], need[3 + 4 * nb]))
+        y = _PlaneScoreFn.forward(c3, h, sw, sb)
+        ctx.tape, ctx.score_ctx, ctx.nb = tape, c3, nb
+        return y
+
+    @staticmethod
+    def backward(ctx, ds):
+        nb = ctx.nb
+        grads = [None] * (4 * nb + 2)
+        dh, dsw, dsb = _PlaneScoreFn.backward(ctx.score_ctx, ds)
+        grads[4 * nb], grads[4 * nb + 1] = dsw, dsb
+        for b in range(nb - 1, -1, -1):
+            c1, c2 = ctx.tape[b]
+            dy4, _, dg, dbeta, _ = _CropDropNormFn.backward(c2, dh)
+            dh, dw, dbias, _ = _Conv2dS2Fn.backward(c1, dy4)
+            grads[4 * b:4 * b + 4] = [dw, dbias, dg, dbeta]
+        ctx.tape = ctx.score_ctx = None
+        return (dh, None) + tuple(grads)
+
+
+def critic_tower(x4, planes, blocks, score_weight, score_bias, lrelu_slope=0.2):
+    """blocks: [(conv weight, conv bias, drop_p, gamma|None, beta|None, eps), ...]; x4: the first block's space-to-depth input of
+    planes (N, C, H, W).  -> scores [N, 1]."""
+    params = []
+    for w, b, _, gamma, beta, _ in blocks:
+        params += [w, b, gamma, beta]
+    cfg = (tuple(planes), lrelu_slope, tuple(float(bl[2] or 0.0) for bl in blocks), tuple(float(bl[5]) for bl in blocks))
+    return _CriticTowerFn.apply(x4, cfg, *params, score_weight, score_bias)
 
 
 def plane_score(h, weight, bias):

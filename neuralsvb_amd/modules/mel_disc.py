@@ -73,6 +73,26 @@ def _tower(tower, h, want_fmaps, fmaps, planes=None):
     return h
 
 
+def _tower_score(tower, x4, planes):
+    """The whole tower + score layer as one autograd node (SF.critic_tower) when every block chains through the conv's
+    space-to-depth layout (3x3 kernels, planes even down to the last block, InstanceNorm2d or no norm); None otherwise."""
+    if not SF.FUSE_CRITIC_TOWER:
+        return None
+    blocks, (N, C, H, W) = list(tower.model), planes
+    spec = []
+    for i, blk in enumerate(blocks):
+        conv, drop = blk[0], blk[2]
+        norm = blk[3] if len(blk) > 3 else None
+        if not _fast_plane(conv, H, W) or (norm is not None and not isinstance(norm, nn.InstanceNorm2d)):
+            return None
+        if i + 1 < len(blocks) and ((H // 2) % 2 or (W // 2) % 2):
+            return None
+        spec.append((conv.weight, conv.bias, drop.p if drop.training else 0.0, norm.weight if norm is not None else None,
+                     norm.bias if norm is not None else None, norm.eps if norm is not None else 1e-5))
+        H, W = H // 2, W // 2
+    return SF.critic_tower(x4, planes, spec, tower.adv_layer.weight, tower.adv_layer.bias)
+
+
 def _critic_tower(time_length, freq_length, kernel, c_in, hidden, norm_type, reduction):
     """One window's conv tower as bare containers named like the reference's Discriminator2DFactory (:6-44)."""
     tower = nn.Module()
@@ -164,6 +184,10 @@ class Discriminator(nn.Module):
                         h = _block(blk, h)
                         fmaps.append(h)
                 else:
+                    y = _tower_score(tower, x4, planes)
+                    if y is not None:
+                        scores.append(y)
+                        continue
                     h = _tower(tower, x4, want_fmaps, fmaps, planes=planes)
                 scores.append(_adv_score(tower.adv_layer, h))
                 continue

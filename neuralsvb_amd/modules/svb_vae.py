@@ -96,11 +96,49 @@ class MleSVBVAE(nn.Module):
         self.stack_ways = bool(hp.get("stack_ways", True))     # see forward()
 
     # ---- conditioning (svb_vae.py:60-86); all tensors NCT --------------------------------------------------------
-    def prepare_condition(self, mels_content, pitch, spk_ids, groups=1):
+    # ---- the frozen PPG encoder one step ahead ----------------------------------------------------------------------------
+    @staticmethod
+    def _content_key(*mels):
+        return tuple((m.data_ptr(), tuple(m.shape), m._version) for m in mels)
+
+    def prefetch_content(self, amateur_mel, prof_mel):
+        """Run the frozen PPG encoder on the mels of the NEXT batch now, on its side stream (the Trainer calls this between the
+        forward and the backward of the current step).  Its output depends on the batch alone -- the encoder never trains
+        (svb_vae.py:66-72) -- but everything in the next forward waits for it: 1.8 ms at the head of the step's dependency chain
+        that now run beside this step's backward instead.  The result is consumed (once) by the forward that finds the same
+        mel tensors, unchanged; any other forward simply computes it."""
+        if not (PPG_SIDE_STREAM and amateur_mel.is_cuda and not SF.CAPTURING):
+            return
+        stacked = self.stack_ways and amateur_mel.shape == prof_mel.shape
+        jobs = [((amateur_mel, prof_mel), None)] if stacked else [((amateur_mel,), None), ((prof_mel,), None)]
+        cur = torch.cuda.current_stream(amateur_mel.device)
+        side = _PPG_STREAMS.get(amateur_mel.device.index)
+        if side is None:
+            side = _PPG_STREAMS[amateur_mel.device.index] = torch.cuda.Stream(amateur_mel.device)
+        side.wait_stream(cur)
+        cache = self.__dict__.setdefault("_content_cache", {})
+        cache.clear()
+        with torch.no_grad(), torch.cuda.stream(side):
+            for mels, _ in jobs:
+                x = torch.cat(list(mels)) if len(mels) > 1 else mels[0]
+                for m in mels:
+                    m.record_stream(side)
+                cache[self._content_key(*mels)] = (self.vc_asr(x)["h_content"].detach(), mels)
+
+    def _cached_content(self, key):
+        cache = self.__dict__.get("_content_cache")
+        return cache.pop(key, None) if cache and key is not None else None
+
+    def prepare_condition(self, mels_content, pitch, spk_ids, groups=1, content_key=None):
         T = pitch.shape[1]
         pe = self.pitch_embed          # nn.Embedding(300, H, padding_idx=0) + transpose, as one gather into [B,H,T]
         side = None
-        if PPG_SIDE_STREAM and mels_content.is_cuda and not SF.CAPTURING:
+        hit = self._cached_content(content_key)
+        if hit is not None:
+            # computed one step ahead on the PPG stream (prefetch_content): the current stream waits where it is first read
+            h, side = hit[0], _PPG_STREAMS[mels_content.device.index]
+            cur = torch.cuda.current_stream(mels_content.device)
+        elif PPG_SIDE_STREAM and mels_content.is_cuda and not SF.CAPTURING:
             # independent branches (svb_vae.py:66-72): PPG encoder on a side stream that first catches up with the producers of
             # the mel, pitch encoder on the current one; the current stream waits where the content features are first read
             cur = torch.cuda.current_stream(mels_content.device)
@@ -156,11 +194,12 @@ class MleSVBVAE(nn.Module):
             # batch-coupled layers on the path, the train-mode BatchNorms, are applied per half (bn_groups).
             B = amateur_mel.shape[0]
             c2 = self.prepare_condition(torch.cat([amateur_mel, prof_mel]), torch.cat([amateur_pitch, prof_pitch]),
-                                        torch.cat([amateur_spk_id, prof_spk_id]), groups=2)
+                                        torch.cat([amateur_spk_id, prof_spk_id]), groups=2,
+                                        content_key=self._content_key(amateur_mel, prof_mel))
             ca, cp = {k: v[:B] for k, v in c2.items()}, {k: v[B:] for k, v in c2.items()}
         else:
-            ca = self.prepare_condition(amateur_mel, amateur_pitch, amateur_spk_id)
-            cp = self.prepare_condition(prof_mel, prof_pitch, prof_spk_id)
+            ca = self.prepare_condition(amateur_mel, amateur_pitch, amateur_spk_id, content_key=self._content_key(amateur_mel))
+            cp = self.prepare_condition(prof_mel, prof_pitch, prof_spk_id, content_key=self._content_key(prof_mel))
         self._last_conds = (ca, cp)
         self._last_stacked_kl = None
         if stacked and "a2a" in ways and "p2p" in ways:

@@ -157,7 +157,8 @@ class BaseTask(nn.Module):
                           num_ckpt_keep=hparams["num_ckpt_keep"], save_best=hparams["save_best"], seed=hparams["seed"],
                           debug=hparams["debug"], hip_graph=hparams.get("hip_graph", False),
                           hip_graph_warmup=hparams.get("hip_graph_warmup", 2),
-                          hip_graph_max_shapes=hparams.get("hip_graph_max_shapes", 4))
+                          hip_graph_max_shapes=hparams.get("hip_graph_max_shapes", 4),
+                          hip_graph_mode=hparams.get("hip_graph_mode", "step"))
         if not hparams["infer"]:
             trainer.fit(cls)
         else:

@@ -97,6 +97,10 @@ class HifiGanTask(BaseTask):
     def on_before_optimization(self, opt_idx):
         params, norm = ((self.gen_params, hparams["generator_grad_norm"]),
                         (self.disc_params, hparams["discriminator_grad_norm"]))[opt_idx]
+        flat = getattr(self.trainer, "flat_optim", None) if self.trainer is not None else None
+        if flat and opt_idx < len(flat) and flat[opt_idx] is not None:
+            flat[opt_idx].set_clip(norm)          # applied inside the flat AdamW launch (utils/flat_optim.py)
+            return
         torch.nn.utils.clip_grad_norm_(params, norm, foreach=True)
 
     def on_after_optimization(self, epoch, batch_idx, optimizer, optimizer_idx):

@@ -222,22 +222,47 @@ class SVBVAEMleTask(BaseTask):
             rand["structure"].append(tuple(s is not None for s in starts))
         self._step_rand = rand
         if stage_device:
+            # static device tensors (a captured hipGraph has their addresses baked in), refilled by ONE async copy from a
+            # ring of pinned host rows: a pageable source would make the copy wait for the stream -- a full device sync
+            # per step (round 4: the host needed 16 ms per "graph" step for exactly that reason)
             dev = self.model.z_mapping_function.parameters().__next__().device
             n_calls, n_win = 8, max(len(wins), 1)
+            n = n_calls * n_win
             if self._rand_dev is None:
-                self._rand_dev = {"spk": torch.zeros(1, dtype=torch.long, device=dev),
-                                  "starts": torch.zeros(n_calls, n_win, dtype=torch.long, device=dev)}
-            host = torch.zeros(n_calls, n_win, dtype=torch.long)
+                flat = torch.zeros(n + 1, dtype=torch.long, device=dev)
+                self._rand_dev = {"flat": flat, "starts": flat[:n].view(n_calls, n_win), "spk": flat[n:n + 1]}
+                if dev.type == "cuda":
+                    self._rand_ring = (torch.zeros(32, n + 1, dtype=torch.long).pin_memory(), [None] * 32, [0])
+            if dev.type == "cuda":
+                ring, events, cursor = self._rand_ring
+                slot = cursor[0] % ring.shape[0]
+                cursor[0] += 1
+                if events[slot] is not None:
+                    events[slot].synchronize()        # (only ever waits when the host is 32 steps ahead of the device)
+                host = ring[slot]
+            else:
+                host = torch.zeros(n + 1, dtype=torch.long)
+            host.zero_()
             for i, d in enumerate(rand["disc"][:n_calls]):
                 for w, s in enumerate(d["starts"]):
-                    host[i, w] = s[0] if s is not None else 0
-            self._rand_dev["starts"].copy_(host, non_blocking=True)
-            self._rand_dev["spk"].fill_(rand["spk"])
+                    host[i * n_win + w] = s[0] if s is not None else 0
+            host[n] = rand["spk"]
+            self._rand_dev["flat"].copy_(host, non_blocking=True)
+            if dev.type == "cuda":
+                ev = torch.cuda.Event()
+                ev.record()
+                events[slot] = ev
             rand["dev"] = True
         return rand
 
     def end_step(self):
         self._step_rand = None
+
+    def prefetch(self, sample):
+        """Called by the Trainer with the NEXT step's batch (already on the device) while the current step is between its
+        forward and its backward: the frozen PPG encoder of that batch runs now, beside this step's backward."""
+        if "mels" in sample and "prof_mels" in sample:
+            self.model.prefetch_content(sample["mels"], sample["prof_mels"])
 
     def graph_key(self, global_step):
         """Everything host-side that shapes the launch sequence of a step (a captured graph is only replayed for an equal key)."""
@@ -432,6 +457,10 @@ class SVBVAEMleTask(BaseTask):
         params, norm = ((self.gen_params, hparams["generator_grad_norm"]),
                         (self.disc_params, hparams["discriminator_grad_norm"]),
                         (self.mapping_params, hparams["generator_grad_norm"]))[opt_idx]
+        flat = getattr(self.trainer, "flat_optim", None) if self.trainer is not None else None
+        if flat and opt_idx < len(flat) and flat[opt_idx] is not None:
+            flat[opt_idx].set_clip(norm)          # the clip factor is applied inside the flat AdamW launch (utils/flat_optim.py)
+            return
         torch.nn.utils.clip_grad_norm_(params, norm, foreach=True)
 
     def on_after_optimization(self, epoch, batch_idx, optimizer, optimizer_idx):

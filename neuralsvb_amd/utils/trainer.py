@@ -14,11 +14,15 @@ MI355X-first differences (none changes results):
   * launch: `torchrun --nproc-per-node N` (RANK/LOCAL_RANK/WORLD_SIZE) or, like the reference, self-spawn when
     CUDA_VISIBLE_DEVICES lists several devices;
   * loss terms are only synchronised to the host when they are logged;
-  * `hip_graph: true`: the forward+backward of each optimizer pass is captured once per (batch shape, phase) into a
-    hipGraph and replayed -- the step issues ~3500 kernel launches, which costs the host ~37 ms per step when issued
-    one by one from Python, more than the GPU needs to execute them.  Host-side randoms (window starts, speaker pick)
-    are drawn up front in the reference's order and read by the graph from device buffers; all-reduce, clipping and
-    the optimizer step stay outside the graph.
+  * `hip_graph: true`: the forward+backward of ALL optimizer passes of a step is captured once per (batch shape, phase)
+    into ONE multi-stream hipGraph and replayed (`hip_graph_mode: step`, round 4): the weight gradients fork onto their
+    side stream inside the capture, the frozen PPG encoder onto its own, and the critic's pass forks off the generator
+    pass right after the generator's forward -- it only reads what that forward produced -- and runs beside the
+    generator's backward; the streams join before the capture ends.  The host then issues one graph launch plus the
+    ~25 launches of clipping / AdamW / repack per step instead of ~650.  Host-side randoms (window starts, speaker
+    pick) are drawn up front in the reference's order and read by the graph from device buffers; all-reduce, clipping
+    and the optimizer steps stay outside the graph.  (`hip_graph_mode: pass` is the round-2 form: one single-stream
+    graph per optimizer pass.)
 """
 import copy
 import logging
@@ -36,11 +40,29 @@ from .ckpt_utils import get_all_ckpts, get_last_checkpoint
 from .hparams import hparams
 
 
+def L_is_emu():
+    from .. import _lib
+    return _lib._LIB_IS_EMU
+
+
 def _note_weights_updated(params=None, repack=False):
     from .. import functional as SF          # weight images packed for the kernels are stale after an in-place update
     SF.note_weights_updated(params)
     if repack and params is not None:
         SF.repack_registered(params)          # ... and refilled at once: one multi-tensor launch per optimizer step
+
+
+def _with_lookahead(it):
+    """(item, next item or None) pairs: the Trainer hands the task the batch AFTER the current one (see Trainer._prefetch)."""
+    it = iter(it)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
 
 
 def move_to_device(batch, device):
@@ -250,7 +272,7 @@ class Trainer:
     def __init__(self, work_dir, accumulate_grad_batches=1, max_updates=160000, print_nan_grads=False,
                  val_check_interval=2000, num_sanity_val_steps=5, amp=False, tb_log_interval=10, monitor_key="val_loss",
                  monitor_mode="min", num_ckpt_keep=5, save_best=True, resume_from_checkpoint=0, seed=1234, debug=False,
-                 hip_graph=False, hip_graph_warmup=2, hip_graph_max_shapes=4, **_):
+                 hip_graph=False, hip_graph_warmup=2, hip_graph_max_shapes=4, hip_graph_mode="step", **_):
         if work_dir:
             os.makedirs(work_dir, exist_ok=True)
         self.work_dir = work_dir
@@ -266,13 +288,18 @@ class Trainer:
             raise NotImplementedError("amp is not supported by the MI355X kernels: use conv_precision=bf16x3 (fp32 storage, "
                                       "bf16 matrix cores with an fp32-class operand split) instead of autocast")
         self.task, self.optimizers, self.grad_sync = None, [], []
+        self.flat_optim = []
         self._critic_stream, self._critic_busy = None, False
         self._wgrad_stream = None            # side stream of the weight gradients; kernels.WGRAD_STREAM only while a step runs
         self._grad_enabled_for = None        # (task, optimizer index) whose parameters currently have requires_grad = True
+        self._fwd_done = None                # step-graph capture: callable(opt_idx) invoked between a pass's forward and backward
+        self._upcoming, self._moved = None, None    # the next step's batch (host side) / its device copy made one step early
         self._param_cache = None
         # hipGraph replay of each optimizer pass's forward+backward (fixed-shape batches; see _graphed_forward_backward)
         self.hip_graph, self.hip_graph_warmup, self.hip_graph_max_shapes = bool(hip_graph), hip_graph_warmup, hip_graph_max_shapes
         self._static, self._graphs, self._graph_pool, self._graph_stream = {}, {}, None, None
+        self.hip_graph_mode = hip_graph_mode
+        self._static_pins = {}               # (shape signature, batch key) -> pinned staging ring of host-side batch tensors
         self.testing = False
         self.global_step = self.current_epoch = 0
         self.monitor_key, self.num_ckpt_keep, self.save_best = monitor_key, num_ckpt_keep, save_best
@@ -351,11 +378,22 @@ class Trainer:
             self.grad_sync = [FlatGradSync([p for g in o.param_groups for p in g["params"]], self.world_size,
                                            bucket_bytes=int(hparams.get("ddp_bucket_mb", 8) * (1 << 20)),
                                            overlap=hparams.get("ddp_overlap", True),
-                                           drop_autograd_grads=not self.hip_graph and hparams.get("drop_autograd_grads", True))
+                                           drop_autograd_grads=(not self.hip_graph and hparams.get("drop_autograd_grads", True)
+                                                                and not hparams.get("flat_adamw", True)))
                               if o is not None else None for o in self.optimizers]
         if checkpoint is not None:
             self.restore_opt_state(checkpoint)
         del checkpoint
+        # clipping + AdamW as two launches over flat parameter / gradient / moment buffers (utils/flat_optim.py)
+        self.flat_optim = [None] * len(self.optimizers)
+        if not self.testing and hparams.get("flat_adamw", True):
+            from .flat_optim import FlatAdamW
+            for i, (o, gs) in enumerate(zip(self.optimizers, self.grad_sync)):
+                if (o is not None and isinstance(o, torch.optim.AdamW) and gs is not None and len(o.param_groups) == 1
+                        and (gs.flat.is_cuda or L_is_emu())):
+                    self.flat_optim[i] = FlatAdamW(o, gs)
+            if any(f is not None for f in self.flat_optim):
+                _note_weights_updated()            # (the parameters moved into the flat buffers: packed images are stale)
         if self.use_ddp:
             self._broadcast_module_state(params=True)
             dist.barrier()
@@ -429,8 +467,8 @@ class Trainer:
         while True:
             task.current_epoch = self.current_epoch = epoch
             task.on_epoch_start()
-            for batch_idx, batch in enumerate(loader):
-                _, tb_metrics = self.run_training_batch(batch_idx, batch)
+            for batch_idx, (batch, upcoming) in enumerate(_with_lookahead(loader)):
+                _, tb_metrics = self.run_training_batch(batch_idx, batch, next_batch=upcoming)
                 if self.global_step % self.val_check_interval == 0 and not self.first_epoch:
                     self.run_evaluation()
                 self.first_epoch = False
@@ -459,13 +497,32 @@ class Trainer:
             self._static[sig] = bufs
         out = dict(batch)
         for k, b in bufs.items():
-            b.copy_(batch[k], non_blocking=True)
+            src = batch[k]
+            if not src.is_cuda and b.is_cuda:
+                # host tensors go through a two-deep ring of pinned rows: a pageable source makes the "async" copy wait for the
+                # stream -- one full device sync per step, the whole point of replaying a graph gone
+                ring = self._static_pins.get((sig, k))
+                if ring is None:
+                    ring = self._static_pins[(sig, k)] = [[torch.empty(src.shape, dtype=src.dtype).pin_memory(), None]
+                                                          for _ in range(2)] + [0]
+                slot = ring[ring[2] % 2]
+                ring[2] += 1
+                if slot[1] is not None:
+                    slot[1].synchronize()
+                slot[0].copy_(src)
+                b.copy_(slot[0], non_blocking=True)
+                slot[1] = torch.cuda.Event()
+                slot[1].record()
+            else:
+                b.copy_(src, non_blocking=True)
             out[k] = b
         return sig, out
 
     def _forward_backward(self, batch, batch_idx, opt_idx):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(self.amp) and self.on_gpu):
             out = self.task.training_step(batch, batch_idx, opt_idx)
+        if self._fwd_done is not None:       # step-graph capture: where an independent later pass may fork off this one
+            self._fwd_done(opt_idx)
         loss = out["loss"]
         if loss is not None:
             loss = loss / self.accumulate_grad_batches
@@ -517,10 +574,94 @@ class Trainer:
         graph.replay()                      # capture only records: this replay is the step's actual execution
         return out
 
-    def run_training_batch(self, batch_idx, batch):
-        """One step = every non-None optimizer in order (reference :269-342)."""
+    def _prefetch(self, opt_idx):
+        """Between the forward and the backward of the step's first pass: copy the NEXT batch to the device and let the task
+        start whatever depends on that batch alone (SVBVAEMleTask.prefetch: the frozen PPG encoder, on its side stream)."""
+        nxt, self._upcoming = self._upcoming, None
+        self._fwd_done = None
+        if nxt is None:
+            return
+        moved = move_to_device(nxt, self.device)
+        self._moved = (nxt, moved)
+        self.task.prefetch(moved)
+
+    def _graphed_step(self, task, batch, batch_idx, sig, multi, pbar, tb):
+        """`hip_graph_mode: step`: forward + backward of every optimizer pass of the step as ONE captured multi-stream hipGraph
+        (after `hip_graph_warmup` eager steps of the same key -- kernel autotuning and lazy initialisation happen there),
+        then per pass what stays outside: gradient clipping, the optimizer step, the weight repack, zeroing.
+
+        Streams inside the capture: weight gradients fork onto kernels.WGRAD_STREAM and the frozen PPG encoder onto its own
+        stream exactly as in eager mode (each joins where its results are read); the pass `task.independent_critic_pass`
+        reads only what the generator's FORWARD produced (the kept generated mels, the batch, the critic's weights -- which
+        the generator's backward reads but never writes), so it forks off an event recorded between the generator's forward
+        and backward and runs beside that backward on the critic stream; everything joins before the capture ends.  The
+        passes' optimizer steps commute with this order: the critic pass does not read a generator weight (the reference
+        runs G-step, then D-pass on the kept `model_out`: utils/trainer.py:269-342, svb_vae_task.py:610-640)."""
+        from .. import functional as SF
+        from .. import kernels as _K
+        key = (sig, task.graph_key(self.global_step) if hasattr(task, "graph_key") else None, task.training)
+        ent = self._graphs.setdefault(key, {"seen": 0, "graph": None, "outs": None})
+        if ent["graph"] is None and ent["seen"] < max(self.hip_graph_warmup, 1):
+            ent["seen"] += 1
+            for opt_idx, optimizer in enumerate(self.optimizers):
+                if optimizer is not None:
+                    self._optimizer_pass(task, batch, batch_idx, opt_idx, optimizer, multi, False, sig, pbar, tb)
+            return
+        if ent["graph"] is None:
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            disc_idx = getattr(task, "independent_critic_pass", None)
+            fork = disc_idx is not None and hparams.get("overlap_critic_pass", True)
+            if fork and self._critic_stream is None:
+                self._critic_stream = torch.cuda.Stream(self.device)
+            outs, forked, fwd_event = {}, False, {}
+
+            def fwd_done(opt_idx):
+                if fork and opt_idx != disc_idx:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    fwd_event["ev"] = ev
+            SF.CAPTURING = True
+            self._fwd_done = fwd_done
+            try:
+                with torch.cuda.graph(graph, pool=self._graph_pool, stream=self._graph_stream):
+                    main = torch.cuda.current_stream(self.device)
+                    for opt_idx, optimizer in enumerate(self.optimizers):
+                        if optimizer is None:
+                            continue
+                        self._enable_grads_for(task, opt_idx, multi)
+                        if fork and opt_idx == disc_idx and "ev" in fwd_event:
+                            s2 = self._critic_stream
+                            s2.wait_event(fwd_event["ev"])
+                            side, _K.WGRAD_STREAM = _K.WGRAD_STREAM, None     # (its few weight gradients stay on its own stream)
+                            try:
+                                with torch.cuda.stream(s2):
+                                    out = self._forward_backward(batch, batch_idx, opt_idx)
+                            finally:
+                                _K.WGRAD_STREAM = side
+                            forked = True
+                        else:
+                            out = self._forward_backward(batch, batch_idx, opt_idx)
+                        outs[opt_idx] = out
+                    if forked:
+                        main.wait_stream(self._critic_stream)
+            finally:
+                SF.CAPTURING = False
+                self._fwd_done = None
+            if self._graph_pool is None:
+                self._graph_pool = graph.pool()
+            ent["graph"], ent["outs"] = graph, outs
+        ent["graph"].replay()                   # (capture only records: the replay is the step's execution)
+        for opt_idx, optimizer in enumerate(self.optimizers):
+            if optimizer is not None and opt_idx in ent["outs"]:
+                self._finish_pass(task, batch_idx, opt_idx, optimizer, ent["outs"][opt_idx], pbar, tb)
+
+    def run_training_batch(self, batch_idx, batch, next_batch=None):
+        """One step = every non-None optimizer in order (reference :269-342).  next_batch (optional): the batch of the following
+        step -- work of that step which depends on nothing but its batch (the frozen PPG encoder) is issued one step early."""
         if batch is None:
             return {}, {}
+        self._upcoming = next_batch
         if self.hip_graph and self.on_gpu:
             # hipGraph mode works on ONE side stream throughout (eager warm-up runs, capture, replay, optimizer): the
             # autograd AccumulateGrad nodes must live on the stream that is captured, never on the default stream.
@@ -542,16 +683,26 @@ class Trainer:
         # step returns (validation, user code, the next test) must get their results on the stream they launch from.
         prev_side = _K.WGRAD_STREAM
         graph_mode = self.hip_graph and self.on_gpu
-        want_side = self.on_gpu and not graph_mode and hparams.get("wgrad_side_stream", True)
+        step_graph = graph_mode and self.hip_graph_mode == "step" and self.world_size == 1 and self.accumulate_grad_batches == 1
+        want_side = self.on_gpu and (not graph_mode or step_graph) and hparams.get("wgrad_side_stream", True)
         if want_side and self._wgrad_stream is None:
             self._wgrad_stream = torch.cuda.Stream(self.device)
         _K.WGRAD_STREAM = self._wgrad_stream if want_side else None
+        done = False
         try:
-            return self._run_training_batch_body(batch_idx, batch)
+            ret = self._run_training_batch_body(batch_idx, batch)
+            done = True
+            return ret
         finally:
             side, _K.WGRAD_STREAM = _K.WGRAD_STREAM, prev_side
-            if side is not None:              # (every pass already joined it after its backward; an exception may not have)
+            # Every pass joins the side stream right after its own backward, on the stream that pass runs on; only a pass that
+            # raised may not have.  (Round 4: an unconditional join here made the COMPUTE stream wait for the weight gradients
+            # of the critic's pass -- issued from the critic's stream onto this side stream -- i.e. for most of the critic pass
+            # that is supposed to overlap the next step: 2.3 ms of idle compute stream per step, tools/gpu_split.py.)
+            if side is not None and (not done or hparams.get("step_end_side_join", False)):
                 torch.cuda.current_stream(self.device).wait_stream(side)
+            if not (self.hip_graph and self.on_gpu):
+                self._fwd_done = None
             _K.abort_deferred_reduces()       # (a pass that raised inside backward leaves no recorded reduce behind)
             SF.GRAD_READY = None
             SF.end_weight_epoch()             # outside a managed step trainable weights are never served from the cache
@@ -571,9 +722,22 @@ class Trainer:
             graph_mode = sig is not None
             batch = sbatch if graph_mode else batch
         if not graph_mode:
-            batch = move_to_device(batch, self.device)            # once per step
+            if self._moved is not None and self._moved[0] is batch:
+                batch = self._moved[1]                            # copied to the device during the previous step (_prefetch)
+            else:
+                batch = move_to_device(batch, self.device)        # once per step
+            self._moved = None
+            if (self.on_gpu and self._upcoming is not None and hasattr(task, "prefetch")
+                    and hparams.get("prefetch_next_batch", True)):
+                self._fwd_done = self._prefetch
         pbar, tb = {}, {}
         multi = len(self.optimizers) > 1
+        if graph_mode and self.hip_graph_mode == "step" and self.world_size == 1 and self.accumulate_grad_batches == 1:
+            task.critic_barrier = None
+            self._graphed_step(task, batch, batch_idx, sig, multi, pbar, tb)
+            if hasattr(task, "end_step"):
+                task.end_step()
+            return pbar, tb
         # The critic's own optimizer pass depends on nothing the generator pass of the NEXT step does before it calls the
         # critic (it reads the generated mels kept from this step's forward, the batch and the critic; it writes the critic):
         # it runs on a second stream that starts once everything issued so far is done, and the compute stream only waits
@@ -612,6 +776,27 @@ class Trainer:
 
     def _optimizer_pass(self, task, batch, batch_idx, opt_idx, optimizer, multi, graph_mode, sig, pbar, tb):
         """One optimizer of the step: forward + backward of its pass, gradient exchange, clipping, update."""
+        self._enable_grads_for(task, opt_idx, multi)
+        sync = self.grad_sync[opt_idx] if opt_idx < len(self.grad_sync) else None
+        final_micro = (self.global_step + 1) % self.accumulate_grad_batches == 0
+        if sync is not None and not graph_mode and final_micro:
+            # overlapped exchange: buckets are all-reduced as their gradients become final during backward (only on the
+            # micro-batch that is followed by the optimizer step: earlier ones just accumulate locally)
+            from .. import functional as SF
+            key = (opt_idx, task.graph_key(self.global_step) if hasattr(task, "graph_key") else None)
+            sync.begin_pass(key)
+            SF.GRAD_READY = sync.grad_ready if sync.overlap else None
+        try:
+            if graph_mode:
+                out = self._graphed_forward_backward(sig, batch, batch_idx, opt_idx)
+            else:
+                out = self._forward_backward(batch, batch_idx, opt_idx)
+        finally:
+            if sync is not None and not graph_mode and final_micro:
+                SF.GRAD_READY = None
+        self._finish_pass(task, batch_idx, opt_idx, optimizer, out, pbar, tb)
+
+    def _enable_grads_for(self, task, opt_idx, multi):
         if multi:   # only this optimizer's parameters receive gradients in this pass (:280-285)
             # (the parameter lists are cached: walking task.parameters() -- a recursive named_modules() generator --
             # three times per step cost 2 ms of a host-bound 22 ms step)
@@ -632,23 +817,10 @@ class Trainer:
                 for p in self._param_cache[2][opt_idx]:
                     p.requires_grad = True
                 self._grad_enabled_for = (task, opt_idx)
+
+    def _finish_pass(self, task, batch_idx, opt_idx, optimizer, out, pbar, tb):
+        """After a pass's backward: logging values, gradient exchange, clipping, update, repack, zero."""
         sync = self.grad_sync[opt_idx] if opt_idx < len(self.grad_sync) else None
-        final_micro = (self.global_step + 1) % self.accumulate_grad_batches == 0
-        if sync is not None and not graph_mode and final_micro:
-            # overlapped exchange: buckets are all-reduced as their gradients become final during backward (only on the
-            # micro-batch that is followed by the optimizer step: earlier ones just accumulate locally)
-            from .. import functional as SF
-            key = (opt_idx, task.graph_key(self.global_step) if hasattr(task, "graph_key") else None)
-            sync.begin_pass(key)
-            SF.GRAD_READY = sync.grad_ready if sync.overlap else None
-        try:
-            if graph_mode:
-                out = self._graphed_forward_backward(sig, batch, batch_idx, opt_idx)
-            else:
-                out = self._forward_backward(batch, batch_idx, opt_idx)
-        finally:
-            if sync is not None and not graph_mode and final_micro:
-                SF.GRAD_READY = None
         if out["loss"] is None:
             if sync is not None:
                 sync._counts = None          # nothing to exchange in this pass
@@ -664,7 +836,11 @@ class Trainer:
             sync = self.grad_sync[opt_idx]
             sync.finish()
             task.on_before_optimization(opt_idx)
-            optimizer.step()
+            flat = self.flat_optim[opt_idx] if opt_idx < len(self.flat_optim) else None
+            if flat is not None:
+                flat.step()
+            else:
+                optimizer.step()
             _note_weights_updated(self._param_cache[2][opt_idx] if self._param_cache is not None else
                                   [p for g in optimizer.param_groups for p in g["params"]], repack=True)
             sync.zero()
@@ -696,8 +872,14 @@ class Trainer:
                 optimizer.load_state_dict(next(states))
             except (ValueError, StopIteration):
                 print("| WARMING: optimizer parameters not match !!!")
+        for f in self.flat_optim:
+            if f is not None:
+                f.reattach()
 
     def dump_checkpoint(self):
+        for f in self.flat_optim:
+            if f is not None:
+                f.export_state()
         return {"epoch": self.current_epoch, "global_step": self.global_step,
                 "checkpoint_callback_best": self.best_val_results,
                 "optimizer_states": [o.state_dict() for o in self.optimizers if o is not None],

@@ -55,6 +55,42 @@ def test_stacked_critic_calls_equal_separate_calls(dev):
         assert (a - b).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item())
 
 
+def test_fused_tower_node_equals_per_op_nodes(dev):
+    """SF.critic_tower (a whole tower + score layer as ONE autograd node, the per-op bodies replayed on a private tape) must give
+    bit for bit what the per-op autograd nodes give: scores, input gradients and every parameter gradient -- with Dropout2d ON
+    (same draw order from the same generator state) and with the critic's parameters frozen (the generator's pass)."""
+    from neuralsvb_amd import functional as SF
+    from neuralsvb_amd.modules.mel_disc import Discriminator
+    torch.manual_seed(0)
+    disc = Discriminator(time_lengths=[32, 64], freq_length=80, hidden_size=16, kernel=(3, 3), cond_size=0,
+                         norm_type="in", reduction="stack").to(dev)
+    disc.train()
+    g = torch.Generator().manual_seed(2)
+    xs0 = [torch.randn(2, 90, 80, generator=g).to(dev) for _ in range(2)]
+    starts = [[[5, 5], [11, 11]], [[40, 40], [0, 0]]]
+    res = {}
+    for frozen in (False, True):
+        for p in disc.parameters():
+            p.requires_grad_(not frozen)
+        for fused in (True, False):
+            SF.FUSE_CRITIC_TOWER = fused
+            try:
+                torch.manual_seed(7)          # the Dropout2d draws
+                xs = [x.clone().requires_grad_(True) for x in xs0]
+                outs = disc.forward_many([(x, [list(s) for s in st], None, 90) for x, st in zip(xs, starts)], want_fmaps=False)
+                loss = sum(((o["y"] - 1) ** 2).mean() * (i + 1) for i, o in enumerate(outs))
+                wrt = xs + ([] if frozen else list(disc.parameters()))
+                res[(frozen, fused)] = ([o["y"].detach().clone() for o in outs], torch.autograd.grad(loss, wrt))
+            finally:
+                SF.FUSE_CRITIC_TOWER = True
+        (ya, ga), (yb, gb) = res[(frozen, True)], res[(frozen, False)]
+        for a, b in zip(ya, yb):
+            assert torch.equal(a, b)
+        assert len(ga) == len(gb)
+        for a, b in zip(ga, gb):
+            assert torch.equal(a, b)
+
+
 def test_critic_general_shapes_match_stock_torch(dev):
     """Reference-legal critic configurations outside the fast path (multi_window_disc.py:14-65): a number of mel bins whose
     halvings turn odd (60 -> 30 -> 15 -> 8) and a 5x5 kernel.  Both used to raise inside SF.critic_block; they now take the

@@ -116,9 +116,83 @@ def test_phase2_training_step_matches_cpu_oracle(dev, tmp_path):
 
 
 @pytest.mark.gpu
-def test_hipgraph_replay_matches_eager_steps(gpu_only, tmp_path):
-    """Trainer hip_graph mode (forward+backward of each optimizer pass captured once, then replayed with fresh host randoms
-    staged to device buffers) must produce the same losses and weights as issuing every launch eagerly."""
+def test_prefetched_ppg_encoder_gives_the_same_steps(gpu_only, tmp_path):
+    """Trainer.run_training_batch(..., next_batch=...) runs the frozen PPG encoder of the following batch one step early, on
+    its side stream beside the current backward, and copies that batch to the device early; the following step must consume
+    exactly that result.  Four steps over two alternating batches with and without the look-ahead: identical losses, identical
+    weights (same kernels on the same inputs -- only their place on the time line differs)."""
+    dev = gpu_only
+    res = {}
+    for mode in ("plain", "lookahead"):
+        task, trainer, batch, hp = _setup(tmp_path / mode, dev)
+        b2 = {k: (v.flip(0).contiguous() if isinstance(v, torch.Tensor) and v.dim() > 0 else v) for k, v in batch.items()}
+        seq = [batch, b2, batch, b2]
+        logs = []
+        for step in range(1, 5):
+            np.random.seed(300 + step)
+            torch.manual_seed(300 + step)
+            task.global_step = trainer.global_step = step
+            nxt = seq[step] if (mode == "lookahead" and step < 4) else None
+            pbar, _ = trainer.run_training_batch(0, seq[step - 1], next_batch=nxt)
+            logs.append({k: float(v) for k, v in pbar.items() if isinstance(v, torch.Tensor)})
+        if mode == "lookahead":
+            assert not task.model.__dict__.get("_content_cache")          # every prefetched result was consumed
+        res[mode] = (logs, {k: v.detach().clone() for k, v in task.state_dict().items() if v.is_floating_point()})
+    for a, b in zip(res["plain"][0], res["lookahead"][0]):
+        assert a == b
+    for k, v in res["plain"][1].items():
+        assert torch.equal(v, res["lookahead"][1][k]), k
+
+
+def test_flat_adamw_matches_torch_clip_and_adamw(dev):
+    """utils/flat_optim.FlatAdamW (csrc/optim.hip: the clip factor of clip_grad_norm_ + AdamW over flat parameter / gradient /
+    moment buffers, two launches) against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW on the same gradients for several
+    steps -- clipping active and inactive, weight decay, a learning-rate change -- and the optimizer's state_dict keeps the
+    reference layout (step / exp_avg / exp_avg_sq per parameter) and survives a save / load."""
+    from neuralsvb_amd.utils.trainer import FlatGradSync
+    from neuralsvb_amd.utils.flat_optim import FlatAdamW
+    g = torch.Generator().manual_seed(5)
+    shapes = [(7, 3, 5), (13,), (4, 6), (1,), (33, 2)]
+    ref_p = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    our_p = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref_p]
+    kw = dict(lr=3e-3, betas=(0.5, 0.999), eps=1e-6, weight_decay=0.01)
+    ref_o, our_o = torch.optim.AdamW(ref_p, **kw), torch.optim.AdamW(our_p, **kw)
+    sync = FlatGradSync(our_p, 1)
+    flat = FlatAdamW(our_o, sync)
+    for step, (max_norm, scale) in enumerate([(5.0, 10.0), (5.0, 0.01), (0.0, 1.0), (1.0, 3.0)]):
+        if step == 2:
+            for o in (ref_o, our_o):
+                o.param_groups[0]["lr"] = 1e-3
+        grads = [torch.randn(s, generator=g) * scale for s in shapes]
+        for p, q, gr in zip(ref_p, our_p, grads):
+            p.grad = gr.clone()
+            q.grad.copy_(gr.to(dev))
+        norm = torch.nn.utils.clip_grad_norm_(ref_p, max_norm) if max_norm else None
+        ref_o.step()
+        flat.set_clip(max_norm)
+        flat.step()
+        if norm is not None:
+            assert abs(float(flat.norm) - float(norm)) <= 1e-5 * float(norm)
+        for p, q in zip(ref_p, our_p):
+            assert (p.detach() - q.detach().cpu()).abs().max().item() <= 2e-6 * max(1.0, p.abs().max().item()), step
+    flat.export_state()
+    sd = our_o.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 4.0
+    for i, p in enumerate(ref_p):
+        assert (ref_o.state[p]["exp_avg_sq"] - sd["state"][i]["exp_avg_sq"].cpu()).abs().max().item() <= 1e-6
+    our_o.load_state_dict({"state": {k: {kk: vv.clone() for kk, vv in v.items()} for k, v in sd["state"].items()},
+                           "param_groups": sd["param_groups"]})
+    flat.reattach()
+    assert our_o.state[our_p[0]]["exp_avg"].data_ptr() == flat.m.data_ptr()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph_mode", ["step", "pass"])
+def test_hipgraph_replay_matches_eager_steps(gpu_only, tmp_path, graph_mode):
+    """Trainer hip_graph mode must produce the same losses and weights as issuing every launch eagerly.  `step` (round 4): the
+    forward+backward of both optimizer passes as ONE multi-stream graph -- weight gradients and the PPG encoder on their side
+    streams, the critic's pass forked off the generator's forward beside the generator's backward -- replayed with fresh host
+    randoms staged to device buffers; `pass`: one single-stream graph per optimizer pass."""
     dev = gpu_only
     results = {}
     # Replay must reproduce the eager launches bit for bit, so both modes have to take the same arithmetic: graph mode crops
@@ -128,15 +202,15 @@ def test_hipgraph_replay_matches_eager_steps(gpu_only, tmp_path):
     from neuralsvb_amd.modules import mel_disc
     mel_disc.FUSED_CROP = False
     try:
-        _hipgraph_vs_eager(dev, tmp_path, results)
+        _hipgraph_vs_eager(dev, tmp_path, results, graph_mode)
     finally:
         mel_disc.FUSED_CROP = True
 
 
-def _hipgraph_vs_eager(dev, tmp_path, results):
+def _hipgraph_vs_eager(dev, tmp_path, results, graph_mode):
     for mode in ("eager", "graph"):
         task, trainer, batch, hp = _setup(tmp_path / mode, dev)
-        trainer.hip_graph, trainer.hip_graph_warmup = mode == "graph", 1
+        trainer.hip_graph, trainer.hip_graph_warmup, trainer.hip_graph_mode = mode == "graph", 1, graph_mode
         for m in task.modules():
             if isinstance(m, torch.nn.Dropout):
                 m.p = 0.0
@@ -153,7 +227,8 @@ def _hipgraph_vs_eager(dev, tmp_path, results):
             pbar, _ = trainer.run_training_batch(0, dict(batch, **host_lens))
             logs.append({k: float(v) for k, v in pbar.items() if isinstance(v, torch.Tensor)})
         if mode == "graph":
-            assert sum(1 for e in trainer._graphs.values() if e["graph"] is not None) == 2   # gen pass + critic pass
+            n_graphs = sum(1 for e in trainer._graphs.values() if e["graph"] is not None)
+            assert n_graphs == (1 if graph_mode == "step" else 2)        # the step  |  gen pass + critic pass
         results[mode] = (logs, {k: v.detach().clone() for k, v in task.state_dict().items() if v.is_floating_point()})
     for step, (le, lg) in enumerate(zip(results["eager"][0], results["graph"][0])):
         assert le.keys() == lg.keys()

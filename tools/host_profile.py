@@ -13,15 +13,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-args = argparse.Namespace(gpus=1, steps=1, warmup=1, batch=16, seconds=6.0, sample_rate=24000, precision="bf16x3", graph=False)
+args = argparse.Namespace(gpus=1, steps=1, warmup=1, batch=16, seconds=6.0, sample_rate=24000, precision="bf16x3", graph=bool(os.environ.get("SVB_PROFILE_GRAPH")), extra_hparams="")
 dev = torch.device("cuda:0")
 with tempfile.TemporaryDirectory() as tmp:
     task, trainer, batch, hp = bench.build_task(args, 0, 1, dev, tmp)
-    bench.run_steps(trainer, task, batch, 5, 1)
+    bench.run_steps(trainer, task, batch, 8, 1)
     torch.cuda.synchronize()
     pr = cProfile.Profile()
     pr.enable()
-    bench.run_steps(trainer, task, batch, 5, 6)
+    bench.run_steps(trainer, task, batch, 5, 9)
     pr.disable()
     torch.cuda.synchronize()
 st = pstats.Stats(pr)

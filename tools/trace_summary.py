@@ -69,3 +69,18 @@ for g, (d, c) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
 print(f"{'ms/step':>9} {'calls/step':>10} {'avg us':>8}  kernel")
 for nm, (d, c) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:top]:
     print(f"{d / 1e6 / steps:9.3f} {c / steps:10.1f} {d / c / 1e3:8.1f}  {nm[:110]}")
+# per-queue view (a HIP stream maps to a hardware queue): busy time, launches, idle gaps inside the queue's own span
+qcol = next((c for c in ("Queue_Id", "Stream_Id", "queue_id") if c in rows[0]), None)
+if qcol:
+    byq = defaultdict(list)
+    for r in rows:
+        byq[r[qcol]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    print(f"per {qcol}:")
+    for q, ivs in sorted(byq.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])):
+        ivs.sort()
+        b = sum(e - s for s, e, _ in ivs)
+        gaps_q = [ivs[i + 1][0] - ivs[i][1] for i in range(len(ivs) - 1) if ivs[i + 1][0] > ivs[i][1]]
+        small = sum(g for g in gaps_q if g <= 20000)
+        print(f"  queue {q}: busy {b / 1e6 / steps:7.3f} ms/step, {len(ivs) / steps:6.1f} launches/step, gaps <= 20 us "
+              f"{small / 1e6 / steps:6.3f} ms/step ({len([g for g in gaps_q if g <= 20000]) / steps:.0f}/step), gaps > 20 us "
+              f"{(sum(gaps_q) - small) / 1e6 / steps:6.3f} ms/step")
