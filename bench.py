@@ -67,11 +67,66 @@ def build_task(args, rank, world, device, tmp, extra_hparams=""):
     return task, trainer, batch, hparams
 
 
-def run_steps(trainer, task, batch, n, start_step):
+def run_steps(trainer, task, batch, n, start_step, step_events=None):
     for i in range(n):
         task.global_step = trainer.global_step = start_step + i      # phase 2, disc active (global_step >= 1)
         # (the training loop hands every step the batch that follows it, utils/trainer.py _with_lookahead: here the same clips)
         trainer.run_training_batch(i, batch, next_batch=batch)
+        if step_events is not None:          # one event per step on the compute stream: per-step times without a host sync
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            step_events.append(ev)
+
+
+def step_split(trainer, task, batch, n, start_step):
+    """Device-time windows of the compute stream per step (HIP events around forward / backward / the rest of the generator's
+    pass, and around the critic's pass on its own stream): where a step's critical path goes.  An interval includes whatever the
+    stream waits for inside it."""
+    marks = []
+
+    def mark(label):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append((label, torch.cuda.current_stream().cuda_stream, ev))
+    o_ts, o_bw, o_pass = task.training_step, torch.Tensor.backward, trainer._optimizer_pass
+
+    def ts(sample, batch_idx, opt_idx):
+        mark(f"p{opt_idx}.fwd0")
+        r = o_ts(sample, batch_idx, opt_idx)
+        mark(f"p{opt_idx}.fwd1")
+        return r
+
+    def bw(self, *x, **k):
+        r = o_bw(self, *x, **k)
+        mark("bwd1")
+        return r
+
+    def opass(task_, batch_, batch_idx, opt_idx, *rest):
+        r = o_pass(task_, batch_, batch_idx, opt_idx, *rest)
+        mark(f"p{opt_idx}.end")
+        return r
+    task.training_step, torch.Tensor.backward, trainer._optimizer_pass = ts, bw, opass
+    try:
+        t0 = time.perf_counter()
+        run_steps(trainer, task, batch, n, start_step)
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+    finally:
+        task.training_step, torch.Tensor.backward, trainer._optimizer_pass = o_ts, o_bw, o_pass
+    acc = {}
+    by_stream = {}
+    for lab, sid, ev in marks:
+        by_stream.setdefault(sid, []).append((lab, ev))
+    for lst in by_stream.values():
+        for (l0, e0), (l1, e1) in zip(lst[:-1], lst[1:]):
+            acc[(l0, l1)] = acc.get((l0, l1), 0.0) + e0.elapsed_time(e1)
+    g = lambda a, b: acc.get((a, b), 0.0) / n
+    return {"generator_forward_ms": g("p0.fwd0", "p0.fwd1"), "generator_backward_ms": g("p0.fwd1", "bwd1"),
+            "generator_clip_adamw_repack_ms": g("bwd1", "p0.end"),
+            "critic_pass_forward_ms": g("p1.fwd0", "p1.fwd1"), "critic_pass_backward_ms": g("p1.fwd1", "bwd1"),
+            "critic_pass_clip_adamw_ms": g("bwd1", "p1.end"), "host_issue_ms": t_host / n * 1e3,
+            "note": "HIP-event windows per step; generator_* on the compute stream, critic_pass_* on the critic's stream (it runs "
+                    "beside the next step's generator forward); a window includes what its stream waits for"}
 
 
 def conv_roofline(trainer, task, batch, steps, start_step, precision="fp32"):
@@ -138,11 +193,11 @@ def conv_alg_bytes(tag):
 
 
 def pmc_traffic(tag_counts):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r03_pmc_traffic.json -- r02's if absent --, written by
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r04_pmc_traffic.json -- an earlier round's if absent --, written by
     tools/pmc_traffic.py on the MI355X: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, each calibrated
     on a launch of known traffic with the same access pattern).  Launch-weighted over the shapes the kernel ran in this
     step; (None, why) when the file does not cover at least 60 % of its launches."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (3, 2)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (4, 3, 2)) if os.path.exists(q)), None)
     if path is None:
         return None, "no PMC file"
     db = json.load(open(path)).get("shapes", {})
@@ -320,12 +375,14 @@ def bench_infer(args, device):
         torch.set_num_threads(min(16, os.cpu_count() or 1))
         msd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         gsd = {k: v.detach().cpu() for k, v in gen.state_dict().items()}
-        nb = 1
+        nb = 4                                    # a stated batch >= 4 (the GPU leg: 32 clips); ~6 s per run on 16 threads
         a = (msd, gsd, mels[:nb].cpu(), pitch[:nb].cpu(), spk[:nb].cpu(), al[:nb].cpu(), f0[:nb].cpu(), dict(hparams), hifi)
+        infer_clip(msd, gsd, mels[:1].cpu(), pitch[:1].cpu(), spk[:1].cpu(), al[:1].cpu(), f0[:1].cpu(), dict(hparams), hifi)   # warm
+        t_c = time.perf_counter()
         infer_clip(*a)
-        tt = infer_clip(*a)
+        tt = time.perf_counter() - t_c
         cpu = {"value": nb * T * 128 / sr / tt, "unit": "audio-seconds/sec", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": f"oracle CPU port of the same pipeline on {nb} x {T * 128 / sr:.1f} s clip, second of two runs, torch fp32",
+               "sample": f"oracle CPU port of the same pipeline on a batch of {nb} x {T * 128 / sr:.1f} s clips (after a 1-clip warm-up run), torch fp32",
                "s_per_batch": tt, "rtf": tt / (nb * T * 128 / sr)}
     SF.set_precision("fp32")
     return {"metric": "audio-seconds/sec, end-to-end inference (PPG+pitch -> VAE mel -> NSF-HifiGAN)", "value": audio / dt,
@@ -458,8 +515,11 @@ def main():
         for gsync in trainer.grad_sync:
             if gsync is not None and world > 1:
                 gsync.measure_wait = True           # two event records per pass: device time the compute stream waits for RCCL
+        step_events = []
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
         t0 = time.perf_counter()
-        run_steps(trainer, task, batch, args.steps, 1 + args.warmup)
+        run_steps(trainer, task, batch, args.steps, 1 + args.warmup, step_events)
         t_host = time.perf_counter() - t0           # host side done issuing; the GPU may still be working
         torch.cuda.synchronize()
         log(f"host finished issuing {args.steps} steps after {t_host / args.steps * 1e3:.2f} ms/step")
@@ -481,7 +541,9 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = tt.item()
         ms = dt / args.steps * 1e3
-        log(f"{ms:.2f} ms/step")
+        per_step = sorted(a.elapsed_time(b) for a, b in zip([ev0] + step_events[:-1], step_events))
+        ms_median = per_step[len(per_step) // 2] if per_step else None
+        log(f"{ms:.2f} ms/step (median of the per-step device times {ms_median:.2f})")
         value = args.batch * args.seconds * world / (dt / args.steps)
         # the same steps with the batch handed over as (pinned) HOST buffers: one H2D copy per step inside the timed region
         # (SURVEY 8d's step definition; reported beside `value`, never as it)
@@ -492,11 +554,50 @@ def main():
         t1 = time.perf_counter()
         for i in range(n_h2d):
             task.global_step = trainer.global_step = 1 + args.warmup + args.steps + i
-            hb = dict(host)
-            trainer.run_training_batch(i, hb)
+            hb, hb_next = dict(host), dict(host)
+            if i == 0:
+                cur_hb = hb
+            trainer.run_training_batch(i, cur_hb, next_batch=hb_next)      # (the loop's look-ahead: the next batch's copy overlaps)
+            cur_hb = hb_next
         torch.cuda.synchronize()
         ms_h2d = (time.perf_counter() - t1) / n_h2d * 1e3
         log(f"{ms_h2d:.2f} ms/step with the H2D copy of the batch inside the step")
+        split = n1_ddp = phase3 = None
+        if rank == 0 and world == 1 and not args.graph:
+            nxt = 1 + args.warmup + args.steps + n_h2d
+            split = step_split(trainer, task, batch, 10, nxt)
+            log("step split: " + ", ".join(f"{k} {v:.2f}" for k, v in split.items() if isinstance(v, float)))
+            # the N > 1 step's per-GPU compute at N = 1: a gradient must be final when it is announced to the bucketed
+            # exchange, so weight-gradient reduces are immediate instead of batched per 48 MB of partials; autograd-only
+            # gradients keep their slice of the flat buffer (already the case with the flat AdamW) -- no collective here
+            saved = hp.get("defer_wgrad_reduce")
+            hp["defer_wgrad_reduce"] = False
+            try:
+                run_steps(trainer, task, batch, 3, nxt + 10)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                run_steps(trainer, task, batch, 12, nxt + 13)
+                torch.cuda.synchronize()
+                n1_ddp = (time.perf_counter() - t2) / 12 * 1e3
+            finally:
+                if saved is None:
+                    hp.pop("defer_wgrad_reduce", None)
+                else:
+                    hp["defer_wgrad_reduce"] = saved
+            log(f"N=1 step under the N>1 constraints (immediate weight-gradient reduces): {n1_ddp:.2f} ms/step")
+            # phase 3 (reported separately): the latent-map optimizer's pass -- a2a + p2p + a2p ways forward, MLE term,
+            # the a2p way's critic term, backward into the map only (svb_vae_task.py:593-676)
+            p3 = int(hp["phase_2_steps"]) + 10
+            run_steps(trainer, task, batch, 6, p3)            # warm-up: new launch signatures get their tiles measured
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            run_steps(trainer, task, batch, 15, p3 + 6)
+            torch.cuda.synchronize()
+            ms3 = (time.perf_counter() - t3) / 15 * 1e3
+            phase3 = {"ms_per_step": ms3, "value": args.batch * args.seconds / (ms3 * 1e-3), "unit": "audio-seconds/sec", "steps": 15,
+                      "warmup": 6, "workload": "vae_global_mle_eng phase-3 step (latent-map optimizer: a2a + p2p + a2p forward, MLE + "
+                                               "critic term, backward into the map), same batch"}
+            log(f"phase 3: {ms3:.2f} ms/step")
         # the data side of a step, rank 0 only: the same B clips from the binary dataset to a batch resident in HBM
         # -- host collater + one H2D copy per field (the reference's way) against slicing into pinned staging buffers + the
         # collate / norm_interp_f0 kernels (tasks/device_collate.py).  Not part of `value`.
@@ -596,7 +697,9 @@ def main():
                                        f"{'hipGraph replay' if args.graph else 'eager launches'}, "
                                        f"hop 128, T={T}, 80-bin mel", "global_batch": args.batch * world,
                            "parallelism": f"dp{world}", "random_init_weights": True},
+                "ms_per_step_median": ms_median,
                 "value_with_h2d": args.batch * args.seconds * world / (ms_h2d * 1e-3), "ms_per_step_with_h2d": ms_h2d,
+                "step_split": split, "n1_with_ddp_constraints_ms": n1_ddp, "phase3": phase3,
                 "comm": comm, "data_side": data_side, "roofline": roof, "cpu_baseline": cpu,
                 "extra_workloads": extra_w}))
     if world > 1:

@@ -1,4 +1,5 @@
-"""smoke(): one tiny forward+backward of MleSVBVAE on the GPU (HIP kernels), checked against the CPU oracle."""
+"""TEST INFRASTRUCTURE (used by __graft_entry__.smoke only): one tiny forward+backward of MleSVBVAE on the GPU (HIP kernels),
+checked against the CPU oracle."""
 import torch
 
 

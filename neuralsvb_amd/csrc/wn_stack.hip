@@ -13,14 +13,22 @@
 // the side stream catches up with the main one (an event per layer and direction), and the caller joins the side stream after
 // the call.  Their split-K partials collect in `arena`; svb_wgrad_reduce_multi finishes the pending ones whenever the next
 // does not fit and at the end of the stack (the capped deferral of kernels.py, inside the executor).
-static hipEvent_t g_wn_events[2 * SVB_WN_MAX_LAYERS];
-static bool g_wn_events_ready = false;
+// (one event set per device: an event belongs to the device it was created on.  A record / wait pair is consumed at once by the
+//  single host thread that issues it, so the callers of one device can share the set.)
+#define SVB_WN_MAX_DEVICES 16
+static hipEvent_t g_wn_events_all[SVB_WN_MAX_DEVICES][2 * SVB_WN_MAX_LAYERS];
+static bool g_wn_events_ready[SVB_WN_MAX_DEVICES];
+static hipEvent_t* g_wn_events = nullptr;        // the calling device's set (selected by wn_events())
 
 static int wn_events() {
-    if (g_wn_events_ready) return SVB_OK;
-    for (int i = 0; i < 2 * SVB_WN_MAX_LAYERS; ++i)
-        if (hipEventCreateWithFlags(&g_wn_events[i], hipEventDisableTiming) != hipSuccess) return SVB_ERR_LAUNCH;
-    g_wn_events_ready = true;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SVB_WN_MAX_DEVICES) return SVB_ERR_LAUNCH;
+    if (!g_wn_events_ready[dev]) {
+        for (int i = 0; i < 2 * SVB_WN_MAX_LAYERS; ++i)
+            if (hipEventCreateWithFlags(&g_wn_events_all[dev][i], hipEventDisableTiming) != hipSuccess) return SVB_ERR_LAUNCH;
+        g_wn_events_ready[dev] = true;
+    }
+    g_wn_events = g_wn_events_all[dev];
     return SVB_OK;
 }
 

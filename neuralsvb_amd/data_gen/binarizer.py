@@ -60,8 +60,17 @@ def _read_wav(w, sr):
         fs, data = wavfile.read(w)
         if fs != sr:
             raise BinarizationError(f"{w}: {fs} Hz, expected {sr} Hz (resampling is not part of this path)")
-        scale = 32768.0 if data.dtype == np.int16 else (2147483648.0 if data.dtype == np.int32 else 1.0)
-        data = data.astype(np.float32) / scale
+        # librosa.load's conventions (data_gen_utils.py:123 via wav2spec): integer PCM scaled to [-1, 1), 8-bit PCM is unsigned
+        if data.dtype == np.uint8:
+            data = (data.astype(np.float32) - 128.0) / 128.0
+        elif data.dtype == np.int16:
+            data = data.astype(np.float32) / 32768.0
+        elif data.dtype == np.int32:
+            data = data.astype(np.float32) / 2147483648.0
+        elif data.dtype in (np.float32, np.float64):
+            data = data.astype(np.float32)
+        else:
+            raise BinarizationError(f"{w}: unsupported sample type {data.dtype}")
         return data if data.ndim == 1 else data.mean(1)
     return np.asarray(w, dtype=np.float32).reshape(-1)
 
@@ -93,6 +102,12 @@ class ParaBinarizer:
         self.f0_fn = f0_fn or praat_f0
         self.batch_pairs = int(batch_pairs)
         self.args = dict(hparams.get("binarization_args", {}) if binarization_args is None else binarization_args)
+        # the reference's wav2spec also applies these when configured (data_gen_utils.py:98-121: pyloudnorm to -22 LUFS + peak
+        # clamp, silence trimming); this path does not -- refuse instead of writing a dataset that silently differs
+        for key in ("loud_norm", "trim_long_sil"):
+            if hparams.get(key):
+                raise NotImplementedError(f"ParaBinarizer: hparams['{key}'] is not supported by the batched wav2spec "
+                                          f"(the shipped vae_global_mle_eng config has it off)")
         self.fe = MelFrontend(hparams, self.device)
         self.eps = float(hparams.get("wav2spec_eps", 1e-10))
 

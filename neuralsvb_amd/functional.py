@@ -418,13 +418,20 @@ def _wn_exec_plan(x, layers, n_layers, ks, dr):
         dil = dr ** i
         pad = (ks * dil - dil) // 2
         rc = layers[i][3].shape[0]
-        c = (K.tuned_choice(("qf", B, C, 2 * C, 1, T, ks, 1, pad, dil, False), gpu),
+        c = [K.tuned_choice(("qf", B, C, 2 * C, 1, T, ks, 1, pad, dil, False), gpu),
              K.tuned_choice(("qf", B, C, rc, 1, T, 1, 1, 0, 1, False), gpu),
              K.tuned_choice(("qt", B, 2 * C, C, 1, T, T, ks, 1, pad, dil, False), gpu),
-             K.tuned_choice(("qt", B, rc, C, 1, T, T, 1, 1, 0, 1, False), gpu))
-        if None in c:
+             K.tuned_choice(("qt", B, rc, C, 1, T, T, 1, 1, 0, 1, False), gpu)]
+        if None in c[:2]:
             return None
-        plan.append(c)
+        if None in c[2:]:
+            # the data-gradient tiles are still unmeasured.  Without autograd (validation, inference) they are never launched and
+            # must not keep the forward off the executor; in training the per-launch path runs once more and measures them
+            # (layer 0's in-conv data gradient is never launched when the stack's input needs no gradient: heuristic tile)
+            if torch.is_grad_enabled() and not (i == 0 and c[3] is not None):
+                return None
+            c = [c[0], c[1], c[2] or 0, c[3] or 0]
+        plan.append(tuple(c))
     return plan
 
 
@@ -506,6 +513,12 @@ def _wn_exec_backward(ctx, dout, xs, mask, G, dG, params, grads, need, need_x):
     bw.dout, bw.dx, bw.dG = dout.data_ptr(), scratch[2].data_ptr(), K._ptr(dG)
     bw.drs, bw.dxin, bw.dacts, bw.dxm = DRS.data_ptr(), DXIN.data_ptr(), scratch[0].data_ptr(), scratch[1].data_ptr()
     arena = K.wn_arena(dev, side)
+    # every layer's split-K partials (+ bias partials) must fit the arena BEFORE anything is launched: the executor returns
+    # "unsupported" from the middle of the stack otherwise, with the earlier layers' gradients already accumulated
+    for i, (in_v, in_g, in_b, rs_v, rs_g, rs_b) in enumerate(params):
+        for v, kk, dil in ((in_v, ks, dr ** i), (rs_v, 1, 1)):
+            if K.wgrad_partials_floats(B, v.shape[0], v.shape[1], T, kk, (kk * dil - dil) // 2, dil) > arena.numel():
+                return False
     bw.arena, bw.arena_floats, bw.need_dx0 = arena.data_ptr(), arena.numel(), int(bool(need_x))
     if side is not None:          # the weight gradients read these on the side stream after the caller has dropped them
         for t in (dout, DRS, DXIN) + tuple(ctx.saved_tensors[6:9]) + (x0,):

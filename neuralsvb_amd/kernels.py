@@ -352,7 +352,9 @@ WN_ARENA_FLOATS = 12 << 20
 
 
 def wn_arena(dev, side):
-    key = (dev.index, side.cuda_stream if side is not None else 0)
+    # keyed by the stream the weight gradients actually run on: the side stream, or -- without one -- the CURRENT stream (two
+    # stacks running backward on different streams must not share their partials)
+    key = (dev.index, side.cuda_stream if side is not None else (_raw_stream(dev) if dev.type == "cuda" else 0))
     a = _WN_ARENA.get(key)
     if a is None:
         if side is not None:
@@ -362,6 +364,15 @@ def wn_arena(dev, side):
             a = torch.empty((WN_ARENA_FLOATS,), device=dev, dtype=torch.float32)
         _WN_ARENA[key] = a
     return a
+
+
+def wgrad_partials_floats(B, ca, cb, T, k, pad, dil):
+    """Arena floats one stride-1 bf16x3 weight gradient needs: its split-K partials plus, 16-float aligned, the bias partials
+    (0: outside the bf16x3 kernel's envelope)."""
+    lib = L._LIB if L._LIB is not None else L.get_lib()
+    ns = C.c_int(0)
+    nfl = lib.svb_conv1d_wgrad_bf16x3_workspace_floats(B, ca, cb, 1, T, k, 1, pad, dil, C.byref(ns))
+    return ((nfl + 15) & ~15) + ((ns.value * ca + 15) & ~15) if nfl else 0
 
 
 def wn_stack_desc(x, mask, G, n_layers, k, dil_rate):

@@ -160,13 +160,20 @@ def main():
     run_task()
     assert len(rec["steps"]) == C.N_STEPS, len(rec["steps"])
     out_dir = os.environ.get("SVB_STEP_OUT", HERE)
-    with open(os.path.join(out_dir, "step_ref.json"), "w") as f:
-        json.dump(rec, f)
-    C.save_events(os.path.join(out_dir, "step_ref_draws.npz"), events_per_step)
+    # the primary seed writes the full record (dataset digests + steps); the additional draw sets of C.EXTRA_SEEDS only their steps
+    sfx = "" if seed == C.STEP_SEED else f"_seed{seed}"
+    if not sfx:
+        with open(os.path.join(out_dir, "step_ref.json"), "w") as f:
+            json.dump(rec, f)
+    else:
+        import gzip                                  # (deterministic bytes: no timestamp in the gzip header)
+        with gzip.GzipFile(os.path.join(out_dir, f"step_ref{sfx}.json.gz"), "wb", mtime=0) as f:
+            f.write(json.dumps({"seed": seed, "steps": rec["steps"]}).encode())
+    C.save_events(os.path.join(out_dir, f"step_ref_draws{sfx}.npz"), events_per_step)
     print("critic min plane variance per step:", [st.get("critic_min_plane_var") for st in rec["steps"]])
     os.chdir(ROOT)
     shutil.rmtree(tmp, ignore_errors=True)
-    print("step golden written:", os.path.getsize(os.path.join(HERE, "step_ref.json")), "bytes json")
+    print("step golden written:", os.path.getsize(os.path.join(out_dir, f"step_ref{sfx}.json" + (".gz" if sfx else ""))), "bytes json")
 
 
 if __name__ == "__main__":

@@ -27,6 +27,8 @@ STEP_SEED = 11                            # torch / numpy global streams of the 
 # 11: 8e-4 / 2.9e-3   12: 6e-4 / 8.2e-3   13: 6e-4 / 6.3e-3   20260926: 6e-4 / 1.4e-1 (step 2 only; fp32 on all layers of
 # the generator brings it back to 4e-4, a serial single-stream run changes nothing: arithmetic sensitivity, not a race --
 # profiles/r03_step_golden_seed_diagnosis.md).  The test's bounds are for a typical draw set; 11 is one.
+EXTRA_SEEDS = (12, 13, 20260926)          # further draw sets of the same run (`SVB_STEP_SEED=<s> python make_step_golden.py` ->
+                                          # step_ref_seed<s>.json.gz / step_ref_draws_seed<s>.npz): the step test runs all four
 SAMPLE_PARAMS = 24                        # elements sampled per parameter for the gradient / weight probes
 
 

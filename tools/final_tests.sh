@@ -1,6 +1,7 @@
 #!/bin/bash
-# the round's closing GPU call: full suite with -x, then smoke()
-O=gpurun_out/r03_final_tests
+# the round's closing GPU call: full suite with -x, then smoke()      usage: bash tools/final_tests.sh [round tag, default r04]
+R=${1:-r04}
+O=gpurun_out/${R}_final_tests
 mkdir -p $O
 export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest_gpu_full.log 2>&1
