@@ -549,18 +549,19 @@ def main():
         # (SURVEY 8d's step definition; reported beside `value`, never as it)
         from neuralsvb_amd.utils.trainer import move_to_device
         host = {k: (v.cpu().pin_memory() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
-        n_h2d = max(5, args.steps // 2)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(n_h2d):
+        n_h2d, w_h2d = max(20, args.steps), 3      # (3 untimed steps first: the look-ahead pipeline is full when the clock starts)
+        cur_hb = dict(host)
+        for i in range(w_h2d + n_h2d):
+            if i == w_h2d:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
             task.global_step = trainer.global_step = 1 + args.warmup + args.steps + i
-            hb, hb_next = dict(host), dict(host)
-            if i == 0:
-                cur_hb = hb
+            hb_next = dict(host)
             trainer.run_training_batch(i, cur_hb, next_batch=hb_next)      # (the loop's look-ahead: the next batch's copy overlaps)
             cur_hb = hb_next
         torch.cuda.synchronize()
         ms_h2d = (time.perf_counter() - t1) / n_h2d * 1e3
+        n_h2d += w_h2d
         log(f"{ms_h2d:.2f} ms/step with the H2D copy of the batch inside the step")
         split = n1_ddp = phase3 = None
         if rank == 0 and world == 1 and not args.graph:

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define SVB_ABI_VERSION 5
+#define SVB_ABI_VERSION 6
 int svb_abi_version(void);
 
 /* ---- fused conv epilogue / prologue description ------------------------------------------------------
@@ -430,6 +430,26 @@ int svb_adamw_flat_workspace_floats(void);
 int svb_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, float bias_correction1, float bias_correction2_sqrt, float max_norm, float* workspace,
                    float* norm_out, void* stream);
+
+/* Copies `count` fp32 arrays (src[i], n[i] elements) to dst + dst_off[i]: the gradients autograd handed over as tensors of their
+ * own (a parameter's `.grad` was None, reference semantics of optimizer.zero_grad()) into their slices of the flat gradient
+ * buffer before svb_adamw_flat, one launch per 48 arrays.  src / dst_off / n are HOST arrays.                                   */
+int svb_gather_segments(const void* const* src, const size_t* dst_off, const size_t* n, int count, float* dst, void* stream);
+
+/* nn.BatchNorm1d on x [B,C,T] (reference: the `poolings` of modules/voice_conversion/vae_models.py -- train mode -- and the PPG
+ * pre-net modules/voice_conversion/pe.py:23-41 -- eval mode, followed by `* nonpadding`).
+ * training != 0: the batch is `groups` equal slices along dim 0, each normalised with its own biased batch statistics (what
+ *   `groups` separate calls of the module compute); running_mean / running_var (NULL: not tracked) receive the groups' momentum
+ *   updates in order (unbiased variance), *num_batches (NULL: none) += groups; save [2][groups][C] receives mean and rstd for
+ *   the backward.  mask must be NULL.
+ * training == 0: y = (x - running_mean) rsqrt(running_var + eps) gamma + beta, times mask[b,t] when mask != NULL; groups == 1.
+ * gamma / beta NULL: affine=False.                                                                                             */
+int svb_batchnorm_nct_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          long long* num_batches, const float* mask, float* y, float* save, int B, int C, int T, int groups,
+                          int training, float momentum, float eps, void* stream);
+/* Backward of the train-mode form: dx (NULL: skip), dgamma / dbeta [C] (written, summed over the groups; NULL: skip).           */
+int svb_batchnorm_nct_bwd(const float* dy, const float* x, const float* gamma, const float* save, float* dx, float* dgamma,
+                          float* dbeta, int B, int C, int T, int groups, void* stream);
 
 #ifdef __cplusplus
 }

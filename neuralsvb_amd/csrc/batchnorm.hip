@@ -1,0 +1,164 @@
+// batchnorm.hip -- nn.BatchNorm1d on [B,C,T] tensors of the hot path, replacing the MIOpen batch-norm kernels torch dispatches to.
+//
+// Where the reference runs it: the latent-pooling stack of the global VAE encoder (modules/voice_conversion/vae_models.py
+// `poolings`: Conv1d s2 -> ReLU -> BatchNorm1d, twice; train mode) and the PPG extractor's mel pre-net (modules/voice_conversion/
+// pe.py:23-41: Conv1d -> ReLU -> BatchNorm1d, `* nonpadding`; frozen, eval mode).
+//
+// Train mode, `groups` > 1: the batch holds `groups` independent forward calls of the reference stacked along dim 0 (the a2a
+// and p2p ways of a train step run as one wide launch sequence, modules/fs2_vae.py); each group is normalised with its own
+// batch statistics and the running statistics are updated group after group, in order -- exactly what the separate calls do.
+// One workgroup per channel walks the groups in sequence (so the running-stat updates of a channel are ordered without atomics);
+// the tensors are small (32 channels x 16 clips x ~140 frames): the point is ONE launch where torch issued chunk + 2 x
+// (batch_norm + num_batches_tracked += 1) + cat, and as many again in backward.
+// Eval mode: y = (x - running_mean) * rsqrt(running_var + eps) * gamma + beta [* mask[b,t]], one row (b,c) per workgroup,
+// HBM-bound (8 B / element).
+#include "svb_common.h"
+
+#define SVB_BN_THREADS 256
+
+struct SvbBnArgs {
+    const float* x;
+    const float* gamma;        // may be NULL (affine=False)
+    const float* beta;
+    float* running_mean;       // may be NULL (track_running_stats=False): batch statistics, nothing to update
+    float* running_var;
+    long long* num_batches;    // may be NULL; += groups
+    const float* mask;         // eval only: [B,T] or NULL
+    float* y;
+    float* save;               // train: [2][G][C] mean, rstd
+    int B, C, T, G;
+    float momentum, eps;
+};
+
+__global__ __launch_bounds__(SVB_BN_THREADS) void svb_bn_train_fwd_kernel(SvbBnArgs a) {
+    __shared__ float red[SVB_BN_THREADS / 64];
+    const int c = blockIdx.x, Bg = a.B / a.G;
+    const size_t n = (size_t)Bg * a.T;
+    const float ga = a.gamma ? a.gamma[c] : 1.f, be = a.beta ? a.beta[c] : 0.f;
+    float rm = a.running_mean ? a.running_mean[c] : 0.f, rv = a.running_var ? a.running_var[c] : 1.f;
+    for (int g = 0; g < a.G; ++g) {
+        const float* xg = a.x + ((size_t)g * Bg * a.C + c) * a.T;
+        float s = 0.f;
+        for (size_t i = threadIdx.x; i < n; i += SVB_BN_THREADS) {
+            const size_t b = i / a.T, t = i - b * a.T;
+            s += xg[b * (size_t)a.C * a.T + t];
+        }
+        const float mean = svb_block_sum<SVB_BN_THREADS>(s, red) / (float)n;
+        float q = 0.f;
+        for (size_t i = threadIdx.x; i < n; i += SVB_BN_THREADS) {
+            const size_t b = i / a.T, t = i - b * a.T;
+            const float d = xg[b * (size_t)a.C * a.T + t] - mean;
+            q += d * d;
+        }
+        const float var = svb_block_sum<SVB_BN_THREADS>(q, red) / (float)n;
+        const float rstd = rsqrtf(var + a.eps);
+        rm = (1.f - a.momentum) * rm + a.momentum * mean;
+        rv = (1.f - a.momentum) * rv + a.momentum * (n > 1 ? var * ((float)n / (float)(n - 1)) : var);
+        if (threadIdx.x == 0) {
+            a.save[(size_t)g * a.C + c] = mean;
+            a.save[((size_t)a.G + g) * a.C + c] = rstd;
+        }
+        float* yg = a.y + ((size_t)g * Bg * a.C + c) * a.T;
+        const float sc = rstd * ga;
+        for (size_t i = threadIdx.x; i < n; i += SVB_BN_THREADS) {
+            const size_t b = i / a.T, t = i - b * a.T, o = b * (size_t)a.C * a.T + t;
+            yg[o] = (xg[o] - mean) * sc + be;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (a.running_mean) { a.running_mean[c] = rm; a.running_var[c] = rv; }
+        if (a.num_batches && c == 0) a.num_batches[0] += a.G;
+    }
+}
+
+struct SvbBnBwdArgs {
+    const float* dy;
+    const float* x;
+    const float* gamma;
+    const float* save;         // [2][G][C]
+    float* dx;
+    float* dgamma;             // [C] (written; NULL: not wanted)
+    float* dbeta;
+    int B, C, T, G;
+};
+
+__global__ __launch_bounds__(SVB_BN_THREADS) void svb_bn_train_bwd_kernel(SvbBnBwdArgs a) {
+    __shared__ float red[SVB_BN_THREADS / 64];
+    const int c = blockIdx.x, Bg = a.B / a.G;
+    const size_t n = (size_t)Bg * a.T;
+    const float ga = a.gamma ? a.gamma[c] : 1.f;
+    float dg = 0.f, db = 0.f;
+    for (int g = 0; g < a.G; ++g) {
+        const size_t base = ((size_t)g * Bg * a.C + c) * a.T;
+        const float mean = a.save[(size_t)g * a.C + c], rstd = a.save[((size_t)a.G + g) * a.C + c];
+        float s1 = 0.f, s2 = 0.f;
+        for (size_t i = threadIdx.x; i < n; i += SVB_BN_THREADS) {
+            const size_t b = i / a.T, t = i - b * a.T, o = base + b * (size_t)a.C * a.T + t;
+            const float d = a.dy[o];
+            s1 += d;
+            s2 += d * (a.x[o] - mean) * rstd;
+        }
+        s1 = svb_block_sum<SVB_BN_THREADS>(s1, red);
+        s2 = svb_block_sum<SVB_BN_THREADS>(s2, red);
+        dg += s2;
+        db += s1;
+        const float m1 = s1 / (float)n, m2 = s2 / (float)n, sc = ga * rstd;
+        if (a.dx)
+            for (size_t i = threadIdx.x; i < n; i += SVB_BN_THREADS) {
+                const size_t b = i / a.T, t = i - b * a.T, o = base + b * (size_t)a.C * a.T + t;
+                a.dx[o] = sc * (a.dy[o] - m1 - (a.x[o] - mean) * rstd * m2);
+            }
+    }
+    if (threadIdx.x == 0) {
+        if (a.dgamma) a.dgamma[c] = dg;
+        if (a.dbeta) a.dbeta[c] = db;
+    }
+}
+
+__global__ __launch_bounds__(SVB_BN_THREADS) void svb_bn_eval_kernel(SvbBnArgs a) {
+    const size_t row = blockIdx.x;                       // (b, c)
+    const int c = (int)(row % a.C);
+    const size_t b = row / a.C;
+    const float sc = rsqrtf(a.running_var[c] + a.eps) * (a.gamma ? a.gamma[c] : 1.f);
+    const float sh = (a.beta ? a.beta[c] : 0.f) - a.running_mean[c] * sc;
+    const float* xr = a.x + row * a.T;
+    float* yr = a.y + row * a.T;
+    const float* mr = a.mask ? a.mask + b * a.T : nullptr;
+    for (int t = threadIdx.x; t < a.T; t += SVB_BN_THREADS) {
+        float v = xr[t] * sc + sh;
+        if (mr) v *= mr[t];
+        yr[t] = v;
+    }
+}
+
+extern "C" int svb_batchnorm_nct_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+                                     float* running_var, long long* num_batches, const float* mask, float* y, float* save,
+                                     int B, int C, int T, int groups, int training, float momentum, float eps, void* stream) {
+    if (B <= 0 || C <= 0 || T <= 0 || groups < 1 || B % groups) return SVB_ERR_ARG;
+    if ((beta != nullptr) != (gamma != nullptr) || (running_mean != nullptr) != (running_var != nullptr)) return SVB_ERR_ARG;
+    SvbBnArgs a;
+    a.x = x; a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
+    a.num_batches = num_batches; a.mask = mask; a.y = y; a.save = save;
+    a.B = B; a.C = C; a.T = T; a.G = groups; a.momentum = momentum; a.eps = eps;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (training) {
+        if (!save || mask) return SVB_ERR_ARG;
+        hipLaunchKernelGGL(svb_bn_train_fwd_kernel, dim3(C), dim3(SVB_BN_THREADS), 0, st, a);
+    } else {
+        if (!running_mean || groups != 1 || (size_t)B * C >= (1ull << 31)) return SVB_ERR_ARG;
+        hipLaunchKernelGGL(svb_bn_eval_kernel, dim3((unsigned)((size_t)B * C)), dim3(SVB_BN_THREADS), 0, st, a);
+    }
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_batchnorm_nct_bwd(const float* dy, const float* x, const float* gamma, const float* save, float* dx,
+                                     float* dgamma, float* dbeta, int B, int C, int T, int groups, void* stream) {
+    if (B <= 0 || C <= 0 || T <= 0 || groups < 1 || B % groups || !save) return SVB_ERR_ARG;
+    SvbBnBwdArgs a;
+    a.dy = dy; a.x = x; a.gamma = gamma; a.save = save; a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.B = B; a.C = C; a.T = T; a.G = groups;
+    hipLaunchKernelGGL(svb_bn_train_bwd_kernel, dim3(C), dim3(SVB_BN_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}

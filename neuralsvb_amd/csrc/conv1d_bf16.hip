@@ -932,6 +932,7 @@ struct SvbWgradQArgs {
                         // contiguous), so that a 64x64 tile holds gp diagonal blocks of gp_ca x gp_cb REAL per-group channels instead
                         // of one (MSD's grouped k41 convs: 16 x 8 channels per group); only those blocks are stored.  0 = off.
     int pa, pb;   // LDS row pitches in dwords (2 * odd)
+    int xcd_map;  // 1: XCD-aware work ids (the product's constant; the instrumentation build can switch it off for an A/B)
     // tap groups.  Stride 1: group i = taps [i*TGW, ...), Bt position of tile index t: q0 + off0 + j0*dil + t.
     // Stride s > 1 (dil 1): taps are grouped by phase r = (j - pad) mod s; within a phase the strided gather
     // q*s + j - pad = (q + o_j)*s + r is a stride-1 walk over the phase-r subsequence of Bt, so a group is a stride-1
@@ -960,7 +961,15 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
     const int wm = wave & 1, wn = wave >> 1;
     const int kb = lane >> 5, l31 = lane & 31;
 
-    int idx = blockIdx.x;
+    // XCD-aware bijective remap (round 4; block id b runs on XCD b % 8): consecutive work ids stay on one XCD, and the work id
+    // walks the tiles of ONE split first -- the (a_tiles x b_tiles x tap groups) workgroups that read the same position chunks
+    // in the same order share that XCD's L2 instead of each fetching its A / Bt rows through the fabric (with the identity map
+    // tile t of every split ran on XCD t % 8: 16 tiles of a 256 x 256 gradient = every chunk fetched by 8 L2s, 4-16 times).
+    const int orig = blockIdx.x + gridDim.x * blockIdx.y, nwg = gridDim.x * gridDim.y;
+    const int qd = nwg >> 3, rd = nwg & 7, xcd = orig & 7;
+    const int wgid = a.xcd_map ? (xcd < rd ? xcd * (qd + 1) : rd * (qd + 1) + (xcd - rd) * qd) + (orig >> 3) : orig;
+    const int vsplit = wgid / (int)gridDim.x;
+    int idx = wgid - vsplit * (int)gridDim.x;
     const int tgi = idx % a.n_tg; idx /= a.n_tg;
     const int bt = idx % a.b_tiles; idx /= a.b_tiles;
     const int at = idx % a.a_tiles;
@@ -1190,7 +1199,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
         }
     };
 
-    int chunk = blockIdx.y;
+    int chunk = vsplit;
     if (chunk < a.total_chunks) {
         load_tiles(chunk);
         store_tiles();
@@ -1209,7 +1218,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
     }
 
     const int cb_real = a.gp_cb ? a.gp_cb : a.CB_g;         // row pitch of the gradient: REAL input channels per group
-    float* part = a.part + (size_t)blockIdx.y * a.CA * cb_real * a.k;
+    float* part = a.part + (size_t)vsplit * a.CA * cb_real * a.k;
 #pragma unroll
     for (int ia = 0; ia < AT; ++ia)
 #pragma unroll
@@ -1237,7 +1246,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
 #pragma unroll
             for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
             const int r = srow + 8 * rr;
-            if (spair == 0 && (a0 + r) < a.CA_g) a.bias_part[(size_t)blockIdx.y * a.CA + g * a.CA_g + a0 + r] = v;
+            if (spair == 0 && (a0 + r) < a.CA_g) a.bias_part[(size_t)vsplit * a.CA + g * a.CA_g + a0 + r] = v;
         }
     }
 }
@@ -1530,6 +1539,7 @@ static const long g_svbq_wg_small_blocks = SVB_ENV_LONG("SVB_WG_SMALL_BLOCKS", 2
 static const long g_svbq_wg_blocks = SVB_ENV_LONG("SVB_WG_BLOCKS", 512);   // split-K target: workgroups per launch
 // Group packing factor (see SvbWgradQArgs::gp_ca): the largest power of two m dividing `groups` with m*CA_g <= 64 and m*CB_g <= 64.
 static const bool g_svbq_wg_nopack = SVB_ENV_FLAG("SVB_WG_NO_GROUP_PACK");      // A/B switch
+static const bool g_svbq_wg_no_xcd = SVB_ENV_FLAG("SVB_WG_NO_XCD");             // A/B switch: identity block -> work map
 static int wgq_pack(int groups, int CA_g, int CB_g) {
     int m = 1;
     if (g_svbq_wg_nopack) return 1;
@@ -1661,6 +1671,7 @@ extern "C" int svb_conv1d_wgrad_bf16x3(const float* a_t, const float* b_t, float
     a.chunks_per_b = svb_cdiv(TA, SVBQ_WG_QC); a.total_chunks = B * a.chunks_per_b;
     if (nsplit > a.total_chunks) return SVB_ERR_ARG;
     a.nsplit = nsplit;
+    a.xcd_map = g_svbq_wg_no_xcd ? 0 : 1;
     a.pa = 34;
     a.pb = 32 + ((tgw - 1) * dil + 1) / 2 + 6;
     a.pb += a.pb & 1;

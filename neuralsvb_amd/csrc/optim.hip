@@ -107,3 +107,46 @@ extern "C" int svb_adamw_flat(float* p, const float* g, float* m, float* v, size
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
+
+// ---- gradients autograd handed over as tensors of their own -> their slices of the flat gradient buffer --------------------------
+// A parameter whose gradient only ever arrives through torch's autograd (norm affines, biases of torch ops, embeddings ...) has
+// `.grad = None` between steps, so AccumulateGrad adopts the incoming tensor instead of launching `grad += new` into a zeroed
+// view (one small launch per parameter, ~30 per train step).  Before the flat AdamW step those tensors are copied into the flat
+// buffer by ONE launch: up to SVB_GATHER_BATCH segments per launch, pointers by value in the kernel arguments.
+#define SVB_GATHER_BATCH 48
+struct SvbGatherBatch {
+    const float* src[SVB_GATHER_BATCH];
+    size_t off[SVB_GATHER_BATCH];
+    size_t n[SVB_GATHER_BATCH];
+};
+
+__global__ __launch_bounds__(SVB_OPT_THREADS) void svb_gather_segments_kernel(SvbGatherBatch bt, float* dst) {
+    const int s = blockIdx.y;
+    const float* src = bt.src[s];
+    float* d = dst + bt.off[s];
+    const size_t n = bt.n[s];
+    for (size_t i = (size_t)blockIdx.x * SVB_OPT_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * SVB_OPT_THREADS) d[i] = src[i];
+}
+
+extern "C" int svb_gather_segments(const void* const* src, const size_t* dst_off, const size_t* n, int count, float* dst, void* stream) {
+    if (count < 0 || (count && (!src || !dst_off || !n || !dst))) return SVB_ERR_ARG;
+    for (int s0 = 0; s0 < count; s0 += SVB_GATHER_BATCH) {
+        const int c = count - s0 < SVB_GATHER_BATCH ? count - s0 : SVB_GATHER_BATCH;
+        SvbGatherBatch bt;
+        size_t nmax = 0;
+        for (int s = 0; s < c; ++s) {
+            if (!src[s0 + s] && n[s0 + s]) return SVB_ERR_ARG;
+            bt.src[s] = static_cast<const float*>(src[s0 + s]);
+            bt.off[s] = dst_off[s0 + s];
+            bt.n[s] = n[s0 + s];
+            if (bt.n[s] > nmax) nmax = bt.n[s];
+        }
+        for (int s = c; s < SVB_GATHER_BATCH; ++s) { bt.src[s] = nullptr; bt.off[s] = 0; bt.n[s] = 0; }
+        size_t bx = (nmax + 4 * SVB_OPT_THREADS - 1) / (4 * SVB_OPT_THREADS);
+        if (bx < 1) bx = 1;
+        if (bx > 256) bx = 256;
+        hipLaunchKernelGGL(svb_gather_segments_kernel, dim3((unsigned)bx, (unsigned)c), dim3(SVB_OPT_THREADS), 0, (hipStream_t)stream, bt, dst);
+        SVB_CHECK_LAUNCH();
+    }
+    return SVB_OK;
+}

@@ -795,6 +795,46 @@ class _GNReluFn(torch.autograd.Function):
         return dh, (gy if ctx.has_res else None), dg, db, None, None
 
 
+class _BatchNormNCTFn(torch.autograd.Function):
+    """Train-mode nn.BatchNorm1d on [B,C,T] per batch group (kernels.batchnorm_nct_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches, momentum, eps, groups):
+        x = x.contiguous()
+        y, save = K.batchnorm_nct_fwd(x, _c(gamma), _c(beta), running_mean, running_var, num_batches, momentum, eps, groups, True)
+        ctx.groups = groups
+        ctx.save_for_backward(x, gamma, save)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, save = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dx, dg, db = K.batchnorm_nct_bwd(dy.contiguous(), x, _c(gamma), save, ctx.groups, need[0], gamma is not None and (need[1] or need[2]))
+        return dx, dg, db, None, None, None, None, None, None
+
+
+def batch_norm_nct(bn, x, groups=1, mask=None):
+    """`bn(x)` for an nn.BatchNorm1d module on x [B,C,T] as one kernel.  Train mode with groups > 1: the batch is `groups`
+    stacked calls of the reference, normalised -- and counted into the running statistics -- one after the other (the
+    reference's vae_models.py `poolings`, see modules/fs2_vae.py).  Eval mode: running statistics, optionally `* mask[b,t]`
+    (the PPG pre-net's `bn(x) * nonpadding`, reference pe.py:36-40)."""
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm with momentum=None (cumulative average)")
+    train = bn.training or bn.running_mean is None
+    if train:
+        if mask is not None:
+            raise NotImplementedError("train-mode BatchNorm with an output mask")
+        return _BatchNormNCTFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                     bn.num_batches_tracked if bn.running_mean is not None else None,
+                                     float(bn.momentum), float(bn.eps), int(groups))
+    if torch.is_grad_enabled() and (x.requires_grad or (bn.weight is not None and bn.weight.requires_grad)):
+        raise NotImplementedError("eval-mode BatchNorm is forward-only here (frozen extractor)")
+    y, _ = K.batchnorm_nct_fwd(x.contiguous(), _c(bn.weight), _c(bn.bias), bn.running_mean, bn.running_var, None, 0.0,
+                               float(bn.eps), 1, False, None if mask is None else mask.contiguous())
+    return y
+
+
 def group_norm_relu(h, gamma, beta, num_groups, eps=1e-5, residual=None):
     """residual + relu(GroupNorm(h)) on [B,C,T] (reference common_layers.py:739-773 inside ConvStacks :688-707)."""
     return _GNReluFn.apply(h, residual, gamma, beta, int(num_groups), float(eps))
@@ -1141,10 +1181,47 @@ def embedding_nct(idx, weight, padding_idx=None):
     return _EmbedNCTFn.apply(idx, weight, padding_idx)
 
 
+_KEEP_POOL = None        # [flat factors, cursor, p] while a dropout2d_pool is open
+
+
 def dropout2d_keep(n, c, p, device):
     """Dropout2d's per-(clip, channel) factor: 0 with probability p, else 1/(1-p) (F.dropout2d draws the same Bernoulli
-    field, shape [N,C,1,1]).  One function so that a test can replay recorded masks."""
+    field, shape [N,C,1,1]).  One function so that a test can replay recorded masks.  Inside a `dropout2d_pool` the factors
+    are the next n*c of the pool's single draw."""
+    pool = _KEEP_POOL
+    if pool is not None and pool[2] == p and pool[1] + n * c <= pool[0].numel() and pool[0].device == torch.device(device):
+        k = pool[0][pool[1]:pool[1] + n * c].view(n, c)
+        pool[1] += (n * c + 3) // 4 * 4
+        return k
     return torch.empty((n, c), device=device, dtype=torch.float32).bernoulli_(1.0 - p).div_(1.0 - p)
+
+
+_dropout2d_keep_draw = dropout2d_keep
+
+
+class dropout2d_pool:
+    """All Dropout2d factors of a stacked critic call as ONE Bernoulli draw (two launches) instead of two launches per block
+    (36 per train step): `shapes` lists the (n, c) fields the blocks inside the `with` body will ask for, in order.  The
+    fields are i.i.d. Bernoulli either way; a test that replays recorded masks replaces `dropout2d_keep`, and then no pool
+    is opened (no draw is consumed)."""
+
+    def __init__(self, shapes, p, device):
+        self.total = sum((n * c + 3) // 4 * 4 for n, c in shapes) if p else 0
+        self.p, self.device = p, device
+
+    def __enter__(self):
+        global _KEEP_POOL
+        self.opened = self.total > 0 and _KEEP_POOL is None and dropout2d_keep is _dropout2d_keep_draw
+        if self.opened:
+            flat = torch.empty((self.total,), device=self.device, dtype=torch.float32).bernoulli_(1.0 - self.p).div_(1.0 - self.p)
+            _KEEP_POOL = [flat, 0, self.p]
+        return self
+
+    def __exit__(self, *exc):
+        global _KEEP_POOL
+        if self.opened:
+            _KEEP_POOL = None
+        return False
 
 
 def critic_block(x, weight, bias, lrelu_slope, drop_p, gamma, beta, eps=1e-5, planes=None, s2d_out=False):

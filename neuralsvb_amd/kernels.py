@@ -813,6 +813,46 @@ def layernorm_nct_fwd(x, gamma, beta, eps=1e-5):
     return y
 
 
+def batchnorm_nct_fwd(x, gamma, beta, running_mean, running_var, num_batches, momentum, eps, groups=1, training=True, mask=None):
+    """nn.BatchNorm1d on [B,C,T] (csrc/batchnorm.hip): train mode per batch group (running statistics and the batch counter
+    updated in place, in group order) -> (y, save [2,groups,C]); eval mode (optionally `* mask[b,t]`) -> (y, None)."""
+    _f32(x)
+    lib, st = _prep(x)
+    B, c, t = x.shape
+    y = torch.empty_like(x)
+    save = torch.empty((2, groups, c), device=x.device, dtype=torch.float32) if training else None
+    if num_batches is not None and num_batches.dtype != torch.int64:
+        raise TypeError("num_batches_tracked must be int64")
+    L.check(lib.svb_batchnorm_nct_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                      _ptr(num_batches) if training else None, _ptr(mask), _ptr(y), _ptr(save), B, c, t, int(groups),
+                                      1 if training else 0, float(momentum), float(eps), st), "svb_batchnorm_nct_fwd")
+    return y, save
+
+
+def batchnorm_nct_bwd(dy, x, gamma, save, groups, need_dx=True, need_affine=True):
+    _f32(dy, x, save)
+    lib, st = _prep(dy, x, save)
+    B, c, t = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    dgb = torch.empty((2, c), device=x.device, dtype=torch.float32) if need_affine else None
+    L.check(lib.svb_batchnorm_nct_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(save), _ptr(dx), _ptr(dgb[0]) if need_affine else None,
+                                      _ptr(dgb[1]) if need_affine else None, B, c, t, int(groups), st), "svb_batchnorm_nct_bwd")
+    return dx, (dgb[0] if need_affine else None), (dgb[1] if need_affine else None)
+
+
+def gather_segments(srcs, offsets, dst):
+    """srcs: contiguous fp32 tensors; dst[offsets[i] : offsets[i] + srcs[i].numel()] = srcs[i], one launch per 48 tensors."""
+    if not srcs:
+        return
+    import ctypes as C
+    n = len(srcs)
+    lib, st = _prep(dst)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    offs = (C.c_size_t * n)(*[int(o) for o in offsets])
+    cnts = (C.c_size_t * n)(*[t.numel() for t in srcs])
+    L.check(lib.svb_gather_segments(ptrs, offs, cnts, n, _ptr(dst), st), "svb_gather_segments")
+
+
 def layernorm_bwd(x, gamma, dy, mean, rstd, n_part=128):
     _f32(x, gamma, dy, mean, rstd)
     lib, st = _prep(x, gamma, dy, mean, rstd)

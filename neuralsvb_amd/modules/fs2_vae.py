@@ -108,9 +108,7 @@ class GlobalFVAEEncoder(nn.Module):
 
 def bn_groups(bn, x, groups):
     """BatchNorm over each of `groups` equal batch slices separately (see GlobalFVAEEncoder.forward)."""
-    if groups == 1:
-        return bn(x)
-    return torch.cat([bn(c) for c in x.chunk(groups, 0)], 0)
+    return SF.batch_norm_nct(bn, x, groups)
 
 
 def conv_len(t, s):

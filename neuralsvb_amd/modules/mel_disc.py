@@ -174,6 +174,21 @@ class Discriminator(nn.Module):
                         for b in t.model)):
             fused = SF.window_crop_s2d([x[:, 0] for x in xs], self.time_lengths,
                                        [[c[1][w][0] for c in calls] for w in range(len(self.time_lengths))])
+        with SF.dropout2d_pool(*self._keep_fields(len(xs) * B), xs[0].device):
+            return self._forward_many_towers(calls, xs, B, fused, want_fmaps)
+
+    def _keep_fields(self, n):
+        """(shapes, p) of the Dropout2d fields a stacked pass over all towers draws, in order (one p for all blocks, else none)."""
+        shapes, ps = [], set()
+        for tower in self.discriminator.conv_layers:
+            for blk in tower.model:
+                if blk[2].training and blk[2].p:
+                    shapes.append((n, blk[0].out_channels))
+                    ps.add(blk[2].p)
+        return (shapes, ps.pop()) if len(ps) == 1 else ([], 0.0)
+
+    def _forward_many_towers(self, calls, xs, B, fused, want_fmaps):
+        scores, fmaps = [], []
         for w, (tower, wl) in enumerate(zip(self.discriminator.conv_layers, self.time_lengths)):
             if fused is not None:
                 x4, planes = fused[w]

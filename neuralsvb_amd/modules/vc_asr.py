@@ -42,7 +42,7 @@ class Prenet(nn.Module):
         for i, l in enumerate(self.layers):
             nonpad = nonpad[:, ::self.strides[i]]
             x = l[0](x, out_act=SF.ACT_RELU)
-            x = l[2](x) * nonpad[:, None, :]
+            x = SF.batch_norm_nct(l[2], x, mask=nonpad)           # bn(x) * nonpadding, one kernel
         nonpad = nonpad.contiguous()
         return self.out_proj(x, mask=nonpad), nonpad
 

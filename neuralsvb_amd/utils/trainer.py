@@ -112,8 +112,10 @@ class FlatGradSync:
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
         self.overlap = bool(overlap) and world_size > 1
         self.buckets, self._bucket_of = [], {}
+        self._offsets = []               # element offset of every parameter's slice
         off = start = 0
         for p in self.params:
+            self._offsets.append(off)
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             self._bucket_of[p.grad.data_ptr()] = len(self.buckets)
             off += (p.numel() + 3) // 4 * 4
@@ -140,6 +142,25 @@ class FlatGradSync:
             for p in self.params:
                 if not getattr(p, "_svb_sink", False):
                     p.grad = None
+
+    def gather_adopted(self):
+        """Before an update that reads the FLAT buffer (utils/flat_optim.py): gradients autograd handed over as tensors of
+        their own (`drop_autograd_grads`) are copied into their slices, all of them by one launch."""
+        if not self.drop_autograd_grads:
+            return
+        srcs, offs = [], []
+        base, esz = self.flat.data_ptr(), self.flat.element_size()
+        for p, off in zip(self.params, self._offsets):
+            g = p.grad
+            if g is None or g.data_ptr() == base + off * esz:
+                continue
+            if g.dtype != torch.float32 or g.numel() != p.numel():
+                raise RuntimeError("an adopted gradient does not match its parameter's slice of the flat buffer")
+            srcs.append(g if g.is_contiguous() else g.contiguous())
+            offs.append(off)
+        if srcs:
+            from .. import kernels as _K
+            _K.gather_segments(srcs, offs, self.flat)
 
     def pin_views(self):
         """Back to one fixed gradient buffer per parameter (hipGraph capture needs stable addresses)."""
@@ -378,8 +399,7 @@ class Trainer:
             self.grad_sync = [FlatGradSync([p for g in o.param_groups for p in g["params"]], self.world_size,
                                            bucket_bytes=int(hparams.get("ddp_bucket_mb", 8) * (1 << 20)),
                                            overlap=hparams.get("ddp_overlap", True),
-                                           drop_autograd_grads=(not self.hip_graph and hparams.get("drop_autograd_grads", True)
-                                                                and not hparams.get("flat_adamw", True)))
+                                           drop_autograd_grads=(not self.hip_graph and hparams.get("drop_autograd_grads", True)))
                               if o is not None else None for o in self.optimizers]
         if checkpoint is not None:
             self.restore_opt_state(checkpoint)
@@ -838,6 +858,7 @@ class Trainer:
             task.on_before_optimization(opt_idx)
             flat = self.flat_optim[opt_idx] if opt_idx < len(self.flat_optim) else None
             if flat is not None:
+                sync.gather_adopted()
                 flat.step()
             else:
                 optimizer.step()

@@ -327,6 +327,39 @@ def test_dropout2d_keep_is_a_bernoulli_field(dev):
     assert abs(float((k > 0).float().mean()) - 0.75) < 0.03
 
 
+def test_dropout2d_pool_serves_the_fields_of_one_draw(dev):
+    """SF.dropout2d_pool: the Dropout2d fields of a stacked critic pass come out of ONE Bernoulli draw, in order, disjoint;
+    a field the pool cannot serve (other p, pool exhausted) is drawn on its own; a replaced dropout2d_keep (mask replay in the
+    golden-step tests) opens no pool and consumes no draw."""
+    shapes = [(6, 32), (6, 31), (6, 64)]
+    with SF.dropout2d_pool(shapes, 0.25, dev) as pool:
+        assert pool.opened
+        flat = SF._KEEP_POOL[0]
+        ks = [SF.dropout2d_keep(n, c, 0.25, dev) for n, c in shapes]
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        spans = [(k.data_ptr(), k.data_ptr() + k.numel() * 4) for k in ks]
+        assert all(lo <= a and b <= hi and a % 16 == lo % 16 for a, b in spans)
+        assert all(spans[i][1] <= spans[i + 1][0] for i in range(2))
+        other = SF.dropout2d_keep(6, 8, 0.5, dev)                      # another p: its own draw
+        extra = SF.dropout2d_keep(6, 64, 0.25, dev)                    # beyond the reserved fields: its own draw
+        assert not (lo <= other.data_ptr() < hi) and not (lo <= extra.data_ptr() < hi)
+    assert SF._KEEP_POOL is None
+    for k, (n, c) in zip(ks, shapes):
+        vals = sorted(torch.unique(k).tolist())
+        assert k.shape == (n, c) and k.is_contiguous() and vals[0] == 0.0 and abs(vals[-1] - 1.0 / 0.75) < 1e-6
+    allk = torch.cat([k.flatten() for k in ks])
+    assert abs(float((allk > 0).float().mean()) - 0.75) < 0.05
+    old = SF.dropout2d_keep
+    SF.dropout2d_keep = lambda n, c, pp, device: torch.ones(n, c, device=device)
+    try:
+        with SF.dropout2d_pool(shapes, 0.25, dev) as pool:
+            assert not pool.opened and SF._KEEP_POOL is None
+    finally:
+        SF.dropout2d_keep = old
+    with SF.dropout2d_pool([], 0.0, dev) as pool:
+        assert not pool.opened
+
+
 def test_plane_score_autograd(dev):
     """adv_layer (nn.Linear(C*H*W, 1), multi_window_disc.py:62-64) on channel-major feature maps."""
     g_ = torch.Generator().manual_seed(45)

@@ -790,3 +790,79 @@ def _join(dev):
         if K.WGRAD_STREAM is not None:
             torch.cuda.current_stream().wait_stream(K.WGRAD_STREAM)
         torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+@pytest.mark.parametrize("affine", [True, False])
+def test_batchnorm_nct_train_groups(dev, groups, affine):
+    """csrc/batchnorm.hip, train mode: each batch group normalised with its own statistics, running statistics and the batch
+    counter updated group after group -- against nn.BatchNorm1d called once per group (what the reference does: the a2a / p2p
+    ways are separate forward calls); forward, running buffers, dx, dgamma, dbeta.  fp32 kernel vs torch fp32: 2e-5."""
+    from neuralsvb_amd import functional as SF
+    g_ = torch.Generator().manual_seed(31 + groups)
+    B, C, T = 6, 40, 37
+    x = torch.randn(B, C, T, generator=g_) * 1.7 + 0.4
+    dy = torch.randn(B, C, T, generator=g_)
+    ref_bn = torch.nn.BatchNorm1d(C, affine=affine, momentum=0.1)
+    if affine:
+        with torch.no_grad():
+            ref_bn.weight.copy_(torch.randn(C, generator=g_))
+            ref_bn.bias.copy_(torch.randn(C, generator=g_))
+    ref_bn.running_mean.copy_(torch.randn(C, generator=g_))
+    ref_bn.running_var.copy_(torch.rand(C, generator=g_) + 0.5)
+    import copy
+    bn = copy.deepcopy(ref_bn).to(dev)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.cat([ref_bn(c) for c in xr.chunk(groups, 0)], 0)
+    ref.backward(dy)
+    xd = x.to(dev).requires_grad_(True)
+    y = SF.batch_norm_nct(bn, xd, groups)
+    y.backward(dy.to(dev))
+    assert (y.detach().cpu() - ref.detach()).abs().max() < 2e-5
+    assert (xd.grad.cpu() - xr.grad).abs().max() < 2e-5
+    assert (bn.running_mean.cpu() - ref_bn.running_mean).abs().max() < 1e-6
+    assert (bn.running_var.cpu() - ref_bn.running_var).abs().max() < 2e-6
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == groups
+    if affine:
+        assert rel_err(bn.weight.grad, ref_bn.weight.grad) < 2e-5
+        assert rel_err(bn.bias.grad, ref_bn.bias.grad) < 2e-5
+
+
+def test_batchnorm_nct_eval_mask(dev):
+    """Eval mode: running statistics, output times the [B,T] mask (the PPG pre-net's `bn(x) * nonpadding`, pe.py:36-40)."""
+    from neuralsvb_amd import functional as SF
+    g_ = torch.Generator().manual_seed(5)
+    B, C, T = 3, 24, 301
+    x = torch.randn(B, C, T, generator=g_)
+    mask = (torch.rand(B, T, generator=g_) > 0.3).float()
+    bn = torch.nn.BatchNorm1d(C).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C, generator=g_))
+        bn.bias.copy_(torch.randn(C, generator=g_))
+        bn.running_mean.copy_(torch.randn(C, generator=g_))
+        bn.running_var.copy_(torch.rand(C, generator=g_) + 0.5)
+        ref = bn(x) * mask[:, None, :]
+        ref0 = bn(x)
+        import copy
+        bd = copy.deepcopy(bn).to(dev)
+        assert (SF.batch_norm_nct(bd, x.to(dev), mask=mask.to(dev)).cpu() - ref).abs().max() < 2e-6
+        assert (SF.batch_norm_nct(bd, x.to(dev)).cpu() - ref0).abs().max() < 2e-6
+    assert int(bd.num_batches_tracked) == 0
+
+
+def test_gather_segments(dev):
+    """Adopted gradients -> their slices of the flat buffer, one launch for all (csrc/optim.hip); more segments than one
+    launch carries, an empty one, unaligned lengths; untouched gaps stay as they were."""
+    g_ = torch.Generator().manual_seed(2)
+    lens = [1, 7, 1000, 0, 33, 4099] + [5] * 60
+    srcs = [torch.randn(n, generator=g_).to(dev) for n in lens]
+    offs, off = [], 3
+    for n in lens:
+        offs.append(off)
+        off += n + 2
+    dst = torch.full((off + 5,), -7.0, device=dev)
+    K.gather_segments(srcs, offs, dst)
+    ref = torch.full((off + 5,), -7.0)
+    for s_, o in zip(srcs, offs):
+        ref[o:o + s_.numel()] = s_.cpu()
+    assert torch.equal(dst.cpu(), ref)

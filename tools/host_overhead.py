@@ -42,10 +42,49 @@ def null_library():
     return lib
 
 
+_NO_KERNEL = ("aten::empty", "aten::view", "aten::reshape", "aten::as_strided", "aten::transpose", "aten::permute", "aten::select",
+              "aten::slice", "aten::unsqueeze", "aten::squeeze", "aten::expand", "aten::detach", "aten::alias", "aten::t", "aten::_unsafe_view",
+              "aten::narrow", "aten::unbind", "aten::split", "aten::chunk", "aten::size", "aten::stride", "aten::is_", "aten::lift", "aten::to",
+              "aten::_to_copy", "aten::contiguous", "aten::result_type", "aten::item", "aten::_local_scalar", "aten::unflatten", "aten::flatten",
+              "aten::resize_", "aten::set_", "aten::view_as", "aten::expand_as", "aten::numpy_T", "aten::movedim", "aten::unfold", "aten::new_",
+              "aten::zeros_like", "aten::ones_like", "aten::empty_like", "aten::_reshape_alias", "aten::diagonal", "aten::broadcast_")
+
+
+def aten_ops(run, steps):
+    """torch ops that launch a kernel of their own on the GPU (views and allocations dropped), per step, with the innermost
+    repository frame that issued them (backward nodes of torch's own ops have none): the launches that are not the library's."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    by_site = {}
+
+    class Log(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            nm = "aten::" + func.__name__.split(".")[0] if not str(func).startswith("aten") else str(func)
+            nm = "aten::" + str(func).split(".")[1] if str(func).startswith("aten.") else nm
+            if not nm.startswith(_NO_KERNEL):
+                f = sys._getframe(1)
+                site = "(autograd engine: backward of a torch op)"
+                while f is not None:
+                    fn = f.f_code.co_filename
+                    if ("/neuralsvb_amd/" in fn or fn.endswith("/bench.py")) and "host_overhead" not in fn:
+                        site = f"{fn.split('/neuralsvb_amd/')[-1]}:{f.f_lineno} {f.f_code.co_name}"
+                        break
+                    f = f.f_back
+                by_site[(site, nm)] = by_site.get((site, nm), 0) + 1
+            return func(*args, **(kwargs or {}))
+
+    with Log():
+        run()
+    tot = sum(by_site.values()) / steps
+    print(f"torch ops with a kernel of their own: {tot:.1f} per step")
+    for (site, nm), n in sorted(by_site.items(), key=lambda kv: (-kv[1], kv[0])):
+        print(f"  {n / steps:6.1f}  {nm:34s} {site}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--aten", action="store_true", help="list the torch (ATen) ops a step issues next to the library's kernels, by call site")
     ap.add_argument("--extra-hparams", default="")
     ap.add_argument("--no-stack-executor", action="store_true")
     a = ap.parse_args()
@@ -79,6 +118,9 @@ def main():
         if hasattr(tk, "clip_grad_norm_"):
             tk.clip_grad_norm_ = lambda *a, **k: torch.zeros(())
         bench.run_steps(trainer, task, batch, 3, 1)
+        if a.aten:
+            aten_ops(lambda: bench.run_steps(trainer, task, batch, 2, 0), 2)
+            return
         t0 = time.perf_counter()
         if a.profile:
             pr = cProfile.Profile()

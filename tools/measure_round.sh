@@ -5,29 +5,31 @@
 # One-off A/B runs of step variants: tools/ab_bench.sh "<hparams overrides | bench flag>" ...   (both scripts are parameterised:
 # the 50 single-purpose scripts of round 3 are gone; git history has them)
 set -x
-R=${1:-r04}
-O=gpurun_out/${R}_final
+TAG=${1:-r04}
+O=gpurun_out/${TAG}_final
 mkdir -p $O
 export TMPDIR=/tmp
+export SVB_ROUND=$TAG
 R=$PWD
+# (PMC traffic first: the bench line's roofline.traffic reads profiles/<tag>_pmc_traffic.json of THIS commit's kernels)
+SVB_PMC_SHAPES=10 timeout 500 python tools/pmc_traffic.py > $O/pmc_traffic.log 2>&1
+cp profiles/${TAG}_pmc_traffic.json $O/ 2>/dev/null
 timeout 600 python bench.py > $O/bench_train_bf16x3.json 2> $O/bench_train_bf16x3.log
 SVB_BENCH_SHAPES=1 timeout 300 python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-extra-workloads > /dev/null 2> $O/conv_per_shape.log
-SVB_PMC_SHAPES=10 timeout 500 python tools/pmc_traffic.py > $O/pmc_traffic.log 2>&1
-cp profiles/${R}_pmc_traffic.json $O/ 2>/dev/null
 cd /tmp
 for v in default noside; do
   fl=""; [ $v = noside ] && fl="--no-side-stream --extra-hparams overlap_critic_pass=False,overlap_ppg_encoder=False"
   rm -rf /tmp/prof_$v
-  SVB_BENCH_MARKERS=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$v -o $R --output-format csv -- \
+  SVB_BENCH_MARKERS=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$v -o $TAG --output-format csv -- \
      python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-extra-workloads $fl \
      > $R/$O/bench_under_rocprof_$v.json 2> $R/$O/bench_under_rocprof_$v.err
-  python $R/tools/trace_summary.py /tmp/prof_$v/${R}_kernel_trace.csv 20 80 > $R/$O/kernel_summary_$v.txt
-  cp /tmp/prof_$v/${R}_kernel_stats.csv $R/$O/kernel_stats_$v.csv 2>/dev/null
+  python $R/tools/trace_summary.py /tmp/prof_$v/${TAG}_kernel_trace.csv 20 80 > $R/$O/kernel_summary_$v.txt
+  cp /tmp/prof_$v/${TAG}_kernel_stats.csv $R/$O/kernel_stats_$v.csv 2>/dev/null
 done
 rm -rf /tmp/prof_voc
-SVB_BENCH_MARKERS=1 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_voc -o $R --output-format csv -- \
+SVB_BENCH_MARKERS=1 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_voc -o $TAG --output-format csv -- \
    python $R/bench.py --workload vocoder --steps 4 --warmup 3 --no-cpu-baseline > $R/$O/bench_under_rocprof_vocoder.json 2> $R/$O/bench_under_rocprof_vocoder.err
-python $R/tools/trace_summary.py /tmp/prof_voc/${R}_kernel_trace.csv 4 60 > $R/$O/kernel_summary_vocoder.txt
+python $R/tools/trace_summary.py /tmp/prof_voc/${TAG}_kernel_trace.csv 4 60 > $R/$O/kernel_summary_vocoder.txt
 (cd $R && timeout 100 python tools/ewbench.py > $O/streaming_kernels.log 2>&1)
 C="SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 for shp in "32 192 384 1124 5" "32 192 384 281 5"; do
