@@ -599,6 +599,8 @@ def main():
                       "warmup": 6, "workload": "vae_global_mle_eng phase-3 step (latent-map optimizer: a2a + p2p + a2p forward, MLE + "
                                                "critic term, backward into the map), same batch"}
             log(f"phase 3: {ms3:.2f} ms/step")
+            task.train()        # (phase 3 puts the generator into eval mode for good, svb_vae_task.py:593-599; the measurements
+                                #  below are phase-2 steps again)
         # the data side of a step, rank 0 only: the same B clips from the binary dataset to a batch resident in HBM
         # -- host collater + one H2D copy per field (the reference's way) against slicing into pinned staging buffers + the
         # collate / norm_interp_f0 kernels (tasks/device_collate.py).  Not part of `value`.

@@ -814,6 +814,37 @@ class _BatchNormNCTFn(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, None, None
 
 
+class _BatchNormEvalFn(torch.autograd.Function):
+    """Eval-mode nn.BatchNorm1d on [B,C,T] under autograd (a module frozen with .eval() inside a pass that still trains its
+    input side, e.g. the phase-3 latent map in front of the frozen decoder): y = (x - rm) * rstd * gamma + beta [* mask].
+    dx = dy [* mask] * gamma * rstd is the same kernel with mean 0 / shift 0; dgamma / dbeta come from the train-mode backward
+    kernel fed with (rm, rstd) as its saved statistics (its dx is not requested)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, eps, mask):
+        x = x.contiguous()
+        mask = None if mask is None else mask.contiguous()
+        y, _ = K.batchnorm_nct_fwd(x, _c(gamma), _c(beta), rm, rv, None, 0.0, eps, 1, False, mask)
+        ctx.eps = eps
+        ctx.save_for_backward(x, gamma, rm, rv, mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, rm, rv, mask = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dy = dy.contiguous()
+        dx = dg = db = None
+        if need[0]:
+            dx, _ = K.batchnorm_nct_fwd(dy, _c(gamma), None if gamma is None else torch.zeros_like(gamma), torch.zeros_like(rm), rv,
+                                        None, 0.0, ctx.eps, 1, False, mask)
+        if gamma is not None and (need[1] or need[2]):
+            dym = dy if mask is None else dy * mask[:, None, :]
+            save = torch.stack([rm, torch.rsqrt(rv + ctx.eps)]).view(2, 1, -1).contiguous()
+            _, dg, db = K.batchnorm_nct_bwd(dym, x, _c(gamma), save, 1, need_dx=False)
+        return dx, dg, db, None, None, None, None
+
+
 def batch_norm_nct(bn, x, groups=1, mask=None):
     """`bn(x)` for an nn.BatchNorm1d module on x [B,C,T] as one kernel.  Train mode with groups > 1: the batch is `groups`
     stacked calls of the reference, normalised -- and counted into the running statistics -- one after the other (the
@@ -829,7 +860,7 @@ def batch_norm_nct(bn, x, groups=1, mask=None):
                                      bn.num_batches_tracked if bn.running_mean is not None else None,
                                      float(bn.momentum), float(bn.eps), int(groups))
     if torch.is_grad_enabled() and (x.requires_grad or (bn.weight is not None and bn.weight.requires_grad)):
-        raise NotImplementedError("eval-mode BatchNorm is forward-only here (frozen extractor)")
+        return _BatchNormEvalFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), mask)
     y, _ = K.batchnorm_nct_fwd(x.contiguous(), _c(bn.weight), _c(bn.bias), bn.running_mean, bn.running_var, None, 0.0,
                                float(bn.eps), 1, False, None if mask is None else mask.contiguous())
     return y

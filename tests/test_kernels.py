@@ -866,3 +866,34 @@ def test_gather_segments(dev):
     for s_, o in zip(srcs, offs):
         ref[o:o + s_.numel()] = s_.cpu()
     assert torch.equal(dst.cpu(), ref)
+
+
+def test_batchnorm_nct_eval_under_autograd(dev):
+    """A BatchNorm1d frozen with .eval() whose input (and affine) still take gradients: forward on the running statistics,
+    dx / dgamma / dbeta against torch, with and without the output mask."""
+    from neuralsvb_amd import functional as SF
+    import copy
+    g_ = torch.Generator().manual_seed(9)
+    B, C, T = 4, 20, 53
+    x = torch.randn(B, C, T, generator=g_)
+    dy = torch.randn(B, C, T, generator=g_)
+    mask = (torch.rand(B, T, generator=g_) > 0.3).float()
+    bn = torch.nn.BatchNorm1d(C).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C, generator=g_))
+        bn.bias.copy_(torch.randn(C, generator=g_))
+        bn.running_mean.copy_(torch.randn(C, generator=g_))
+        bn.running_var.copy_(torch.rand(C, generator=g_) + 0.5)
+    for m in (None, mask):
+        rb = copy.deepcopy(bn)
+        xr = x.detach().clone().requires_grad_(True)
+        ref = rb(xr) if m is None else rb(xr) * m[:, None, :]
+        ref.backward(dy)
+        bd = copy.deepcopy(bn).to(dev)
+        xd = x.detach().clone().to(dev).requires_grad_(True)
+        y = SF.batch_norm_nct(bd, xd, mask=None if m is None else m.to(dev))
+        y.backward(dy.to(dev))
+        assert (y.detach().cpu() - ref.detach()).abs().max() < 2e-6
+        assert (xd.grad.cpu() - xr.grad).abs().max() < 2e-6
+        assert rel_err(bd.weight.grad, rb.weight.grad) < 1e-5 and rel_err(bd.bias.grad, rb.bias.grad) < 1e-5
+        assert torch.equal(bd.running_mean.cpu(), bn.running_mean) and int(bd.num_batches_tracked) == 0
