@@ -347,12 +347,8 @@ def test_fused_step_paths_equal_elementwise_paths(dev, tmp_path, phase):
             through_critic = dev.type == "cuda" and not no_critic and oi in (0, 1)
             # (1e-3, not 5e-4: a GroupNorm output within an ulp of zero gates differently in the two forms -- the row-resident
             #  kernels of round 3 moved one element of pitch_embed.weight's gradient by 6.8e-4 of the largest one)
-            # Round 4: the emulator variant holds the passes across the critic to the same 1.5e-2.  With the train-mode
-            # BatchNorm kernel (csrc/batchnorm.hip) in the pooling stack the critic pass reads 5.8e-3 on ONE element (the bias
-            # gradient of the widest window's first conv; every other gradient of the pass <= 6e-5) where torch's batch_norm
-            # gave 4.9e-5: the kernel is bit-identical for a grouped call and separate calls, as accurate as torch's against
-            # float64 (1e-7) and exactly as sensitive to a 1e-7 input perturbation (4.9e-6) -- the 1e-7 difference it makes
-            # to the generated mels moves that window's InstanceNorm onto a near-constant plane.
-            crosses = not no_critic and oi in (0, 1)
-            tol = 1.5e-2 if through_critic or crosses else (2e-3 if oi == 2 else 1e-3)
+            # (round 4: the pooling stack's BatchNorm is csrc/batchnorm.hip, which accumulates in double like the reference's CPU
+            #  batch_norm; an fp32-accumulating draft of it moved ONE critic gradient of this test to 5.8e-3 -- with double sums the
+            #  worst element of the emulator run is 6.7e-5)
+            tol = 1.5e-2 if through_critic else (2e-3 if oi == 2 else 1e-3)
             assert err <= tol * max(r.abs().max().item(), 1e-3), (oi, n, err, r.abs().max().item())
