@@ -110,6 +110,7 @@ def _c(t):
 CAPTURING = False        # set by the Trainer while it captures a hipGraph (a cache hit there would record no pack kernel; asking
                          # the driver on every call instead costs ~10 us x 140 calls per step on a host-bound step)
 PACK_CACHE = True        # reuse a weight's packed image while the weight is known to be unchanged
+S2_REGISTERED = True     # the critic's derived space-to-depth kernels keep persistent packed images too (see _Conv2dS2Fn.forward)
 PACK_REGISTRY = True     # bf16x3 + Trainer-managed step: trainable conv weights keep PERSISTENT packed images that are refilled
                          # by one multi-tensor launch per optimizer step (repack_registered) instead of one launch per conv call
 PACK_EPOCH = None        # None: nobody tells us when trainable weights change -> only weights that cannot train are cached.
@@ -155,7 +156,7 @@ def note_weights_updated(params=None):
 class _PackEntry:
     """Persistent bf16x3 image of one trainable conv weight: buffers live as long as the weight, are refilled in place --
     one by one on a miss, or all weights of an optimizer in ONE launch right after its step (repack_registered)."""
-    __slots__ = ("v", "g", "vid", "gid", "groups", "qa", "qb", "dirty", "ver")
+    __slots__ = ("v", "g", "vid", "gid", "groups", "qa", "qb", "dirty", "ver", "src")
 
     def alive(self):
         return self.v() is not None and (self.g is None or self.g() is not None)
@@ -169,13 +170,16 @@ _REG = {}                # (id(v), id(g) or 0, groups) -> _PackEntry
 _REG_TABLES = {}         # tuple of registry keys -> (descriptor table on the device, n, rows, layout signature)
 
 
-def _pack_registered(v, g, groups, want_a, want_b):
+def _pack_registered(v, g, groups, want_a, want_b, src=0):
+    """src: id of the trainable weight `v` is a derived image of (the critic's space-to-depth kernels, _s2_image): the entry
+    is then refilled with the weights of the optimizer that owns `src` (repack_registered)."""
     key = (id(v), id(g) if g is not None else 0, groups)
     e = _REG.get(key)
     if e is None or e.v() is not v or (g is not None and (e.g is None or e.g() is not g)):
         e = _PackEntry()
         e.v, e.g = weakref.ref(v), (weakref.ref(g) if g is not None else None)
         e.vid, e.gid, e.groups = id(v), (id(g) if g is not None else 0), groups
+        e.src = src
         e.qa = e.qb = None
         e.dirty, e.ver = True, None
         _REG[key] = e
@@ -196,7 +200,16 @@ def repack_registered(params):
     if PRECISION != "bf16x3" or not _REG:
         return 0
     ids = {id(p) for p in params}
-    keys = tuple(k for k, e in _REG.items() if (e.vid in ids or e.gid in ids) and e.alive() and (e.qa or e.qb))
+    # derived images first (the critic's 3x3 stride-2 kernels as space-to-depth kernels): one gather launch each, here -- on the
+    # stream of the optimizer step, off the next generator pass's critical path -- instead of on their first use
+    for wid, ent in _S2W.items():
+        if wid in ids and ent[2] is not None and ent[3]:
+            w = ent[0]()
+            if w is not None:
+                K.s2_weight(w, out=ent[2])
+                torch.autograd.graph.increment_version(ent[2])
+                ent[1], ent[3] = (w._version, w.data_ptr()), False
+    keys = tuple(k for k, e in _REG.items() if (e.vid in ids or e.gid in ids or e.src in ids) and e.alive() and (e.qa or e.qb))
     if not keys:
         return 0
     ents = [_REG[k] for k in keys]
@@ -1069,7 +1082,15 @@ class _Conv2dS2Fn(torch.autograd.Function):
         weight = weight.contiguous()
         offsets = (-P - 1, -P, -1, 0)
         x4 = x4.contiguous().view(1, 4 * C, N * (Ho + 1) * P)
-        pa, pb = _pack(_s2_image(weight), None, 1, want_a=True, want_b=ctx.needs_input_grad[0])
+        img = _s2_image(weight)
+        if (S2_REGISTERED and PRECISION == "bf16x3" and PACK_REGISTRY and PACK_CACHE and PACK_EPOCH is not None and not CAPTURING
+                and (weight.requires_grad or weight.grad is not None or (id(img), 0, 1) in _REG)):
+            # persistent packed images of the derived kernel, refilled with the critic's other weights by ONE launch after its
+            # optimizer step (both layouts: the generator pass needs the data-gradient image too)
+            pa, pb = _pack_registered(img, None, 1, True, True, src=id(weight))
+            pb = pb if ctx.needs_input_grad[0] else None
+        else:
+            pa, pb = _pack(img, None, 1, want_a=True, want_b=ctx.needs_input_grad[0])
         y4 = K.conv1d_taps(x4, pa, cout, offsets, bias=_c(bias), out_act=ACT_LRELU if slope is not None else ACT_NONE,
                            out_slope=slope if slope is not None else 0.0)
         ctx.dims, ctx.slope, ctx.pb, ctx.has_bias, ctx.offsets = (N, C, H, W, cout), slope, pb, bias is not None, offsets
