@@ -263,6 +263,9 @@ def bench_vocoder(args, device):
     hparams.clear()
     hparams.update(default_hparams())
     hparams["conv_precision"] = args.precision
+    for kv in filter(None, (getattr(args, "extra_hparams", "") or "").split(",")):       # (A/B switches of the vocoder task)
+        k, v = kv.split("=", 1)
+        hparams[k] = {"true": True, "false": False}.get(v.lower(), v)
     B, L, sr = 64, 8192, hparams["audio_sample_rate"]
     trainer = Trainer(work_dir="", num_sanity_val_steps=0)
     torch.manual_seed(0)

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define SVB_ABI_VERSION 6
+#define SVB_ABI_VERSION 7
 int svb_abi_version(void);
 
 /* ---- fused conv epilogue / prologue description ------------------------------------------------------
@@ -450,6 +450,19 @@ int svb_batchnorm_nct_fwd(const float* x, const float* gamma, const float* beta,
 /* Backward of the train-mode form: dx (NULL: skip), dgamma / dbeta [C] (written, summed over the groups; NULL: skip).           */
 int svb_batchnorm_nct_bwd(const float* dy, const float* x, const float* gamma, const float* save, float* dx, float* dgamma,
                           float* dbeta, int B, int C, int T, int groups, void* stream);
+
+/* torch.nn.utils.spectral_norm of a conv weight (reference modules/hifigan/hifigan.py:238-250, DiscriminatorS with
+ * use_spectral_norm=True): w [R][C] = weight_orig.flatten(1), u [R], v [C] the module's buffers.
+ * training != 0: one power iteration -- v = normalize(w^T u), u = normalize(w v), eps-clamped norms -- written to u / v in
+ *   place; sigma = u . (w v); w_sn = w / sigma.  training == 0: sigma from the stored u, v; nothing written back.
+ * u_save / v_save receive the vectors the graph treats as constants (the backward reads them), sigma_out [1] the scalar.
+ * workspace: svb_spectral_norm_workspace_floats(R, C) floats.  3 launches (2 in eval mode).                                     */
+size_t svb_spectral_norm_workspace_floats(int R, int C);
+int svb_spectral_norm_fwd(const float* w, float* u, float* v, float* w_sn, float* u_save, float* v_save, float* sigma_out, int R,
+                          int C, int training, float eps, float* workspace, void* stream);
+/* dw = dw_sn / sigma - (sum dw_sn * w) / sigma^2 * u v^T  (u, v, sigma as saved by the forward).  2 launches.                  */
+int svb_spectral_norm_bwd(const float* dw_sn, const float* w, const float* u, const float* v, const float* sigma, float* dw, int R,
+                          int C, float* workspace, void* stream);
 
 #ifdef __cplusplus
 }

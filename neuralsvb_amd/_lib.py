@@ -62,6 +62,9 @@ SIGNATURES = {
     "svb_adamw_flat_workspace_floats": (I, []),
     "svb_adamw_flat": (I, [P, P, P, P, SZ, F, F, F, F, F, F, F, F, P, P, P]),
     "svb_gather_segments": (I, [P, P, P, I, P, P]),
+    "svb_spectral_norm_workspace_floats": (SZ, [I, I]),
+    "svb_spectral_norm_fwd": (I, [P, P, P, P, P, P, P, I, I, I, F, P, P]),
+    "svb_spectral_norm_bwd": (I, [P, P, P, P, P, P, I, I, P, P]),
     "svb_batchnorm_nct_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, F, P]),
     "svb_batchnorm_nct_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
     "svb_weight_pack": (I, [P, P, P, P, I, I, I, I, P]),

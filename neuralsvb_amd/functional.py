@@ -808,6 +808,30 @@ class _GNReluFn(torch.autograd.Function):
         return dh, (gy if ctx.has_res else None), dg, db, None, None
 
 
+class _SpectralNormFn(torch.autograd.Function):
+    """weight_orig / sigma of torch.nn.utils.spectral_norm (one power iteration per training-mode call, buffers updated in place;
+    u and v are constants of the graph) -- kernels.spectral_norm_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, weight, u, v, training, eps):
+        w = weight.contiguous()
+        w_sn, saved = K.spectral_norm_fwd(w, u, v, training, eps)
+        ctx.saved = saved
+        ctx.save_for_backward(w)
+        return w_sn
+
+    @staticmethod
+    def backward(ctx, dw_sn):
+        (w,) = ctx.saved_tensors
+        return K.spectral_norm_bwd(dw_sn.contiguous(), w, ctx.saved), None, None, None, None
+
+
+def spectral_norm_weight(weight_orig, u, v, training, eps=1e-12):
+    """The weight a spectral_norm-ed conv uses (reference hifigan.py:238-250 via torch.nn.utils.spectral_norm: dim 0, one power
+    iteration, eps 1e-12)."""
+    return _SpectralNormFn.apply(weight_orig, u, v, bool(training), float(eps))
+
+
 class _BatchNormNCTFn(torch.autograd.Function):
     """Train-mode nn.BatchNorm1d on [B,C,T] per batch group (kernels.batchnorm_nct_fwd / _bwd)."""
 

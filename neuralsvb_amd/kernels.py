@@ -840,6 +840,34 @@ def batchnorm_nct_bwd(dy, x, gamma, save, groups, need_dx=True, need_affine=True
     return dx, (dgb[0] if need_affine else None), (dgb[1] if need_affine else None)
 
 
+def spectral_norm_fwd(w, u, v, training, eps=1e-12):
+    """torch.nn.utils.spectral_norm's weight: w [R, ...] (flattened to [R, C]), u [R], v [C] (updated in place when training).
+    -> (w / sigma with w's shape, (u_save, v_save, sigma, workspace)) -- 3 launches (csrc/spectral_norm.hip)."""
+    _f32(w, u, v)
+    lib, st = _prep(w, u, v)
+    R = w.shape[0]
+    Cc = w.numel() // R
+    w_sn = torch.empty_like(w)
+    save = torch.empty((R + Cc + 1,), device=w.device, dtype=torch.float32)
+    ws = torch.empty((lib.svb_spectral_norm_workspace_floats(R, Cc),), device=w.device, dtype=torch.float32)
+    us, vs, sg = save[:R], save[R:R + Cc], save[R + Cc:]
+    L.check(lib.svb_spectral_norm_fwd(_ptr(w), _ptr(u), _ptr(v), _ptr(w_sn), us.data_ptr(), vs.data_ptr(), sg.data_ptr(), R, Cc,
+                                      1 if training else 0, float(eps), _ptr(ws), st), "svb_spectral_norm_fwd")
+    return w_sn, (us, vs, sg, ws)
+
+
+def spectral_norm_bwd(dw_sn, w, saved):
+    us, vs, sg, ws = saved
+    _f32(dw_sn, w)
+    lib, st = _prep(dw_sn, w)
+    R = w.shape[0]
+    Cc = w.numel() // R
+    dw = torch.empty_like(w)
+    L.check(lib.svb_spectral_norm_bwd(_ptr(dw_sn), _ptr(w), us.data_ptr(), vs.data_ptr(), sg.data_ptr(), _ptr(dw), R, Cc, _ptr(ws),
+                                      st), "svb_spectral_norm_bwd")
+    return dw
+
+
 def gather_segments(srcs, offsets, dst):
     """srcs: contiguous fp32 tensors; dst[offsets[i] : offsets[i] + srcs[i].numel()] = srcs[i], one launch per 48 tensors."""
     if not srcs:

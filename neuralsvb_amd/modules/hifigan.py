@@ -219,6 +219,9 @@ class MultiPeriodDiscriminator(nn.Module):
         return y_d_rs, y_d_gs, fmap_rs, fmap_gs
 
 
+FUSED_SPECTRAL_NORM = True      # hparam `fused_spectral_norm` (HifiGanTask): False = torch.nn.utils.spectral_norm's op-by-op formulation
+
+
 class _SpectralConv1d(nn.Module):
     """spectral_norm(Conv1d) state: weight_orig (param), weight_u / weight_v (buffers), bias  (SURVEY Appendix A.12)."""
 
@@ -235,6 +238,14 @@ class _SpectralConv1d(nn.Module):
         self.register_buffer("weight_v", v)
 
     def _weight(self):
+        """weight_orig / sigma after one power iteration (training) -- one fused op (SF.spectral_norm_weight: 3 launches where
+        torch.nn.utils.spectral_norm's formulation issues 15, and 2 instead of ~12 in backward)."""
+        if not FUSED_SPECTRAL_NORM:
+            return self._weight_torch()
+        return SF.spectral_norm_weight(self.weight_orig, self.weight_u, self.weight_v, self.training)
+
+    def _weight_torch(self):
+        """The same in torch ops, as torch.nn.utils.spectral_norm computes it (kept for the parity test)."""
         wm = self.weight_orig.flatten(1)
         if self.training:   # one power iteration per forward, buffers updated in place (torch.nn.utils.spectral_norm)
             with torch.no_grad():

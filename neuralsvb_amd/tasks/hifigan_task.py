@@ -45,6 +45,8 @@ class HifiGanTask(BaseTask):
     def build_model(self):
         from .. import functional as SF
         SF.set_precision(hparams.get("conv_precision", "fp32"))
+        from ..modules import hifigan as _hg
+        _hg.FUSED_SPECTRAL_NORM = bool(hparams.get("fused_spectral_norm", True))
         self.model_gen = HifiGanGenerator(hparams)
         self.model_disc = nn.ModuleDict()
         self.model_disc["mpd"] = MultiPeriodDiscriminator()

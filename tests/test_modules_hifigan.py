@@ -175,3 +175,38 @@ def test_discriminators_train_mode_losses_and_gradients(dev, name):
             if k.startswith("msd.buf1."):
                 assert np.abs(sd[k[len("msd.buf1."):]].cpu().numpy() - z[k]).max() < 2e-5, k
     print(name, "worst grad-norm rel err", worst)
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("shape", [(128, 1, 15, 1), (128, 128, 41, 4), (64, 256, 5, 1), (1, 96, 3, 1)])
+def test_spectral_norm_weight_matches_torch_formulation(dev, shape):
+    """SF.spectral_norm_weight (csrc/spectral_norm.hip) against torch.nn.utils.spectral_norm's own formulation in torch ops
+    (_SpectralConv1d._weight_torch): normalised weight, updated u / v buffers over two consecutive training-mode calls, the
+    eval-mode weight, and the gradient w.r.t. weight_orig (u, v constants of the graph).  fp32 vs fp32: 2e-6 relative."""
+    import copy
+    from neuralsvb_amd.modules.hifigan import _SpectralConv1d
+    cout, cin, k, groups = shape
+    torch.manual_seed(7 + cout + k)
+    ref = _SpectralConv1d(cin, cout, k, 1, k // 2, groups)
+    mod = copy.deepcopy(ref).to(dev)
+    g_ = torch.Generator().manual_seed(1)
+    for it in range(2):
+        ref.train()
+        mod.train()
+        wr = ref._weight_torch()
+        wd = mod._weight()
+        dy = torch.randn(wr.shape, generator=g_)
+        (gr,) = torch.autograd.grad(wr, ref.weight_orig, dy)
+        (gd,) = torch.autograd.grad(wd, mod.weight_orig, dy.to(dev))
+        assert _rel(wd, wr) < 2e-6, it
+        assert _rel(mod.weight_u, ref.weight_u) < 2e-6 and _rel(mod.weight_v, ref.weight_v) < 2e-6
+        assert _rel(gd, gr) < 5e-6, it
+    ref.eval()
+    mod.eval()
+    u0 = mod.weight_u.clone()
+    assert _rel(mod._weight(), ref._weight_torch()) < 2e-6
+    assert torch.equal(mod.weight_u, u0)                       # eval mode: no power iteration, buffers untouched
