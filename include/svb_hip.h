@@ -236,10 +236,11 @@ int svb_relpos_softmax(const float* ac, const float* bd, const float* keep, floa
 /* ---- the same attention fused end to end (forward only; the PPG encoder is frozen): content scores (q + pos_u) . k, the
  * rel-shifted position scores read from `bd` (UNSHIFTED (q + pos_v) . linear_pos(pos_emb), element strides batch / head /
  * row), 1/sqrt(dk) scale, key mask, softmax and the product with v in one kernel -- no [B,h,T,T] score or attention
- * tensor is written.  q, k, v, out: [B][H*dk][T] (conv layout); pos_u [H][dk]; keep [B][T]; dk must be 64.
+ * tensor is written.  q, k, v: [B][H*dk][T] with batch pitch qkv_sb elements (>= H*dk*T: they may be slices of one fused
+ * projection's output, ABI v7); out: contiguous [B][H*dk][T] (conv layout); pos_u [H][dk]; keep [B][T]; dk must be 64.
  * Split-bf16 MFMA arithmetic (fp32-class), online softmax in fp32.                                                       */
-int svb_relpos_attn_fwd(const float* q, const float* k, const float* v, const float* pos_u, const float* bd, long bd_sb,
-                        long bd_sh, long bd_sr, const float* keep, float* out, int B, int H, int dk, int T, float scale,
+int svb_relpos_attn_fwd(const float* q, const float* k, const float* v, long qkv_sb, const float* pos_u, const float* bd,
+                        long bd_sb, long bd_sh, long bd_sr, const float* keep, float* out, int B, int H, int dk, int T, float scale,
                         void* stream);
 
 /* ---- Conformer convolution module between its pointwise convs, eval mode (reference

@@ -170,7 +170,7 @@ __device__ __forceinline__ void svba_split8(const float* v, svba_bf16x8& hi, svb
 __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float* q, const float* k, const float* v, const float* pos_u,
                                                                   const float* bd, long bd_sb, long bd_sh, long bd_sr,
                                                                   const float* keep, float* out, int B, int H, int T,
-                                                                  float scale) {
+                                                                  float scale, long qkv_sb) {
     constexpr int DK = SVB_ATTN_DK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kb = lane >> 5;
@@ -180,10 +180,11 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
     const int i = i0 + l31;
     const bool iv = i < T;
     const int ic = iv ? i : T - 1;
-    const size_t head = ((size_t)b * H + hh) * DK * T;
-    const float* qh = q + head;
-    const float* kh = k + head;
-    const float* vh = v + head;
+    const size_t head = ((size_t)b * H + hh) * DK * T;                // (out: contiguous [B][H*dk][T])
+    const size_t head_in = (size_t)b * qkv_sb + (size_t)hh * DK * T;  // (q, k, v: batch pitch qkv_sb -- slices of a fused projection)
+    const float* qh = q + head_in;
+    const float* kh = k + head_in;
+    const float* vh = v + head_in;
     const float* bdh = bd + (size_t)b * bd_sb + (size_t)hh * bd_sh;
     const float* keepb = keep + (size_t)b * T;
 
@@ -344,13 +345,14 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
     }
 }
 
-extern "C" int svb_relpos_attn_fwd(const float* q, const float* k, const float* v, const float* pos_u, const float* bd, long bd_sb,
-                                   long bd_sh, long bd_sr, const float* keep, float* out, int B, int H, int dk, int T, float scale,
-                                   void* stream) {
+extern "C" int svb_relpos_attn_fwd(const float* q, const float* k, const float* v, long qkv_sb, const float* pos_u, const float* bd,
+                                   long bd_sb, long bd_sh, long bd_sr, const float* keep, float* out, int B, int H, int dk, int T,
+                                   float scale, void* stream) {
     if (!q || !k || !v || !pos_u || !bd || !keep || !out || B <= 0 || H <= 0 || T <= 0) return SVB_ERR_ARG;
     if (dk != SVB_ATTN_DK || (long)B * H > 65535) return SVB_ERR_UNSUPPORTED;
+    if (qkv_sb < (long)H * dk * T) return SVB_ERR_ARG;
     hipLaunchKernelGGL(svb_relpos_attn_fwd_kernel, dim3((T + 63) / 64, B * H), dim3(128), 0, (hipStream_t)stream, q, k, v, pos_u, bd,
-                       bd_sb, bd_sh, bd_sr, keep, out, B, H, T, scale);
+                       bd_sb, bd_sh, bd_sr, keep, out, B, H, T, scale, qkv_sb);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }

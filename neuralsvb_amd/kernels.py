@@ -775,16 +775,21 @@ def relpos_softmax(ac, bd, keep, scale):
 
 
 def relpos_attention(q, k, v, pos_u, bd, keep, scale, n_head):
-    """Fused rel-pos self-attention forward.  q, k, v [B, H*dk, T] (dk = 64); pos_u [H, dk]; bd [B, H, T, T] (any batch / head /
-    row strides, unit column stride): the unshifted position scores; keep [B, T] float.  -> [B, H*dk, T]."""
+    """Fused rel-pos self-attention forward.  q, k, v [B, H*dk, T] (dk = 64; contiguous, or equal-pitch slices along dim 1 of one
+    [B, n*H*dk, T] tensor -- a fused projection's output); pos_u [H, dk]; bd [B, H, T, T] (any batch / head / row strides, unit
+    column stride): the unshifted position scores; keep [B, T] float.  -> [B, H*dk, T]."""
     _f32(q, k, v, pos_u, bd, keep)
-    lib, st = _prep(q, k, v, pos_u, keep)
+    lib, st = _prep(pos_u, keep)
     B, D, T = q.shape
     dk = D // n_head
+    sb = q.stride(0)
+    for t in (q, k, v):
+        if tuple(t.shape) != (B, D, T) or t.stride(2) != 1 or t.stride(1) != T or t.stride(0) != sb or t.device != q.device:
+            raise ValueError("q, k, v must be [B, D, T] with contiguous [D, T] blocks and one common batch pitch")
     if bd.stride(3) != 1 or tuple(bd.shape) != (B, n_head, T, T):
         raise ValueError("bd must be [B, H, T, T] with contiguous rows")
-    out = torch.empty_like(q)
-    L.check(lib.svb_relpos_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(pos_u), _ptr(bd), bd.stride(0), bd.stride(1), bd.stride(2),
+    out = torch.empty((B, D, T), device=q.device, dtype=torch.float32)
+    L.check(lib.svb_relpos_attn_fwd(_ptr(q), _ptr(k), _ptr(v), sb, _ptr(pos_u), _ptr(bd), bd.stride(0), bd.stride(1), bd.stride(2),
                                     _ptr(keep), _ptr(out), B, n_head, dk, T, float(scale), st), "svb_relpos_attn_fwd")
     return out
 

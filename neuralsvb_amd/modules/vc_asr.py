@@ -47,6 +47,9 @@ class Prenet(nn.Module):
         return self.out_proj(x, mask=nonpad), nonpad
 
 
+FUSE_QKV = True          # frozen encoder: one D -> 4D projection instead of three + an add (see RelPositionMultiHeadedAttention.forward)
+
+
 class RelPositionMultiHeadedAttention(nn.Module):
     def __init__(self, n_head, n_feat):
         super().__init__()
@@ -59,18 +62,56 @@ class RelPositionMultiHeadedAttention(nn.Module):
         nn.init.xavier_uniform_(self.pos_bias_u)
         nn.init.xavier_uniform_(self.pos_bias_v)
 
+    def _fused_qkv(self):
+        """([4D, D, 1], [4D]) = rows of linear_q, linear_k, linear_v, linear_q again with `+ pos_bias_v` folded into its bias;
+        rebuilt when any of the (frozen) tensors changes."""
+        ts = (self.linear_q.weight, self.linear_k.weight, self.linear_v.weight, self.linear_q.bias, self.linear_k.bias,
+              self.linear_v.bias, self.pos_bias_v)
+        key = tuple((t._version, t.data_ptr()) for t in ts)
+        c = getattr(self, "_qkv_cache", None)
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                w4 = torch.cat([ts[0], ts[1], ts[2], ts[0]], 0)[:, :, None].contiguous()
+                b4 = torch.cat([ts[3], ts[4], ts[5], ts[3] + ts[6].reshape(-1)], 0).contiguous()
+            c = self._qkv_cache = (key, w4, b4)
+        return c[1], c[2]
+
+    def _pos_proj(self, pos_emb):
+        """linear_pos(pos_emb) of the frozen encoder, cached per (length, weights): the position embedding is a constant."""
+        w = self.linear_pos.weight
+        key = (w._version, w.data_ptr(), pos_emb.data_ptr(), tuple(pos_emb.shape))
+        c = getattr(self, "_pos_cache", None)
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                c = self._pos_cache = (key, self.linear_pos(pos_emb), pos_emb)      # (pos_emb kept alive: its address keys the entry)
+        return c[1]
+
     def forward(self, x, pos_emb, mask, residual=None):
         """x [B,D,T]; pos_emb [1,D,T]; mask [B,T] bool (True = keep)  (espnet_transformer_attn.py:150-186).
         residual: added to the result in the output projection's epilogue (the block's `x + self_attn(...)`)."""
         B, D, T = x.shape
         h, dk = self.h, self.d_k
-        q, k, v = self.linear_q(x), self.linear_k(x), self.linear_v(x)              # [B, D, T]
-        p = self.linear_pos(pos_emb).view(1, h, dk, T)
-        q4 = q.view(B, h, dk, T)
-        q_v = (q4 + self.pos_bias_v[None, :, :, None]).transpose(-1, -2)
+        frozen = not (torch.is_grad_enabled() and (x.requires_grad or self.pos_bias_u.requires_grad
+                                                   or self.linear_q.weight.requires_grad))
+        if frozen and FUSE_QKV:
+            # frozen encoder: q, k, v and q + pos_bias_v as ONE 1x1 conv D -> 4D (the three projections read the same x; the
+            # fourth block is linear_q again with pos_bias_v folded into its bias), the position projection of the (constant)
+            # position embedding cached per length
+            w4, b4 = self._fused_qkv()
+            with SF.precision_scope(self.linear_q.precision):
+                y = SF.conv1d(x, w4, b4)                                            # [B, 4D, T]
+            q, k, v, qv = y[:, :D], y[:, D:2 * D], y[:, 2 * D:3 * D], y[:, 3 * D:]
+            p = self._pos_proj(pos_emb).view(1, h, dk, T)
+            q4 = q.view(B, h, dk, T)
+            q_v = qv.view(B, h, dk, T).transpose(-1, -2)
+        else:
+            q, k, v = self.linear_q(x), self.linear_k(x), self.linear_v(x)              # [B, D, T]
+            p = self.linear_pos(pos_emb).view(1, h, dk, T)
+            q4 = q.view(B, h, dk, T)
+            q_v = (q4 + self.pos_bias_v[None, :, :, None]).transpose(-1, -2)
         bd = torch.matmul(q_v, p)                                   # [B,h,T,T] position scores, unshifted
         scale = 1.0 / math.sqrt(dk)
-        if dk == 64 and not (torch.is_grad_enabled() and (x.requires_grad or self.pos_bias_u.requires_grad)):
+        if dk == 64 and frozen:
             # frozen encoder (the hot path): content scores, rel_shift (:125-148), scale, key mask, softmax and the value
             # product in ONE kernel -- neither `ac` nor `attn` ([B,h,T,T] each) is ever written
             o = K.relpos_attention(q, k, v, self.pos_bias_u.contiguous(), bd, mask.float().contiguous(), scale, h)
@@ -183,7 +224,10 @@ class ConformerLayers(nn.Module):
             pe[:, 0::2] = torch.sin(pos * div)
             pe[:, 1::2] = torch.cos(pos * div)
             self._pe = pe.t().contiguous().to(device)              # [D, 5000]
-        return self._pe[None, :, :T].contiguous()
+        c = getattr(self, "_pe_T", None)
+        if c is None or c[0] != (T, self._pe.data_ptr()):
+            c = self._pe_T = ((T, self._pe.data_ptr()), self._pe[None, :, :T].contiguous())     # (one copy per length, reused:
+        return c[1]                                                   # the attention layers key their cached projection on it)
 
     def forward(self, x):
         """x [B,D,T] -> [B,D,T]  (conformer.py:37-53)."""

@@ -326,3 +326,27 @@ def test_mle_svb_vae_bench_shape_gradients(gpu_only, precision):
             bad.append((name, rn, rs))
     print(precision, "worst gradient norm / sample relative error at the bench shape:", worst)
     assert not bad, (precision, bad)
+
+
+def test_conformer_fused_qkv_projection_equals_separate_projections(dev):
+    """Frozen PPG encoder: q, k, v and q + pos_bias_v as one D -> 4D projection (vc_asr.FUSE_QKV; the attention kernel then
+    reads q / k / v as equal-pitch slices of that output, d_k = 64) and the cached position projection must reproduce the three
+    separate projections + add of espnet_transformer_attn.py:150-186 -- also on a second call with another length (cache keys)."""
+    from neuralsvb_amd.modules import vc_asr
+    from neuralsvb_amd.modules.vc_asr import ConformerLayers
+    torch.manual_seed(5)
+    enc = ConformerLayers(128, 2, kernel_size=7, num_heads=2).to(dev).eval()       # d_k = 64: the fused attention kernel
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    for T in (45, 70, 45):
+        x = torch.randn(3, 128, T, device=dev)
+        x[2, :, T - 9:] = 0.0
+        with torch.no_grad():
+            y_fused = enc(x)
+            vc_asr.FUSE_QKV = False
+            try:
+                y_plain = enc(x)
+            finally:
+                vc_asr.FUSE_QKV = True
+        assert (y_fused - y_plain).abs().max().item() < 2e-5 * y_plain.abs().max().item(), T
