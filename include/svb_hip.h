@@ -243,6 +243,14 @@ int svb_relpos_attn_fwd(const float* q, const float* k, const float* v, long qkv
                         long bd_sb, long bd_sh, long bd_sr, const float* keep, float* out, int B, int H, int dk, int T, float scale,
                         void* stream);
 
+/* The same attention with the position scores computed in the kernel (no [B,H,T,T] tensor at all): pos_v [H][dk] (the `v` bias of
+ * espnet_transformer_attn.py:150-186), pt_hi / pt_lo [H][T][dk] bf16 = linear_pos(pos_emb) transposed and split into
+ * bf16 hi + lo (p = hi + lo to fp32 class; constant for a frozen encoder and a given T: prepared once by the host).
+ * Each key block computes the 63-column band of (q + pos_v) . p it needs as one MFMA product and skews it through LDS.      */
+int svb_relpos_attn_pos_fwd(const float* q, const float* k, const float* v, long qkv_sb, const float* pos_u, const float* pos_v,
+                            const unsigned short* pt_hi, const unsigned short* pt_lo, const float* keep, float* out, int B, int H,
+                            int dk, int T, float scale, void* stream);
+
 /* ---- Conformer convolution module between its pointwise convs, eval mode (reference
  * modules/fastspeech/conformer/layers.py:47-63): out = Swish(BatchNorm_eval(depthwise_conv1d(GLU(y)))).  y [B, 2C, T],
  * w [C][K] (K odd <= 63, padding (K-1)/2), bias [C] or NULL, BatchNorm weight / bias (NULL = 1 / 0), running mean / var,

@@ -167,10 +167,23 @@ __device__ __forceinline__ void svba_split8(const float* v, svba_bf16x8& hi, svb
 }
 
 #define SVB_ATTN_DK 64
+#define SVB_ATTN_SKEW_P 34      // row pitch (floats) of the skew buffer: lane il reads row jl + 31 - il -> word stride 33, conflict-free
+
+// POS = true (round 4): the position scores are computed HERE instead of being read from a [B,H,T,T] tensor a GEMM wrote:
+//   bd[i][c] = sum_d (q[i][d] + pos_v[d]) * p[d][c],   p = linear_pos(pos_emb) of the frozen encoder, handed over transposed and
+//   pre-split (pt_hi / pt_lo: [H][T][dk] bf16).
+// A key block needs bd[i][T-1-i+j] (j <= i) or bd[i+1][j-i-2] (j > i+1): for the wave's 32 queries and the block's 32 keys that is
+// a band of 63 columns c = cb + (jl + 31 - il).  The band is one MFMA product  M[cl][il] = sum_d p^T[cb + cl][d] * Qv[il][d]
+// (64 x 32, two A tiles of p^T rows -- 16-byte loads, the rows are contiguous in d), whose element for (key jl, query il) sits at
+// row jl + 31 - il: the accumulators go through a per-wave LDS buffer once (written [cl][il], read skewed, conflict-free with a
+// pitch of 34 floats).  The second form uses the frags of the queries i + 1.  +24 MFMAs per block against 36, and neither the
+// 4 B per score element of HBM traffic nor the rocBLAS GEMM that wrote them.
+template <bool POS>
 __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float* q, const float* k, const float* v, const float* pos_u,
                                                                   const float* bd, long bd_sb, long bd_sh, long bd_sr,
                                                                   const float* keep, float* out, int B, int H, int T,
-                                                                  float scale, long qkv_sb) {
+                                                                  float scale, long qkv_sb, const float* pos_v,
+                                                                  const unsigned short* pt_hi, const unsigned short* pt_lo) {
     constexpr int DK = SVB_ATTN_DK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kb = lane >> 5;
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
     const float* qh = q + head_in;
     const float* kh = k + head_in;
     const float* vh = v + head_in;
-    const float* bdh = bd + (size_t)b * bd_sb + (size_t)hh * bd_sh;
+    const float* bdh = POS ? nullptr : bd + (size_t)b * bd_sb + (size_t)hh * bd_sh;
     const float* keepb = keep + (size_t)b * T;
 
     // ---- B operand of the score product: Qu[i][d], d = 16s + 8kb + e.  The 8 fragments are this lane's alone; they live in a
@@ -205,12 +218,75 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
         __builtin_memcpy(&q_frag[wave][2 * s][lane], &fh, 16);
         __builtin_memcpy(&q_frag[wave][2 * s + 1][lane], &fl, 16);
     }
+    // POS: Qv[i][d] = q[i][d] + pos_v[d] of this lane's query and of the next one (the j > i + 1 form reads row i + 1 of bd)
+    __shared__ uint4 qv_frag[POS ? 2 : 1][POS ? 2 : 1][POS ? 8 : 1][POS ? 64 : 1];       // [wave][query i / i+1][fragment][lane]
+    __shared__ float m_skew[POS ? 2 : 1][POS ? 64 * SVB_ATTN_SKEW_P : 1];
+    if (POS) {
+        const int i1 = i + 1 < T ? i + 1 : T - 1;
+#pragma unroll
+        for (int w1 = 0; w1 < 2; ++w1)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float t[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int d = 16 * s + 8 * kb + e;
+                    t[e] = qh[(size_t)d * T + (w1 ? i1 : ic)] + pos_v[hh * DK + d];
+                }
+                svba_bf16x8 fh, fl;
+                svba_split8(t, fh, fl);
+                __builtin_memcpy(&qv_frag[POS ? wave : 0][POS ? w1 : 0][POS ? 2 * s : 0][POS ? lane : 0], &fh, 16);
+                __builtin_memcpy(&qv_frag[POS ? wave : 0][POS ? w1 : 0][POS ? 2 * s + 1 : 0][POS ? lane : 0], &fl, 16);
+            }
+    }
+    // the band product + skew (see the header of the kernel): sh[r] = position score of key j0 + 8*(r>>2) + 4*kb + (r&3) for this
+    // lane's query, taken from band column cb + (jl + 31 - il)
+    auto pos_band = [&](int which, int cb, float* sh) {
+        f32x16 m[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m[tt][r] = 0.f;
+            int rc = cb + 32 * tt + l31;
+            rc = rc < 0 ? 0 : (rc > T - 1 ? T - 1 : rc);                 // (columns outside [0, T) are never selected below)
+            const unsigned short* ph = pt_hi + ((size_t)hh * T + rc) * DK + 8 * kb;
+            const unsigned short* pl = pt_lo + ((size_t)hh * T + rc) * DK + 8 * kb;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                svba_bf16x8 ah, al, qh8, ql8;
+                __builtin_memcpy(&ah, ph + 16 * s, 16);
+                __builtin_memcpy(&al, pl + 16 * s, 16);
+                __builtin_memcpy(&qh8, &qv_frag[POS ? wave : 0][POS ? which : 0][POS ? 2 * s : 0][POS ? lane : 0], 16);
+                __builtin_memcpy(&ql8, &qv_frag[POS ? wave : 0][POS ? which : 0][POS ? 2 * s + 1 : 0][POS ? lane : 0], 16);
+                m[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh8, m[tt], 0, 0, 0);
+                m[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql8, m[tt], 0, 0, 0);
+                m[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh8, m[tt], 0, 0, 0);
+            }
+        }
+        float* ms = m_skew[POS ? wave : 0];
+        __builtin_amdgcn_wave_barrier();                                  // (the previous band's reads are done)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = 32 * tt + (r & 3) + 8 * (r >> 2) + 4 * kb;
+                ms[cl * SVB_ATTN_SKEW_P + l31] = m[tt][r];
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jl = (r & 3) + 8 * (r >> 2) + 4 * kb;
+            sh[r] = ms[(jl + 31 - l31) * SVB_ATTN_SKEW_P + l31];
+        }
+    };
     f32x16 o[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
-    const float* bd_i = bdh + (size_t)ic * bd_sr;                    // bd[i][.]
-    const float* bd_i1 = bdh + (size_t)(ic + 1 < T ? ic + 1 : ic) * bd_sr;      // bd[i+1][.] (never used for i = T-1)
+    const float* bd_i = POS ? nullptr : bdh + (size_t)ic * bd_sr;                    // bd[i][.]
+    const float* bd_i1 = POS ? nullptr : bdh + (size_t)(ic + 1 < T ? ic + 1 : ic) * bd_sr;      // bd[i+1][.] (never used for i = T-1)
 
     // One key block.  CLS (wave-uniform): 0 = the whole 32x32 block lies on or below the diagonal (every position score comes
     // from bd[i][T-1-i+j]: one 16-byte read per 4 keys), 1 = the whole block lies beyond the zero diagonal (bd[i+1][j-i-2]),
@@ -241,6 +317,23 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
         float p[16];
         unsigned okm = 0u;                                          // bit r: key of register r is a real, unpadded key
         float mb = -INFINITY;
+        float shp[16];                                              // POS: the block's position scores, by register
+        if (POS) {
+            if (CLS == 0) {
+                pos_band(0, T - 1 - (i0 + 31) + j0, shp);
+            } else if (CLS == 1) {
+                pos_band(1, j0 - (i0 + 31) - 2, shp);
+            } else {
+                float sh1[16];
+                pos_band(0, T - 1 - (i0 + 31) + j0, shp);
+                pos_band(1, j0 - (i0 + 31) - 2, sh1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+                    shp[r] = (j >= T || j == ic + 1) ? 0.f : (j <= ic ? shp[r] : sh1[r]);
+                }
+            }
+        }
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const int jb = j0 + 8 * g4 + 4 * kb;                    // 4 consecutive keys jb .. jb+3
@@ -252,7 +345,10 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
 #pragma unroll
                 for (int e = 0; e < 4; ++e) kp[e] = jb + e < T ? keepb[jb + e] : 0.f;
             }
-            if (CLS == 0) {
+            if (POS) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sh[e] = shp[4 * g4 + e];
+            } else if (CLS == 0) {
                 const svba_f4u t = *reinterpret_cast<const svba_f4u*>(bd_i + (T - 1 - ic + jb));
                 sh[0] = t.x; sh[1] = t.y; sh[2] = t.z; sh[3] = t.w;
             } else if (CLS == 1) {
@@ -351,8 +447,21 @@ extern "C" int svb_relpos_attn_fwd(const float* q, const float* k, const float* 
     if (!q || !k || !v || !pos_u || !bd || !keep || !out || B <= 0 || H <= 0 || T <= 0) return SVB_ERR_ARG;
     if (dk != SVB_ATTN_DK || (long)B * H > 65535) return SVB_ERR_UNSUPPORTED;
     if (qkv_sb < (long)H * dk * T) return SVB_ERR_ARG;
-    hipLaunchKernelGGL(svb_relpos_attn_fwd_kernel, dim3((T + 63) / 64, B * H), dim3(128), 0, (hipStream_t)stream, q, k, v, pos_u, bd,
-                       bd_sb, bd_sh, bd_sr, keep, out, B, H, T, scale, qkv_sb);
+    hipLaunchKernelGGL(svb_relpos_attn_fwd_kernel<false>, dim3((T + 63) / 64, B * H), dim3(128), 0, (hipStream_t)stream, q, k, v, pos_u,
+                       bd, bd_sb, bd_sh, bd_sr, keep, out, B, H, T, scale, qkv_sb, (const float*)nullptr,
+                       (const unsigned short*)nullptr, (const unsigned short*)nullptr);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+
+extern "C" int svb_relpos_attn_pos_fwd(const float* q, const float* k, const float* v, long qkv_sb, const float* pos_u,
+                                       const float* pos_v, const unsigned short* pt_hi, const unsigned short* pt_lo,
+                                       const float* keep, float* out, int B, int H, int dk, int T, float scale, void* stream) {
+    if (!q || !k || !v || !pos_u || !pos_v || !pt_hi || !pt_lo || !keep || !out || B <= 0 || H <= 0 || T <= 0) return SVB_ERR_ARG;
+    if (dk != SVB_ATTN_DK || (long)B * H > 65535) return SVB_ERR_UNSUPPORTED;
+    if (qkv_sb < (long)H * dk * T) return SVB_ERR_ARG;
+    hipLaunchKernelGGL(svb_relpos_attn_fwd_kernel<true>, dim3((T + 63) / 64, B * H), dim3(128), 0, (hipStream_t)stream, q, k, v, pos_u,
+                       (const float*)nullptr, 0L, 0L, 0L, keep, out, B, H, T, scale, qkv_sb, pos_v, pt_hi, pt_lo);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }

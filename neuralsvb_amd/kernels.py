@@ -794,6 +794,35 @@ def relpos_attention(q, k, v, pos_u, bd, keep, scale, n_head):
     return out
 
 
+def relpos_pos_table(p, n_head):
+    """p = linear_pos(pos_emb) [1, H*dk, T] -> (pt_hi, pt_lo) int16 [H, T, dk]: transposed, split into bf16 hi + lo (the operand
+    layout of relpos_attention_pos; computed once per length for a frozen encoder)."""
+    D, T = p.shape[-2], p.shape[-1]
+    pt = p.reshape(n_head, D // n_head, T).transpose(1, 2).contiguous().float()
+    hi = pt.to(torch.bfloat16)
+    lo = (pt - hi.float()).to(torch.bfloat16)
+    return hi.view(torch.int16).contiguous(), lo.view(torch.int16).contiguous()
+
+
+def relpos_attention_pos(q, k, v, pos_u, pos_v, pt_hi, pt_lo, keep, scale, n_head):
+    """relpos_attention with the position scores (q + pos_v) . p computed inside the kernel from the table of relpos_pos_table:
+    no [B,H,T,T] tensor is written or read."""
+    _f32(q, k, v, pos_u, pos_v, keep)
+    lib, st = _prep(pos_u, pos_v, keep, pt_hi, pt_lo)
+    B, D, T = q.shape
+    dk = D // n_head
+    sb = q.stride(0)
+    for t in (q, k, v):
+        if tuple(t.shape) != (B, D, T) or t.stride(2) != 1 or t.stride(1) != T or t.stride(0) != sb or t.device != q.device:
+            raise ValueError("q, k, v must be [B, D, T] with contiguous [D, T] blocks and one common batch pitch")
+    if tuple(pt_hi.shape) != (n_head, T, dk) or tuple(pt_lo.shape) != (n_head, T, dk) or pt_hi.dtype != torch.int16:
+        raise ValueError("pt_hi / pt_lo must be int16 [H, T, dk] (relpos_pos_table)")
+    out = torch.empty((B, D, T), device=q.device, dtype=torch.float32)
+    L.check(lib.svb_relpos_attn_pos_fwd(_ptr(q), _ptr(k), _ptr(v), sb, _ptr(pos_u), _ptr(pos_v), _ptr(pt_hi), _ptr(pt_lo), _ptr(keep),
+                                        _ptr(out), B, n_head, dk, T, float(scale), st), "svb_relpos_attn_pos_fwd")
+    return out
+
+
 def glu_dwconv_bn_swish(y, w, bias, bn_w, bn_b, bn_mean, bn_var, eps):
     """Swish(BatchNorm_eval(depthwise_conv1d(GLU(y)))): y [B,2C,T], w [C,1,K] or [C,K] -> [B,C,T] (forward only)."""
     w = w.reshape(w.shape[0], -1).contiguous()

@@ -47,6 +47,7 @@ class Prenet(nn.Module):
         return self.out_proj(x, mask=nonpad), nonpad
 
 
+POS_IN_KERNEL = True     # frozen encoder, d_k = 64: position scores computed inside the attention kernel (K.relpos_attention_pos)
 FUSE_QKV = True          # frozen encoder: one D -> 4D projection instead of three + an add (see RelPositionMultiHeadedAttention.forward)
 
 
@@ -73,8 +74,9 @@ class RelPositionMultiHeadedAttention(nn.Module):
             with torch.no_grad():
                 w4 = torch.cat([ts[0], ts[1], ts[2], ts[0]], 0)[:, :, None].contiguous()
                 b4 = torch.cat([ts[3], ts[4], ts[5], ts[3] + ts[6].reshape(-1)], 0).contiguous()
-            c = self._qkv_cache = (key, w4, b4)
-        return c[1], c[2]
+            D = ts[0].shape[0]
+            c = self._qkv_cache = (key, w4, b4, w4[:3 * D].contiguous(), b4[:3 * D].contiguous())
+        return c[1], c[2], c[3], c[4]
 
     def _pos_proj(self, pos_emb):
         """linear_pos(pos_emb) of the frozen encoder, cached per (length, weights): the position embedding is a constant."""
@@ -86,6 +88,14 @@ class RelPositionMultiHeadedAttention(nn.Module):
                 c = self._pos_cache = (key, self.linear_pos(pos_emb), pos_emb)      # (pos_emb kept alive: its address keys the entry)
         return c[1]
 
+    def _pos_table(self, pos_emb):
+        """(pt_hi, pt_lo): the position projection in the attention kernel's operand layout (K.relpos_pos_table), cached with it."""
+        p = self._pos_proj(pos_emb)
+        c = getattr(self, "_pt_cache", None)
+        if c is None or c[0] is not p:
+            c = self._pt_cache = (p,) + K.relpos_pos_table(p, self.h)
+        return c[1], c[2]
+
     def forward(self, x, pos_emb, mask, residual=None):
         """x [B,D,T]; pos_emb [1,D,T]; mask [B,T] bool (True = keep)  (espnet_transformer_attn.py:150-186).
         residual: added to the result in the output projection's epilogue (the block's `x + self_attn(...)`)."""
@@ -93,11 +103,20 @@ class RelPositionMultiHeadedAttention(nn.Module):
         h, dk = self.h, self.d_k
         frozen = not (torch.is_grad_enabled() and (x.requires_grad or self.pos_bias_u.requires_grad
                                                    or self.linear_q.weight.requires_grad))
+        if frozen and FUSE_QKV and POS_IN_KERNEL and dk == 64:
+            # ... and the position scores inside the attention kernel: no [B,h,T,T] tensor, no GEMM (round 4)
+            w4, b4, w3, b3 = self._fused_qkv()
+            with SF.precision_scope(self.linear_q.precision):
+                y = SF.conv1d(x, w3, b3)                                            # [B, 3D, T]
+            pt_hi, pt_lo = self._pos_table(pos_emb)
+            o = K.relpos_attention_pos(y[:, :D], y[:, D:2 * D], y[:, 2 * D:], self.pos_bias_u.contiguous(),
+                                       self.pos_bias_v.contiguous(), pt_hi, pt_lo, mask.float().contiguous(), 1.0 / math.sqrt(dk), h)
+            return self.linear_out(o, residual=residual)
         if frozen and FUSE_QKV:
             # frozen encoder: q, k, v and q + pos_bias_v as ONE 1x1 conv D -> 4D (the three projections read the same x; the
             # fourth block is linear_q again with pos_bias_v folded into its bias), the position projection of the (constant)
             # position embedding cached per length
-            w4, b4 = self._fused_qkv()
+            w4, b4, _, _ = self._fused_qkv()
             with SF.precision_scope(self.linear_q.precision):
                 y = SF.conv1d(x, w4, b4)                                            # [B, 4D, T]
             q, k, v, qv = y[:, :D], y[:, D:2 * D], y[:, 2 * D:3 * D], y[:, 3 * D:]

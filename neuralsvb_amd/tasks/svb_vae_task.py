@@ -103,6 +103,7 @@ class SVBVAEMleTask(BaseTask):
         SF.S2_REGISTERED = bool(hparams.get("critic_s2_registered", True))
         from ..modules import vc_asr as _va
         _va.FUSE_QKV = bool(hparams.get("ppg_fuse_qkv", True))
+        _va.POS_IN_KERNEL = bool(hparams.get("ppg_pos_in_kernel", True))
         from ..modules import svb_vae as _svb
         _svb.PPG_SIDE_STREAM = bool(hparams.get("overlap_ppg_encoder", True)) and os.environ.get("SVB_PPG_SIDE", "1") != "0"
         self.build_tts_model()

@@ -80,6 +80,7 @@ static inline void __builtin_amdgcn_s_barrier_emu() { emu_syncthreads(); }
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 void emu_wave_sync();                                             // all lanes of the calling wave arrive before any continues
 #define __builtin_amdgcn_wave_barrier() emu_wave_sync()
+#define __builtin_amdgcn_fence(order, scope) ((void)0)             // (the emulator's lanes run one at a time: program order is memory order)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 // buffer descriptors: (base, bytes); loads outside the range return 0, stores outside are dropped
 struct emu_buffer_rsrc { char* base; unsigned bytes; };

@@ -658,7 +658,7 @@ def test_conv1d_bf16x3_clip_edges(dev, cfg, T, k, pad, dil):
     assert rel_err(yg, refg) < 6e-5
 
 
-@pytest.mark.parametrize("T", [37, 64, 130])
+@pytest.mark.parametrize("T", [37, 64, 97, 130])
 def test_relpos_attention_fused_matches_espnet(dev, T):
     """svb_relpos_attn_fwd (content scores + rel-shifted position scores + scale + key mask + softmax + value product in one
     kernel) against the reference's op sequence (espnet_transformer_attn.py:125-186) in fp32: legacy rel_shift via
@@ -685,6 +685,15 @@ def test_relpos_attention_fused_matches_espnet(dev, T):
     assert out.shape == ref.shape
     assert float(out[2].abs().max()) == 0.0                      # fully padded clip: zeros, as the reference
     assert rel_err(out, ref) < 5e-5
+    # the same with the position scores computed in the kernel (svb_relpos_attn_pos_fwd: band product + skew through LDS; no bd
+    # tensor), q / k / v handed over as equal-pitch slices of one [B, 3D, T] tensor (a fused projection's output)
+    qkv = torch.cat([q.reshape(B, H * dk, T), k.reshape(B, H * dk, T), v.reshape(B, H * dk, T)], 1).to(dev)
+    D = H * dk
+    pt_hi, pt_lo = K.relpos_pos_table(pe.reshape(1, D, T).to(dev), H)
+    out2 = K.relpos_attention_pos(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], pu.to(dev), pv.to(dev), pt_hi, pt_lo, keep.to(dev),
+                                  1.0 / dk ** 0.5, H)
+    assert float(out2[2].abs().max()) == 0.0
+    assert rel_err(out2, ref) < 5e-5
 
 
 @pytest.mark.parametrize("T", [37, 130])

@@ -343,10 +343,13 @@ def test_conformer_fused_qkv_projection_equals_separate_projections(dev):
         x = torch.randn(3, 128, T, device=dev)
         x[2, :, T - 9:] = 0.0
         with torch.no_grad():
-            y_fused = enc(x)
-            vc_asr.FUSE_QKV = False
+            y_fused = enc(x)                                  # fused projection + position scores in the attention kernel
+            vc_asr.POS_IN_KERNEL = False
             try:
+                y_bd = enc(x)                                 # fused D -> 4D projection, position scores by a GEMM
+                vc_asr.FUSE_QKV = False
                 y_plain = enc(x)
             finally:
-                vc_asr.FUSE_QKV = True
-        assert (y_fused - y_plain).abs().max().item() < 2e-5 * y_plain.abs().max().item(), T
+                vc_asr.FUSE_QKV = vc_asr.POS_IN_KERNEL = True
+        assert (y_bd - y_plain).abs().max().item() < 2e-5 * y_plain.abs().max().item(), T
+        assert (y_fused - y_plain).abs().max().item() < 5e-5 * y_plain.abs().max().item(), T

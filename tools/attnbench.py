@@ -34,3 +34,9 @@ print(f"relpos_attention B{B} H{H} T{T}: {t:.1f} us  ({fl / t / 1e6:.1f} TFLOP/s
 q4 = q.view(B, H, dk, T)
 t2 = timeit(lambda: torch.matmul(q4.transpose(-1, -2), q4))
 print(f"rocBLAS fp32 q^T k ([B,H,T,T] out): {t2:.1f} us")
+pv = torch.randn(H, dk, device=dev)
+p = torch.randn(1, H * dk, T, device=dev)
+pt_hi, pt_lo = K.relpos_pos_table(p, H)
+t3 = timeit(lambda: K.relpos_attention_pos(q, k, v, pu, pv, pt_hi, pt_lo, keep, 0.125, H))
+print(f"relpos_attention_pos (position scores in the kernel): {t3:.1f} us  ({3 * 2.0 * B * H * T * T * dk / t3 / 1e6:.1f} TFLOP/s algorithmic incl. the "
+      f"position product)   vs  {t:.1f} + {t2:.1f} us for the bd form + the GEMM that writes bd")
