@@ -242,11 +242,13 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
     // the band product + skew (see the header of the kernel): sh[r] = position score of key j0 + 8*(r>>2) + 4*kb + (r&3) for this
     // lane's query, taken from band column cb + (jl + 31 - il)
     auto pos_band = [&](int which, int cb, float* sh) {
-        f32x16 m[2];
+        float* ms = m_skew[POS ? wave : 0];
+        __builtin_amdgcn_wave_barrier();                                  // (the previous band's reads are done)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < 2; ++tt) {                                  // one 32-row tile of the band at a time: 16 accumulators
+            f32x16 m;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m[tt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) m[r] = 0.f;
             int rc = cb + 32 * tt + l31;
             rc = rc < 0 ? 0 : (rc > T - 1 ? T - 1 : rc);                 // (columns outside [0, T) are never selected below)
             const unsigned short* ph = pt_hi + ((size_t)hh * T + rc) * DK + 8 * kb;
@@ -258,20 +260,20 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
                 __builtin_memcpy(&al, pl + 16 * s, 16);
                 __builtin_memcpy(&qh8, &qv_frag[POS ? wave : 0][POS ? which : 0][POS ? 2 * s : 0][POS ? lane : 0], 16);
                 __builtin_memcpy(&ql8, &qv_frag[POS ? wave : 0][POS ? which : 0][POS ? 2 * s + 1 : 0][POS ? lane : 0], 16);
-                m[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh8, m[tt], 0, 0, 0);
-                m[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql8, m[tt], 0, 0, 0);
-                m[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh8, m[tt], 0, 0, 0);
+                // four products, not three: the position scores used to come from an fp32 GEMM, and the exact-parity mode's
+                // gradient check at the bench shape (1e-4 on norms) sees a three-term band (2^-16 per product) as 1.6e-4 on the
+                // first layer behind the encoder
+                m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ql8, m, 0, 0, 0);
+                m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh8, m, 0, 0, 0);
+                m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql8, m, 0, 0, 0);
+                m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh8, m, 0, 0, 0);
             }
-        }
-        float* ms = m_skew[POS ? wave : 0];
-        __builtin_amdgcn_wave_barrier();                                  // (the previous band's reads are done)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cl = 32 * tt + (r & 3) + 8 * (r >> 2) + 4 * kb;
-                ms[cl * SVB_ATTN_SKEW_P + l31] = m[tt][r];
+                ms[cl * SVB_ATTN_SKEW_P + l31] = m[r];
             }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -317,20 +319,22 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
         float p[16];
         unsigned okm = 0u;                                          // bit r: key of register r is a real, unpadded key
         float mb = -INFINITY;
-        float shp[16];                                              // POS: the block's position scores, by register
-        if (POS) {
-            if (CLS == 0) {
+        if (POS) {                                                  // the block's position scores go straight into s_acc
+            float shp[16];
+            if (CLS != 1) {
                 pos_band(0, T - 1 - (i0 + 31) + j0, shp);
-            } else if (CLS == 1) {
-                pos_band(1, j0 - (i0 + 31) - 2, shp);
-            } else {
-                float sh1[16];
-                pos_band(0, T - 1 - (i0 + 31) + j0, shp);
-                pos_band(1, j0 - (i0 + 31) - 2, sh1);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kb;
-                    shp[r] = (j >= T || j == ic + 1) ? 0.f : (j <= ic ? shp[r] : sh1[r]);
+                    s_acc[r] += (CLS == 0 || (j < T && j <= ic)) ? shp[r] : 0.f;
+                }
+            }
+            if (CLS != 0) {
+                pos_band(1, j0 - (i0 + 31) - 2, shp);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+                    s_acc[r] += (CLS == 1 || (j < T && j > ic + 1)) ? shp[r] : 0.f;
                 }
             }
         }
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
             }
             if (POS) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sh[e] = shp[4 * g4 + e];
+                for (int e = 0; e < 4; ++e) sh[e] = 0.f;                // (already in s_acc)
             } else if (CLS == 0) {
                 const svba_f4u t = *reinterpret_cast<const svba_f4u*>(bd_i + (T - 1 - ic + jb));
                 sh[0] = t.x; sh[1] = t.y; sh[2] = t.z; sh[3] = t.w;
