@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 export SVB_ROUND=$TAG
 R=$PWD
 # (PMC traffic first: the bench line's roofline.traffic reads profiles/<tag>_pmc_traffic.json of THIS commit's kernels)
-SVB_PMC_SHAPES=10 timeout 500 python tools/pmc_traffic.py > $O/pmc_traffic.log 2>&1
+SVB_PMC_SHAPES=16 timeout 700 python tools/pmc_traffic.py > $O/pmc_traffic.log 2>&1
 cp profiles/${TAG}_pmc_traffic.json $O/ 2>/dev/null
 timeout 600 python bench.py > $O/bench_train_bf16x3.json 2> $O/bench_train_bf16x3.log
 SVB_BENCH_SHAPES=1 timeout 300 python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-extra-workloads > /dev/null 2> $O/conv_per_shape.log
