@@ -12,7 +12,9 @@
 
 #define SSIM_W 11
 #define SSIM_R 5
+#ifndef SSIM_TT
 #define SSIM_TT 16
+#endif
 #define SSIM_FMAX 128
 #define SSIM_ROWS_ (SSIM_TT + 2 * SSIM_R)
 

@@ -6,6 +6,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neuralsvb_amd import _lib  # noqa: E402
+
+if os.environ.get("SVB_LIB_FILE"):           # (experiments: a variant build of the library, e.g. another SSIM tile height)
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["SVB_LIB_FILE"])
 from neuralsvb_amd import kernels as K  # noqa: E402
 
 dev = torch.device('cuda:0')
