@@ -84,3 +84,21 @@ if qcol:
         print(f"  queue {q}: busy {b / 1e6 / steps:7.3f} ms/step, {len(ivs) / steps:6.1f} launches/step, gaps <= 20 us "
               f"{small / 1e6 / steps:6.3f} ms/step ({len([g for g in gaps_q if g <= 20000]) / steps:.0f}/step), gaps > 20 us "
               f"{(sum(gaps_q) - small) / 1e6 / steps:6.3f} ms/step")
+    # where the busiest queue (the compute stream) waits: its gaps > 20 us grouped by the kernels on either side -- a wait for
+    # another stream, a host stall or a step boundary each leave a recognisable pair
+    q, ivs = max(byq.items(), key=lambda kv: sum(e - s for s, e, _ in kv[1]))
+    ivs.sort()
+    pairs = defaultdict(lambda: [0, 0])
+
+    def short(nm):
+        nm = nm.replace("void ", "")
+        return nm[:nm.index("(")][:58] if "(" in nm else nm[:58]
+    for i in range(len(ivs) - 1):
+        g = ivs[i + 1][0] - ivs[i][1]
+        if g > 20000:
+            k = (short(ivs[i][2]), short(ivs[i + 1][2]))
+            pairs[k][0] += g
+            pairs[k][1] += 1
+    print(f"queue {q}: gaps > 20 us by (kernel before -> kernel after), ms/step, count/step, avg us")
+    for (a, b2), (g, c) in sorted(pairs.items(), key=lambda kv: -kv[1][0])[:14]:
+        print(f"  {g / 1e6 / steps:6.3f} {c / steps:5.1f} {g / c / 1e3:7.1f}  {a}  ->  {b2}")
