@@ -489,6 +489,7 @@ WGQ_CASES = [
     (2, 32, 64, 4, 140, 9, 4, 1),        # grouped, 16 x 8 channels per group: all 4 groups packed into one tile
     (1, 48, 96, 6, 100, 3, 1, 1),        # 6 groups of 16 x 8: packed in pairs (largest power of two dividing 6)
     (2, 128, 64, 2, 90, 3, 1, 1),        # 32 x 64 per group: nothing to pack
+    (2, 40, 200, 1, 150, 5, 2, 1),       # 5 taps, 200 output channels: the 128 x 64 tile at one workgroup per CU (round 4), ragged rows
 ]
 
 
