@@ -326,11 +326,11 @@ __global__ __launch_bounds__(256) void svb_crop_drop_inorm_fwd_kernel(const floa
     float mean = 0.f, mul = s, add = 0.f;           // out = u * mul' + add with u = y4 * s
     if (gamma) {
         float sum = 0.f;
-        for (int e = threadIdx.x; e < HW; e += 256) sum += src[(e / Wo) * P + e % Wo] * s;
+        for (SvbDiv256 dv(Wo); dv.q < Ho; dv.next()) sum += src[dv.q * P + dv.m] * s;
         mean = svb_block_sum<256>(sum, red) / (float)HW;
         float sq = 0.f;
-        for (int e = threadIdx.x; e < HW; e += 256) {
-            const float d = src[(e / Wo) * P + e % Wo] * s - mean;
+        for (SvbDiv256 dv(Wo); dv.q < Ho; dv.next()) {
+            const float d = src[dv.q * P + dv.m] * s - mean;
             sq += d * d;
         }
         const float var = svb_block_sum<256>(sq, red) / (float)HW;
@@ -342,12 +342,12 @@ __global__ __launch_bounds__(256) void svb_crop_drop_inorm_fwd_kernel(const floa
             stats[2L * blockIdx.x + 1] = rstd;
         }
     }
-    for (int e = threadIdx.x; e < HW; e += 256) {
-        const int i = e / Wo, j = e - i * Wo;
+    for (SvbDiv256 dv(Wo); dv.q < Ho; dv.next()) {
+        const int i = dv.q, j = dv.m;
         const float u = src[i * P + j] * s;
         const float v = gamma ? (u - mean) * mul + add : u;
         if (s2d) out[svb_s2d_index(c, n, i, j, N, C, Ho, Wo)] = v;
-        else dst[e] = v;
+        else dst[i * Wo + j] = v;
     }
 }
 
@@ -369,16 +369,16 @@ __global__ __launch_bounds__(256) void svb_crop_drop_inorm_bwd_kernel(const floa
     };
     for (int e = threadIdx.x; e < P + Ho; e += 256) dy4[plane + (e < P ? e : (long)(e - P + 1) * P)] = 0.f;      // border
     if (!gamma) {
-        for (int e = threadIdx.x; e < HW; e += 256) {
-            const int i = e / Wo, j = e - i * Wo;
+        for (SvbDiv256 dv(Wo); dv.q < Ho; dv.next()) {
+            const int i = dv.q, j = dv.m;
             dst[i * P + j] = dval(i, j) * s;
         }
         return;
     }
     const float mean = stats[2L * blockIdx.x], rstd = stats[2L * blockIdx.x + 1], g = gamma[c];
     float s1 = 0.f, s2 = 0.f;
-    for (int e = threadIdx.x; e < HW; e += 256) {
-        const int i = e / Wo, j = e - i * Wo;
+    for (SvbDiv256 dv(Wo); dv.q < Ho; dv.next()) {
+        const int i = dv.q, j = dv.m;
         const float d = dval(i, j);
         s1 += d;
         s2 += d * ((src[i * P + j] * s - mean) * rstd);
@@ -386,8 +386,8 @@ __global__ __launch_bounds__(256) void svb_crop_drop_inorm_bwd_kernel(const floa
     s1 = svb_block_sum<256>(s1, red);
     s2 = svb_block_sum<256>(s2, red);
     const float m1 = s1 * g / (float)HW, m2 = s2 * g / (float)HW;
-    for (int e = threadIdx.x; e < HW; e += 256) {
-        const int i = e / Wo, j = e - i * Wo;
+    for (SvbDiv256 dv(Wo); dv.q < Ho; dv.next()) {
+        const int i = dv.q, j = dv.m;
         const float xh = (src[i * P + j] * s - mean) * rstd;
         dst[i * P + j] = rstd * (dval(i, j) * g - m1 - xh * m2) * s;
     }

@@ -22,14 +22,17 @@ struct SsimWin { float g[SSIM_W]; };
 
 struct SsimStats { float mu1, mu2, e11, e22, e12; };
 
+typedef SvbDiv256 SsimDiv;        // (svb_common.h: division-free (row, column) walk of a 256-thread workgroup)
+
 // The gaussian window is separable: the five moment images are filtered along the bins first (every staged row, into `hm`:
 // 5 planes of rows x F), then along the frames per output pixel -- 11 + 11 taps per moment instead of 121.  (Round 3: the
 // full 2-D windows made these kernels VALU/LDS-bound -- ~1.2 k VALU ops and 242 LDS reads per pixel, 70 us per call at
 // [32, 1124, 80] for 23 MB of input -- the separable form needs ~150 and ~90.)
 __device__ __forceinline__ void ssim_hpass5(const float* xs, const float* ys, int ld, int F, int rows, const SsimWin& w, float* hm) {
     const int n = rows * F;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int r = i / F, c = i - r * F;
+    SsimDiv dv(F);
+    for (int i = threadIdx.x; i < n; i += 256, dv.next()) {
+        const int r = dv.q, c = dv.m;
         const float* xr = xs + r * ld + c;
         const float* yr = ys + r * ld + c;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
@@ -65,8 +68,9 @@ __device__ __forceinline__ SsimStats ssim_vpass5(const float* hm, int n, int row
 __device__ __forceinline__ void ssim_hpass3(const float* ga, const float* gb, const float* gc, int ld, int F, int rows,
                                             const SsimWin& w, float* hm) {
     const int n = rows * F;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int r = i / F, c = i - r * F;
+    SsimDiv dv(F);
+    for (int i = threadIdx.x; i < n; i += 256, dv.next()) {
+        const int r = dv.q, c = dv.m;
         const int base = r * ld + c;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
@@ -110,11 +114,11 @@ __device__ __forceinline__ void ssim_stage(const float* p, long sb, long st, lon
     const float* pb = p + (long)b * sb;
     float v[SSIM_STAGE_IT];
     int di[SSIM_STAGE_IT];
+    SsimDiv dv(tmaj ? rows : ld);
 #pragma unroll
-    for (int k = 0; k < SSIM_STAGE_IT; ++k) {
+    for (int k = 0; k < SSIM_STAGE_IT; ++k, dv.next()) {
         const int i = threadIdx.x + 256 * k;
-        int r, c;
-        if (tmaj) { c = i / rows; r = i - c * rows; } else { r = i / ld; c = i - r * ld; }
+        const int r = tmaj ? dv.m : dv.q, c = tmaj ? dv.q : dv.m;
         const int t = t_first + r, f = c - SSIM_R;
         const bool ok = i < n && t >= 0 && t < T && f >= 0 && f < F;
         di[k] = i < n ? r * ld + c : -1;
@@ -141,8 +145,8 @@ __global__ __launch_bounds__(256) void svb_ssim_fwd_kernel(const float* pred, lo
     ssim_hpass5(xs, ys, ld, F, rows, w, hm);
     __syncthreads();
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-    for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
-        const int r = i / F, c = i - r * F;
+    for (SsimDiv dv(F); dv.q < SSIM_TT; dv.next()) {
+        const int r = dv.q, c = dv.m;
         const int t = t0 + r;
         if (t >= T) continue;
         const SsimStats s = ssim_vpass5(hm, hn, r, c, F, w);
@@ -170,8 +174,8 @@ __global__ __launch_bounds__(256) void svb_ssim_bwd1_kernel(const float* pred, l
     __syncthreads();
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     const long plane = (long)B * T * F;
-    for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
-        const int r = i / F, c = i - r * F;
+    for (SsimDiv dv(F); dv.q < SSIM_TT; dv.next()) {
+        const int r = dv.q, c = dv.m;
         const int t = t0 + r;
         if (t >= T) continue;
         const SsimStats s = ssim_vpass5(hm, hn, r, c, F, w);
@@ -209,8 +213,8 @@ __global__ __launch_bounds__(256) void svb_ssim_bwd2_kernel(const float* pred, l
     __syncthreads();
     ssim_hpass3(ga, gb, gc, ld, F, rows, w, hm);
     __syncthreads();
-    for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
-        const int r = i / F, c = i - r * F;
+    for (SsimDiv dv(F); dv.q < SSIM_TT; dv.next()) {
+        const int r = dv.q, c = dv.m;
         const int t = t0 + r;
         if (t >= T) continue;
         float fa, fb, fc;
@@ -235,8 +239,8 @@ __device__ __forceinline__ void mel_speech_rows(const float* tgt, long tsb, long
                                                 float* wrow) {
     if (threadIdx.x < SSIM_TT) wrow[threadIdx.x] = 0.f;
     __syncthreads();
-    for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
-        const int r = i / F, c = i - r * F;
+    for (SsimDiv dv(F); dv.q < SSIM_TT; dv.next()) {
+        const int r = dv.q, c = dv.m;
         const int t = t0 + r;
         if (t < T && tgt[(long)b * tsb + (long)t * tst + (long)c * tsf] != 0.f) wrow[r] = 1.f;   // (benign race: one value)
     }
@@ -266,8 +270,8 @@ __global__ __launch_bounds__(256) void svb_mel_loss_fwd_kernel(const float* pred
     }
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     float a_l1 = 0.f, a_ss = 0.f, a_w = 0.f;
-    for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
-        const int r = i / F, c = i - r * F;
+    for (SsimDiv dv(F); dv.q < SSIM_TT; dv.next()) {
+        const int r = dv.q, c = dv.m;
         const int t = t0 + r;
         if (t >= T) continue;
         const float wt = wrow[r];
@@ -325,8 +329,8 @@ __global__ __launch_bounds__(256) void svb_mel_loss_bwd1_kernel(const float* pre
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     const long plane = (long)B * T * F;
     const float gs = -gout[1] / sums[2];
-    for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
-        const int r = i / F, c = i - r * F;
+    for (SsimDiv dv(F); dv.q < SSIM_TT; dv.next()) {
+        const int r = dv.q, c = dv.m;
         const int t = t0 + r;
         if (t >= T) continue;
         const SsimStats s = ssim_vpass5(hm, hn, r, c, F, w);
@@ -371,8 +375,8 @@ __global__ __launch_bounds__(256) void svb_mel_loss_bwd2_kernel(const float* pre
         __syncthreads();
     }
     const float gl = (terms & 1) ? gout[0] / sums[2] : 0.f;
-    for (int i = threadIdx.x; i < SSIM_TT * F; i += 256) {
-        const int r = i / F, c = i - r * F;
+    for (SsimDiv dv(F); dv.q < SSIM_TT; dv.next()) {
+        const int r = dv.q, c = dv.m;
         const int t = t0 + r;
         if (t >= T) continue;
         const float p = pred[(long)b * psb + (long)t * pst + (long)c * psf];

@@ -52,6 +52,21 @@ __device__ __forceinline__ float svb_block_sum(float v, float* red) {
     return t;
 }
 
+// (q, m) = (i / W, i % W) of the elements i = threadIdx.x + 256 k a thread of a 256-thread workgroup visits, without a division per
+// element.  A wave64 VALU instruction issues in 4 cycles on CDNA and a runtime integer division is ~20 of them: in the stencil and
+// plane kernels (ssim.hip, conv2d.hip) the index arithmetic was a third to a half of the instruction stream (round 4).
+struct SvbDiv256 {
+    int q, m, dq, dm, W;
+    __device__ __forceinline__ explicit SvbDiv256(int W_) : W(W_) {
+        q = (int)threadIdx.x / W_; m = (int)threadIdx.x - q * W_;
+        dq = 256 / W_; dm = 256 - dq * W_;
+    }
+    __device__ __forceinline__ void next() {
+        q += dq; m += dm;
+        if (m >= W) { m -= W; ++q; }
+    }
+};
+
 static inline int svb_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Experiment switches and cycle stamps exist only in the instrumentation build (`make instr` -> libsvb_hip_instr.so,

@@ -723,3 +723,36 @@ def test_period_strided_conv_matches_conv2d(dev, case, precision):
     assert rel_err(y.view(yr.shape), yr) < tol
     for got, ref in ((xd.grad, rl[0].grad), (vd.grad, rl[1].grad), (gd.grad, rl[2].grad), (bd.grad, rl[3].grad)):
         assert rel_err(got, ref) < 5 * tol
+
+
+@pytest.mark.parametrize("big", [False, pytest.param(True, marks=pytest.mark.gpu)])
+def test_period_s2d_index_walk(dev, big):
+    """svb_period_s2d walks the element index as a mixed-radix counter advancing by the grid's stride (no division per element);
+    `big` (MI355X only) is a tensor of 5.9 M elements, more than the 16384 x 256 threads of the capped grid, so every thread
+    wraps its digits several times.  Forward and inverse against index arithmetic in torch, bit for bit."""
+    from neuralsvb_amd import kernels as K
+    if big and dev.type != "cuda":
+        pytest.skip("needs more elements than the lane emulator walks in reasonable time")
+    B, C, H, p, s, lead = (6, 96, 173, 7, 3, 2) if big else (2, 5, 23, 3, 3, 1)
+    h_out = (H + 2 * 2 - 5) // s + 1
+    R = lead + h_out + 1
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, C, H * p, generator=g)
+    x3 = x.view(B, C, H, p)
+    img = torch.zeros(B, C, s, R, p)
+    for r in range(s):
+        for row in range(lead, R):
+            hh = s * (row - lead) + r
+            if hh < H:
+                img[:, :, r, row] = x3[:, :, hh]
+    got = K.period_s2d(x.to(dev), H, p, s, lead, R)
+    assert torch.equal(got.cpu(), img.view(B, C * s, R * p))
+    gi = torch.randn(B, C * s, R * p, generator=g)
+    gi5 = gi.view(B, C, s, R, p)
+    back = torch.zeros(B, C, H, p)
+    for hh in range(H):
+        r, row = hh % s, lead + hh // s
+        if row < R:
+            back[:, :, hh] = gi5[:, :, r, row]
+    got_b = K.period_s2d(gi.to(dev), H, p, s, lead, R, inverse=True)
+    assert torch.equal(got_b.cpu(), back.view(B, C, H * p))
