@@ -288,17 +288,20 @@ extern "C" int svb_f0_to_coarse_f32(const float* f0, int64_t* out, int64_t n, vo
 // (vocabulary row, clip) scans the clip's indices in t order -- a coalesced 64-index read + ballot per wave step -- and thread h
 // adds dy[b][h][t] of every match to its register; a second kernel adds the per-clip partial sums [B][V][H] in clip order.
 // ------------------------------------------------------------------------------------------------------------------
+// grid (T / 256, channel slabs, B): a thread owns one position t of one clip, reads its index once and walks the slab's channels --
+// out rows are written coalesced along t, the embedding row w[v][.] is read along h (L1 / L2 resident: V x H floats), and there is
+// no index arithmetic per element (the flat form's two 64-bit divisions per element made this 37 MB write take 99 us, round 4).
+#define SVB_EMBED_HSLAB 32
 __global__ __launch_bounds__(256) void svb_embed_nct_fwd_kernel(const int64_t* idx, const float* w, float* out, int B, int H, int T,
                                                                 int V) {
-    const long total = (long)B * H * T;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int t = (int)(i % T);
-        const long r = i / T;
-        const int h = (int)(r % H);
-        const int b = (int)(r / H);
-        const int64_t v = idx[(long)b * T + t];
-        out[i] = (v >= 0 && v < V) ? w[v * H + h] : 0.f;
-    }
+    const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.z;
+    if (t >= T) return;
+    const int h0 = blockIdx.y * SVB_EMBED_HSLAB, h1 = h0 + SVB_EMBED_HSLAB < H ? h0 + SVB_EMBED_HSLAB : H;
+    const int64_t v = idx[(long)b * T + t];
+    const bool ok = v >= 0 && v < V;
+    const float* wr = w + (ok ? v : 0) * H;
+    float* o = out + ((long)b * H + h0) * T + t;
+    for (int h = h0; h < h1; ++h, o += T) *o = ok ? wr[h] : 0.f;
 }
 
 // part[b][v][h] = sum over t with idx[b][t] == v of dy[b][h][t], in t order.  grid (V, B): a (row, clip) pair without a match
@@ -346,9 +349,9 @@ __global__ __launch_bounds__(256) void svb_embed_nct_bwd_sum_kernel(const float*
 
 extern "C" int svb_embed_nct_fwd(const int64_t* idx, const float* w, float* out, int B, int H, int T, int V, void* stream) {
     if (!idx || !w || !out || B <= 0 || H <= 0 || T <= 0 || V <= 0) return SVB_ERR_ARG;
-    const long total = (long)B * H * T;
-    const int grid = (int)((total + 255) / 256 > 65535 * 8 ? 65535 * 8 : (total + 255) / 256);
-    hipLaunchKernelGGL(svb_embed_nct_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, w, out, B, H, T, V);
+    if (B > 65535 || (H + SVB_EMBED_HSLAB - 1) / SVB_EMBED_HSLAB > 65535) return SVB_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(svb_embed_nct_fwd_kernel, dim3((T + 255) / 256, (H + SVB_EMBED_HSLAB - 1) / SVB_EMBED_HSLAB, B), dim3(256), 0,
+                       (hipStream_t)stream, idx, w, out, B, H, T, V);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
