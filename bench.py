@@ -431,6 +431,23 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: re-exec this command line under torch.distributed.run with one
+    rank per GPU (the reference's Trainer spawns its own ranks the same way, utils/trainer.py:453-466; tasks/run.py here does
+    too).  Under torchrun / the driver's own launcher WORLD_SIZE is set and this is never reached."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {n} without WORLD_SIZE: starting {n} ranks: {' '.join(cmd[1:9])} ...")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     import faulthandler
     faulthandler.dump_traceback_later(600, exit=False, file=sys.stderr)
@@ -471,13 +488,24 @@ def main():
                          "longer stalls: 40.1 vs 38.1 ms/step)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))          # `python bench.py --gpus N`: start the N ranks ourselves
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py measures the HIP path: an MI355X is required"
-    local = local % torch.cuda.device_count()
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    emu = os.environ.get("SVB_BENCH_EMU_LIB")      # TEST HARNESS ONLY (tests/test_ddp_gloo.py): the CPU lane emulator build of
+    if emu:                                        # the kernel sources, so the launcher + N > 1 path run in a GPU-less container
+        from neuralsvb_amd import _lib
+        _lib._LIB, _lib._LIB_IS_EMU = _lib.bind(emu), True
+        device = torch.device("cpu")
+        os.environ.setdefault("SVB_DIST_BACKEND", "gloo")
+    else:
+        assert torch.cuda.is_available(), "bench.py measures the HIP path: an MI355X is required"
+        local = local % torch.cuda.device_count()
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    gpu = device.type == "cuda"
+    sync = torch.cuda.synchronize if gpu else (lambda: None)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # ("nccl" = RCCL on ROCm.  SVB_DIST_BACKEND=gloo: the 2-ranks-on-one-GPU test of the N > 1 stream handling, where RCCL
@@ -507,31 +535,32 @@ def main():
         T = batch["mels"].shape[1]
         log(f"task ready, batch mels {tuple(batch['mels'].shape)}; warmup")
         run_steps(trainer, task, batch, args.warmup, 1)
-        torch.cuda.synchronize()
+        sync()
         log("timed region")
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         if os.environ.get("SVB_BENCH_MARKERS"):      # rocprofv3 runs: a spin kernel brackets the timed region in the kernel trace
             torch.cuda._sleep(1000)
-            torch.cuda.synchronize()
+            sync()
         for gsync in trainer.grad_sync:
             if gsync is not None and world > 1:
                 gsync.measure_wait = True           # two event records per pass: device time the compute stream waits for RCCL
-        step_events = []
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev0.record()
+        step_events = [] if gpu else None
+        if gpu:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         t0 = time.perf_counter()
         run_steps(trainer, task, batch, args.steps, 1 + args.warmup, step_events)
         t_host = time.perf_counter() - t0           # host side done issuing; the GPU may still be working
-        torch.cuda.synchronize()
+        sync()
         log(f"host finished issuing {args.steps} steps after {t_host / args.steps * 1e3:.2f} ms/step")
         if os.environ.get("SVB_BENCH_MARKERS"):
             torch.cuda._sleep(1000)
-            torch.cuda.synchronize()
+            sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         dt = time.perf_counter() - t0
         t_rank = dt
         exposed_ms = 0.0
@@ -544,30 +573,30 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = tt.item()
         ms = dt / args.steps * 1e3
-        per_step = sorted(a.elapsed_time(b) for a, b in zip([ev0] + step_events[:-1], step_events))
+        per_step = sorted(a.elapsed_time(b) for a, b in zip([ev0] + step_events[:-1], step_events)) if gpu else []
         ms_median = per_step[len(per_step) // 2] if per_step else None
-        log(f"{ms:.2f} ms/step (median of the per-step device times {ms_median:.2f})")
+        log(f"{ms:.2f} ms/step (median of the per-step device times {ms_median})")
         value = args.batch * args.seconds * world / (dt / args.steps)
         # the same steps with the batch handed over as (pinned) HOST buffers: one H2D copy per step inside the timed region
         # (SURVEY 8d's step definition; reported beside `value`, never as it)
         from neuralsvb_amd.utils.trainer import move_to_device
-        host = {k: (v.cpu().pin_memory() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
-        n_h2d, w_h2d = max(20, args.steps), 3      # (3 untimed steps first: the look-ahead pipeline is full when the clock starts)
+        host = {k: (v.cpu().pin_memory() if isinstance(v, torch.Tensor) and gpu else v) for k, v in batch.items()}
+        n_h2d, w_h2d = (max(20, args.steps), 3) if gpu else (1, 0)  # (3 untimed steps first: the look-ahead pipeline is full when the clock starts)
         cur_hb = dict(host)
         for i in range(w_h2d + n_h2d):
             if i == w_h2d:
-                torch.cuda.synchronize()
+                sync()
                 t1 = time.perf_counter()
             task.global_step = trainer.global_step = 1 + args.warmup + args.steps + i
             hb_next = dict(host)
             trainer.run_training_batch(i, cur_hb, next_batch=hb_next)      # (the loop's look-ahead: the next batch's copy overlaps)
             cur_hb = hb_next
-        torch.cuda.synchronize()
+        sync()
         ms_h2d = (time.perf_counter() - t1) / n_h2d * 1e3
         n_h2d += w_h2d
         log(f"{ms_h2d:.2f} ms/step with the H2D copy of the batch inside the step")
         split = n1_ddp = phase3 = None
-        if rank == 0 and world == 1 and not args.graph:
+        if rank == 0 and world == 1 and not args.graph and gpu:
             nxt = 1 + args.warmup + args.steps + n_h2d
             split = step_split(trainer, task, batch, 10, nxt)
             log("step split: " + ", ".join(f"{k} {v:.2f}" for k, v in split.items() if isinstance(v, float)))
@@ -578,10 +607,10 @@ def main():
             hp["defer_wgrad_reduce"] = False
             try:
                 run_steps(trainer, task, batch, 3, nxt + 10)
-                torch.cuda.synchronize()
+                sync()
                 t2 = time.perf_counter()
                 run_steps(trainer, task, batch, 12, nxt + 13)
-                torch.cuda.synchronize()
+                sync()
                 n1_ddp = (time.perf_counter() - t2) / 12 * 1e3
             finally:
                 if saved is None:
@@ -593,10 +622,10 @@ def main():
             # the a2p way's critic term, backward into the map only (svb_vae_task.py:593-676)
             p3 = int(hp["phase_2_steps"]) + 10
             run_steps(trainer, task, batch, 6, p3)            # warm-up: new launch signatures get their tiles measured
-            torch.cuda.synchronize()
+            sync()
             t3 = time.perf_counter()
             run_steps(trainer, task, batch, 15, p3 + 6)
-            torch.cuda.synchronize()
+            sync()
             ms3 = (time.perf_counter() - t3) / 15 * 1e3
             phase3 = {"ms_per_step": ms3, "value": args.batch * args.seconds / (ms3 * 1e-3), "unit": "audio-seconds/sec", "steps": 15,
                       "warmup": 6, "workload": "vae_global_mle_eng phase-3 step (latent-map optimizer: a2a + p2p + a2p forward, MLE + "
@@ -608,7 +637,7 @@ def main():
         # -- host collater + one H2D copy per field (the reference's way) against slicing into pinned staging buffers + the
         # collate / norm_interp_f0 kernels (tasks/device_collate.py).  Not part of `value`.
         data_side = None
-        if rank == 0 and world == 1:
+        if rank == 0 and world == 1 and gpu:
             from neuralsvb_amd.tasks.device_collate import DeviceCollater
             ds = task.dataset_cls("train", False)
             idx = list(range(min(args.batch, len(ds))))
@@ -616,11 +645,11 @@ def main():
 
             def clock(fn, n=5):
                 fn()
-                torch.cuda.synchronize()
+                sync()
                 t = time.perf_counter()
                 for _ in range(n):
                     fn()
-                torch.cuda.synchronize()
+                sync()
                 return (time.perf_counter() - t) / n * 1e3
             data_side = {"clips": len(idx),
                          "host_collate_h2d_ms": clock(lambda: move_to_device(ds.collater([ds[i] for i in idx]), device)),
@@ -642,8 +671,9 @@ def main():
                     "side_stream_weight_gradients": hp.get("wgrad_side_stream", True) and not args.no_side_stream,
                     "critic_pass_on_own_stream": hp.get("overlap_critic_pass", True)}
         roof = cpu = None
-        if rank == 0 and not args.no_roofline:
-            roof = conv_roofline(trainer, task, batch, 3, 1 + args.warmup + args.steps, args.precision) if world == 1 else None
+        if not args.no_roofline and gpu:
+            # (N > 1: every rank runs the profiled steps -- they hold collectives --, rank 0 reports its own launches)
+            roof = conv_roofline(trainer, task, batch, 3, 1 + args.warmup + args.steps, args.precision)
             if roof is not None:
                 # the same launches with nothing beside them: in the benchmarked configuration weight gradients, the critic pass
                 # and the PPG encoder run on their own streams, and a conv's HIP events then include the time it shared the CUs

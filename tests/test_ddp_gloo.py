@@ -197,6 +197,32 @@ def test_bench_multi_rank_path_two_ranks_gloo(tmp_path, _emu_lib):
     assert np.isfinite(w0).all() and np.array_equal(w0, w1)
 
 
+def test_bench_command_line_starts_its_own_ranks(tmp_path, _emu_lib):
+    """`python bench.py --gpus 2` with no launcher around it (the driver's form of the command, as it runs `--gpus 1`): bench.py
+    re-execs itself under torch.distributed.run with one rank per device (reference utils/trainer.py:453-466 spawns its own
+    ranks too), the ranks run the N > 1 step over gloo on the lane emulator, and rank 0 prints ONE JSON line whose
+    `comm.ranks` is 2 and whose value counts both ranks' clips."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import EMU_LIB
+    small = ("hidden_size=32,fvae_enc_dec_hidden=32,latent_size=16,fvae_enc_n_layers=2,fvae_dec_n_layers=2,"
+             "mel_disc_hidden_size=16,warmup_updates=4")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SVB_BENCH_EMU_LIB=EMU_LIB, SVB_DIST_BACKEND="gloo", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2",
+                        "--seconds", "0.71", "--precision", "fp32", "--no-cpu-baseline", "--no-extra-workloads",
+                        "--extra-hparams", small], env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["comm"]["ranks"] == 2 and res["scaling"] == "weak"
+    assert res["config"]["global_batch"] == 4 and res["config"]["parallelism"] == "dp2"
+    assert abs(res["value"] - 2 * 2 * 0.71 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]
+    assert res["comm"]["buckets_launched_in_backward"] > 0
+
+
 def _gpu_pair_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
