@@ -427,6 +427,27 @@ def _roofline_from_records(rec, steps, precision):
                                  "ms_per_step": tot_s / steps * 1e3}}
 
 
+def gpu_state():
+    """sclk / mclk / power cap of device 0 as rocm-smi reports them right after the timed work (None where unavailable): the
+    box-to-box spread of the step time follows these, so they ride on the line."""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        r = subprocess.run([exe, "-d", "0", "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        d = json.loads(r.stdout)
+        card = d.get("card0") or next(iter(d.values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "power", "performance level")):
+                keep[k] = v
+        return keep or None
+    except Exception as e:                 # never fail the line for a monitoring field
+        return {"error": repr(e)[:200]}
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -482,6 +503,7 @@ def main():
                     help="default N=1 line only: skip the short configs[2] (vocoder step) and configs[4] (inference RTF) runs that "
                          "are reported under `extra_workloads`")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-settle", action="store_true", help="skip the extra untimed warm-up groups (see `warmup_settle` in the line)")
     ap.add_argument("--graph", action="store_true",
                     help="replay each optimizer pass's forward+backward as a captured hipGraph instead of issuing the launches "
                          "from Python (measured slower than the asynchronous eager stream on ROCm 7.2 once the host no "
@@ -536,6 +558,28 @@ def main():
         log(f"task ready, batch mels {tuple(batch['mels'].shape)}; warmup")
         run_steps(trainer, task, batch, args.warmup, 1)
         sync()
+        # the W warm-up steps are followed by (untimed) groups of 5 steps until two consecutive group medians agree to 1 %: a
+        # fresh box ramps its clocks over the first tens of milliseconds of load, and the timed region should not hold the ramp
+        settle = {"extra_steps": 0, "group_median_ms": []}
+        if gpu and not args.no_settle:
+            nxt_step = 1 + args.warmup
+            for _ in range(12):
+                evs = [torch.cuda.Event(enable_timing=True)]
+                evs[0].record()
+                run_steps(trainer, task, batch, 5, nxt_step, evs)
+                sync()
+                nxt_step += 5
+                ts = sorted(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
+                if world > 1:           # every rank must run the same number of steps (they hold collectives): slowest rank decides
+                    tm = torch.tensor([ts[2]], device=device, dtype=torch.float64)
+                    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                    ts[2] = tm.item()
+                settle["group_median_ms"].append(round(ts[2], 3))
+                settle["extra_steps"] += 5
+                g = settle["group_median_ms"]
+                if len(g) >= 2 and abs(g[-1] - g[-2]) <= 0.01 * g[-2]:
+                    break
+            log(f"settled after {settle['extra_steps']} extra warm-up steps: group medians {settle['group_median_ms']}")
         log("timed region")
         if world > 1:
             dist.barrier()
@@ -550,9 +594,13 @@ def main():
         if gpu:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record()
+        from neuralsvb_amd import kernels as K
+        calls0 = K.ABI_CALLS
         t0 = time.perf_counter()
         run_steps(trainer, task, batch, args.steps, 1 + args.warmup, step_events)
         t_host = time.perf_counter() - t0           # host side done issuing; the GPU may still be working
+        abi_calls = K.ABI_CALLS - calls0
+        tile_info = K.tile_table_info()             # (taken here: what the TIMED steps ran with)
         sync()
         log(f"host finished issuing {args.steps} steps after {t_host / args.steps * 1e3:.2f} ms/step")
         if os.environ.get("SVB_BENCH_MARKERS"):
@@ -733,7 +781,9 @@ def main():
                                        f"{'hipGraph replay' if args.graph else 'eager launches'}, "
                                        f"hop 128, T={T}, 80-bin mel", "global_batch": args.batch * world,
                            "parallelism": f"dp{world}", "random_init_weights": True},
-                "ms_per_step_median": ms_median,
+                "ms_per_step_median": ms_median, "host_issue_ms": t_host / args.steps * 1e3,
+                "c_abi_calls_per_step": abi_calls / args.steps, "warmup_settle": settle,
+                "tile_table": tile_info, "gpu_state": gpu_state(),
                 "value_with_h2d": args.batch * args.seconds * world / (ms_h2d * 1e-3), "ms_per_step_with_h2d": ms_h2d,
                 "step_split": split, "n1_with_ddp_constraints_ms": n1_ddp, "phase3": phase3,
                 "comm": comm, "data_side": data_side, "roofline": roof, "cpu_baseline": cpu,

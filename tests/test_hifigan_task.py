@@ -88,8 +88,9 @@ def test_multi_resolution_stft_loss_matches_numpy_restatement():
     assert abs(s.item() - sc / 3) < 1e-4 and abs(m.item() - mg / 3) < 1e-4
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("ms_stft", [False, True])
-def test_vocoder_training_step_matches_cpu_oracle(dev, tmp_path, ms_stft):
+def test_vocoder_training_step_matches_cpu_oracle(dev, tmp_path, ms_stft, precision):
     """One Trainer step of HifiGanTask (generator pass: mel L1 [+ ms-STFT] + adversarial terms; discriminator pass) on the HIP
     kernels vs the oracle's CPU port of the same step: loss terms and every parameter gradient (pre-clipping)."""
     if dev.type == "cpu" and not os.environ.get("SVB_SLOW_EMU"):
@@ -97,7 +98,8 @@ def test_vocoder_training_step_matches_cpu_oracle(dev, tmp_path, ms_stft):
     from neuralsvb_amd.tasks.hifigan_task import HifiGanTask
     from neuralsvb_amd.utils.trainer import Trainer, move_to_device
     from oracle.vocoder_step_ref import vocoder_step_terms
-    hp = _env(tmp_path, ",use_ms_stft=True" if ms_stft else "")
+    hp = _env(tmp_path, (",use_ms_stft=True" if ms_stft else "") + f",conv_precision={precision}")
+    ttol, gtol = (2e-4, 5e-3) if precision == "fp32" else (1e-3, 1.5e-2)      # stated: loss terms (rel), gradients (rel l2)
     trainer = Trainer(work_dir="", num_sanity_val_steps=0)
     trainer.on_gpu = dev.type == "cuda"
     trainer.world_size, trainer.use_ddp = 1, False
@@ -132,9 +134,9 @@ def test_vocoder_training_step_matches_cpu_oracle(dev, tmp_path, ms_stft):
     task.global_step = trainer.global_step = 1
     trainer.run_training_batch(0, move_to_device(host, dev))
     for k, v in tg.items():
-        assert abs(rec[0][k] - v) <= 2e-4 * max(1.0, abs(v)), ("gen", k, rec[0][k], v)
+        assert abs(rec[0][k] - v) <= ttol * max(1.0, abs(v)), ("gen", k, rec[0][k], v)
     for k, v in td.items():
-        assert abs(rec[1][k] - v) <= 2e-4 * max(1.0, abs(v)), ("disc", k, rec[1][k], v)
+        assert abs(rec[1][k] - v) <= ttol * max(1.0, abs(v)), ("disc", k, rec[1][k], v)
 
     def cmp(mine, ref, tag, tol):
         worst = 0.0
@@ -143,6 +145,6 @@ def test_vocoder_training_step_matches_cpu_oracle(dev, tmp_path, ms_stft):
             worst = max(worst, rel)
             assert rel < tol, (tag, k, rel)
         return worst
-    w = [cmp(rec[("g", 0)][0], gg, "generator", 5e-3), cmp(rec[("g", 1)][0], pg, "mpd", 5e-3),
-         cmp(rec[("g", 1)][1], sg, "msd", 5e-3)]
-    print("worst relative gradient errors (G, MPD, MSD):", w)
+    w = [cmp(rec[("g", 0)][0], gg, "generator", gtol), cmp(rec[("g", 1)][0], pg, "mpd", gtol),
+         cmp(rec[("g", 1)][1], sg, "msd", gtol)]
+    print(f"[{precision}] worst relative gradient errors (G, MPD, MSD):", w)

@@ -33,21 +33,40 @@ def test_state_dict_layouts_match_reference():
     _load(MultiScaleDiscriminator(), "MultiScaleDiscriminator", "model_disc.msd.")
 
 
+# Stated tolerances per conv arithmetic (`conv_precision`): fp32 = fp32 MFMA, bf16x3 = bf16 matrix cores with the fp32-class operand
+# split.  |wav| <= 1.  bf16x3 bounds are 2.5x the fp32 ones (one product carries ~1e-5 relative noise instead of ~1e-7; the
+# 72-conv generator with x128 upsampling is where it compounds -- measured values are printed by the tests).
+PREC = ["fp32", "bf16x3"]
+WAV_TOL = {"fp32": 2e-4, "bf16x3": 5e-4}
+SCORE_TOL = {"fp32": 5e-5, "bf16x3": 2e-4}
+GRAD_TOL = {"fp32": 3e-3, "bf16x3": 1e-2}
+
+
+def _set_precision(precision):
+    from neuralsvb_amd import functional as SF
+    SF.set_precision(precision)          # (tests/conftest.py's autouse fixture restores fp32 afterwards)
+
+
 def _slow(dev):
     if dev.type == "cpu" and not os.environ.get("SVB_SLOW_EMU"):
         pytest.skip("full-size vocoder through the lane emulator takes minutes; set SVB_SLOW_EMU=1 (runs on the GPU by default)")
 
 
-def test_generator_matches_reference_golden(dev):
+@pytest.mark.parametrize("precision", PREC)
+def test_generator_matches_reference_golden(dev, precision):
     _slow(dev)
+    _set_precision(precision)
     from neuralsvb_amd.modules.hifigan import HifiGanGenerator
     d = np.load(os.path.join(G, "hifigan_gen.npz"))
     gen = _load(HifiGanGenerator(HIFIGAN_CFG), "HifiGanGenerator", "model_gen.").to(dev).eval()
     with torch.no_grad():
         wav = gen(t(d["mel"]).to(dev), t(d["f0"]).to(dev), rand_ini=t(d["rand_ini"]).to(dev), noise=t(d["noise"]).to(dev))
     assert wav.shape == d["wav"].shape
-    # waveform tolerance: 2e-4 abs (|wav| <= 1); the NSF phase differs from the reference's fp32 cumsum by its own rounding
-    assert np.abs(wav.cpu().numpy() - d["wav"]).max() < 2e-4
+    # waveform tolerance: 2e-4 abs in fp32, 5e-4 in bf16x3 (|wav| <= 1); the NSF phase differs from the reference's fp32 cumsum
+    # by its own rounding
+    err = np.abs(wav.cpu().numpy() - d["wav"]).max()
+    print(f"[{precision}] generator golden: waveform max abs error {err:.3e}")
+    assert err < WAV_TOL[precision]
     # weight-norm folding (vocoders/hifigan.py:29) must not change the output
     gen.remove_weight_norm()
     with torch.no_grad():
@@ -55,9 +74,11 @@ def test_generator_matches_reference_golden(dev):
     assert (wav2 - wav).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("precision", PREC)
 @pytest.mark.parametrize("name", ["mpd", "msd"])
-def test_discriminators_match_reference_golden(dev, name):
+def test_discriminators_match_reference_golden(dev, name, precision):
     _slow(dev)
+    _set_precision(precision)
     from neuralsvb_amd.modules.hifigan import MultiPeriodDiscriminator, MultiScaleDiscriminator
     from tests.golden.make_golden import fmap_stats
     d = np.load(os.path.join(G, "hifigan_disc.npz"))
@@ -68,16 +89,21 @@ def test_discriminators_match_reference_golden(dev, name):
     m = m.to(dev).eval()
     with torch.no_grad():
         rs, gs, fr, fg = m(t(d["y"]).to(dev), t(d["y_hat"]).to(dev))
+    worst = 0.0
     for i, (a, b) in enumerate(zip(rs, gs)):
         assert a.shape == d[f"{name}.y_d_r.{i}"].shape
         for got, ref in ((a, d[f"{name}.y_d_r.{i}"]), (b, d[f"{name}.y_d_g.{i}"])):
             # relative bound: the procedural spectral-norm buffers give the MSD scale-0 logits a ~1e13 magnitude
-            assert np.abs(got.cpu().numpy() - ref).max() < 5e-5 * max(1.0, np.abs(ref).max()), (name, i)
+            e = np.abs(got.cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
+            worst = max(worst, e)
+            assert e < SCORE_TOL[precision], (name, i, e)
     shapes = [list(x.shape) + [0] * (4 - x.dim()) for fm in fr for x in fm]
     assert np.array_equal(np.array(shapes), d[f"{name}.fmap_shapes"])
     st = np.stack([fmap_stats(x.cpu()) for fm in fr for x in fm])
     ref_st = d[f"{name}.fmap_r_stats"]
-    assert (np.abs(st - ref_st) <= 5e-5 + 3e-4 * np.abs(ref_st).max(axis=1, keepdims=True)).all()
+    k_ = SCORE_TOL[precision] / 5e-5
+    assert (np.abs(st - ref_st) <= k_ * (5e-5 + 3e-4 * np.abs(ref_st).max(axis=1, keepdims=True))).all()
+    print(f"[{precision}] {name} eval-mode logits: worst relative error {worst:.3e}")
 
 
 def test_small_generator_and_discriminators_autograd(dev):
@@ -129,12 +155,15 @@ def test_ingraph_mel_with_grad_matches_fused_kernel_and_oracle(dev):
     assert ((yd.grad.cpu() - y.grad).abs().max() / y.grad.abs().max()).item() < 2e-3
 
 
+@pytest.mark.parametrize("precision", PREC)
 @pytest.mark.parametrize("name", ["mpd", "msd"])
-def test_discriminators_train_mode_losses_and_gradients(dev, name):
+def test_discriminators_train_mode_losses_and_gradients(dev, name, precision):
     """V3 / V4 in TRAIN mode + V5 against the unmodified reference (tests/golden/make_golden.py:hifigan_train_golden):
     discriminator pass (discriminator_loss -> every parameter gradient), generator pass (generator_loss + feature_loss ->
     d/d y_hat), and the spectral-norm power iteration of MSD scale 0 (u / v buffers after the four forwards)."""
     _slow(dev)
+    _set_precision(precision)
+    gtol = GRAD_TOL[precision]
     from neuralsvb_amd.modules import hifigan as H
     from tests.golden.make_golden import grad_digest
     d = np.load(os.path.join(G, "hifigan_disc.npz"))
@@ -153,28 +182,29 @@ def test_discriminators_train_mode_losses_and_gradients(dev, name):
     y_d_rs, y_d_gs, _, _ = m(y, yh)
     lr_, lg_ = H.discriminator_loss(y_d_rs, y_d_gs)
     (lr_ + lg_).backward()
-    assert np.allclose([lr_.item(), lg_.item()], z[f"{name}.d_loss"], rtol=2e-4, atol=1e-6), (lr_.item(), lg_.item(), z[f"{name}.d_loss"])
+    assert np.allclose([lr_.item(), lg_.item()], z[f"{name}.d_loss"], rtol=2e-4 if precision == "fp32" else 1e-3, atol=1e-6), (lr_.item(), lg_.item(), z[f"{name}.d_loss"])
     worst = 0.0
     for k, p in m.named_parameters():
         ref, got = z[f"{name}.dgrad.{k}"], grad_digest(p.grad.cpu())
         rel = abs(got[0] - ref[0]) / max(ref[0], 1e-12)
         worst = max(worst, rel)
-        assert rel < 3e-3, (k, got[0], ref[0])
+        assert rel < gtol, (k, got[0], ref[0])
         rms = ref[0] / np.sqrt(p.numel())
-        assert np.abs(got[1:] - ref[1:]).max() <= 2e-2 * max(rms, np.abs(ref[1:]).max()), k
+        assert np.abs(got[1:] - ref[1:]).max() <= (gtol / 3e-3) * 2e-2 * max(rms, np.abs(ref[1:]).max()), k
     yh2 = yh.clone().requires_grad_(True)
     y_d_rs, y_d_gs, fmap_rs, fmap_gs = m(y, yh2)
     la, lf = H.generator_loss(y_d_gs), H.feature_loss(fmap_rs, fmap_gs)
     (la + lf).backward()
-    assert np.allclose([la.item(), lf.item()], z[f"{name}.g_loss"], rtol=2e-4, atol=1e-6), (la.item(), lf.item(), z[f"{name}.g_loss"])
+    assert np.allclose([la.item(), lf.item()], z[f"{name}.g_loss"], rtol=2e-4 if precision == "fp32" else 1e-3, atol=1e-6), (la.item(), lf.item(), z[f"{name}.g_loss"])
     gref = t(z[f"{name}.g_grad_yhat"])
-    assert ((yh2.grad.cpu() - gref).abs().max() / gref.abs().max()).item() < 3e-3
+    e_gy = ((yh2.grad.cpu() - gref).abs().max() / gref.abs().max()).item()
+    assert e_gy < gtol, e_gy
     if name == "msd":
         sd = m.state_dict()
         for k in z.files:
             if k.startswith("msd.buf1."):
                 assert np.abs(sd[k[len("msd.buf1."):]].cpu().numpy() - z[k]).max() < 2e-5, k
-    print(name, "worst grad-norm rel err", worst)
+    print(f"[{precision}] {name} train mode: worst grad-norm rel err {worst:.3e}, d/d y_hat {e_gy:.3e}")
 
 
 def _rel(a, b):

@@ -1,0 +1,196 @@
+"""Parity AT THE PUBLISHED SHAPES of BASELINE configs[2] (NSF-HifiGAN training, B = 64 x 8192 samples) and configs[4] (end-to-end
+inference, T = 1872 frames), in BOTH arithmetics bench.py can quote them in (`conv_precision` fp32 / bf16x3), against the
+unmodified reference (tests/golden/make_vocoder_shape_golden.py -> vocoder_b64.npz, infer_t1872.npz).
+
+Reference code under test: modules/hifigan/hifigan.py:144-169 (generator), :237-250 (MPD), :309-325 (MSD), :328-365 (losses),
+modules/voice_conversion/svb_vae.py:258-312 (MleSVBVAE), vocoders/hifigan.py:55-69 (spec2wav's generator call).
+
+STATED TOLERANCES (|wav| <= 1; measured values are printed by each test and recorded in DESIGN.md section 2):
+
+| quantity                                     | fp32   | bf16x3 |
+|----------------------------------------------|--------|--------|
+| waveform, max abs                            | 2e-4   | 5e-4   |
+| waveform, mean abs                           | 2e-5   | 5e-5   |
+| mel-L1 per way (north-star bound 1e-4)       | 1e-5   | 1e-4   |
+| discriminator / generator loss terms, rel    | 2e-4   | 1e-3   |
+| parameter-gradient l2 norms, rel             | 5e-3   | 2e-2   |
+
+GPU only: the lane emulator would need hours for these shapes.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import procedural
+from tests.golden import make_vocoder_shape_golden as MG
+from tests.test_oracle_golden import HIFIGAN_CFG
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+KEYS = json.load(open(os.path.join(G, "ref_state_keys.json")))
+
+TOL = {"fp32": dict(wav_max=2e-4, wav_mean=2e-5, mel_l1=1e-5, terms=2e-4, gnorm=5e-3, gsample=2e-2, score=2e-4),
+       "bf16x3": dict(wav_max=5e-4, wav_mean=5e-5, mel_l1=1e-4, terms=1e-3, gnorm=2e-2, gsample=6e-2, score=1e-3)}
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(module, name, prefix):
+    module.load_state_dict(procedural.state_dict_for(KEYS[name], prefix=prefix), strict=True)
+    return module
+
+
+def _check_regenerated(d, **tensors):
+    for k, v in tensors.items():
+        got, ref = MG.checksum(v.double() if not v.is_floating_point() else v), d[f"cs.{k}"]
+        assert np.allclose(got, ref, rtol=1e-12, atol=1e-12), f"regenerated `{k}` differs from the generator's (torch CPU RNG changed?)"
+
+
+class _Soft:
+    """Collect every violated bound and fail at the end, so that one run reports all measured deviations."""
+
+    def __init__(self):
+        self.fails = []
+
+    def __call__(self, ok, *what):
+        if not ok:
+            self.fails.append(what)
+
+    def done(self):
+        assert not self.fails, self.fails[:12]
+
+
+def _digest_err(got, ref, numel):
+    """(relative l2-norm error, worst sample error relative to max(rms, |samples|max)) of a [norm, 24 samples] digest."""
+    rel = abs(got[0] - ref[0]) / max(ref[0], 1e-12)
+    rms = ref[0] / np.sqrt(numel)
+    samp = np.abs(got[1:] - ref[1:]).max() / max(rms, np.abs(ref[1:]).max(), 1e-30)
+    return rel, samp
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_vocoder_b64_generator_mpd_msd_match_reference(gpu_only, precision):
+    """configs[2] shape: generator forward (train mode), discriminator pass and generator pass of both discriminators, every
+    parameter gradient, the spectral-norm buffers -- all against the reference's own run at B = 64 x 8192."""
+    from neuralsvb_amd import functional as SF
+    from neuralsvb_amd.modules import hifigan as H
+    dev, tol, soft = gpu_only, TOL[precision], _Soft()
+    d = np.load(os.path.join(G, "vocoder_b64.npz"))
+    mel, f0, y = MG.inputs_vocoder()
+    ri, nz = MG.nsf_draws(MG.VOC_B, MG.VOC_L, 32)
+    _check_regenerated(d, mel=mel, f0=f0, y=y, rand_ini=ri, noise=nz)
+    SF.set_precision(precision)
+    gen = _load(H.HifiGanGenerator(HIFIGAN_CFG), "HifiGanGenerator", "model_gen.").to(dev).train()
+    mpd = _load(H.MultiPeriodDiscriminator(), "MultiPeriodDiscriminator", "model_disc.mpd.")
+    msd = _load(H.MultiScaleDiscriminator(), "MultiScaleDiscriminator", "model_disc.msd.")
+    sd = msd.state_dict()
+    for k in d.files:
+        if k.startswith("msd.buf0."):
+            sd[k[len("msd.buf0."):]].copy_(torch.from_numpy(d[k]))
+    mpd, msd = mpd.to(dev).train(), msd.to(dev).train()
+    y = y.to(dev)
+    y_hat = gen(mel.to(dev), f0.to(dev), rand_ini=ri.to(dev), noise=nz.to(dev))
+    assert y_hat.shape == (MG.VOC_B, 1, MG.VOC_L)
+    st = int(d["wav_stride"])
+    got = y_hat.detach()[:, 0, ::st].cpu().numpy()
+    e_max, e_mean = np.abs(got - d["y_hat"]).max(), np.abs(got - d["y_hat"]).mean()
+    e_dense = np.abs(y_hat.detach()[0, 0, :MG.DENSE].cpu().numpy() - d["y_hat_dense"]).max()
+    print(f"[{precision}] B=64x8192 y_hat: max abs {e_max:.3e} (dense window {e_dense:.3e}), mean abs {e_mean:.3e}, |y_hat| mean {float(d['y_hat_abs_mean']):.3f}")
+    soft(max(e_max, e_dense) < tol["wav_max"] and e_mean < tol["wav_mean"], 'max(e_max, e_dense) < tol["wav_max"] and e_mean < tol["wav_mean"]')
+    # ---- discriminator pass (on this implementation's own y_hat, as a training step does)
+    worst = {"score": 0.0, "dnorm": 0.0, "dsample": 0.0}
+    d_terms = []
+    for name, m in (("mpd", mpd), ("msd", msd)):
+        m.zero_grad()
+        y_d_rs, y_d_gs, _, _ = m(y, y_hat.detach())
+        lr_, lg_ = H.discriminator_loss(y_d_rs, y_d_gs)
+        (lr_ + lg_).backward()
+        d_terms += [lr_.item(), lg_.item()]
+        for i, (a, b) in enumerate(zip(y_d_rs, y_d_gs)):
+            for t_, key in ((a, f"{name}.score_r.{i}"), (b, f"{name}.score_g.{i}")):
+                ref = d[key]
+                e = np.abs(MG.score_digest(t_.cpu()) - ref).max() / max(1.0, np.abs(ref).max())
+                worst["score"] = max(worst["score"], e)
+                soft(e < tol["score"], (key, e))
+        for k, p in m.named_parameters():
+            rel, samp = _digest_err(MG.grad_digest(p.grad.cpu()), d[f"{name}.dgrad.{k}"], p.numel())
+            worst["dnorm"], worst["dsample"] = max(worst["dnorm"], rel), max(worst["dsample"], samp)
+            soft(rel < tol["gnorm"] and samp < tol["gsample"], (name, k, rel, samp))
+        m.zero_grad()
+    soft(np.allclose(d_terms, d["d_terms"], rtol=tol["terms"], atol=1e-6), (d_terms, d["d_terms"]))
+    sd = msd.state_dict()
+    for k in d.files:
+        if k.startswith("msd.buf1."):
+            soft(np.abs(sd[k[len("msd.buf1."):]].cpu().numpy() - d[k]).max() < 2e-5, k)
+    # ---- generator pass
+    gen.zero_grad()
+    g_terms, loss = [], 0.0
+    for name, m in (("mpd", mpd), ("msd", msd)):
+        _, y_d_gs, fmap_rs, fmap_gs = m(y, y_hat)
+        la, lf = H.generator_loss(y_d_gs), H.feature_loss(fmap_rs, fmap_gs)
+        g_terms += [la.item(), lf.item()]
+        loss = loss + la + lf
+    y_hat.retain_grad()
+    loss.backward()
+    soft(np.allclose(g_terms, d["g_terms"], rtol=tol["terms"], atol=1e-6), (g_terms, d["g_terms"]))
+    gy = y_hat.grad[:, 0, ::st].cpu().numpy()
+    e_gy = np.abs(gy - d["g_grad_yhat"]).max() / np.abs(d["g_grad_yhat"]).max()
+    e_gyn = abs(float(y_hat.grad.double().norm()) - float(d["g_grad_yhat_norm"])) / float(d["g_grad_yhat_norm"])
+    soft(e_gy < tol["gsample"] and e_gyn < tol["gnorm"], (e_gy, e_gyn))
+    worst.update(gnorm=0.0, gsample=0.0)
+    for k, p in gen.named_parameters():
+        rel, samp = _digest_err(MG.grad_digest(p.grad.cpu()), d[f"gen.ggrad.{k}"], p.numel())
+        worst["gnorm"], worst["gsample"] = max(worst["gnorm"], rel), max(worst["gsample"], samp)
+        soft(rel < tol["gnorm"] and samp < tol["gsample"], ("gen", k, rel, samp))
+    print(f"[{precision}] B=64x8192 worst errors: {json.dumps({k: float(f'{v:.3e}') for k, v in worst.items()})}; d(loss)/d(y_hat): samples {e_gy:.3e}, norm {e_gyn:.3e}; "
+          f"d_terms {np.abs(np.array(d_terms) / d['d_terms'] - 1).max():.3e}, g_terms {np.abs(np.array(g_terms) / d['g_terms'] - 1).max():.3e}")
+    soft.done()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_infer_t1872_pipeline_matches_reference(gpu_only, precision):
+    """configs[4] shape: MleSVBVAE (eval) three ways at T = 1872 -> mel-L1 per way; the weight-norm-folded generator on the
+    REFERENCE's a2p mel (the vocoder's own deviation) and on this implementation's a2p mel (bench.py's pipeline end to end)."""
+    from neuralsvb_amd import functional as SF
+    from neuralsvb_amd.modules.hifigan import HifiGanGenerator
+    from neuralsvb_amd.modules.svb_vae import MleSVBVAE
+    dev, tol, soft = gpu_only, TOL[precision], _Soft()
+    HP = json.load(open(os.path.join(G, "ref_hparams_vae_global_mle_eng.json")))
+    d = np.load(os.path.join(G, "infer_t1872.npz"))
+    inp, f0 = MG.inputs_infer(), MG.infer_f0()
+    L = MG.INF_T * HIFIGAN_CFG["hop_size"]
+    ri, nz = MG.nsf_draws(MG.INF_B, L, 36)
+    _check_regenerated(d, f0=f0, rand_ini=ri, noise=nz, **inp)
+    if True:
+        SF.set_precision(precision)
+        model = MleSVBVAE(70, HP)
+        _load(model, "MleSVBVAE", "model.")
+        model = model.to(dev).eval()
+        gen = _load(HifiGanGenerator(HIFIGAN_CFG), "HifiGanGenerator", "model_gen.")
+        gen.remove_weight_norm()
+        gen = gen.to(dev).eval()
+        x = {k: v.to(dev) for k, v in inp.items()}
+        with torch.no_grad():
+            out = model(amateur_mel=x["mels"], prof_mel=x["prof_mels"], amateur_pitch=x["pitch"], prof_pitch=x["prof_pitch"],
+                        amateur_spk_id=x["spk"], prof_spk_id=x["spk"], a2p_alignment=x["a2p_alignment"], p2a_alignment=None,
+                        infer=False, concurrent_ways=["a2a", "p2p", "a2p"],
+                        eps_a2a=torch.from_numpy(d["eps_a2a"]).to(dev), eps_p2p=torch.from_numpy(d["eps_p2p"]).to(dev))
+            fs = int(d["frame_stride"])
+            for way in ("a2a", "p2p", "a2p"):
+                mo = out[way]["mel_out"]
+                l1 = np.abs(mo[:, ::fs].cpu().numpy() - d[f"{way}.mel_out"]).mean()
+                print(f"[{precision}] T=1872 {way}: mel-L1 {l1:.3e} (|mel| mean {float(d[f'{way}.mel_out_abs_mean']):.3f})")
+                soft(l1 < tol["mel_l1"], (way, l1))
+            ws = int(d["wav_stride"])
+            kw = dict(rand_ini=ri.to(dev), noise=nz.to(dev))
+            f0d = f0.to(dev)
+            for tag, mel in (("reference a2p mel", torch.from_numpy(d["a2p.mel_out_full"]).to(dev)), ("own a2p mel (pipeline)", out["a2p"]["mel_out"])):
+                wav = gen(mel.transpose(1, 2).contiguous(), f0d, **kw)
+                assert wav.shape == (MG.INF_B, 1, L)
+                err = np.abs(wav[:, 0, ::ws].cpu().numpy() - d["wav"])
+                e_dense = np.abs(wav[0, 0, :MG.DENSE].cpu().numpy() - d["wav_dense"]).max()
+                print(f"[{precision}] T=1872 waveform on the {tag}: max abs {max(err.max(), e_dense):.3e}, mean abs {err.mean():.3e} (|wav| mean {float(d['wav_abs_mean']):.3f})")
+                soft(max(err.max(), e_dense) < tol["wav_max"] and err.mean() < tol["wav_mean"], tag)
+    soft.done()
