@@ -472,24 +472,33 @@ __global__ __launch_bounds__(512, 2) void svb_conv1d_tw_kernel(SvbTwArgs arg) {
 struct TwCfg { int CM, CN; };
 static const TwCfg kTwCfgs[SVB_TW_NVARIANTS] = {{2, 2}, {1, 4}, {4, 1}};      // 128x128, 64x256, 256x64
 
+// (the dynamic-LDS attribute belongs to the (function, device) pair and the CU count to the device: both are kept per device, so a
+//  process that drives several GPUs gets them on each.  Racing first calls of two host threads set the same value twice.)
+#define SVB_TW_MAX_DEVICES 16
+static int tw_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SVB_TW_MAX_DEVICES) return -1;
+    return dev;
+}
+
 template <int CM, int CN, bool GATE>
-static void tw_launch_kernel(const SvbTwArgs& a, int grid, size_t lds, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+static void tw_launch_kernel(const SvbTwArgs& a, int grid, size_t lds, hipStream_t stream, int dev) {
+    static bool attr_set[SVB_TW_MAX_DEVICES] = {};
+    if (dev < 0 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svb_conv1d_tw_kernel<CM, CN, GATE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        if (dev >= 0) attr_set[dev] = true;
     }
     hipLaunchKernelGGL((svb_conv1d_tw_kernel<CM, CN, GATE>), dim3(grid), dim3(512), lds, stream, a);
 }
 
 template <int CM, int CN>
-static void tw_launch_gate(const SvbTwArgs& a, int grid, size_t lds, hipStream_t stream) {
-    if (a.in_gate) tw_launch_kernel<CM, CN, true>(a, grid, lds, stream);
-    else tw_launch_kernel<CM, CN, false>(a, grid, lds, stream);
+static void tw_launch_gate(const SvbTwArgs& a, int grid, size_t lds, hipStream_t stream, int dev) {
+    if (a.in_gate) tw_launch_kernel<CM, CN, true>(a, grid, lds, stream, dev);
+    else tw_launch_kernel<CM, CN, false>(a, grid, lds, stream, dev);
 }
 
-static int g_tw_cus = 0;
+static int g_tw_cus[SVB_TW_MAX_DEVICES] = {};
 
 int svb_tw_launch(const SvbConvQArgs& q, const SvbConvPlan& p, int variant, hipStream_t stream) {
     if (variant < 0 || variant >= SVB_TW_NVARIANTS) return SVB_ERR_UNSUPPORTED;
@@ -555,19 +564,20 @@ int svb_tw_launch(const SvbConvQArgs& q, const SvbConvPlan& p, int variant, hipS
     a.ntiles = (int)(a.m_tiles * n_tiles);
     size_t lds = (size_t)2 * ((size_t)a.S * 4 * BM + (size_t)4 * kch * a.span) * 16;
     if (lds < 82 * 1024) lds = 82 * 1024;          // one workgroup per CU whatever the tile needs (grid = CUs)
-    if (!g_tw_cus) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            g_tw_cus = cus;
-        else
-            g_tw_cus = 256;
+    const int dev = tw_device();
+    int cus = dev >= 0 ? g_tw_cus[dev] : 0;
+    if (!cus) {
+        if (dev < 0 || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        if (dev >= 0) g_tw_cus[dev] = cus;
     }
-    const int grid = a.ntiles < g_tw_cus ? a.ntiles : g_tw_cus;
+    const int grid = a.ntiles < cus ? a.ntiles : cus;
     switch (variant) {
-        case 0: tw_launch_gate<2, 2>(a, grid, lds, stream); break;
-        case 1: tw_launch_gate<1, 4>(a, grid, lds, stream); break;
-        default: tw_launch_gate<4, 1>(a, grid, lds, stream); break;
+        case 0: tw_launch_gate<2, 2>(a, grid, lds, stream, dev); break;
+        case 1: tw_launch_gate<1, 4>(a, grid, lds, stream, dev); break;
+        default: tw_launch_gate<4, 1>(a, grid, lds, stream, dev); break;
     }
-    SVB_CHECK_LAUNCH();
+    // a launch the runtime refuses (e.g. the LDS attribute could not be set on this device) is reported as "outside this kernel's
+    // domain": the dispatcher then runs the heuristic tile of conv1d_bf16.hip instead of failing the conv
+    if (hipGetLastError() != hipSuccess) return SVB_ERR_UNSUPPORTED;
     return SVB_OK;
 }

@@ -13,22 +13,23 @@
 // the side stream catches up with the main one (an event per layer and direction), and the caller joins the side stream after
 // the call.  Their split-K partials collect in `arena`; svb_wgrad_reduce_multi finishes the pending ones whenever the next
 // does not fit and at the end of the stack (the capped deferral of kernels.py, inside the executor).
-// (one event set per device: an event belongs to the device it was created on.  A record / wait pair is consumed at once by the
-//  single host thread that issues it, so the callers of one device can share the set.)
+// (one event set per HOST THREAD and device: an event belongs to the device it was created on, and a record / wait pair must not
+//  be interleaved with another caller's -- two host threads driving two streams, or two devices, each use their own set, so the
+//  executor is re-entrant per stream as the rest of the C ABI is.  The set is handed down as a local pointer, never through a
+//  process-wide variable.)
 #define SVB_WN_MAX_DEVICES 16
-static hipEvent_t g_wn_events_all[SVB_WN_MAX_DEVICES][2 * SVB_WN_MAX_LAYERS];
-static bool g_wn_events_ready[SVB_WN_MAX_DEVICES];
-static hipEvent_t* g_wn_events = nullptr;        // the calling device's set (selected by wn_events())
+static thread_local hipEvent_t t_wn_events_all[SVB_WN_MAX_DEVICES][2 * SVB_WN_MAX_LAYERS];
+static thread_local bool t_wn_events_ready[SVB_WN_MAX_DEVICES];
 
-static int wn_events() {
+static int wn_events(hipEvent_t** set) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SVB_WN_MAX_DEVICES) return SVB_ERR_LAUNCH;
-    if (!g_wn_events_ready[dev]) {
+    if (!t_wn_events_ready[dev]) {
         for (int i = 0; i < 2 * SVB_WN_MAX_LAYERS; ++i)
-            if (hipEventCreateWithFlags(&g_wn_events_all[dev][i], hipEventDisableTiming) != hipSuccess) return SVB_ERR_LAUNCH;
-        g_wn_events_ready[dev] = true;
+            if (hipEventCreateWithFlags(&t_wn_events_all[dev][i], hipEventDisableTiming) != hipSuccess) return SVB_ERR_LAUNCH;
+        t_wn_events_ready[dev] = true;
     }
-    g_wn_events = g_wn_events_all[dev];
+    *set = t_wn_events_all[dev];
     return SVB_OK;
 }
 
@@ -122,7 +123,8 @@ static int wn_wgrad(const SvbWnStack* s, const SvbWnBackward* b, WnPending& p, c
 extern "C" int svb_wn_stack_backward(const SvbWnStack* s, const SvbWnBackward* b, void* stream, void* side_stream) {
     WN_TRY(wn_check(s));
     if (!b || !b->dout || !b->drs || !b->dxin || !b->dacts || !b->dxm || !b->dx || !b->arena) return SVB_ERR_ARG;
-    WN_TRY(wn_events());
+    hipEvent_t* events = nullptr;
+    WN_TRY(wn_events(&events));
     hipStream_t main = (hipStream_t)stream;
     hipStream_t side = side_stream ? (hipStream_t)side_stream : main;
     const size_t nC = (size_t)s->B * s->C * s->T;
@@ -154,8 +156,8 @@ extern "C" int svb_wn_stack_backward(const SvbWnStack* s, const SvbWnBackward* b
         }
         if (need_rs_w) {
             if (side != main) {
-                if (hipEventRecord(g_wn_events[2 * i], main) != hipSuccess) return SVB_ERR_LAUNCH;
-                if (hipStreamWaitEvent(side, g_wn_events[2 * i], 0) != hipSuccess) return SVB_ERR_LAUNCH;
+                if (hipEventRecord(events[2 * i], main) != hipSuccess) return SVB_ERR_LAUNCH;
+                if (hipStreamWaitEvent(side, events[2 * i], 0) != hipSuccess) return SVB_ERR_LAUNCH;
             }
             WN_TRY(wn_wgrad(s, b, pend, drs, acts, L.rs_cout, s->C, 1, 0, 1, L.rs_g ? L.rs_v : nullptr, L.rs_g, L.d_rs_v, L.d_rs_g,
                             L.d_rs_b, side));
@@ -174,8 +176,8 @@ extern "C" int svb_wn_stack_backward(const SvbWnStack* s, const SvbWnBackward* b
                                i * 2 * s->C, stream));
         if (need_in_w) {
             if (side != main) {
-                if (hipEventRecord(g_wn_events[2 * i + 1], main) != hipSuccess) return SVB_ERR_LAUNCH;
-                if (hipStreamWaitEvent(side, g_wn_events[2 * i + 1], 0) != hipSuccess) return SVB_ERR_LAUNCH;
+                if (hipEventRecord(events[2 * i + 1], main) != hipSuccess) return SVB_ERR_LAUNCH;
+                if (hipStreamWaitEvent(side, events[2 * i + 1], 0) != hipSuccess) return SVB_ERR_LAUNCH;
             }
             WN_TRY(wn_wgrad(s, b, pend, dxin, x, 2 * s->C, s->C, s->k, pad, dil, L.in_g ? L.in_v : nullptr, L.in_g, L.d_in_v, L.d_in_g,
                             L.d_in_b, side));

@@ -66,8 +66,15 @@ def _with_lookahead(it):
 
 
 def move_to_device(batch, device):
+    """Batch -> device, asynchronously.  A PAGEABLE host tensor would make `.to(device, non_blocking=True)` wait for the stream (a
+    host stall in the middle of a step when the look-ahead copy runs between forward and backward), so such a tensor goes through
+    a pinned staging copy first (torch's caching host allocator recycles the block once the copy has run)."""
+    cuda = torch.device(device).type == "cuda"
+
     def mv(v):
         if isinstance(v, torch.Tensor):
+            if cuda and not v.is_cuda and v.numel() and not v.is_pinned():
+                v = v.pin_memory()
             return v.to(device, non_blocking=True)
         if isinstance(v, dict):
             return {k: mv(x) for k, x in v.items()}
@@ -145,14 +152,18 @@ class FlatGradSync:
 
     def gather_adopted(self):
         """Before an update that reads the FLAT buffer (utils/flat_optim.py): gradients autograd handed over as tensors of
-        their own (`drop_autograd_grads`) are copied into their slices, all of them by one launch."""
+        their own (`drop_autograd_grads`) are copied into their slices, all of them by one launch.  Returns the indices of the
+        parameters that received NO gradient in this pass (`.grad is None`)."""
         if not self.drop_autograd_grads:
-            return
-        srcs, offs = [], []
+            return []
+        srcs, offs, skipped = [], [], []
         base, esz = self.flat.data_ptr(), self.flat.element_size()
-        for p, off in zip(self.params, self._offsets):
+        for i, (p, off) in enumerate(zip(self.params, self._offsets)):
             g = p.grad
-            if g is None or g.data_ptr() == base + off * esz:
+            if g is None:
+                skipped.append(i)          # no gradient in this pass: torch.optim.AdamW leaves such a parameter alone
+                continue
+            if g.data_ptr() == base + off * esz:
                 continue
             if g.dtype != torch.float32 or g.numel() != p.numel():
                 raise RuntimeError("an adopted gradient does not match its parameter's slice of the flat buffer")
@@ -161,6 +172,7 @@ class FlatGradSync:
         if srcs:
             from .. import kernels as _K
             _K.gather_segments(srcs, offs, self.flat)
+        return skipped
 
     def pin_views(self):
         """Back to one fixed gradient buffer per parameter (hipGraph capture needs stable addresses)."""
@@ -409,8 +421,7 @@ class Trainer:
         if not self.testing and hparams.get("flat_adamw", True):
             from .flat_optim import FlatAdamW
             for i, (o, gs) in enumerate(zip(self.optimizers, self.grad_sync)):
-                if (o is not None and isinstance(o, torch.optim.AdamW) and gs is not None and len(o.param_groups) == 1
-                        and (gs.flat.is_cuda or L_is_emu())):
+                if (o is not None and gs is not None and FlatAdamW.eligible(o) and (gs.flat.is_cuda or L_is_emu())):
                     self.flat_optim[i] = FlatAdamW(o, gs)
             if any(f is not None for f in self.flat_optim):
                 _note_weights_updated()            # (the parameters moved into the flat buffers: packed images are stale)
@@ -858,8 +869,7 @@ class Trainer:
             task.on_before_optimization(opt_idx)
             flat = self.flat_optim[opt_idx] if opt_idx < len(self.flat_optim) else None
             if flat is not None:
-                sync.gather_adopted()
-                flat.step()
+                flat.step(sync.gather_adopted())
             else:
                 optimizer.step()
             _note_weights_updated(self._param_cache[2][opt_idx] if self._param_cache is not None else

@@ -725,14 +725,21 @@ def test_period_strided_conv_matches_conv2d(dev, case, precision):
         assert rel_err(got, ref) < 5 * tol
 
 
-@pytest.mark.parametrize("big", [False, pytest.param(True, marks=pytest.mark.gpu)])
-def test_period_s2d_index_walk(dev, big):
-    """svb_period_s2d walks the element index as a mixed-radix counter advancing by the grid's stride (no division per element);
-    `big` (MI355X only) is a tensor of 5.9 M elements, more than the 16384 x 256 threads of the capped grid, so every thread
-    wraps its digits several times.  Forward and inverse against index arithmetic in torch, bit for bit."""
+def test_period_s2d_index_walk(dev):
+    """svb_period_s2d walks the element index as a mixed-radix counter advancing by the grid's stride (no division per element).
+    Forward and inverse against index arithmetic in torch, bit for bit."""
+    _period_s2d_index_walk(dev, False)
+
+
+@pytest.mark.gpu
+def test_period_s2d_index_walk_big(gpu_only):
+    """The same on a tensor of 5.9 M elements, more than the 16384 x 256 threads of the capped grid, so every thread wraps its
+    digits several times (MI355X only: more elements than the lane emulator walks in reasonable time)."""
+    _period_s2d_index_walk(gpu_only, True)
+
+
+def _period_s2d_index_walk(dev, big):
     from neuralsvb_amd import kernels as K
-    if big and dev.type != "cuda":
-        pytest.skip("needs more elements than the lane emulator walks in reasonable time")
     B, C, H, p, s, lead = (6, 96, 173, 7, 3, 2) if big else (2, 5, 23, 3, 3, 1)
     h_out = (H + 2 * 2 - 5) // s + 1
     R = lead + h_out + 1

@@ -907,3 +907,29 @@ def test_batchnorm_nct_eval_under_autograd(dev):
         assert (xd.grad.cpu() - xr.grad).abs().max() < 2e-6
         assert rel_err(bd.weight.grad, rb.weight.grad) < 1e-5 and rel_err(bd.bias.grad, rb.bias.grad) < 1e-5
         assert torch.equal(bd.running_mean.cpu(), bn.running_mean) and int(bd.num_batches_tracked) == 0
+
+
+def test_tile_table_is_committed_and_well_formed():
+    """The tile configuration of a conv signature comes from the committed table (tools/tune_tiles.py on the MI355X), not from a
+    first-sight measurement: the table loads at import, every choice names an existing configuration of its kernel family, the
+    three bench workloads' dominant signatures are in it, and a missing table degrades to the on-line tuner, not to an error."""
+    import json
+    from neuralsvb_amd import kernels as K
+    info = K.load_tile_table()
+    try:
+        assert info["entries"] >= 300 and info["sha256_16"] and info["path"] == "tile_table.json"
+        doc = json.load(open(K.TILE_TABLE_PATH))
+        assert doc["reps"] >= 20 and doc["arch"] == "gfx950" and len(doc["configurations"]) == len(K._CFG_NAMES)
+        for sig, cfg in K._TUNED.items():
+            ncfg = 5 if sig[0] in ("f", "t") or (sig[0] == "taps" and not sig[1]) else K._NCFG_Q
+            assert 1 <= cfg <= ncfg, (sig, cfg)
+            med = doc["medians_us"][K._sig_key(sig)]
+            assert len(med) == ncfg and med[cfg - 1] <= min(med) + 0.011      # the choice is the measured best (file rounds to 0.01 us)
+        # configs[1]: the decoder stack's k=5 conv and the 1x1 res/skip conv at B=32 (two ways stacked) x T=1124
+        assert ("qf", 32, 192, 384, 1, 1124, 5, 1, 2, 1, False) in K._TUNED
+        assert ("qf", 32, 192, 384, 1, 1124, 1, 1, 0, 1, False) in K._TUNED
+        assert K.tuned_choice(("qf", 32, 192, 384, 1, 1124, 5, 1, 2, 1, False), True) == K._TUNED[("qf", 32, 192, 384, 1, 1124, 5, 1, 2, 1, False)]
+        assert K.load_tile_table(None)["entries"] == 0 and not K._TUNED
+        assert K.tuned_choice(("qf", 1, 2, 3), True) is None          # unseen signature on the GPU: measured on line
+    finally:
+        K.load_tile_table()

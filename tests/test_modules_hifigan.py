@@ -34,12 +34,14 @@ def test_state_dict_layouts_match_reference():
 
 
 # Stated tolerances per conv arithmetic (`conv_precision`): fp32 = fp32 MFMA, bf16x3 = bf16 matrix cores with the fp32-class operand
-# split.  |wav| <= 1.  bf16x3 bounds are 2.5x the fp32 ones (one product carries ~1e-5 relative noise instead of ~1e-7; the
-# 72-conv generator with x128 upsampling is where it compounds -- measured values are printed by the tests).
+# split.  |wav| <= 1.  Measured on the MI355X in round 5 (profiles/r05_vocoder_parity_bf16x3_first.log): generator waveform
+# 5.7e-7 / 4.2e-6 (fp32 / bf16x3), eval-mode logits 3.9e-6 / 1.5e-5, train-mode gradient norms 7.4e-6 / 2.7e-4,
+# d(loss)/d(y_hat) samples 5.0e-4 / 5.6e-3 (the feature-matching L1 and LeakyReLU kinks flip single samples on rounding noise).
 PREC = ["fp32", "bf16x3"]
-WAV_TOL = {"fp32": 2e-4, "bf16x3": 5e-4}
-SCORE_TOL = {"fp32": 5e-5, "bf16x3": 2e-4}
-GRAD_TOL = {"fp32": 3e-3, "bf16x3": 1e-2}
+WAV_TOL = {"fp32": 2e-5, "bf16x3": 5e-5}
+SCORE_TOL = {"fp32": 5e-5, "bf16x3": 1e-4}
+GRAD_TOL = {"fp32": 3e-3, "bf16x3": 3e-3}
+GY_TOL = {"fp32": 3e-3, "bf16x3": 3e-2}
 
 
 def _set_precision(precision):
@@ -198,7 +200,7 @@ def test_discriminators_train_mode_losses_and_gradients(dev, name, precision):
     assert np.allclose([la.item(), lf.item()], z[f"{name}.g_loss"], rtol=2e-4 if precision == "fp32" else 1e-3, atol=1e-6), (la.item(), lf.item(), z[f"{name}.g_loss"])
     gref = t(z[f"{name}.g_grad_yhat"])
     e_gy = ((yh2.grad.cpu() - gref).abs().max() / gref.abs().max()).item()
-    assert e_gy < gtol, e_gy
+    assert e_gy < GY_TOL[precision], e_gy
     if name == "msd":
         sd = m.state_dict()
         for k in z.files:

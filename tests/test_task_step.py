@@ -186,6 +186,74 @@ def test_flat_adamw_matches_torch_clip_and_adamw(dev):
     assert our_o.state[our_p[0]]["exp_avg"].data_ptr() == flat.m.data_ptr()
 
 
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_flat_adamw_parameter_without_gradient_is_left_alone_like_torch(dev, wd):
+    """torch.optim.AdamW skips a parameter whose `.grad` is None: no weight decay, no moment decay, its own `step` does not
+    advance (reference tasks/singing/svb_vae_task.py:84-118 steps stock AdamW).  FlatAdamW + FlatGradSync(drop_autograd_grads)
+    through `gather_adopted`: parameter 1 NEVER gets a gradient, parameter 3 gets one only in some passes (so it has history
+    when it is skipped), parameter 0 is a kernel sink (always a flat view).  Weights, moments and per-parameter step counts
+    must equal torch's after every step, with and without weight decay; the fast flat launch must still be the one that runs
+    while it is exact (wd = 0, only the never-updated parameter skipped)."""
+    from neuralsvb_amd.utils.trainer import FlatGradSync
+    from neuralsvb_amd.utils.flat_optim import FlatAdamW
+    g = torch.Generator().manual_seed(11)
+    shapes = [(6, 3, 5), (13,), (4, 6), (9,), (2, 2)]
+    ref_p = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    our_p = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref_p]
+    our_p[0]._svb_sink = True                      # (what functional._gbuf marks: a kernel accumulates into its flat view)
+    kw = dict(lr=2e-3, betas=(0.8, 0.99), eps=1e-8, weight_decay=wd)
+    ref_o, our_o = torch.optim.AdamW(ref_p, **kw), torch.optim.AdamW(our_p, **kw)
+    sync = FlatGradSync(our_p, 1, drop_autograd_grads=True)
+    flat = FlatAdamW(our_o, sync)
+    flat.set_clip(1.5)
+    sync.zero()                                    # as the Trainer does after set-up: autograd-only parameters drop their views
+    assert our_p[0].grad is not None and all(q.grad is None for q in our_p[1:])
+    torch_steps = 0
+    orig = flat._torch_step
+
+    def spy(skipped):
+        nonlocal torch_steps
+        torch_steps += 1
+        return orig(skipped)
+    flat._torch_step = spy
+    has_grad = [(0, 2, 3, 4), (0, 2, 3, 4), (0, 2, 4), (0, 2, 3, 4), (0, 2, 4)]      # parameter 1 never, parameter 3 not in passes 2, 4
+    for step, idx in enumerate(has_grad):
+        for i, (p, q) in enumerate(zip(ref_p, our_p)):
+            if i in idx:
+                gr = torch.randn(shapes[i], generator=g) * 2.0
+                p.grad = gr.clone()
+                if i == 0:
+                    q.grad.copy_(gr.to(dev))       # the sink: written in place
+                else:
+                    q.grad = gr.clone().to(dev)    # adopted tensor, as autograd hands it over
+            else:
+                p.grad = None
+        torch.nn.utils.clip_grad_norm_(ref_p, 1.5)
+        ref_o.step()
+        flat.step(sync.gather_adopted())
+        sync.zero()
+        for i, (p, q) in enumerate(zip(ref_p, our_p)):
+            assert (p.detach() - q.detach().cpu()).abs().max().item() <= 3e-6 * max(1.0, p.abs().max().item()), (step, i)
+        if step == 1:
+            assert torch_steps == (0 if wd == 0.0 else 2)       # only the never-updated parameter skipped: flat launch iff wd == 0
+    flat.export_state()
+    sd = our_o.state_dict()["state"]
+    for i, p in enumerate(ref_p):
+        rs = ref_o.state[p]
+        want = float(rs["step"]) if "step" in rs else 0.0
+        assert float(sd[i]["step"]) == want, (i, float(sd[i]["step"]), want)
+        if "exp_avg" in rs:
+            assert (rs["exp_avg"] - sd[i]["exp_avg"].cpu()).abs().max().item() <= 1e-6
+            assert (rs["exp_avg_sq"] - sd[i]["exp_avg_sq"].cpu()).abs().max().item() <= 1e-6
+        else:
+            assert float(sd[i]["exp_avg"].abs().max()) == 0.0 and float(sd[i]["exp_avg_sq"].abs().max()) == 0.0
+    assert torch_steps >= 3                                       # passes 2..4: a parameter with history was skipped / steps diverged
+    # an optimizer FlatAdamW cannot represent is reported as not eligible (Trainer.setup then keeps optimizer.step())
+    assert not FlatAdamW.eligible(torch.optim.AdamW([torch.nn.Parameter(torch.zeros(2))], amsgrad=True))
+    assert not FlatAdamW.eligible(torch.optim.AdamW([torch.nn.Parameter(torch.zeros(2))], maximize=True))
+    assert FlatAdamW.eligible(torch.optim.AdamW([torch.nn.Parameter(torch.zeros(2))]))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("graph_mode", ["step", "pass"])
 def test_hipgraph_replay_matches_eager_steps(gpu_only, tmp_path, graph_mode):

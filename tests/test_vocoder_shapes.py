@@ -5,15 +5,23 @@ unmodified reference (tests/golden/make_vocoder_shape_golden.py -> vocoder_b64.n
 Reference code under test: modules/hifigan/hifigan.py:144-169 (generator), :237-250 (MPD), :309-325 (MSD), :328-365 (losses),
 modules/voice_conversion/svb_vae.py:258-312 (MleSVBVAE), vocoders/hifigan.py:55-69 (spec2wav's generator call).
 
-STATED TOLERANCES (|wav| <= 1; measured values are printed by each test and recorded in DESIGN.md section 2):
+STATED TOLERANCES (|wav| <= 1) and what the MI355X measured (round 5, profiles/r05_vocoder_parity_bf16x3_first.log); every bound
+is >= 5x the measured value:
 
-| quantity                                     | fp32   | bf16x3 |
-|----------------------------------------------|--------|--------|
-| waveform, max abs                            | 2e-4   | 5e-4   |
-| waveform, mean abs                           | 2e-5   | 5e-5   |
-| mel-L1 per way (north-star bound 1e-4)       | 1e-5   | 1e-4   |
-| discriminator / generator loss terms, rel    | 2e-4   | 1e-3   |
-| parameter-gradient l2 norms, rel             | 5e-3   | 2e-2   |
+| quantity                                             | fp32 bound (measured) | bf16x3 bound (measured) |
+|------------------------------------------------------|-----------------------|-------------------------|
+| waveform, max abs (B=64x8192 / T=1872 pipeline)      | 3e-5 (1.8e-6 / 5.9e-6)| 5e-5 (6.1e-6 / 7.4e-6)  |
+| waveform, mean abs                                   | 4e-6 (7.6e-7)         | 6e-6 (1.2e-6)           |
+| mel-L1 per way at T=1872 (north-star bound 1e-4)     | 3e-6 (5.6e-7)         | 3e-5 (5.0e-6)           |
+| discriminator / generator loss terms, relative       | 1e-5 (1.1e-7)         | 3e-5 (3.1e-6)           |
+| discriminator logits (digest), rel. to max(1, |ref|) | 5e-6 (3.9e-7)         | 1e-5 (1.3e-6)           |
+| parameter-gradient l2 norms, relative                | 2e-4 (2.0e-5)         | 6e-4 (8.5e-5)           |
+| parameter-gradient samples, rel. to max(rms, |ref|)  | 2e-3 (2.7e-4)         | 5e-3 (7.7e-4)           |
+| d(loss)/d(y_hat): l2 norm / samples rel. to max      | 2e-4 / 3e-2 (3e-7 / 5.0e-3) | 6e-4 / 2e-1 (4.7e-6 / 5.2e-2) |
+
+(d(loss)/d(y_hat) sample by sample is the one loose row: the feature-matching term is an L1 over 2 x 10^8 feature values and
+the LeakyReLU / |.| kinks flip on rounding noise, which moves single samples by a few percent of the largest one while the
+gradient's norm agrees to 5e-6 -- the reference's own fp32 result has the same property, see the fp32 column.)
 
 GPU only: the lane emulator would need hours for these shapes.
 """
@@ -31,8 +39,8 @@ from tests.test_oracle_golden import HIFIGAN_CFG
 G = os.path.join(os.path.dirname(__file__), "golden")
 KEYS = json.load(open(os.path.join(G, "ref_state_keys.json")))
 
-TOL = {"fp32": dict(wav_max=2e-4, wav_mean=2e-5, mel_l1=1e-5, terms=2e-4, gnorm=5e-3, gsample=2e-2, score=2e-4),
-       "bf16x3": dict(wav_max=5e-4, wav_mean=5e-5, mel_l1=1e-4, terms=1e-3, gnorm=2e-2, gsample=6e-2, score=1e-3)}
+TOL = {"fp32": dict(wav_max=3e-5, wav_mean=4e-6, mel_l1=3e-6, terms=1e-5, gnorm=2e-4, gsample=2e-3, score=5e-6, gy_sample=3e-2),
+       "bf16x3": dict(wav_max=5e-5, wav_mean=6e-6, mel_l1=3e-5, terms=3e-5, gnorm=6e-4, gsample=5e-3, score=1e-5, gy_sample=2e-1)}
 
 pytestmark = pytest.mark.gpu
 
@@ -138,7 +146,7 @@ def test_vocoder_b64_generator_mpd_msd_match_reference(gpu_only, precision):
     gy = y_hat.grad[:, 0, ::st].cpu().numpy()
     e_gy = np.abs(gy - d["g_grad_yhat"]).max() / np.abs(d["g_grad_yhat"]).max()
     e_gyn = abs(float(y_hat.grad.double().norm()) - float(d["g_grad_yhat_norm"])) / float(d["g_grad_yhat_norm"])
-    soft(e_gy < tol["gsample"] and e_gyn < tol["gnorm"], (e_gy, e_gyn))
+    soft(e_gy < tol["gy_sample"] and e_gyn < tol["gnorm"], (e_gy, e_gyn))
     worst.update(gnorm=0.0, gsample=0.0)
     for k, p in gen.named_parameters():
         rel, samp = _digest_err(MG.grad_digest(p.grad.cpu()), d[f"gen.ggrad.{k}"], p.numel())
@@ -163,7 +171,7 @@ def test_infer_t1872_pipeline_matches_reference(gpu_only, precision):
     L = MG.INF_T * HIFIGAN_CFG["hop_size"]
     ri, nz = MG.nsf_draws(MG.INF_B, L, 36)
     _check_regenerated(d, f0=f0, rand_ini=ri, noise=nz, **inp)
-    if True:
+    with torch.no_grad():
         SF.set_precision(precision)
         model = MleSVBVAE(70, HP)
         _load(model, "MleSVBVAE", "model.")
@@ -172,7 +180,7 @@ def test_infer_t1872_pipeline_matches_reference(gpu_only, precision):
         gen.remove_weight_norm()
         gen = gen.to(dev).eval()
         x = {k: v.to(dev) for k, v in inp.items()}
-        with torch.no_grad():
+        if True:
             out = model(amateur_mel=x["mels"], prof_mel=x["prof_mels"], amateur_pitch=x["pitch"], prof_pitch=x["prof_pitch"],
                         amateur_spk_id=x["spk"], prof_spk_id=x["spk"], a2p_alignment=x["a2p_alignment"], p2a_alignment=None,
                         infer=False, concurrent_ways=["a2a", "p2p", "a2p"],

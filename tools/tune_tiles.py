@@ -73,7 +73,7 @@ def main():
         bench.bench_infer(v, dev)
         print(f"[tune] +infer: {len(K._TUNE_LOG)} signatures after {time.perf_counter() - t0:.1f} s", flush=True)
     choices = {K._sig_key(s): c for s, c in sorted(K._TUNED_ONLINE.items(), key=lambda kv: K._sig_key(kv[0]))}
-    med = {K._sig_key(s): [round(x, 2) for x in m] for s, m in sorted(K._TUNE_LOG.items(), key=lambda kv: K._sig_key(kv[0]))}
+    med = {K._sig_key(s): [round(x, 3) for x in m] for s, m in sorted(K._TUNE_LOG.items(), key=lambda kv: K._sig_key(kv[0]))}
     doc = {"device": torch.cuda.get_device_name(0), "arch": "gfx950", "precision": a.precision, "reps": a.reps,
            "method": "interleaved rounds, HIP events around each launch, median per configuration, ties to the lowest index",
            "workloads": wl, "configurations": K._CFG_NAMES, "choices": choices, "medians_us": med}
