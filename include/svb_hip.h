@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define SVB_ABI_VERSION 7
+#define SVB_ABI_VERSION 8
 int svb_abi_version(void);
 
 /* ---- fused conv epilogue / prologue description ------------------------------------------------------
@@ -421,6 +421,11 @@ int svb_dtw_align(const float* cost, const int* len_b, const int* len_a, float* 
 int svb_embed_nct_fwd(const int64_t* idx, const float* w, float* out, int B, int H, int T, int V, void* stream);
 int svb_embed_nct_bwd(const int64_t* idx, const float* dy, float* part, float* dw, int B, int H, int T, int V, int padding_idx,
                       int accumulate, void* stream);
+
+/* ---- nearest-neighbour upsampling along time, conv layout (reference modules/voice_conversion/svb_vae.py:39-45:
+ * nn.Upsample(scale_factor=s, mode='nearest') of the content features; ABI v8).  adjoint == 0: x [rows][T] -> y [rows][T*scale],
+ * y[r][t*scale + j] = x[r][t].  adjoint != 0: x = dy [rows][T*scale] -> y = dx [rows][T], the sum over each window in j order. */
+int svb_upsample_nearest_nct(const float* x, float* y, long rows, int T, int scale, int adjoint, void* stream);
 
 /* ---- Multi-period discriminator plumbing (reference modules/hifigan/hifigan.py:171-223: `x.view(b, c, t // period, period)` +
  * Conv2d((k,1), (stride,1)) layers).  Feature maps stay in the reference's [B][C][H][p] layout; a (k,1) conv is a 1-D conv with

@@ -368,3 +368,55 @@ extern "C" int svb_embed_nct_bwd(const int64_t* idx, const float* dy, float* par
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
+
+// ---- nearest-neighbour upsampling along time in the conv layout (reference modules/voice_conversion/svb_vae.py:39-45:
+// nn.Upsample(scale_factor=s, mode='nearest') in front of the content features' smoothing conv) ---------------------------------
+//   y[r][t*s + j] = x[r][t]   (rows = B*C, 0 <= j < s);   adjoint: dx[r][t] = sum_j dy[r][t*s + j], added in j order.
+// HBM-bound: 4 B read + 4*s B written per input element.  grid (ceil(T*s / 1024), rows): a thread writes one float4 of the
+// output row (coalesced 16-byte stores along t); the row base is per block, so there is no 64-bit division per element.
+__global__ __launch_bounds__(256) void svb_upsample_nearest_kernel(const float* x, float* y, int T, int s) {
+    const long row = blockIdx.y;
+    const int To = T * s;
+    const int q = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (q >= To) return;
+    const float* xr = x + row * T;
+    float* yr = y + row * To;
+    if (q + 3 < To && (To & 3) == 0) {
+        float4 o;
+        o.x = xr[q / s]; o.y = xr[(q + 1) / s]; o.z = xr[(q + 2) / s]; o.w = xr[(q + 3) / s];
+        *reinterpret_cast<float4*>(yr + q) = o;
+    } else {
+        for (int e = q; e < To && e < q + 4; ++e) yr[e] = xr[e / s];
+    }
+}
+
+__global__ __launch_bounds__(256) void svb_upsample_nearest_bwd_kernel(const float* dy, float* dx, int T, int s) {
+    const long row = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const float* g = dy + row * (long)T * s + (long)t * s;
+    float acc = 0.f;
+    for (int j = 0; j < s; ++j) acc += g[j];
+    dx[row * T + t] = acc;
+}
+
+extern "C" int svb_upsample_nearest_nct(const float* x, float* y, long rows, int T, int scale, int adjoint, void* stream) {
+    if (!x || !y || rows <= 0 || T <= 0 || scale <= 0) return SVB_ERR_ARG;
+    if (rows > 65535L * 32768L || (long)T * scale > 0x7fffffffL) return SVB_ERR_UNSUPPORTED;
+    // rows ride on gridDim.y (<= 65535): larger row counts go out in slabs
+    for (long r0 = 0; r0 < rows; r0 += 65535) {
+        const unsigned nr = (unsigned)(rows - r0 < 65535 ? rows - r0 : 65535);
+        if (!adjoint) {
+            const int To = T * scale;
+            hipLaunchKernelGGL(svb_upsample_nearest_kernel, dim3((To + 1023) / 1024, nr), dim3(256), 0, (hipStream_t)stream,
+                               x + r0 * T, y + r0 * To, T, scale);
+        } else {
+            // x = dy [rows][T*scale], y = dx [rows][T]
+            hipLaunchKernelGGL(svb_upsample_nearest_bwd_kernel, dim3((T + 255) / 256, nr), dim3(256), 0, (hipStream_t)stream,
+                               x + r0 * (long)T * scale, y + r0 * T, T, scale);
+        }
+        SVB_CHECK_LAUNCH();
+    }
+    return SVB_OK;
+}
+

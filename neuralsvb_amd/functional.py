@@ -1211,6 +1211,27 @@ class _EmbedNCTFn(torch.autograd.Function):
         return None, dw, None
 
 
+class _UpsampleNearestFn(torch.autograd.Function):
+    """nn.Upsample(scale_factor=s, mode='nearest') on [B,C,T] (kernels.upsample_nearest_nct); backward = window sums."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return K.upsample_nearest_nct(x.contiguous(), scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.upsample_nearest_nct(dy.contiguous(), ctx.scale, adjoint=True), None
+
+
+def upsample_nearest_nct(x, scale):
+    """F.interpolate(x, scale_factor=scale, mode='nearest') for integer scales on [B,C,T] (reference svb_vae.py:39-45)."""
+    scale = int(scale)
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _UpsampleNearestFn.apply(x, scale)
+    return K.upsample_nearest_nct(x.contiguous(), scale)
+
+
 class _PeriodS2DFn(torch.autograd.Function):
     """Row space-to-depth of the period discriminators' [B,C,H,p] planes (kernels.period_s2d); backward = the gather back."""
 

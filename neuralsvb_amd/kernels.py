@@ -1374,6 +1374,21 @@ def embed_nct(idx, w):
     return out
 
 
+def upsample_nearest_nct(x, scale, adjoint=False):
+    """x [B,C,T] -> [B,C,T*scale] (y[..., t*scale+j] = x[..., t]); adjoint: dy [B,C,T*scale] -> dx [B,C,T] (window sums)."""
+    _f32(x)
+    lib, st = _prep(x)
+    B, Cc, T = x.shape
+    scale = int(scale)
+    if adjoint:
+        if T % scale:
+            raise ValueError("adjoint of the nearest upsampling: length must be a multiple of the scale")
+        T //= scale
+    y = torch.empty((B, Cc, T if adjoint else T * scale), device=x.device, dtype=torch.float32)
+    L.check(lib.svb_upsample_nearest_nct(_ptr(x), _ptr(y), B * Cc, T, scale, int(adjoint), st), "svb_upsample_nearest_nct")
+    return y
+
+
 def embed_nct_bwd(idx, dy, V, padding_idx=-1, into=None):
     """dw [V,H] of embed_nct (row padding_idx zero), deterministic.  `into`: gradient buffer to accumulate into (-> None)."""
     _f32(dy)

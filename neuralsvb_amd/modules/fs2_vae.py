@@ -175,7 +175,10 @@ class GlobalFVAE(nn.Module):
 
 
 class GlobalLatentMap(nn.Module):
-    """vae_models.py:149-172 -- 1x1 convs on [B, 128, 1] (negligible FLOPs; stays on stock torch ops)."""
+    """vae_models.py:149-172 -- 1x1 convs + BatchNorm on [B, 128, 1] (the phase-3 latent map).  The parameter containers are the
+    reference's (`convs.{0,3,6}` / `spk_proj.{0,2}` nn.Conv1d, `convs.{1,4}` nn.BatchNorm1d: same state_dict); the arithmetic runs on
+    the HIP conv (ReLU and the `x + spk_proj(...)` add in its epilogue) and the HIP BatchNorm kernel -- no stock-torch op on the
+    path."""
 
     def __init__(self, hidden_size):
         super().__init__()
@@ -187,5 +190,14 @@ class GlobalLatentMap(nn.Module):
         self.spk_proj = nn.Sequential(nn.Conv1d(256, hidden_size, 1), nn.ReLU(inplace=True),
                                       nn.Conv1d(hidden_size, hidden_size, 1))
 
+    @staticmethod
+    def _c(conv, x, **epi):
+        return SF.conv1d(x, conv.weight, conv.bias, **epi)
+
     def forward(self, x, spk_emb):
-        return self.convs(x + self.spk_proj(spk_emb[:, :, :x.shape[-1]]))
+        c, s = self.convs, self.spk_proj
+        h = self._c(s[0], spk_emb[:, :, :x.shape[-1]].contiguous(), out_act=SF.ACT_RELU)
+        h = self._c(s[2], h, residual=x.contiguous())                          # x + spk_proj(spk)
+        h = SF.batch_norm_nct(c[1], self._c(c[0], h))
+        h = SF.batch_norm_nct(c[4], self._c(c[3], h, in_slope=0.0))            # ReLU applied on the operand load of the next conv
+        return self._c(c[6], h, in_slope=0.0)

@@ -157,12 +157,13 @@ class MleSVBVAE(nn.Module):
             h = self.vc_asr(mels_content)["h_content"].detach()
         for m in self.upsample_layer:
             if isinstance(m, nn.Sequential):
-                h = F.interpolate(h, scale_factor=m[0].scale_factor, mode="nearest")
+                h = SF.upsample_nearest_nct(h, int(m[0].scale_factor))
                 h = bn_groups(m[3], m[1](h, out_act=SF.ACT_RELU), groups)
             else:
                 h = m(h)
         h_content = h[:, :, :mels_content.shape[1]]
-        h_style = self.spk_embed_proj(spk_ids)[:, :, None].expand(-1, -1, T)
+        sp = self.spk_embed_proj      # nn.Linear(256, H) parameters (reference state_dict), computed as a 1x1 HIP conv on [B,256,1]
+        h_style = SF.conv1d(spk_ids[:, :, None].contiguous(), sp.weight[:, :, None], sp.bias).expand(-1, -1, T)
         return {"h_pitch": h_pitch, "h_content": h_content, "h_style": h_style, "tgt_nonpadding": (pitch > 0).float()}
 
     def _cond_sum(self, h_pitch, h_content, h_style):

@@ -763,3 +763,23 @@ def _period_s2d_index_walk(dev, big):
             back[:, :, hh] = gi5[:, :, r, row]
     got_b = K.period_s2d(gi.to(dev), H, p, s, lead, R, inverse=True)
     assert torch.equal(got_b.cpu(), back.view(B, C, H * p))
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 37, 4), (1, 3, 8, 3), (3, 2, 1, 4), (2, 4, 33, 1)])
+def test_upsample_nearest_nct_matches_interpolate(dev, shape):
+    """SF.upsample_nearest_nct (reference svb_vae.py:39-45: nn.Upsample(scale_factor=s, mode='nearest')) against F.interpolate,
+    forward bit for bit and the adjoint against torch autograd (window sums: same values, fp32 summation order may differ)."""
+    from neuralsvb_amd import functional as SF
+    B, C_, T, s = shape
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, C_, T, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.interpolate(xr, scale_factor=s, mode="nearest")
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    assert torch.equal(SF.upsample_nearest_nct(x.to(dev), s).cpu(), yr.detach())
+    xd = x.to(dev).requires_grad_(True)
+    y = SF.upsample_nearest_nct(xd, s)
+    assert torch.equal(y.detach().cpu(), yr.detach())
+    y.backward(dy.to(dev))
+    assert (xd.grad.cpu() - xr.grad).abs().max().item() <= 1e-6 * max(1.0, xr.grad.abs().max().item())
