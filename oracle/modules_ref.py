@@ -194,7 +194,7 @@ def vc_asr_content(sd, mel, hp):
     ce = sub(sd, "content_encoder.")
     nonpadding_mask = x.abs().sum(-1) > 0
     D = x.shape[-1]
-    pos_emb = rel_pos_encoding(x.shape[1], D)
+    pos_emb = rel_pos_encoding(x.shape[1], D).to(x.dtype)     # (fp32 table as the reference builds it; cast for the fp64 arbiter)
     x = x * math.sqrt(D)
     for li in range(hp["asr_enc_layers"]):
         x = conformer_layer(sub(ce, f"encoder_layers.{li}."), x, pos_emb, nonpadding_mask[:, None, :])

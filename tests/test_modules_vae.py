@@ -69,46 +69,68 @@ def test_mle_svb_vae_forward_matches_reference_golden(dev):
     assert abs(out["a2p"]["mle"].item() - mle_ref) < 5e-4 * max(1.0, abs(mle_ref)), (out["a2p"]["mle"].item(), mle_ref)
 
 
+def _oracle_gradients(d, sd, dtype):
+    """d(loss)/d(params) of the a2a + p2p generator objective (KL + L1) through the CPU oracle in `dtype`."""
+    args = [t(d[k]) for k in ("mels", "prof_mels", "pitch", "prof_pitch", "spk", "a2p_alignment")]
+    args = [a.to(dtype) if a.is_floating_point() else a for a in args]
+    sdr = {}
+    for k, v in sd.items():
+        if v.is_floating_point():
+            v = v.to(dtype).clone()
+            if not k.startswith("vc_asr"):
+                v.requires_grad_(True)
+        sdr[k] = v
+    ret, _, _ = R.mle_svb_vae(sdr, *args, ["a2a", "p2p"], t(d["eps_a2a"]).to(dtype), t(d["eps_p2p"]).to(dtype), HP, training=True)
+    loss = sum(ret[w]["kl"] * 0.001 + R.l1_loss(ret[w]["mel_out"], tg) for w, tg in (("a2a", args[0]), ("p2p", args[1])))
+    loss.backward()
+    return {k: v.grad for k, v in sdr.items() if v.is_floating_point() and v.requires_grad and v.grad is not None}, loss.item(), args
+
+
+# |HIP - fp64| <= ARB_K * |oracle fp32 - fp64| + ARB_FLOOR, per parameter, max-abs error relative to the fp64 gradient's max.
+ARB_K, ARB_FLOOR = 4.0, 3e-4
+
+
 @pytest.mark.slow
 def test_mle_svb_vae_gradients_match_oracle(dev):
-    """d(loss)/d(params) of the a2a+p2p generator objective (KL + L1) vs torch autograd over the CPU oracle."""
+    """d(loss)/d(params) of the a2a+p2p generator objective (KL + L1) against torch autograd over the CPU oracle -- arbitrated by
+    a FLOAT64 evaluation of the same oracle.  This B = 2 x T = 64 fixture is ill-conditioned (the latent pooling stack's
+    train-mode BatchNorm1d normalises over 2 clips x 7 frames behind a ReLU: near-constant channels get rstd ~ 1/sqrt(eps) = 316
+    and whatever differs in front of them is amplified through the backward): the ORACLE's OWN fp32 gradients are off the float64
+    ones by up to 1.5e-3 on exactly the parameters where the HIP path differs most (poolings.0.bias / .weight, then the encoder
+    stack behind them).  So instead of an absolute bound (2e-3 until round 4, 6e-3 in round 4) every parameter must satisfy
+    |HIP - fp64| <= ARB_K x |oracle-fp32 - fp64| + ARB_FLOOR: the HIP path may deviate from the truth by a stated multiple of what
+    the reference's own arithmetic does, and no more.  (At the bench shape -- 16 clips x 140 frames per channel -- the same
+    gradients hold 1.2e-5 in the norm against the reference: test_mle_svb_vae_bench_shape_gradients.)"""
     _skip_slow_emu(dev)
     d = np.load(os.path.join(G, "vae_mle.npz"))
     model, sd = build_model(dev)
     model.train()
-    args = [t(d[k]) for k in ("mels", "prof_mels", "pitch", "prof_pitch", "spk", "a2p_alignment")]
-    sdr = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.startswith("vc_asr") else v)
-           for k, v in sd.items()}
-    ret, _, _ = R.mle_svb_vae(sdr, *args, ["a2a", "p2p"], t(d["eps_a2a"]), t(d["eps_p2p"]), HP, training=True)
-    loss_r = sum(ret[w]["kl"] * 0.001 + R.l1_loss(ret[w]["mel_out"], tg) for w, tg in (("a2a", args[0]), ("p2p", args[1])))
-    loss_r.backward()
+    g32, loss32, args = _oracle_gradients(d, sd, torch.float32)
+    g64, loss64, _ = _oracle_gradients(d, sd, torch.float64)
     out = model(amateur_mel=args[0].to(dev), prof_mel=args[1].to(dev), amateur_pitch=args[2].to(dev),
                 prof_pitch=args[3].to(dev), amateur_spk_id=args[4].to(dev), prof_spk_id=args[4].to(dev),
                 a2p_alignment=args[5].to(dev), infer=False, concurrent_ways=["a2a", "p2p"],
                 eps_a2a=t(d["eps_a2a"]).to(dev), eps_p2p=t(d["eps_p2p"]).to(dev))
     loss = sum(out[w]["kl"] * 0.001 + R.l1_loss(out[w]["mel_out"], tg.to(dev))
                for w, tg in (("a2a", args[0]), ("p2p", args[1])))
-    assert abs(loss.item() - loss_r.item()) < 1e-4
+    assert abs(loss.item() - loss64) < 1e-4
     loss.backward()
-    worst = 0.0
+    rows = []
     for k, p in model.named_parameters():
         if k.startswith("vc_asr") or k.startswith("z_mapping_function"):
             continue
-        gr = sdr[k].grad
-        assert gr is not None and p.grad is not None, k
-        rel = ((p.grad.cpu() - gr).abs().max() / gr.abs().max().clamp_min(1e-8)).item()
-        worst = max(worst, rel)
-        # Bound 6e-3 (2e-3 until round 4).  The latent pooling stack's train-mode BatchNorm1d normalises over the 2 clips x 7 frames
-        # of this fixture, behind a ReLU: channels that are almost constant get rstd ~ 1/sqrt(eps) = 316, and whatever differs in
-        # front of it (here: the summation order of the fp32 MFMA convs against the oracle's CPU convs) is amplified through its
-        # backward.  Until round 4 the product ran torch's batch_norm there (the oracle's own code on the emulator: worst element
-        # 1.3e-4; MIOpen's on the MI355X: < 2e-3).  csrc/batchnorm.hip accumulates in double as the oracle's CPU batch_norm does
-        # and agrees with float64 to 3.5e-8 (tests/test_kernels.py), yet this fixture reads 4.6e-4 on the emulator and 3.8e-3 on
-        # the MI355X (poolings.0.bias / .weight, then the encoder stack behind them at 2.5-3e-3; tools/r04/gpu22.sh prints the
-        # list).  At the bench shape (16 clips x 140 frames per channel) the same gradients hold 1.2e-5 in the norm and 1.2e-3 in
-        # single elements against the reference (test_mle_svb_vae_bench_shape_gradients[fp32]): the kernel is not what is loose.
-        assert rel < 6e-3, (k, rel)
-    print("worst relative grad error", worst)
+        assert k in g64 and p.grad is not None, k
+        ref = g64[k]
+        scale = ref.abs().max().clamp_min(1e-8)
+        e_hip = ((p.grad.cpu().double() - ref).abs().max() / scale).item()
+        e_ref = ((g32[k].double() - ref).abs().max() / scale).item()
+        rows.append((e_hip, e_ref, k))
+    rows.sort(reverse=True)
+    print("worst |HIP - fp64| (relative to max |fp64|), with the oracle's own fp32 error beside it:")
+    for e_hip, e_ref, k in rows[:8]:
+        print(f"    {k:56s} e_hip {e_hip:.2e}  e_ref(fp32 oracle) {e_ref:.2e}  ratio {e_hip / max(e_ref, 1e-12):.1f}")
+    bad = [(k, e_hip, e_ref) for e_hip, e_ref, k in rows if e_hip > ARB_K * e_ref + ARB_FLOOR]
+    assert not bad, bad[:6]
 
 
 def _bench_shape_case():

@@ -432,3 +432,32 @@ def test_fused_step_paths_equal_elementwise_paths(dev, tmp_path, phase):
             if dev.type == "cpu" and not no_critic and oi == 0:
                 tol = 1e-1
             assert err <= tol * max(r.abs().max().item(), 1e-3), (oi, n, err, r.abs().max().item())
+
+
+# bands for test_bf16x3_trains_like_fp32 (relative deviation of the 20-step moving averages; PROVISIONAL until measured on the MI355X)
+TRAJ_BAND = {"recon": 0.05, "kl": 0.25, "adv": 0.5}
+
+
+@pytest.mark.gpu
+def test_bf16x3_trains_like_fp32(gpu_only):
+    """300 optimizer steps (generator + critic, reference tasks/singing/svb_vae_task.py:579-676) from identical weights,
+    batches, seeds and draws, once with `conv_precision: fp32` and once with `bf16x3` (tools/train_trajectory.py).  The runs are
+    chaotic, so not bit-comparable; asserted: both stay finite, the reconstruction terms fall, and every loss term's 20-step moving
+    average of the bf16x3 run stays within a stated band of the fp32 run's (reconstruction 5 %, KL 25 %, adversarial 50 %)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import train_trajectory as TT
+    steps = 300
+    a = TT.run("fp32", steps, gpu_only)
+    b = TT.run("bf16x3", steps, gpu_only)
+    cmp_ = TT.compare(a, b)
+    for k in TT.TERMS:
+        assert np.isfinite(a[k]).all() and np.isfinite(b[k]).all(), k
+        kind = "recon" if k.startswith(("l1", "ssim")) else ("kl" if k.endswith("_kl") else "adv")
+        print(f"{k:8s} first-step rel dev {cmp_[k]['first_step_rel_dev']:.2e}  worst smoothed rel dev {cmp_[k]['worst_rel_dev_smoothed']:.3e}  "
+              f"last-50 means fp32 {cmp_[k]['last50_mean_fp32']:.5g} bf16x3 {cmp_[k]['last50_mean_bf16x3']:.5g}")
+        assert cmp_[k]["worst_rel_dev_smoothed"] <= TRAJ_BAND[kind], (k, cmp_[k])
+        assert cmp_[k]["first_step_rel_dev"] <= 1e-3, (k, cmp_[k])            # same weights, same draws: the first step agrees closely
+    for k in ("l1a2a", "l1p2p"):
+        for r in (a, b):
+            assert np.mean(r[k][-20:]) < 0.8 * np.mean(r[k][:5]), (k, np.mean(r[k][:5]), np.mean(r[k][-20:]))     # it trains
