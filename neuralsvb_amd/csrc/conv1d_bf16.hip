@@ -758,6 +758,17 @@ static int q_dispatch(SvbConvQArgs& a, const SvbConvPlan& p, hipStream_t stream)
         if (rc != SVB_ERR_UNSUPPORTED) return rc;
     }
     if (a.force_cfg >= 0 && a.force_cfg < SVBQ_NCFG) cfg = a.force_cfg;
+    // configurations 15, 16 (round 5, after the tile-walking variants so that earlier table entries keep their meaning): 32-row
+    // tiles twice as wide along time for the narrow stages of the vocoder (32 / 64 output channels, 2-4 K chunks: a 32 x 128
+    // workgroup runs three short phases with a barrier pair each and ~24 MFMAs per wave in between; the wide tile doubles the
+    // work per staged phase).  Only ever picked by measurement.
+    const int wide32 = a.force_cfg - (SVBQ_NCFG + SVB_TW_NVARIANTS);
+    if (wide32 == 0 || wide32 == 1) {
+        int rc;
+        if (wide32 == 0) rc = q_launch<1, 4, 2, 8>(a, p, nq_max, span_off_max, ntap_max, stream);
+        else { SVBQ_DIRECT(1, 4, 2) }
+        if (rc != SVB_ERR_UNSUPPORTED) return rc;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
         int rc;
         switch (cfg) {

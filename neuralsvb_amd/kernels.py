@@ -25,8 +25,10 @@ _CFG_NAMES = ["svb_conv1d_mfma_kernel<2,2,2,*,80> (64x128)", "svb_conv1d_mfma_ke
               "svb_conv1d_mfma_kernel<4,1,2,direct> (128x64)", "svb_conv1d_mfma_kernel<4,1,1,direct> (128x32)",
               # 13..15: the producer / consumer tile-walking kernel of csrc/conv1d_tw.hip (stride-1, ungrouped convs; elsewhere
               # the heuristic tile runs)
-              "svb_conv1d_tw_kernel<2,2> (128x128)", "svb_conv1d_tw_kernel<1,4> (64x256)", "svb_conv1d_tw_kernel<4,1> (256x64)"]
-_NCFG_Q = int(os.environ.get("SVB_NCFG_Q", "15"))     # tile configurations of the bf16x3 kernels (the fp32 kernel has the first 5)
+              "svb_conv1d_tw_kernel<2,2> (128x128)", "svb_conv1d_tw_kernel<1,4> (64x256)", "svb_conv1d_tw_kernel<4,1> (256x64)",
+              # 16, 17 (round 5): 32-row tiles, 256 positions wide (the vocoder's 32 / 64-channel stages)
+              "svb_conv1d_mfma_kernel<1,4,2,*,80> (32x256)", "svb_conv1d_mfma_kernel<1,4,2,direct> (32x256)"]
+_NCFG_Q = int(os.environ.get("SVB_NCFG_Q", "17"))     # tile configurations of the bf16x3 kernels (the fp32 kernel has the first 5)
 
 
 # ---- per-shape tile choice ("measure, don't guess" -- once, offline) ----------------------------------------------------------

@@ -34,7 +34,7 @@ def run(precision, steps, device, seed=7, batch=8, seconds=3.0, n_batches=4, ext
         torch.manual_seed(seed)
         np.random.seed(seed)
         # (build_task writes batch x world clips: `world` = n_batches gives n_batches distinct batches to cycle through)
-        task, trainer, _, hp = bench.build_task(args, 0, n_batches, device, tmp, extra_hparams=",warmup_updates=200" + extra_hparams)
+        task, trainer, _, hp = bench.build_task(args, 0, n_batches, device, tmp, extra_hparams=extra_hparams)
         trainer.world_size, trainer.use_ddp = 1, False
         ds = task.dataset_cls("train", False)
         batches = [move_to_device(ds.collater([ds[b * batch + i] for i in range(batch)]), device) for b in range(n_batches)]
@@ -47,6 +47,7 @@ def run(precision, steps, device, seed=7, batch=8, seconds=3.0, n_batches=4, ext
         for i in range(steps):
             task.global_step = trainer.global_step = 1 + i
             pbar, _ = trainer.run_training_batch(i, batches[i % n_batches])
+            torch.cuda.synchronize()       # the critic's pass runs on its own stream: its loss terms are final only after a device sync
             for k in TERMS:
                 v = pbar.get(k)
                 out[k].append(float(v) if v is not None else float("nan"))
