@@ -172,6 +172,8 @@ def conv_roofline(trainer, task, batch, steps, start_step, precision="fp32"):
             "frac": fl / sec / peak, "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": sum(c * conv_alg_bytes(t) for t, c in tags.items()) / max(1, sum(tags.values())),
             "launches_per_step": cnt / steps,
+            # which launch signatures (op, B, C_a, C_b, groups, T, k, stride, dil) the tile table sends to this kernel, launches per step
+            "signatures": [{"sig": list(t), "launches_per_step": c / steps} for t, c in sorted(tags.items(), key=lambda kv: -kv[1])],
             "avg_launch_us": sec / cnt * 1e6, "gflop_per_launch": fl / cnt / 1e9,
             "mfma_macs_per_algorithmic_mac": mult, "frac_executed": mult * fl / sec / peak,
             "all_conv_kernels": {"achieved": tot_fl / tot_s / 1e12, "frac": tot_fl / tot_s / peak,
@@ -193,11 +195,11 @@ def conv_alg_bytes(tag):
 
 
 def pmc_traffic(tag_counts):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r04_pmc_traffic.json -- an earlier round's if absent --, written by
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r05_pmc_traffic.json -- an earlier round's if absent --, written by
     tools/pmc_traffic.py on the MI355X: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, each calibrated
     on a launch of known traffic with the same access pattern).  Launch-weighted over the shapes the kernel ran in this
     step; (None, why) when the file does not cover at least 60 % of its launches."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (4, 3, 2)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (5, 4, 3, 2)) if os.path.exists(q)), None)
     if path is None:
         return None, "no PMC file"
     db = json.load(open(path)).get("shapes", {})

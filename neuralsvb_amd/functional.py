@@ -330,6 +330,106 @@ class _Conv1dFn(torch.autograd.Function):
         return dx, dv, dg, db, d_res, None, None
 
 
+def _wgrad_of(ctx_need, dy, xin, k, pad, dil, v, g, b, gate, slope):
+    """Weight / WeightNorm / bias gradients of y = conv(leaky_relu(xin)) given dy, accumulated straight into `.grad` buffers where
+    the parameters own one (same conventions as _Conv1dFn.backward).  -> (dv, dg, db) with None for what went into a sink."""
+    need_v, need_b = ctx_need
+    dv = dg = db = None
+    want_b = b is not None and need_b
+    if need_v:
+        sk = _sinks(v, g, b if want_b else None)
+        r = K.conv1d_wgrad(dy, xin, k, 1, pad, dil, 1, b_gate=gate, b_slope=slope, v=v if g is not None else None, g=g,
+                           want_bias=want_b, sinks=sk)
+        if want_b:
+            r, db = r[:-1], r[-1]
+            r = r if g is not None else r[0]
+        if g is not None:
+            dv, dg = r
+        else:
+            dv = r
+        _notify(sk, (v, g, b if want_b else None), (dv, dg if g is not None else 0, db if want_b else 0))
+    elif want_b:
+        db = K.bias_grad(dy, None, 0.0)
+    return dv, dg, db
+
+
+class _ResBlock1Fn(torch.autograd.Function):
+    """HifiGAN ResBlock1 (reference modules/hifigan/hifigan.py:30-67) as ONE autograd node: per (c1, c2) pair
+
+        xt = c1(leaky_relu(x));   x = c2(leaky_relu(xt)) + x
+
+    Forward: the launches the per-conv nodes issue (LeakyReLU on the operand load, the skip in the epilogue).  Backward, hand
+    scheduled per pair:   d_xt = c2^T(dy) * lrelu'(xt);   dx = c1^T(d_xt) * lrelu'(x) + dy   -- the skip connection's gradient
+    rides in the data-gradient conv's residual epilogue, so autograd never launches `grad += grad` for the two uses of x (nor
+    the defensive clone of a tensor a side-stream weight gradient still reads): 6 elementwise launches per block and direction
+    less, and 2 autograd nodes per block instead of 12.  Same kernels on the same operands as the per-conv path: bit-identical.
+
+    args: x, slope, geom = ((k, dilation, padding) per conv, order c1_0, c2_0, c1_1, ...), then (v, g, bias) per conv."""
+
+    @staticmethod
+    def forward(ctx, x, slope, geom, *params):
+        x = _c(x)
+        n = len(geom)
+        keep, pbs = [], []
+        C_ = x.shape[1]
+        for i in range(0, n, 2):
+            x_in = x
+            for j in (i, i + 1):
+                v, g, b = (_c(t) for t in params[3 * j:3 * j + 3])
+                k, dil, pad = geom[j]
+                pa, pb = _pack(v, g, 1, want_a=True, want_b=True)
+                pbs.append(pb)
+                src = x_in if j == i else xt
+                y = K.conv1d_forward(src, pa, C_, k, 1, pad, dil, 1, bias=b, in_gate=src, in_slope=slope,
+                                     residual=x_in if j == i + 1 else None)
+                if j == i:
+                    xt = y
+            keep += [x_in, xt]
+            x = y
+        ctx.slope, ctx.geom, ctx.pbs = slope, geom, pbs
+        ctx.save_for_backward(*keep, *params)
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        n = len(ctx.geom)
+        saved = ctx.saved_tensors
+        acts, params = saved[:n], saved[n:]
+        need = ctx.needs_input_grad
+        slope = ctx.slope
+        dy = dy.contiguous()
+        grads = [None] * (3 * n)
+        C_, T = acts[0].shape[1], acts[0].shape[2]
+        for i in range(n - 2, -1, -2):
+            x_in, xt = acts[i], acts[i + 1]
+            (v1, g1, b1), (v2, g2, b2) = params[3 * i:3 * i + 3], params[3 * i + 3:3 * i + 6]
+            (k1, dil1, pad1), (k2, dil2, pad2) = ctx.geom[i], ctx.geom[i + 1]
+            # through c2: y = c2(lrelu(xt)) + x_in
+            d_xt = K.conv1d_transposed(dy, ctx.pbs[i + 1], C_, T, k2, 1, pad2, dil2, 1, out_gate=xt, out_gate_slope=slope)
+            grads[3 * i + 3:3 * i + 6] = _wgrad_of((need[3 + 3 * (i + 1)], need[3 + 3 * (i + 1) + 2]), dy, xt, k2, pad2, dil2,
+                                                   v2, g2, b2, xt, slope)
+            # through c1: xt = c1(lrelu(x_in));  the skip's gradient (dy) is added in the epilogue
+            dx = K.conv1d_transposed(d_xt, ctx.pbs[i], C_, T, k1, 1, pad1, dil1, 1, out_gate=x_in, out_gate_slope=slope,
+                                     residual=dy)
+            grads[3 * i:3 * i + 3] = _wgrad_of((need[3 + 3 * i], need[3 + 3 * i + 2]), d_xt, x_in, k1, pad1, dil1, v1, g1, b1,
+                                               x_in, slope)
+            dy = dx
+        return (dy if need[0] else None, None, None, *grads)
+
+
+def resblock1(x, convs1, convs2, slope):
+    """ResBlock1.forward for modules whose convs are layers.Conv1d (weight-normalised or folded), stride 1, ungrouped."""
+    geom, params = [], []
+    for c1, c2 in zip(convs1, convs2):
+        for c in (c1, c2):
+            geom.append((int(c.kernel_size), int(c.dilation), int(c.padding)))
+            if c.is_weight_norm:
+                params += [c.weight_v, c.weight_g, c.bias]
+            else:
+                params += [c.weight, None, c.bias]
+    return _ResBlock1Fn.apply(x, float(slope), tuple(geom), *params)
+
+
 def conv1d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, weight_g=None, in_slope=None,
            out_act=ACT_NONE, out_slope=0.0, residual=None, mask=None):
     """x [B,Cin,T]; weight [Cout,Cin/groups,k] (or weight_v with weight_g [Cout,1,1]); mask [B,Tout]."""

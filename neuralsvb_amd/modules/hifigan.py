@@ -23,6 +23,7 @@ from .. import kernels as K
 from .layers import Conv1d, ConvTranspose1d
 
 LRELU_SLOPE = 0.1
+FUSED_RESBLOCK = True       # hparam `fused_resblock` (HifiGanTask): False = one autograd node per conv (the A/B form)
 
 
 def get_padding(kernel_size, dilation=1):
@@ -38,6 +39,9 @@ class ResBlock1(nn.Module):
                                             weight_norm=True, init_std=0.01) for _ in dilation])
 
     def forward(self, x):
+        if FUSED_RESBLOCK and torch.is_grad_enabled() and x.requires_grad and all(c.precision is None for c in
+                                                                                   list(self.convs1) + list(self.convs2)):
+            return SF.resblock1(x, self.convs1, self.convs2, LRELU_SLOPE)      # one autograd node, skips summed in conv epilogues
         for c1, c2 in zip(self.convs1, self.convs2):
             xt = c1(x, in_slope=LRELU_SLOPE)                     # c1(leaky_relu(x))
             x = c2(xt, in_slope=LRELU_SLOPE, residual=x)         # c2(leaky_relu(xt)) + x

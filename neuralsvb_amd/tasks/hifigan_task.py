@@ -47,6 +47,7 @@ class HifiGanTask(BaseTask):
         SF.set_precision(hparams.get("conv_precision", "fp32"))
         from ..modules import hifigan as _hg
         _hg.FUSED_SPECTRAL_NORM = bool(hparams.get("fused_spectral_norm", True))
+        _hg.FUSED_RESBLOCK = bool(hparams.get("fused_resblock", True))
         self.model_gen = HifiGanGenerator(hparams)
         self.model_disc = nn.ModuleDict()
         self.model_disc["mpd"] = MultiPeriodDiscriminator()

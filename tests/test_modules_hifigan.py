@@ -242,3 +242,42 @@ def test_spectral_norm_weight_matches_torch_formulation(dev, shape):
     u0 = mod.weight_u.clone()
     assert _rel(mod._weight(), ref._weight_torch()) < 2e-6
     assert torch.equal(mod.weight_u, u0)                       # eval mode: no power iteration, buffers untouched
+
+
+@pytest.mark.parametrize("precision", PREC)
+@pytest.mark.parametrize("folded", [False, True])
+def test_fused_resblock_node_equals_per_conv_nodes(dev, folded, precision):
+    """ResBlock1 as ONE autograd node (SF.resblock1: the skip connections' gradient sums ride in the data-gradient convs'
+    residual epilogue) against the per-conv nodes it replaces (reference modules/hifigan/hifigan.py:30-67): same kernels on the
+    same operands, so output, input gradient and every weight / WeightNorm / bias gradient must be bit-identical -- with
+    weight norm and with folded weights, kernel 7 / dilations (1, 3, 5), a sequence that is not a multiple of any tile."""
+    import copy
+    from neuralsvb_amd.modules import hifigan as H
+    _set_precision(precision)
+    torch.manual_seed(3)
+    blk = H.ResBlock1(None, 24, 7, (1, 3, 5))
+    for p in blk.parameters():
+        p.data.mul_(8.0)                     # (init_std 0.01 would leave every gradient at rounding level)
+    if folded:
+        blk.remove_weight_norm()
+    ref = copy.deepcopy(blk)
+    blk, ref = blk.to(dev).train(), ref.to(dev).train()
+    g_ = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 24, 157, generator=g_)
+    dy = torch.randn(2, 24, 157, generator=g_)
+    outs = []
+    for m, fused in ((blk, True), (ref, False)):
+        H.FUSED_RESBLOCK = fused
+        try:
+            xd = x.to(dev).requires_grad_(True)
+            y = m(xd * 1.0)                # (a non-leaf input, as inside the generator)
+            y.backward(dy.to(dev))
+        finally:
+            H.FUSED_RESBLOCK = True
+        outs.append((y.detach().cpu(), xd.grad.cpu(), {k: p.grad.cpu() for k, p in m.named_parameters()}))
+    (y1, dx1, g1), (y0, dx0, g0) = outs
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
+    assert set(g1) == set(g0) and len(g1) == (12 if folded else 18)
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), k
+    assert float(dx0.abs().max()) > 0 and all(float(v.abs().max()) > 0 for v in g0.values())

@@ -434,8 +434,11 @@ def test_fused_step_paths_equal_elementwise_paths(dev, tmp_path, phase):
             assert err <= tol * max(r.abs().max().item(), 1e-3), (oi, n, err, r.abs().max().item())
 
 
-# bands for test_bf16x3_trains_like_fp32 (relative deviation of the 20-step moving averages; PROVISIONAL until measured on the MI355X)
-TRAJ_BAND = {"recon": 0.05, "kl": 0.25, "adv": 0.5}
+# bands for test_bf16x3_trains_like_fp32: relative deviation of the 20-step moving averages over 300 steps.  Measured on the MI355X
+# (profiles/r05_trajectory_fp32_vs_bf16x3.log): reconstruction terms 2.6 %, KL 5.6 %, the generator's adversarial terms 10.8 %, the
+# critic's own terms 12 ... 29 %; the last-50-step means agree to 0.2 % (reconstruction) ... 4 % (critic).  A second fp32 run from
+# the same seeds reproduces the first bit for bit (deviation 0), so the band is the arithmetic's, not run-to-run noise.
+TRAJ_BAND = {"recon": 0.05, "kl": 0.15, "adv": 0.5}
 
 
 @pytest.mark.gpu
@@ -443,7 +446,7 @@ def test_bf16x3_trains_like_fp32(gpu_only):
     """300 optimizer steps (generator + critic, reference tasks/singing/svb_vae_task.py:579-676) from identical weights,
     batches, seeds and draws, once with `conv_precision: fp32` and once with `bf16x3` (tools/train_trajectory.py).  The runs are
     chaotic, so not bit-comparable; asserted: both stay finite, the reconstruction terms fall, and every loss term's 20-step moving
-    average of the bf16x3 run stays within a stated band of the fp32 run's (reconstruction 5 %, KL 25 %, adversarial 50 %)."""
+    average of the bf16x3 run stays within a stated band of the fp32 run's (reconstruction 5 %, KL 15 %, adversarial / critic terms 50 %)."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import train_trajectory as TT
