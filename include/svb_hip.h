@@ -422,6 +422,13 @@ int svb_embed_nct_fwd(const int64_t* idx, const float* w, float* out, int B, int
 int svb_embed_nct_bwd(const int64_t* idx, const float* dy, float* part, float* dw, int B, int H, int T, int V, int padding_idx,
                       int accumulate, void* stream);
 
+/* ---- `conv_precision: bf16` (ABI v8): the forward / transposed / tap-table convs of the *_bf16x3 entry points evaluate ONE bf16
+ * product per operand pair (hi * hi, fp32 accumulation) instead of the three of the split; weight gradients keep the split.  A
+ * process-wide mode (it mirrors an hparam), to be set before work is issued; default off.  BASELINE configs[1] names "bf16": this
+ * is that arithmetic, reported as a secondary line only (it is narrower than the reference's fp32).                            */
+void svb_conv_set_single_product(int on);
+int svb_conv_get_single_product(void);
+
 /* ---- nearest-neighbour upsampling along time, conv layout (reference modules/voice_conversion/svb_vae.py:39-45:
  * nn.Upsample(scale_factor=s, mode='nearest') of the content features; ABI v8).  adjoint == 0: x [rows][T] -> y [rows][T*scale],
  * y[r][t*scale + j] = x[r][t].  adjoint != 0: x = dy [rows][T*scale] -> y = dx [rows][T], the sum over each window in j order. */

@@ -77,7 +77,10 @@ __device__ __forceinline__ void svbq_split8(const float* v, uint4& hi, uint4& lo
 //  0.2-0.35 ms MORE kernel time per step than the streaming kernels they replaced -- profiles/r03_fused_epilogue_ab.log -- removed.)
 template <int WM, int WN, int NT, int SLB, int MODE>
 __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs a, SvbConvPlan p) {
-    constexpr bool GATE = MODE == 1, QIN = MODE == 2;
+    // MODE 3 / 4 = MODE 0 / 1 with ONE bf16 product per operand pair (hi * hi only: plain bf16 arithmetic with fp32 accumulation,
+    // `conv_precision: bf16`, a secondary, reduced-precision line -- svb_conv_set_single_product); the cross products are compiled out
+    constexpr bool SINGLE = MODE >= 3;
+    constexpr bool GATE = MODE == 1 || MODE == 4, QIN = MODE == 2;
     constexpr int BM = 32 * WM, BN = 32 * WN * NT;
     constexpr int WTASKS = SLB * BM * 2;                 // 16-byte units per (hi|lo) weight tile
     constexpr int WU = (2 * WTASKS + 255) / 256;         // per-thread units, hi and lo together
@@ -325,8 +328,10 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
                 for (int n = 0; n < NT; ++n) {
                     const uint4 bh_u = x_hi[xbase[n] + xoff], bl_u = x_lo[xbase[n] + xoff];
                     const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&bh_u), bl = *reinterpret_cast<const bf16x8*>(&bl_u);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
+                    if constexpr (!SINGLE) {
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
+                    }
                     acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
                 }
             }
@@ -348,8 +353,10 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
                 for (int n = 0; n < NT; ++n) {
                     const uint4 bh_u = x_hi[xbase[n] + xoff], bl_u = x_lo[xbase[n] + xoff];
                     const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&bh_u), bl = *reinterpret_cast<const bf16x8*>(&bl_u);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
+                    if constexpr (!SINGLE) {
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
+                    }
                     acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
                 }
             }
@@ -422,8 +429,8 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
 #pragma unroll
                     for (int j = 0; j < NM; ++j) {
                         const int n = j % NT, prod = j / NT;            // products: lo*hi, hi*lo, hi*hi
-                        if (prod == 0) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, *reinterpret_cast<const bf16x8*>(&bh_u[i & 1][n]), acc[n], 0, 0, 0);
-                        else if (prod == 1) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, *reinterpret_cast<const bf16x8*>(&bl_u[i & 1][n]), acc[n], 0, 0, 0);
+                        if (prod == 0) { if constexpr (!SINGLE) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, *reinterpret_cast<const bf16x8*>(&bh_u[i & 1][n]), acc[n], 0, 0, 0); }
+                        else if (prod == 1) { if constexpr (!SINGLE) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, *reinterpret_cast<const bf16x8*>(&bl_u[i & 1][n]), acc[n], 0, 0, 0); }
                         else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, *reinterpret_cast<const bf16x8*>(&bh_u[i & 1][n]), acc[n], 0, 0, 0);
                         if (i + 1 < SLB && j < 2 * NT) {               // fillers 0 .. 2NT-1: next slab's B fragments
                             const int nn = j >> 1;
@@ -647,6 +654,12 @@ __global__ __launch_bounds__(256) void svb_weight_pack_bf16x3_multi_kernel(const
 }
 
 // ==================================================================================================================
+// `conv_precision: bf16` (single-product arithmetic of the forward / data-gradient convs; weight gradients keep the split).  A
+// process-wide arithmetic mode like the hparam it mirrors: set once before the work is issued, not per call.
+static int g_svbq_single = 0;
+extern "C" void svb_conv_set_single_product(int on) { g_svbq_single = on ? 1 : 0; }
+extern "C" int svb_conv_get_single_product(void) { return g_svbq_single; }
+
 struct QCfg { int BM, BN; };
 #define SVBQ_NCFG 12
 static const QCfg kQCfgs[SVBQ_NCFG] = {{64, 128}, {128, 96}, {128, 128}, {64, 64}, {32, 128}, {64, 192}, {64, 256},
@@ -724,7 +737,10 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     a.w_floats16 = SLB <= 5 ? 0 : a.tg * a.kch * BM * 3;
     a.x_floats16 = a.kch * a.xrows * 3;
     dim3 grid(a.G * svb_cdiv(a.Cout_g, BM), svb_cdiv(nq_max, BN), a.B * p.n_phase);
-    if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, 1>(a, p, grid, lds_bytes(a.kch), stream);
+    if (g_svbq_single && !qin) {
+        if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, 4>(a, p, grid, lds_bytes(a.kch), stream);
+        else q_launch_kernel<WM, WN, NT, SLB, 3>(a, p, grid, lds_bytes(a.kch), stream);
+    } else if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, 1>(a, p, grid, lds_bytes(a.kch), stream);
     else if (qin) q_launch_kernel<WM, WN, NT, SLB, 2>(a, p, grid, lds_bytes(a.kch), stream);
     else q_launch_kernel<WM, WN, NT, SLB, 0>(a, p, grid, lds_bytes(a.kch), stream);
     SVB_CHECK_LAUNCH();
@@ -752,7 +768,7 @@ static int q_dispatch(SvbConvQArgs& a, const SvbConvPlan& p, hipStream_t stream)
     if ((long)a.B * p.n_phase > 65535) return SVB_ERR_UNSUPPORTED;
     if ((long)a.Cout * a.Tout > 0x7fffffffL) return SVB_ERR_UNSUPPORTED;      // the epilogue's per-clip offsets are 32-bit
     int cfg = q_pick(a.Cout_g, nq_max, (long)a.B * p.n_phase * a.G);
-    if (a.force_cfg >= SVBQ_NCFG && a.force_cfg < SVBQ_NCFG + SVB_TW_NVARIANTS) {
+    if (a.force_cfg >= SVBQ_NCFG && a.force_cfg < SVBQ_NCFG + SVB_TW_NVARIANTS && !g_svbq_single) {
         // configurations 12 .. 17: the 8-wave tile-walking kernel (conv1d_tw.hip); outside its domain the heuristic tile runs
         const int rc = svb_tw_launch(a, p, a.force_cfg - SVBQ_NCFG, stream);
         if (rc != SVB_ERR_UNSUPPORTED) return rc;

@@ -24,12 +24,24 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = K.ACT_NONE, K.ACT_RELU, K.ACT_LRELU, K
 PRECISION = "fp32"
 
 
+SINGLE_PRODUCT = False   # `conv_precision: bf16`: the bf16x3 code path with ONE bf16 product per operand pair in the forward / data-gradient
+                         # convs (plain bf16 arithmetic, fp32 accumulation and storage; weight gradients keep the split).  Narrower than
+                         # the reference's fp32: a secondary line, never the parity mode.
+
+
 def set_precision(mode):
-    global PRECISION
-    if mode not in ("fp32", "bf16x3"):
+    """`conv_precision`: "fp32" (fp32 MFMA, exact-parity mode), "bf16x3" (bf16 matrix cores, fp32-class operand split) or "bf16"
+    (bf16 matrix cores, single product -- see SINGLE_PRODUCT)."""
+    global PRECISION, SINGLE_PRODUCT
+    if mode not in ("fp32", "bf16x3", "bf16"):
         raise ValueError(mode)
-    PRECISION = mode
-    K.WGRAD_BF16X3 = mode == "bf16x3"
+    single = mode == "bf16"
+    if single != SINGLE_PRODUCT or single:
+        from . import _lib as _L
+        (_L._LIB if _L._LIB is not None else _L.get_lib()).svb_conv_set_single_product(int(single))
+    SINGLE_PRODUCT = single
+    PRECISION = "bf16x3" if single else mode
+    K.WGRAD_BF16X3 = PRECISION == "bf16x3"
 
 
 class precision_scope:

@@ -958,3 +958,37 @@ def test_tile_table_is_committed_and_well_formed():
         assert K.tuned_choice(("qf", 1, 2, 3), True) is None          # unseen signature on the GPU: measured on line
     finally:
         K.load_tile_table()
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 5, 11, 16])
+def test_conv1d_single_product_bf16_mode(dev, cfg):
+    """`conv_precision: bf16` (svb_conv_set_single_product): the bf16x3 conv entry points with ONE bf16 product per operand pair.
+    The result must equal a conv of the bf16-ROUNDED operands accumulated in fp32 (to summation order), i.e. it is plain bf16
+    arithmetic -- about 1e-3 off the fp32 conv, where the three-product split is 1e-5 off -- forward (LeakyReLU on the operand load,
+    bias, residual) and transposed; and switching the mode off restores the split."""
+    from neuralsvb_amd import functional as SF
+    g = torch.Generator().manual_seed(cfg)
+    B, Cin, Cout, T, k = 2, 48, 72, 300, 5
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) * 0.2
+    bias = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, T, generator=g)
+    bf = lambda t_: t_.to(torch.bfloat16).to(torch.float32)
+    ref32 = oops.conv1d(F.leaky_relu(x, 0.1), w, bias, 1, 2) + res
+    refbf = oops.conv1d(bf(F.leaky_relu(x, 0.1)), bf(w), bias, 1, 2) + res
+    qa, qb = K.weight_pack_q(w.to(dev), None, 1)
+    kw = dict(bias=bias.to(dev), in_gate=x.to(dev), in_slope=0.1, residual=res.to(dev), force_cfg=cfg)
+    SF.set_precision("bf16")
+    try:
+        y1 = K.conv1d_forward(x.to(dev), qa, Cout, k, 1, 2, 1, 1, **kw)
+        dy = torch.randn(ref32.shape, generator=g)
+        d1 = K.conv1d_transposed(dy.to(dev), qb, Cin, T, k, 1, 2, 1, 1, force_cfg=cfg)
+    finally:
+        SF.set_precision("bf16x3")
+    y3 = K.conv1d_forward(x.to(dev), qa, Cout, k, 1, 2, 1, 1, **kw)
+    assert rel_err(y1, refbf) < 2e-6                     # = the conv of the rounded operands
+    assert 2e-4 < rel_err(y1, ref32) < 1e-2               # plain bf16 accuracy
+    assert rel_err(y3, ref32) < 6e-5                      # the split is back
+    dref = torch.autograd.grad(oops.conv1d(x.requires_grad_(True), w, None, 1, 2), x, dy)[0]
+    drefbf = torch.autograd.grad(oops.conv1d(x, bf(w), None, 1, 2), x, bf(dy))[0]
+    assert rel_err(d1, drefbf) < 2e-6 and 2e-4 < rel_err(d1, dref) < 1e-2

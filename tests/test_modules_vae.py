@@ -146,11 +146,12 @@ def _bench_shape_case():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16"])
 def test_mle_svb_vae_bench_shape_mel_l1_per_way(gpu_only, precision):
     """THE north-star parity gate, at the shape and in the arithmetic `bench.py` measures (BASELINE configs[1]: batch 16 x
     6 s clips, T = 1124; `conv_precision: bf16x3`): mel-L1 of EACH way (a2a, p2p, a2p) against the unmodified reference's
-    CPU output <= 1e-4.  Measured on the MI355X: bf16x3 9.8e-6 per way, fp32 1.2e-6."""
+    CPU output <= 1e-4.  Measured on the MI355X: bf16x3 9.8e-6 per way, fp32 1.2e-6.  The third case, `bf16` (single product), is
+    recorded, not gated: it is the arithmetic BASELINE configs[1] literally names, narrower than the reference."""
     from neuralsvb_amd import functional as SF
     dev = gpu_only
     d, inp = _bench_shape_case()
@@ -168,6 +169,12 @@ def test_mle_svb_vae_bench_shape_mel_l1_per_way(gpu_only, precision):
     st = int(d["frame_stride"])
     l1s = {w: (out[w]["mel_out"][:, ::st].cpu() - t(d[f"{w}.mel_out"])).abs().mean().item() for w in ("a2a", "p2p", "a2p")}
     print(precision, l1s)
+    if precision == "bf16":
+        # `conv_precision: bf16` (single product) is NOT a parity mode: plain bf16 arithmetic is narrower than the reference's fp32 and
+        # misses the north-star's 1e-4 by construction.  This records what it gives (the secondary bench line quotes it) and guards
+        # against breakage only.
+        assert 1e-4 < max(l1s.values()) <= 3e-2, (precision, l1s)
+        return
     assert max(l1s.values()) <= (1e-4 if precision == "bf16x3" else 1e-5), (precision, l1s)
     for w in ("a2a", "p2p"):
         for k in ("m_q", "logs_q", "z_q"):
