@@ -223,6 +223,33 @@ def test_bench_command_line_starts_its_own_ranks(tmp_path, _emu_lib):
     assert res["comm"]["buckets_launched_in_backward"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_command_line_two_ranks_on_one_gpu(tmp_path, gpu_only):
+    """The command the driver runs for the scaling curve, end to end on hardware: `python bench.py --gpus 2` starts its two ranks,
+    both on the one MI355X of the box (LOCAL_RANK is taken modulo the device count; gloo carries the exchange because RCCL refuses
+    two ranks per device), runs warm-up + settle + timed steps with the bucketed exchange inside backward, and rank 0 prints ONE JSON
+    line with `comm.ranks == 2` AND its `roofline` (the profiled steps run on rank 0 alone with the exchange switched off, so no
+    rank can be left waiting in a collective)."""
+    import json
+    import subprocess
+    import sys
+    small = ("hidden_size=32,fvae_enc_dec_hidden=32,latent_size=16,fvae_enc_n_layers=2,fvae_dec_n_layers=2,"
+             "mel_disc_hidden_size=16,warmup_updates=4")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SVB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "2",
+                        "--seconds", "0.71", "--no-cpu-baseline", "--no-extra-workloads", "--extra-hparams", small],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["comm"]["ranks"] == 2 and res["config"]["global_batch"] == 4
+    assert res["comm"]["buckets_launched_in_backward"] > 0
+    assert res["roofline"] is not None and res["roofline"]["frac"] > 0 and res["roofline"]["serial_streams"]["frac"] > 0
+    assert res["warmup_settle"]["extra_steps"] >= 10 and res["tile_table"]["entries"] > 300
+
+
 def _gpu_pair_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -1,11 +1,11 @@
 #!/bin/bash
 # A round's measurement artefacts of the benchmarked configuration (one GPU call, ~8 min): default bench line (with the
 # extra workloads), kernel traces with and without the side streams, PMC traffic of the dominant kernel, SQ counters of two shapes.
-#   gpurun --timeout 1500 -- 'bash tools/measure_round.sh r04'          (copy what should be judged from gpurun_out/ to profiles/)
+#   gpurun --timeout 1500 -- 'bash tools/measure_round.sh r05'          (copy what should be judged from gpurun_out/ to profiles/)
 # One-off A/B runs of step variants: tools/ab_bench.sh "<hparams overrides | bench flag>" ...   (both scripts are parameterised:
 # the 50 single-purpose scripts of round 3 are gone; git history has them)
 set -x
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=gpurun_out/${TAG}_final
 mkdir -p $O
 export TMPDIR=/tmp

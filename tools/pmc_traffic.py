@@ -1,4 +1,4 @@
-"""HBM-side traffic (rocprofv3 PMC) of the step's dominant conv kernel, per shape -> profiles/<round>_pmc_traffic.json (GPU box; round tag from SVB_ROUND, default r04).
+"""HBM-side traffic (rocprofv3 PMC) of the step's dominant conv kernel, per shape -> profiles/<round>_pmc_traffic.json (GPU box; round tag from SVB_ROUND, default r05).
 
 As MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (they do not fit one pass), nothing but
 --pmc on the rocprofv3 command line, units of KB, and -- because the gfx950 counters are only calibrated for 16-byte streaming
@@ -95,7 +95,7 @@ def main():
         out["shapes"][json.dumps(list(tag))] = ent
         print(tag, ent, flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    rnd = os.environ.get("SVB_ROUND", "r04")
+    rnd = os.environ.get("SVB_ROUND", "r05")
     for path in (os.path.join(ROOT, "gpurun_out", f"{rnd}_pmc_traffic.json"), os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")):
         with open(path, "w") as f:
             json.dump(out, f, indent=1)
