@@ -529,6 +529,7 @@ def main():
     else:
         assert torch.cuda.is_available(), "bench.py measures the HIP path: an MI355X is required"
         local = local % torch.cuda.device_count()
+        os.environ["LOCAL_RANK"] = str(local)      # (more ranks than devices -- the two-ranks-on-one-GPU test --: the Trainer reads it too)
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
     gpu = device.type == "cuda"
