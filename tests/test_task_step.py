@@ -26,7 +26,7 @@ def _oracle_mel_fn(hp):
     return fn
 
 
-def _setup(tmp_path, dev, extra=""):
+def _setup(tmp_path, dev, extra="", n_clips=2, seconds=0.71):
     from neuralsvb_amd.utils.hparams import set_hparams, hparams
     from neuralsvb_amd.utils import synth
     set_hparams(config=os.path.join(ROOT, "egs/datasets/audio/PopBuTFy/vae_global_mle_eng.yaml"), exp_name="",
@@ -35,8 +35,8 @@ def _setup(tmp_path, dev, extra=""):
     hparams["pretrain_asr_ckpt"] = str(tmp_path / "asr")
     hparams["work_dir"] = str(tmp_path / "ckpt")
     torch.manual_seed(0)
-    synth.write_binary_dataset(hparams["binary_data_dir"], hparams, _oracle_mel_fn(hparams), n_train=2, n_valid=1,
-                               seconds=0.71)
+    synth.write_binary_dataset(hparams["binary_data_dir"], hparams, _oracle_mel_fn(hparams), n_train=n_clips, n_valid=1,
+                               seconds=seconds)
     synth.write_fake_asr_ckpt(hparams["pretrain_asr_ckpt"], 70, hparams)
     from neuralsvb_amd.tasks.svb_vae_task import SVBVAEMleTask
     from neuralsvb_amd.utils.trainer import Trainer, move_to_device
@@ -49,7 +49,7 @@ def _setup(tmp_path, dev, extra=""):
         if isinstance(m, torch.nn.Dropout2d):
             m.p = 0.0
     task.train()
-    loader = task.build_dataloader(task.dataset_cls("train", False), False, hparams["max_tokens"], 2)
+    loader = task.build_dataloader(task.dataset_cls("train", False), False, hparams["max_tokens"], n_clips)
     batch = move_to_device(next(iter(loader)), dev)
     return task, trainer, batch, hparams
 
@@ -334,8 +334,23 @@ def _grads_after_passes(task, trainer, batch, dev, global_step, eps, seed):
     return terms, grads
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("phase", [2, 3])
+def test_fused_step_paths_equal_elementwise_paths_well_conditioned(gpu_only, tmp_path, phase):
+    """The same comparison on a WELL-CONDITIONED fixture, with tight bounds everywhere (advisor finding, round 4: the loose bounds
+    of the small fixture -- 1.5e-2 across the critic, 6e-3 on the latent map -- would let a real 1 % regression of a fused kernel
+    pass): 6 clips of 2.3 s, so the critic's windows see 430 frames of varying content (no near-constant InstanceNorm plane) and the
+    latent map's / pooling stack's train-mode BatchNorm1d normalise over 6 clips instead of 2.  MI355X only (the lane emulator needs
+    an hour for it)."""
+    _fused_vs_elementwise(gpu_only, tmp_path, phase, well_conditioned=True)
+
+
 @pytest.mark.parametrize("phase", [2, 3, "2-no-critic"])
 def test_fused_step_paths_equal_elementwise_paths(dev, tmp_path, phase):
+    _fused_vs_elementwise(dev, tmp_path, phase)
+
+
+def _fused_vs_elementwise(dev, tmp_path, phase, well_conditioned=False):
     """The fused passes of a step (mel loss, latent head + KL, GroupNorm+ReLU+residual, window crops, conformer residual
     epilogues) against the same step with each of them switched back to its stock element-wise form: every logged term
     and every gradient of the pass, in phase 2 (generator + critic) and phase 3 (latent map incl. the a2p way)."""
@@ -348,14 +363,16 @@ def test_fused_step_paths_equal_elementwise_paths(dev, tmp_path, phase):
         pytest.skip("phase-3 step at hidden_size 256 on the lane emulator: set SVB_SLOW_TESTS=1 (passes; ~5 min)")
     # phase 2 runs in the bench's arithmetic (bf16x3: also the deferred multi-tensor reduce of the weight gradients, which only
     # exists on that path), phase 3 in fp32
-    task, trainer, batch, hp = _setup(tmp_path, dev, ",hidden_size=256" if phase == 3 else ",conv_precision=bf16x3")
+    task, trainer, batch, hp = _setup(tmp_path, dev, ",hidden_size=256" if phase == 3 else ",conv_precision=bf16x3",
+                                      **(dict(n_clips=6, seconds=2.3) if well_conditioned else {}))
+    nb = batch["mels"].shape[0]
     hp["phase_2_steps"] = 2 if phase == 3 else 10 ** 6
     if no_critic:
         hp["lambda_mel_adv"] = 0.0
     gs = 3 if phase == 3 else 2
     L = hp["latent_size"]
     g = torch.Generator().manual_seed(5)
-    eps = (torch.randn(2, L, 1, generator=g), torch.randn(2, L, 1, generator=g))
+    eps = (torch.randn(nb, L, 1, generator=g), torch.randn(nb, L, 1, generator=g))
     sd0 = {k: v.detach().clone() for k, v in task.state_dict().items()}
     opt0 = [None if o is None else {"state": {}, "param_groups": o.state_dict()["param_groups"]} for o in trainer.optimizers]
 
@@ -397,6 +414,7 @@ def test_fused_step_paths_equal_elementwise_paths(dev, tmp_path, phase):
         SF.set_precision("fp32")
     assert sorted(t1) == sorted(t0) and len(t1) >= 1
     assert (2 in t1) == (phase == 3)
+    worst = {}
     for oi in t0:
         assert set(t1[oi]) == set(t0[oi]), (oi, set(t1[oi]) ^ set(t0[oi]))
         for k, v in t0[oi].items():
@@ -431,7 +449,17 @@ def test_fused_step_paths_equal_elementwise_paths(dev, tmp_path, phase):
             # pass below (1e-3) and tests/test_modules_disc.py.
             if dev.type == "cpu" and not no_critic and oi == 0:
                 tol = 1e-1
+            if well_conditioned:
+                tol = WELL_COND_TOL[oi]
+            worst[oi] = max(worst.get(oi, 0.0), err / max(r.abs().max().item(), 1e-3))
             assert err <= tol * max(r.abs().max().item(), 1e-3), (oi, n, err, r.abs().max().item())
+    print(f"fused vs element-wise step paths, phase {phase}{' (well-conditioned fixture)' if well_conditioned else ''}: worst gradient "
+          f"element error relative to the tensor's largest, per pass: { {k: float(f'{v:.2e}') for k, v in worst.items()} }")
+
+
+# test_fused_step_paths_equal_elementwise_paths_well_conditioned: bound per optimizer pass (0 generator, 1 critic, 2 latent map);
+# PROVISIONAL until measured on the MI355X
+WELL_COND_TOL = {0: 3e-3, 1: 3e-3, 2: 2e-3}
 
 
 # bands for test_bf16x3_trains_like_fp32: relative deviation of the 20-step moving averages over 300 steps.  Measured on the MI355X
