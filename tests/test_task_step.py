@@ -457,9 +457,10 @@ def _fused_vs_elementwise(dev, tmp_path, phase, well_conditioned=False):
           f"element error relative to the tensor's largest, per pass: { {k: float(f'{v:.2e}') for k, v in worst.items()} }")
 
 
-# test_fused_step_paths_equal_elementwise_paths_well_conditioned: bound per optimizer pass (0 generator, 1 critic, 2 latent map);
-# PROVISIONAL until measured on the MI355X
-WELL_COND_TOL = {0: 3e-3, 1: 3e-3, 2: 2e-3}
+# test_fused_step_paths_equal_elementwise_paths_well_conditioned: bound per optimizer pass (0 generator -- across the critic --,
+# 1 critic, 2 latent map).  Measured on the MI355X (round 5): 5.9e-5 / 1.4e-3 / 1.1e-5, against 1.5e-2 / 1.5e-2 / 6e-3 that the small
+# fixture needs: 30x tighter on the generator's and the latent map's fused paths, 3x on the critic's.
+WELL_COND_TOL = {0: 5e-4, 1: 5e-3, 2: 2e-4}
 
 
 # bands for test_bf16x3_trains_like_fp32: relative deviation of the 20-step moving averages over 300 steps.  Measured on the MI355X
