@@ -172,6 +172,8 @@ def conv_roofline(trainer, task, batch, steps, start_step, precision="fp32"):
     traffic, traffic_src = pmc_traffic(tags)
     return {"bound": "mfma", "kernel": name, "achieved": fl / sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
             "frac": fl / sec / peak, "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+            # the same kernel against the OTHER roof: PMC bytes per launch / live launch duration, of the 8 TB/s HBM peak
+            "hbm_tbps": (traffic / (sec / cnt) / 1e12) if traffic else None, "hbm_frac": (traffic / (sec / cnt) / 8e12) if traffic else None,
             "algorithmic_bytes_per_launch": sum(c * conv_alg_bytes(t) for t, c in tags.items()) / max(1, sum(tags.values())),
             "launches_per_step": cnt / steps,
             # which launch signatures (op, B, C_a, C_b, groups, T, k, stride, dil) the tile table sends to this kernel, launches per step
