@@ -20,6 +20,11 @@ SPLIT_STACKED = True     # stacked ways: per-way mel_out views through SF.split_
 PPG_SIDE_STREAM = True   # prepare_condition: the frozen PPG encoder (no grad, T/2 frames: it under-fills the chip) runs on its own
                          # stream beside the pitch encoder -- the two branches only meet at the conditioning projection
 _PPG_STREAMS = {}
+PPG_GRAPH = False        # hparam `ppg_graph`: the look-ahead run of the frozen PPG encoder (prefetch_content) replayed from a captured
+                         # hipGraph per input shape instead of being issued launch by launch -- ~75 launches / 1.6 ms of HOST time per
+                         # step become one replay.  Frozen weights, persistent packed images and table-driven tiles make the
+                         # captured sequence the eager one: identical results.
+PPG_GRAPH_MAX_SHAPES = 8
 FUSED_GN = True          # ConvBlock: GroupNorm + ReLU + residual as one HIP pass per direction
 
 
@@ -120,10 +125,51 @@ class MleSVBVAE(nn.Module):
         cache.clear()
         with torch.no_grad(), torch.cuda.stream(side):
             for mels, _ in jobs:
-                x = torch.cat(list(mels)) if len(mels) > 1 else mels[0]
                 for m in mels:
                     m.record_stream(side)
-                cache[self._content_key(*mels)] = (self.vc_asr(x)["h_content"].detach(), mels)
+                h = self._ppg_graph_run(mels, side) if PPG_GRAPH else None
+                if h is None:
+                    x = torch.cat(list(mels)) if len(mels) > 1 else mels[0]
+                    h = self.vc_asr(x)["h_content"].detach()
+                cache[self._content_key(*mels)] = (h, mels)
+
+    def _ppg_graph_run(self, mels, side):
+        """The frozen encoder on cat(mels) through a hipGraph captured once per input shape (static input / output buffers; the
+        current stream is `side`).  Returns the (static) output tensor, or None when this shape is not graphed (first sight of
+        a shape runs eagerly -- lazy caches fill, tiles outside the table are measured --, the second captures; more than
+        PPG_GRAPH_MAX_SHAPES shapes, or a capture that fails, fall back to eager launches for good).
+
+        The output buffer is overwritten by the NEXT replay: safe because the consumer's first op (the nearest upsampling /
+        smoothing conv of prepare_condition) has been enqueued on the compute stream before the next prefetch starts, and the
+        PPG stream waits for the compute stream before it replays."""
+        st = self.__dict__.setdefault("_ppg_graphs", {"seen": {}, "graphs": {}, "off": False})
+        if st["off"] or self.vc_asr.training:
+            return None
+        key = tuple((tuple(m.shape), m.dtype) for m in mels)
+        ent = st["graphs"].get(key)
+        if ent is None:
+            st["seen"][key] = st["seen"].get(key, 0) + 1
+            if st["seen"][key] < 2 or len(st["graphs"]) >= PPG_GRAPH_MAX_SHAPES:
+                return None
+            try:
+                x_static = torch.cat(list(mels)) if len(mels) > 1 else mels[0].clone()
+                g = torch.cuda.CUDAGraph()
+                side.synchronize()
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    h_static = self.vc_asr(x_static)["h_content"].detach()
+                ent = st["graphs"][key] = (g, x_static, h_static)
+            except Exception as e:            # a sync or an unsupported call inside the encoder: eager launches from here on
+                st["off"] = True
+                import warnings
+                warnings.warn(f"PPG encoder graph capture failed ({e!r}); falling back to eager launches")
+                return None
+        g, x_static, h_static = ent
+        if len(mels) > 1:
+            torch.cat(list(mels), out=x_static)
+        else:
+            x_static.copy_(mels[0])
+        g.replay()
+        return h_static
 
     def _cached_content(self, key):
         cache = self.__dict__.get("_content_cache")

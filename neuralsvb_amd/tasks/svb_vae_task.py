@@ -106,6 +106,7 @@ class SVBVAEMleTask(BaseTask):
         _va.POS_IN_KERNEL = bool(hparams.get("ppg_pos_in_kernel", True))
         from ..modules import svb_vae as _svb
         _svb.PPG_SIDE_STREAM = bool(hparams.get("overlap_ppg_encoder", True)) and os.environ.get("SVB_PPG_SIDE", "1") != "0"
+        _svb.PPG_GRAPH = bool(hparams.get("ppg_graph", False))
         self.build_tts_model()
         if hparams.get("pretrain_asr_ckpt"):
             ckpt_utils.load_ckpt(self.model.vc_asr, hparams["pretrain_asr_ckpt"], model_name="model",

@@ -116,6 +116,41 @@ def test_phase2_training_step_matches_cpu_oracle(dev, tmp_path):
 
 
 @pytest.mark.gpu
+def test_ppg_prefetch_graph_replay_equals_eager_launches(gpu_only, tmp_path):
+    """`ppg_graph: true`: the look-ahead run of the frozen PPG encoder replayed from a captured hipGraph (one per input shape,
+    captured at the second sight) must hand the following step bit-for-bit what the eager launches hand it -- six steps over two
+    alternating batches, identical losses and weights, and the graph must actually have been replayed."""
+    from neuralsvb_amd.modules import svb_vae
+    dev = gpu_only
+    res = {}
+    for mode in ("eager", "graph"):
+        task, trainer, batch, hp = _setup(tmp_path / mode, dev)
+        svb_vae.PPG_GRAPH = mode == "graph"
+        try:
+            b2 = {k: (v.flip(0).contiguous() if isinstance(v, torch.Tensor) and v.dim() > 0 else v) for k, v in batch.items()}
+            seq = [batch, b2] * 4
+            logs = []
+            for step in range(1, 7):
+                np.random.seed(400 + step)
+                torch.manual_seed(400 + step)
+                task.global_step = trainer.global_step = step
+                pbar, _ = trainer.run_training_batch(0, seq[step - 1], next_batch=seq[step])
+                logs.append({k: float(v) for k, v in pbar.items() if isinstance(v, torch.Tensor)})
+            trainer._join_critic_stream()
+            torch.cuda.synchronize()
+            st = task.model.__dict__.get("_ppg_graphs")
+            if mode == "graph":
+                assert st is not None and len(st["graphs"]) == 1 and not st["off"], st
+            res[mode] = (logs, {k: v.detach().clone() for k, v in task.state_dict().items() if v.is_floating_point()})
+        finally:
+            svb_vae.PPG_GRAPH = False
+    for a, b in zip(res["eager"][0], res["graph"][0]):
+        assert a == b, (a, b)
+    for k, v in res["eager"][1].items():
+        assert torch.equal(v, res["graph"][1][k]), k
+
+
+@pytest.mark.gpu
 def test_prefetched_ppg_encoder_gives_the_same_steps(gpu_only, tmp_path):
     """Trainer.run_training_batch(..., next_batch=...) runs the frozen PPG encoder of the following batch one step early, on
     its side stream beside the current backward, and copies that batch to the device early; the following step must consume
