@@ -79,8 +79,12 @@ template <int WM, int WN, int NT, int SLB, int MODE>
 __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs a, SvbConvPlan p) {
     // MODE 3 / 4 = MODE 0 / 1 with ONE bf16 product per operand pair (hi * hi only: plain bf16 arithmetic with fp32 accumulation,
     // `conv_precision: bf16`, a secondary, reduced-precision line -- svb_conv_set_single_product); the cross products are compiled out
-    constexpr bool SINGLE = MODE >= 3;
-    constexpr bool GATE = MODE == 1 || MODE == 4, QIN = MODE == 2;
+    // MODE 5 = MODE 1 whose gate tensor IS the input (`conv(leaky_relu(x))`, in_gate == x -- every conv of the HifiGAN generator):
+    // the activation derivative is taken from the value just loaded instead of from a second load of the same element, which
+    // halves the x tile's global loads (the staging of that tile is what bounds these kernels).  Same arithmetic: bit-identical.
+    constexpr bool SINGLE = MODE == 3 || MODE == 4;
+    constexpr bool SELFG = MODE == 5;
+    constexpr bool GATE = MODE == 1 || MODE == 4 || MODE == 5, QIN = MODE == 2;
     constexpr int BM = 32 * WM, BN = 32 * WN * NT;
     constexpr int WTASKS = SLB * BM * 2;                 // 16-byte units per (hi|lo) weight tile
     constexpr int WU = (2 * WTASKS + 255) / 256;         // per-thread units, hi and lo together
@@ -208,7 +212,10 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
                 // branch-free: out-of-range lanes read element 0 of the channel row and are zeroed when staged
 #pragma unroll
                 for (int e = 0; e < 8; ++e) xr[u][e] = svbq_ld(pc + (size_t)e * a.Tin, x_off[u]);
-                if (GATE) {
+                if constexpr (SELFG) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xr[u][e] *= svb_gate(xr[u][e], a.in_slope);
+                } else if (GATE) {
                     const float* gc = gb + (size_t)chb * a.Tin;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) xr[u][e] *= svb_gate(svbq_ld(gc + (size_t)e * a.Tin, x_off[u]), a.in_slope);
@@ -740,7 +747,8 @@ static int q_launch(SvbConvQArgs& a, const SvbConvPlan& p, int nq_max, int span_
     if (g_svbq_single && !qin) {
         if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, 4>(a, p, grid, lds_bytes(a.kch), stream);
         else q_launch_kernel<WM, WN, NT, SLB, 3>(a, p, grid, lds_bytes(a.kch), stream);
-    } else if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, 1>(a, p, grid, lds_bytes(a.kch), stream);
+    } else if (a.in_gate && a.in_gate == a.x) q_launch_kernel<WM, WN, NT, SLB, 5>(a, p, grid, lds_bytes(a.kch), stream);
+    else if (a.in_gate) q_launch_kernel<WM, WN, NT, SLB, 1>(a, p, grid, lds_bytes(a.kch), stream);
     else if (qin) q_launch_kernel<WM, WN, NT, SLB, 2>(a, p, grid, lds_bytes(a.kch), stream);
     else q_launch_kernel<WM, WN, NT, SLB, 0>(a, p, grid, lds_bytes(a.kch), stream);
     SVB_CHECK_LAUNCH();
@@ -976,7 +984,11 @@ __device__ __forceinline__ unsigned svbq_funnel(unsigned hi, unsigned lo, unsign
 
 // AT x BT: 32x32 accumulator tiles per wave along the A rows / B rows (workgroup tile 64*AT x 64*BT).  Wide tiles raise the
 // MFMA work per staged element for the tap-poor gradients (1x1 convs: 12 MFMAs per wave and 64-position chunk at 1x1).
-template <int TGW, int DIL, bool GATED, int AT, int BT>
+// GATED: 0 = plain operands; 1 = activation-derivative gates loaded from their own tensors; 2 = only Bt is gated and its gate tensor
+// is Bt itself (the weight gradient of `conv(leaky_relu(x))`, b_gate == b: every conv of the HifiGAN generator) -- the factor comes
+// from the value just loaded: a third fewer global loads and no staging registers for the gate (the general form of the 3 / 4 / 5-tap
+// instantiations spills: 36 ... 200 bytes of scratch per lane at 256 VGPRs).  Same arithmetic: bit-identical.
+template <int TGW, int DIL, int GATED, int AT, int BT>
 __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgradQArgs a) {
     HIP_DYNAMIC_SHARED(unsigned, wg_smem)
     unsigned* A_hi = wg_smem;
@@ -1027,9 +1039,9 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
 #pragma unroll
     for (int rr = 0; rr < RA; ++rr) bsum[rr] = 0.f;
     const float* a_base = a.a + (size_t)g * a.CA_g * a.TA;
-    const float* ag_base = GATED && a.a_gate ? a.a_gate + (size_t)g * a.CA_g * a.TA : nullptr;
+    const float* ag_base = GATED == 1 && a.a_gate ? a.a_gate + (size_t)g * a.CA_g * a.TA : nullptr;
     const float* b_base = a.b + (size_t)g * a.CB_g * a.TB;
-    const float* bg_base = GATED && a.b_gate ? a.b_gate + (size_t)g * a.CB_g * a.TB : nullptr;
+    const float* bg_base = GATED == 1 && a.b_gate ? a.b_gate + (size_t)g * a.CB_g * a.TB : nullptr;
 
     // ---- staging, branch-free: per-thread row offsets and masks are hoisted; per chunk only the (clamped) position
     // changes.  Out-of-range rows / positions read a valid element and are zeroed when written to LDS, so all loads of a
@@ -1095,7 +1107,18 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
             bx[e][0] = svbq_ld(bbp, x_roff[e] + 4u * (unsigned)min(max(p0, 0), a.TB - 1));
             bx[e][1] = svbq_ld(bbp, x_roff[e] + 4u * (unsigned)min(max(p1, 0), a.TB - 1));
         }
-        if (GATED) {
+        if constexpr (GATED == 2) {
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) {
+                br[rr][0] *= svb_gate(br[rr][0], a.b_slope);
+                br[rr][1] *= svb_gate(br[rr][1], a.b_slope);
+            }
+#pragma unroll
+            for (int e = 0; e < SVBQ_WG_NXIT; ++e) {
+                bx[e][0] *= svb_gate(bx[e][0], a.b_slope);
+                bx[e][1] *= svb_gate(bx[e][1], a.b_slope);
+            }
+        } else if (GATED) {
             if (ag_base) {
                 const float* gp = ag_base + (size_t)bb * a.CA * a.TA;
 #pragma unroll
@@ -1619,7 +1642,7 @@ extern "C" size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB
     return (size_t)ns * slab;
 }
 
-template <int TGW, int DIL, bool GATED, int AT, int BT>
+template <int TGW, int DIL, int GATED, int AT, int BT>
 static void wgq_launch_kernel(const SvbWgradQArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1633,20 +1656,23 @@ static void wgq_launch_kernel(const SvbWgradQArgs& a, dim3 grid, size_t lds, hip
 template <int TGW, int AT, int BT>
 static void wgq_launch_t(const SvbWgradQArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     const bool gated = a.a_gate || a.b_gate;
+    const bool self_b = !a.a_gate && a.b_gate && a.b_gate == a.b;
     if (a.dil == 1) {
-        if (gated) wgq_launch_kernel<TGW, 1, true, AT, BT>(a, grid, lds, st);
-        else wgq_launch_kernel<TGW, 1, false, AT, BT>(a, grid, lds, st);
+        if (self_b) wgq_launch_kernel<TGW, 1, 2, AT, BT>(a, grid, lds, st);
+        else if (gated) wgq_launch_kernel<TGW, 1, 1, AT, BT>(a, grid, lds, st);
+        else wgq_launch_kernel<TGW, 1, 0, AT, BT>(a, grid, lds, st);
     } else {
-        if (gated) wgq_launch_kernel<TGW, 0, true, AT, BT>(a, grid, lds, st);
-        else wgq_launch_kernel<TGW, 0, false, AT, BT>(a, grid, lds, st);
+        if (self_b) wgq_launch_kernel<TGW, 0, 2, AT, BT>(a, grid, lds, st);
+        else if (gated) wgq_launch_kernel<TGW, 0, 1, AT, BT>(a, grid, lds, st);
+        else wgq_launch_kernel<TGW, 0, 0, AT, BT>(a, grid, lds, st);
     }
 }
 
 template <int TGW>
 static void wgq_launch(const SvbWgradQArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     if constexpr (TGW == 1) {
-        if (a.at == 2) { wgq_launch_kernel<1, 1, false, 2, 1>(a, grid, lds, st); return; }       // (dil is irrelevant for one tap)
-        if (a.bt == 2) { wgq_launch_kernel<1, 1, false, 1, 2>(a, grid, lds, st); return; }
+        if (a.at == 2) { wgq_launch_kernel<1, 1, 0, 2, 1>(a, grid, lds, st); return; }       // (dil is irrelevant for one tap)
+        if (a.bt == 2) { wgq_launch_kernel<1, 1, 0, 1, 2>(a, grid, lds, st); return; }
     }
     wgq_launch_t<TGW, 1, 1>(a, grid, lds, st);
 }

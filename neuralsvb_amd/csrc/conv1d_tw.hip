@@ -93,7 +93,7 @@ extern "C" void svb_debug_set_tw(void* buf, int ablate, int drain_per_pair) {
 // activation into a second register set and drains it with a few stores per slab of the NEXT tile, behind its MFMAs -- the
 // 25-32 MB write burst of 256 workgroups reaching their epilogue together (20k cycles per tile, measured) becomes a steady
 // ~3 B/clk/CU stream.  Epilogues with gate / residual / mask / tanh run at the end of their tile.
-template <int CM, int CN, bool GATE>
+template <int CM, int CN, int GATE>
 __global__ __launch_bounds__(512, 2) void svb_conv1d_tw_kernel(SvbTwArgs arg) {
     constexpr int AF = 2, BF = 2;
     constexpr int BM = 64 * CM, BN = 64 * CN;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void svb_conv1d_tw_kernel(SvbTwArgs arg) {
                 w_row16[j] = 2u * (unsigned)min(m_base + w_rb[j] * 64 + lane, p_w_rows - 1);
         };
         float xr[TW_XU][8];
-        float gr[GATE ? TW_XU : 1][8];
+        float gr[GATE == 1 ? TW_XU : 1][8];      // (GATE 2: the gate tensor is x itself -- conv(leaky_relu(x)) -- no second load)
         // all loads of a phase are requested at once; a unit outside the tile (or its clip) reads element 0 of the channel row
         auto issue_x = [&](int ph) {
             if (TW_ABL(1)) return;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void svb_conv1d_tw_kernel(SvbTwArgs arg) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         xr[u][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, x_off[u], 4u * (ch0 + e) * (unsigned)p_Tin, 0));
-                    if (GATE) {
+                    if (GATE == 1) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
                             gr[u][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, x_off[u], 4u * (ch0 + e) * (unsigned)p_Tin, 0));
@@ -198,9 +198,12 @@ __global__ __launch_bounds__(512, 2) void svb_conv1d_tw_kernel(SvbTwArgs arg) {
 #pragma unroll
             for (int u = 0; u < TW_XU; ++u)
                 if (u < p_xunits && u * 128 + x_row0 < XR) {
-                    if (GATE) {
+                    if (GATE == 1) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) xr[u][e] *= svb_gate(gr[u][e], in_slope);
+                    } else if (GATE == 2) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) xr[u][e] *= svb_gate(xr[u][e], in_slope);
                     }
                     unsigned h[4], l[4];
 #pragma unroll
@@ -481,7 +484,7 @@ static int tw_device() {
     return dev;
 }
 
-template <int CM, int CN, bool GATE>
+template <int CM, int CN, int GATE>
 static void tw_launch_kernel(const SvbTwArgs& a, int grid, size_t lds, hipStream_t stream, int dev) {
     static bool attr_set[SVB_TW_MAX_DEVICES] = {};
     if (dev < 0 || !attr_set[dev]) {
@@ -494,8 +497,9 @@ static void tw_launch_kernel(const SvbTwArgs& a, int grid, size_t lds, hipStream
 
 template <int CM, int CN>
 static void tw_launch_gate(const SvbTwArgs& a, int grid, size_t lds, hipStream_t stream, int dev) {
-    if (a.in_gate) tw_launch_kernel<CM, CN, true>(a, grid, lds, stream, dev);
-    else tw_launch_kernel<CM, CN, false>(a, grid, lds, stream, dev);
+    if (a.in_gate && a.in_gate == a.x) tw_launch_kernel<CM, CN, 2>(a, grid, lds, stream, dev);
+    else if (a.in_gate) tw_launch_kernel<CM, CN, 1>(a, grid, lds, stream, dev);
+    else tw_launch_kernel<CM, CN, 0>(a, grid, lds, stream, dev);
 }
 
 static int g_tw_cus[SVB_TW_MAX_DEVICES] = {};

@@ -992,3 +992,35 @@ def test_conv1d_single_product_bf16_mode(dev, cfg):
     dref = torch.autograd.grad(oops.conv1d(x.requires_grad_(True), w, None, 1, 2), x, dy)[0]
     drefbf = torch.autograd.grad(oops.conv1d(x, bf(w), None, 1, 2), x, bf(dy))[0]
     assert rel_err(d1, drefbf) < 2e-6 and 2e-4 < rel_err(d1, dref) < 1e-2
+
+
+@pytest.mark.parametrize("cfg", [0, 2, 13, 15, 16])
+@pytest.mark.parametrize("k,dil", [(1, 1), (3, 1), (3, 5), (7, 3), (11, 1)])
+def test_self_gated_conv_and_wgrad_variants_equal_the_general_gate(dev, k, dil, cfg):
+    """`conv(leaky_relu(x))` hands the kernels the input itself as the gate tensor (in_gate == x; b_gate == b in its weight
+    gradient).  Those launches take the self-gated instantiations (forward MODE 5, weight gradient GATED 2: the activation
+    derivative from the value just loaded, no second load, no staging registers for it -- reference modules/hifigan/hifigan.py:
+    54-61); a gate in a tensor of its own takes the general ones.  Same arithmetic, so both must agree bit for bit -- forward with
+    bias + residual on the heuristic tile, a direct-A tile, two tile-walking variants and the 32 x 256 tile, and the weight / bias
+    gradient, over 1 / 3 / 7 / 11 taps and dilations."""
+    g = torch.Generator().manual_seed(7 * k + dil)
+    B, Cin, Cout, T = 2, 48, 40, 333
+    pad = dil * (k - 1) // 2
+    x = torch.randn(B, Cin, T, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, k, generator=g) * 0.2).to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    res = torch.randn(B, Cout, T, generator=g).to(dev)
+    dy = torch.randn(B, Cout, T, generator=g).to(dev)
+    qa, _ = K.weight_pack_q(w, None, 1)
+    y_self = K.conv1d_forward(x, qa, Cout, k, 1, pad, dil, 1, bias=bias, in_gate=x, in_slope=0.1, residual=res, force_cfg=cfg)
+    y_gen = K.conv1d_forward(x, qa, Cout, k, 1, pad, dil, 1, bias=bias, in_gate=x.clone(), in_slope=0.1, residual=res, force_cfg=cfg)
+    assert torch.equal(y_self, y_gen)
+    ref = oops.conv1d(F.leaky_relu(x.cpu(), 0.1), w.cpu(), bias.cpu(), 1, pad, dil) + res.cpu()
+    assert rel_err(y_self, ref) < 6e-5
+    d_self = K.conv1d_wgrad(dy, x, k, 1, pad, dil, 1, b_gate=x, b_slope=0.1, bf16x3=True, want_bias=True)
+    d_gen = K.conv1d_wgrad(dy, x, k, 1, pad, dil, 1, b_gate=x.clone(), b_slope=0.1, bf16x3=True, want_bias=True)
+    assert torch.equal(d_self[0], d_gen[0]) and torch.equal(d_self[1], d_gen[1])
+    xr = x.cpu().clone().requires_grad_(False)
+    wr = w.cpu().clone().requires_grad_(True)
+    oops.conv1d(F.leaky_relu(xr, 0.1), wr, None, 1, pad, dil).backward(dy.cpu())
+    assert rel_err(d_self[0], wr.grad) < 1e-4
