@@ -988,6 +988,9 @@ __device__ __forceinline__ unsigned svbq_funnel(unsigned hi, unsigned lo, unsign
 // is Bt itself (the weight gradient of `conv(leaky_relu(x))`, b_gate == b: every conv of the HifiGAN generator) -- the factor comes
 // from the value just loaded: a third fewer global loads and no staging registers for the gate (the general form of the 3 / 4 / 5-tap
 // instantiations spills: 36 ... 200 bytes of scratch per lane at 256 VGPRs).  Same arithmetic: bit-identical.
+// (Round 5, measured: the general gated 3 / 4 / 5-tap instantiations spill 36 ... 200 bytes per lane at two workgroups per CU; at ONE per
+//  CU -- accumulators in AGPRs, no spills -- the vocoder step is 6 % SLOWER (118.8 / 119.3 against 112.0 ms): occupancy is worth more
+//  than the spills cost.  The self-gated variants (GATED 2) need neither.)
 template <int TGW, int DIL, int GATED, int AT, int BT>
 __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgradQArgs a) {
     HIP_DYNAMIC_SHARED(unsigned, wg_smem)
