@@ -180,25 +180,24 @@ def test_infer_t1872_pipeline_matches_reference(gpu_only, precision):
         gen.remove_weight_norm()
         gen = gen.to(dev).eval()
         x = {k: v.to(dev) for k, v in inp.items()}
-        if True:
-            out = model(amateur_mel=x["mels"], prof_mel=x["prof_mels"], amateur_pitch=x["pitch"], prof_pitch=x["prof_pitch"],
-                        amateur_spk_id=x["spk"], prof_spk_id=x["spk"], a2p_alignment=x["a2p_alignment"], p2a_alignment=None,
-                        infer=False, concurrent_ways=["a2a", "p2p", "a2p"],
-                        eps_a2a=torch.from_numpy(d["eps_a2a"]).to(dev), eps_p2p=torch.from_numpy(d["eps_p2p"]).to(dev))
-            fs = int(d["frame_stride"])
-            for way in ("a2a", "p2p", "a2p"):
-                mo = out[way]["mel_out"]
-                l1 = np.abs(mo[:, ::fs].cpu().numpy() - d[f"{way}.mel_out"]).mean()
-                print(f"[{precision}] T=1872 {way}: mel-L1 {l1:.3e} (|mel| mean {float(d[f'{way}.mel_out_abs_mean']):.3f})")
-                soft(l1 < tol["mel_l1"], (way, l1))
-            ws = int(d["wav_stride"])
-            kw = dict(rand_ini=ri.to(dev), noise=nz.to(dev))
-            f0d = f0.to(dev)
-            for tag, mel in (("reference a2p mel", torch.from_numpy(d["a2p.mel_out_full"]).to(dev)), ("own a2p mel (pipeline)", out["a2p"]["mel_out"])):
-                wav = gen(mel.transpose(1, 2).contiguous(), f0d, **kw)
-                assert wav.shape == (MG.INF_B, 1, L)
-                err = np.abs(wav[:, 0, ::ws].cpu().numpy() - d["wav"])
-                e_dense = np.abs(wav[0, 0, :MG.DENSE].cpu().numpy() - d["wav_dense"]).max()
-                print(f"[{precision}] T=1872 waveform on the {tag}: max abs {max(err.max(), e_dense):.3e}, mean abs {err.mean():.3e} (|wav| mean {float(d['wav_abs_mean']):.3f})")
-                soft(max(err.max(), e_dense) < tol["wav_max"] and err.mean() < tol["wav_mean"], tag)
+        out = model(amateur_mel=x["mels"], prof_mel=x["prof_mels"], amateur_pitch=x["pitch"], prof_pitch=x["prof_pitch"],
+                    amateur_spk_id=x["spk"], prof_spk_id=x["spk"], a2p_alignment=x["a2p_alignment"], p2a_alignment=None,
+                    infer=False, concurrent_ways=["a2a", "p2p", "a2p"],
+                    eps_a2a=torch.from_numpy(d["eps_a2a"]).to(dev), eps_p2p=torch.from_numpy(d["eps_p2p"]).to(dev))
+        fs = int(d["frame_stride"])
+        for way in ("a2a", "p2p", "a2p"):
+            mo = out[way]["mel_out"]
+            l1 = np.abs(mo[:, ::fs].cpu().numpy() - d[f"{way}.mel_out"]).mean()
+            print(f"[{precision}] T=1872 {way}: mel-L1 {l1:.3e} (|mel| mean {float(d[f'{way}.mel_out_abs_mean']):.3f})")
+            soft(l1 < tol["mel_l1"], (way, l1))
+        ws = int(d["wav_stride"])
+        kw = dict(rand_ini=ri.to(dev), noise=nz.to(dev))
+        f0d = f0.to(dev)
+        for tag, mel in (("reference a2p mel", torch.from_numpy(d["a2p.mel_out_full"]).to(dev)), ("own a2p mel (pipeline)", out["a2p"]["mel_out"])):
+            wav = gen(mel.transpose(1, 2).contiguous(), f0d, **kw)
+            assert wav.shape == (MG.INF_B, 1, L)
+            err = np.abs(wav[:, 0, ::ws].cpu().numpy() - d["wav"])
+            e_dense = np.abs(wav[0, 0, :MG.DENSE].cpu().numpy() - d["wav_dense"]).max()
+            print(f"[{precision}] T=1872 waveform on the {tag}: max abs {max(err.max(), e_dense):.3e}, mean abs {err.mean():.3e} (|wav| mean {float(d['wav_abs_mean']):.3f})")
+            soft(max(err.max(), e_dense) < tol["wav_max"] and err.mean() < tol["wav_mean"], tag)
     soft.done()
