@@ -729,6 +729,14 @@ def main():
                     "ms_per_step_this_rank": t_rank / args.steps * 1e3,
                     "side_stream_weight_gradients": hp.get("wgrad_side_stream", True) and not args.no_side_stream,
                     "critic_pass_on_own_stream": hp.get("overlap_critic_pass", True)}
+            # the replicas must hold identical weights after the steps above: float64 (sum, sum of squares) of every trainable
+            # parameter per rank, gathered -- N equal pairs on a correct exchange
+            flat = torch.cat([p.detach().flatten() for p in task.gen_params + task.disc_params]).double()
+            dig = torch.stack([flat.sum(), (flat * flat).sum()])
+            gathered = [torch.zeros_like(dig) for _ in range(world)]
+            dist.all_gather(gathered, dig)
+            comm["replica_digests"] = [[float(v) for v in g_] for g_ in gathered]
+            comm["replicas_identical"] = all(torch.equal(g_, gathered[0]) for g_ in gathered)
         roof = cpu = None
         if not args.no_roofline and gpu and rank == 0:
             # (N > 1: the profiled steps run on rank 0 ALONE with the gradient exchange switched off for them -- no collective is

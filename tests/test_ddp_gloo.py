@@ -158,50 +158,11 @@ def test_batch_sharding_rule():
     assert flat == sorted(i for b in kept for i in b)             # disjoint cover of the kept batches
 
 
-def _bench_worker(rank, world, port, emu_lib, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank))
-    import argparse
-    import sys
-    import tempfile
-    sys.path.insert(0, ROOT)
-    from neuralsvb_amd import _lib
-    _lib._LIB, _lib._LIB_IS_EMU = _lib.bind(emu_lib), True     # test harness: CPU lane emulator
-    import bench
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    args = argparse.Namespace(batch=2, seconds=0.71, sample_rate=24000, bf16=False, precision="fp32", graph=False)
-    small = (",hidden_size=32,fvae_enc_dec_hidden=32,latent_size=16,fvae_enc_n_layers=2,fvae_dec_n_layers=2,"
-             "mel_disc_hidden_size=16,warmup_updates=4")
-    with tempfile.TemporaryDirectory() as tmp:
-        task, trainer, batch, hp = bench.build_task(args, rank, world, torch.device("cpu"), tmp, extra_hparams=small)
-        assert trainer.use_ddp and trainer.world_size == world
-        assert batch["mels"].shape[0] == args.batch                   # weak scaling: per-rank batch is --batch
-        bench.run_steps(trainer, task, batch, 2, 1)
-        w = torch.cat([p.detach().flatten() for p in task.gen_params + task.disc_params])
-        st = [g.stats for g in trainer.grad_sync if g is not None]
-        # step 1 records each pass's announcement counts; step 2 all-reduces buckets from inside backward
-        assert sum(x["launched_in_backward"] for x in st) > 0 and all(x["passes"] in (0, 2) for x in st), st
-    np.save(os.path.join(out, f"b{rank}.npy"), w.numpy())
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_bench_multi_rank_path_two_ranks_gloo(tmp_path, _emu_lib):
-    """bench.py's own N > 1 path (what the driver launches with torchrun) on 2 gloo ranks: batch x world synthetic clips,
-    per-rank batch = --batch, DDP start-up broadcast, two full phase-2 steps through the Trainer with the bucketed
-    gradient exchange overlapped with backward; the replicas must hold identical weights afterwards."""
-    from tests.conftest import EMU_LIB
-    port = _free_port()
-    mp.spawn(_bench_worker, args=(2, port, EMU_LIB, str(tmp_path)), nprocs=2, join=True)
-    w0, w1 = np.load(tmp_path / "b0.npy"), np.load(tmp_path / "b1.npy")
-    assert np.isfinite(w0).all() and np.array_equal(w0, w1)
-
-
 def test_bench_command_line_starts_its_own_ranks(tmp_path, _emu_lib):
     """`python bench.py --gpus 2` with no launcher around it (the driver's form of the command, as it runs `--gpus 1`): bench.py
     re-execs itself under torch.distributed.run with one rank per device (reference utils/trainer.py:453-466 spawns its own
     ranks too), the ranks run the N > 1 step over gloo on the lane emulator, and rank 0 prints ONE JSON line whose
-    `comm.ranks` is 2 and whose value counts both ranks' clips."""
+    `comm.ranks` is 2, whose value counts both ranks' clips, and whose `comm.replica_digests` show bit-identical replicas."""
     import json
     import subprocess
     import sys
@@ -221,6 +182,11 @@ def test_bench_command_line_starts_its_own_ranks(tmp_path, _emu_lib):
     assert res["config"]["global_batch"] == 4 and res["config"]["parallelism"] == "dp2"
     assert abs(res["value"] - 2 * 2 * 0.71 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]
     assert res["comm"]["buckets_launched_in_backward"] > 0
+    # (this test also stands for the former test_bench_multi_rank_path_two_ranks_gloo, which ran the same two steps through workers
+    #  it spawned itself: per-rank batch = --batch, DDP start-up broadcast, bucketed exchange overlapped with backward, and the
+    #  replicas bit-identical afterwards -- now read from the line's `comm.replica_digests`)
+    assert res["comm"]["replicas_identical"] and len(res["comm"]["replica_digests"]) == 2
+    assert all(np.isfinite(v) for d_ in res["comm"]["replica_digests"] for v in d_)
 
 
 @pytest.mark.gpu
@@ -248,6 +214,7 @@ def test_bench_command_line_two_ranks_on_one_gpu(tmp_path, gpu_only):
     assert res["comm"]["buckets_launched_in_backward"] > 0
     assert res["roofline"] is not None and res["roofline"]["frac"] > 0 and res["roofline"]["serial_streams"]["frac"] > 0
     assert res["warmup_settle"]["extra_steps"] >= 10 and res["tile_table"]["entries"] > 300
+    assert res["comm"]["replicas_identical"]
 
 
 def _gpu_pair_worker(rank, world, port, out):
