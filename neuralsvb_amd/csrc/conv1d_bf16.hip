@@ -786,6 +786,12 @@ static int q_dispatch(SvbConvQArgs& a, const SvbConvPlan& p, hipStream_t stream)
     // tiles twice as wide along time for the narrow stages of the vocoder (32 / 64 output channels, 2-4 K chunks: a 32 x 128
     // workgroup runs three short phases with a barrier pair each and ~24 MFMAs per wave in between; the wide tile doubles the
     // work per staged phase).  Only ever picked by measurement.
+    // configurations 17 .. 22 (round 6): the pointwise GEMM form of conv1d_pw.hip (1-tap convs; bit-identical results)
+    const int pw = a.force_cfg - (SVBQ_NCFG + SVB_TW_NVARIANTS + 2);
+    if (pw >= 0 && pw < SVB_PW_NVARIANTS && !g_svbq_single) {
+        const int rc = svb_pw_launch(a, p, pw, stream);
+        if (rc != SVB_ERR_UNSUPPORTED) return rc;
+    }
     const int wide32 = a.force_cfg - (SVBQ_NCFG + SVB_TW_NVARIANTS);
     if (wide32 == 0 || wide32 == 1) {
         int rc;

@@ -27,8 +27,11 @@ _CFG_NAMES = ["svb_conv1d_mfma_kernel<2,2,2,*,80> (64x128)", "svb_conv1d_mfma_ke
               # the heuristic tile runs)
               "svb_conv1d_tw_kernel<2,2> (128x128)", "svb_conv1d_tw_kernel<1,4> (64x256)", "svb_conv1d_tw_kernel<4,1> (256x64)",
               # 16, 17 (round 5): 32-row tiles, 256 positions wide (the vocoder's 32 / 64-channel stages)
-              "svb_conv1d_mfma_kernel<1,4,2,*,80> (32x256)", "svb_conv1d_mfma_kernel<1,4,2,direct> (32x256)"]
-_NCFG_Q = int(os.environ.get("SVB_NCFG_Q", "17"))     # tile configurations of the bf16x3 kernels (the fp32 kernel has the first 5)
+              "svb_conv1d_mfma_kernel<1,4,2,*,80> (32x256)", "svb_conv1d_mfma_kernel<1,4,2,direct> (32x256)",
+              # 18..23 (round 6): the pointwise GEMM form of csrc/conv1d_pw.hip (1-tap, stride-1, ungrouped convs)
+              "svb_conv1d_pw_kernel<4,1> (128x128)", "svb_conv1d_pw_kernel<4,2> (128x256)", "svb_conv1d_pw_kernel<2,2> (64x256)",
+              "svb_conv1d_pw_kernel<2,1> (64x128)", "svb_conv1d_pw_kernel<3,1> (96x128)", "svb_conv1d_pw_kernel<3,2> (96x256)"]
+_NCFG_Q = int(os.environ.get("SVB_NCFG_Q", "23"))     # tile configurations of the bf16x3 kernels (the fp32 kernel has the first 5)
 
 
 # ---- per-shape tile choice ("measure, don't guess" -- once, offline) ----------------------------------------------------------
@@ -118,7 +121,7 @@ class _ConvProbe:
                 self.name = family
             else:
                 self.name = _CFG_NAMES[forced - 1 if forced else lib.svb_conv1d_pick_cfg(int(cout_g), int(nq_max), int(nz))]
-                if not self.name.startswith("svb_conv1d_tw"):
+                if not self.name.startswith(("svb_conv1d_tw", "svb_conv1d_pw")):
                     self.name = self.name.replace("svb_conv1d_mfma_kernel", family)
             self.flops = flops
             self.tag = tag

@@ -91,6 +91,15 @@ static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(emu_buffer_rsrc r, u
     if ((unsigned long long)voff + soff + 4 <= r.bytes) memcpy(&v, r.base + voff + soff, 4);
     return v;
 }
+typedef unsigned emu_u32x4 __attribute__((ext_vector_type(4)));
+static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(emu_buffer_rsrc r, unsigned voff, unsigned soff, int) {
+    emu_u32x4 v = {0u, 0u, 0u, 0u};
+    if ((unsigned long long)voff + soff + 16 <= r.bytes) memcpy(&v, r.base + voff + soff, 16);
+    return v;
+}
+static inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u32x4 v, emu_buffer_rsrc r, unsigned voff, unsigned soff, int) {
+    if ((unsigned long long)voff + soff + 16 <= r.bytes) memcpy(r.base + voff + soff, &v, 16);
+}
 static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, emu_buffer_rsrc r, unsigned voff, unsigned soff, int) {
     if ((unsigned long long)voff + soff + 4 <= r.bytes) memcpy(r.base + voff + soff, &v, 4);
 }

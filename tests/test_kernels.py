@@ -601,6 +601,63 @@ def test_conv1d_bf16x3_tile_walking_kernel(dev, cfg, shape):
     assert rel_err(yg, refg) < 6e-5
 
 
+@pytest.mark.parametrize("cfg", [18, 19, 20, 21, 22, 23])
+@pytest.mark.parametrize("shape", [(64, 72, 150), (128, 96, 150), (192, 264, 37), (64, 40, 281)])
+def test_conv1d_bf16x3_pointwise_gemm_kernel(dev, cfg, shape):
+    """The pointwise GEMM form (csrc/conv1d_pw.hip, configurations 18..23): 1-tap convs with the batch's positions flattened into
+    one column space (3 clips: tiles straddle clip boundaries, the last tile is ragged), the x operand global -> VGPR -> split, the
+    weights by LDS-DMA in 2- / 4-chunk phases, ragged last row tiles (72, 264, 40 outputs on 64- / 96- / 128-row
+    tiles).  Forward with bias + LeakyReLU (the plain epilogue), with output gate + residual + mask and with tanh (the general
+    one), the transposed form (data gradient) with residual + mask -- each against the oracle AND bit for bit against a tap-table
+    tile of the family (same split, same accumulation order per output)."""
+    Cin, Cout, T = shape
+    g = torch.Generator().manual_seed(cfg * 100 + Cin + Cout)
+    B = 3
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, 1, generator=g) * 0.2
+    bias = torch.randn(Cout, generator=g)
+    qa, qb = K.weight_pack_q(w.to(dev), None, 1)
+    xd = x.to(dev)
+    ref = F.leaky_relu(oops.conv1d(x, w, bias, 1, 0), 0.2)
+    kw = dict(bias=bias.to(dev), out_act=K.ACT_LRELU, out_slope=0.2)
+    y = K.conv1d_forward(xd, qa, Cout, 1, 1, 0, 1, 1, force_cfg=cfg, **kw)
+    assert rel_err(y, ref) < 6e-5
+    assert torch.equal(y, K.conv1d_forward(xd, qa, Cout, 1, 1, 0, 1, 1, force_cfg=4, **kw))
+    gate = torch.randn(B, Cout, T, generator=g)
+    res = torch.randn(B, Cout, T, generator=g)
+    mask = (torch.rand(B, T, generator=g) > 0.2).float()
+    ref2 = ((oops.conv1d(x, w, bias, 1, 0)) * torch.where(gate > 0, 1.0, 0.3) + res) * mask[:, None]
+    kw = dict(bias=bias.to(dev), out_gate=gate.to(dev), out_gate_slope=0.3, residual=res.to(dev), mask=mask.to(dev))
+    y2 = K.conv1d_forward(xd, qa, Cout, 1, 1, 0, 1, 1, force_cfg=cfg, **kw)
+    assert rel_err(y2, ref2) < 6e-5
+    assert torch.equal(y2, K.conv1d_forward(xd, qa, Cout, 1, 1, 0, 1, 1, force_cfg=4, **kw))
+    y3 = K.conv1d_forward(xd, qa, Cout, 1, 1, 0, 1, 1, bias=bias.to(dev), out_act=K.ACT_TANH, force_cfg=cfg)
+    assert rel_err(y3, torch.tanh(oops.conv1d(x, w, bias, 1, 0))) < 6e-5
+    if Cout % 64 == 0 or cfg in (18, 21):        # the data gradient contracts over Cout: inside the kernel's domain when Cout % 64 == 0
+        dy = torch.randn(B, Cout, T, generator=g)
+        resx = torch.randn(B, Cin, T, generator=g)
+        dref = (torch.autograd.grad(oops.conv1d(x.requires_grad_(True), w, None, 1, 0), x, dy)[0] + resx) * mask[:, None]
+        kw = dict(residual=resx.to(dev), mask=mask.to(dev))
+        dx = K.conv1d_transposed(dy.to(dev), qb, Cin, T, 1, 1, 0, 1, 1, force_cfg=cfg, **kw)
+        assert rel_err(dx, dref) < 6e-5
+        assert torch.equal(dx, K.conv1d_transposed(dy.to(dev), qb, Cin, T, 1, 1, 0, 1, 1, force_cfg=4, **kw))
+
+
+@pytest.mark.parametrize("cfg", [18, 20])
+def test_conv1d_bf16x3_pointwise_gemm_falls_back_outside_its_domain(dev, cfg):
+    """Convs outside the pointwise kernel's domain (taps, input gates, Cin % 64 != 0, strides) run a tap-table tile of the family
+    when its configuration is forced -- same results as that tile."""
+    g = torch.Generator().manual_seed(cfg)
+    B, T = 2, 90
+    for Cin, Cout, k, s, gated in [(64, 64, 3, 1, False), (48, 64, 1, 1, False), (64, 64, 1, 1, True), (64, 64, 1, 2, False)]:
+        x = torch.randn(B, Cin, T, generator=g).to(dev)
+        w = torch.randn(Cout, Cin, k, generator=g) * 0.2
+        qa, _ = K.weight_pack_q(w.to(dev), None, 1)
+        kw = dict(in_gate=x, in_slope=0.1) if gated else {}
+        y = K.conv1d_forward(x, qa, Cout, k, s, k // 2, 1, 1, force_cfg=cfg, **kw)
+        assert torch.equal(y, K.conv1d_forward(x, qa, Cout, k, s, k // 2, 1, 1, force_cfg=4, **kw))
+
+
 @pytest.mark.parametrize("cfg", [13, 14])
 @pytest.mark.parametrize("T,k,pad,dil", [(4, 3, 1, 1), (7, 3, 9, 9), (131, 5, 2, 1), (260, 3, 27, 27), (66, 3, 5, 1)])
 def test_conv1d_bf16x3_tile_walking_clip_edges(dev, cfg, T, k, pad, dil):
