@@ -258,6 +258,71 @@ def cpu_baseline(task, batch, hp, args):
                       f"({avail} logical CPUs available)", "s_per_step": t}
 
 
+def bench_variable_length(args, device):
+    """Secondary line: the SAME train step on token-budget batches, as the reference's loader builds them from length-sorted clips
+    (utils/__init__.py:163-217, tasks/tts/tts.py:57-101) -- 160 synthetic clips of 3 ... 9 s (mean 6 s), `max_tokens` = B x T of the
+    fixed-length headline (16 x 1124 frames), so every batch has its own (B, T) and the conv launches resolve their tiles through the
+    nearest table entry of their family.  Reported as ms per audio-second next to the fixed-length figure."""
+    import tempfile
+    from neuralsvb_amd.utils.hparams import set_hparams, hparams
+    from neuralsvb_amd.utils import synth
+    from neuralsvb_amd import kernels as K
+    cfg = os.path.join(ROOT, "egs/datasets/audio/PopBuTFy/vae_global_mle_eng.yaml")
+    frames = int(args.batch * (args.seconds * args.sample_rate // 128))
+    n_clips = 160
+    secs = [3.0 + 6.0 * ((i * 37) % n_clips) / (n_clips - 1) for i in range(n_clips)]
+    with tempfile.TemporaryDirectory() as tmp:
+        data_dir, asr_dir = os.path.join(tmp, "binary"), os.path.join(tmp, "asr")
+        set_hparams(config=cfg, exp_name="", print_hparams=False,
+                    hparams_str=f"audio_sample_rate={args.sample_rate},fmax={args.sample_rate // 2},max_sentences=160,"
+                                f"max_tokens={frames},ds_workers=0,num_sanity_val_steps=0,endless_ds=False,sort_by_len=True,"
+                                f"conv_precision={args.precision}" + (("," + args.extra_hparams) if getattr(args, "extra_hparams", "") else ""))
+        hparams["binary_data_dir"], hparams["pretrain_asr_ckpt"], hparams["work_dir"], hparams["amp"] = data_dir, asr_dir, "", False
+        torch.manual_seed(1234)
+        np.random.seed(1234)
+        synth.write_binary_dataset(data_dir, hparams, synth.mel_fn_hip(hparams, device), n_train=n_clips, n_valid=1, seconds=secs)
+        synth.write_fake_asr_ckpt(asr_dir, 70, hparams)
+        from neuralsvb_amd.tasks.svb_vae_task import SVBVAEMleTask
+        from neuralsvb_amd.utils.trainer import Trainer, move_to_device
+        trainer = Trainer(work_dir="", max_updates=10 ** 9, num_sanity_val_steps=0, amp=False, hip_graph=False)
+        torch.manual_seed(1234)
+        task = trainer.setup(SVBVAEMleTask())
+        task.train()
+        # (shuffle=True on the DATASET: the reference's ordered_indices() sorts by length only then -- tasks/base_task.py:78-85;
+        #  the batches themselves are taken in the order batch_by_size built them)
+        loader = task.build_dataloader(task.dataset_cls("train", True), False, hparams["max_tokens"], hparams["max_sentences"])
+        hosts = list(loader)
+        batches = []
+        for h in hosts:
+            b = move_to_device(h, device)
+            for k in ("mel_lengths", "prof_mel_lengths"):
+                b[k] = h[k]
+            batches.append(b)
+        audio_s = sum(float(h["mel_lengths"].sum()) for h in hosts) * 128.0 / args.sample_rate
+        padded_s = sum(int(h["mels"].shape[0]) * int(h["mels"].shape[1]) for h in hosts) * 128.0 / args.sample_rate
+        shapes = sorted({tuple(h["mels"].shape[:2]) for h in hosts})
+
+        def epoch(step0):
+            for i, b in enumerate(batches):
+                task.global_step = trainer.global_step = step0 + i
+                trainer.run_training_batch(i, b, next_batch=batches[(i + 1) % len(batches)])
+        epoch(1)
+        epoch(1 + len(batches))
+        torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for r in range(reps):
+            epoch(1 + (2 + r) * len(batches))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        info = K.tile_table_info()
+    return {"metric": "ms per audio-second, train step on token-budget (variable-length) batches", "ms_per_audio_second": dt * 1e3 / audio_s,
+            "value": audio_s / dt, "unit": "audio-seconds/sec", "ms_per_step": dt * 1e3 / len(batches), "batches_per_epoch": len(batches),
+            "audio_seconds_per_epoch": audio_s, "padded_seconds_per_epoch": padded_s, "ms_per_padded_second": dt * 1e3 / padded_s,
+            "batch_shapes_B_T": [list(x) for x in shapes], "max_tokens": frames,
+            "epochs_timed": reps, "tile_table": {k: info[k] for k in ("entries", "online_tuned_signatures", "nearest_bucket_signatures")}}
+
+
 def bench_vocoder(args, device):
     """BASELINE configs[2]: NSF-HifiGAN vocoder-only training step (G + MPD + MSD, two optimizer passes), B = 64 segments of
     8192 samples @ 24 kHz, the composed HifiGanTask (the reference ships the modules and the YAML but no task)."""
@@ -804,12 +869,18 @@ def main():
             del trainer, task, batch
             torch.cuda.empty_cache()
             extra_w = {}
-            for name, fn, st, wu in (("vocoder", bench_vocoder, 6, 3), ("infer", bench_infer, 12, 4)):
+            for name, fn, st, wu in (("variable_length", bench_variable_length, 0, 0), ("vocoder", bench_vocoder, 6, 3),
+                                     ("infer", bench_infer, 12, 4)):
                 log(f"extra workload: {name}")
                 a2 = argparse.Namespace(**vars(args))
                 a2.steps, a2.warmup = st, wu
                 try:
                     extra_w[name] = fn(a2, device)
+                    if name == "variable_length":
+                        fixed = ms / (args.batch * args.seconds)
+                        extra_w[name]["fixed_length_ms_per_audio_second"] = fixed
+                        extra_w[name]["ratio_to_fixed_length"] = extra_w[name]["ms_per_audio_second"] / fixed
+                        extra_w[name]["ratio_to_fixed_length_per_padded_second"] = extra_w[name]["ms_per_padded_second"] / fixed
                     log(f"  {name}: {extra_w[name]['ms_per_step']:.1f} ms/step, {extra_w[name]['value']:.1f} audio-s/s")
                 except Exception as e:                 # the headline line must survive a failure of an extra
                     extra_w[name] = {"error": repr(e)}

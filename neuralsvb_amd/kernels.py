@@ -38,16 +38,27 @@ _NCFG_Q = int(os.environ.get("SVB_NCFG_Q", "23"))     # tile configurations of t
 # The tile configuration of a conv launch signature comes from a COMMITTED table (neuralsvb_amd/tile_table.json, written by
 # tools/tune_tiles.py on an MI355X: every configuration of every signature of the three bench workloads, >= 20 interleaved
 # repetitions after a clock warm-up, median, ties to the lowest index) that is loaded at import, so that a fresh process on a
-# cold box runs the same kernels as the one that was profiled.  A signature the table does not hold is measured on line the first
-# time it is seen (TUNE_REPS interleaved repetitions per configuration, median) and cached for the life of the process;
-# `tile_table_info()` reports how many there were.
+# cold box runs the same kernels as the one that was profiled.
+#
+# A signature the table does not hold -- every batch of a real run: the reference batches length-sorted clips by a token budget
+# (utils/__init__.py:163-217, tasks/tts/tts.py:57-101), so B and T change from batch to batch -- takes the choice of the NEAREST
+# table entry of its launch FAMILY (the signature without its batch / length fields: same op, channels, taps, stride, dilation),
+# nearest in log(B T) and log(T); a family the table has never seen runs the library's heuristic tile.  Nothing is ever measured
+# inside a training step (round 5 timed 17 configurations x 11 launches and synchronised on an event at the first sight of a
+# signature: ~30 signatures per new batch shape).  On-line measurement remains for the tuner itself (AUTOTUNE_ONLINE, set by
+# tools/tune_tiles.py / SVB_AUTOTUNE_ONLINE=1); `tile_table_info()` reports how many signatures were resolved either way.
 AUTOTUNE = os.environ.get("SVB_AUTOTUNE", "1") != "0"
+AUTOTUNE_ONLINE = os.environ.get("SVB_AUTOTUNE_ONLINE", "0") == "1"
 TUNE_REPS = int(os.environ.get("SVB_TUNE_REPS", "10"))
 TILE_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_table.json")
 _TUNED = {}
 _TUNED_ONLINE = {}        # signatures measured by this process (not in the table): sig -> choice
+_TUNED_NEAREST = {}       # signatures resolved through their family's nearest table entry: sig -> (choice, table signature)
+_FAMILIES = {}            # family key -> [(B, T, choice, sig)] of the table
 _TUNE_LOG = None          # tools/tune_tiles.py: dict sig -> [median us per configuration]
 _TABLE_INFO = {"path": None, "sha256_16": None, "entries": 0}
+# positions of the batch / length fields per signature kind (everything else names the launch family)
+_SIZE_FIELDS = {"qf": (1, 5), "f": (1, 5), "qt": (1, 5, 6), "t": (1, 5, 6), "taps": (2, 5, 6)}
 
 
 def _sig_key(sig):
@@ -60,35 +71,74 @@ def _sig_from_key(key):
     return tup(json.loads(key))
 
 
+def _family(sig):
+    """(family key, B, T) of a launch signature, or None for a kind without size fields."""
+    pos = _SIZE_FIELDS.get(sig[0]) if sig and isinstance(sig[0], str) else None
+    if pos is None or len(sig) <= max(pos):
+        return None
+    return tuple(v for i, v in enumerate(sig) if i not in pos), int(sig[pos[0]]), int(sig[pos[1]])
+
+
 def load_tile_table(path=TILE_TABLE_PATH):
     """Replace the in-process choices by the table at `path` (missing file: empty table)."""
     _TUNED.clear()
     _TUNED_ONLINE.clear()
+    _TUNED_NEAREST.clear()
+    _FAMILIES.clear()
     _TABLE_INFO.update(path=None, sha256_16=None, entries=0)
     if not path or not os.path.exists(path) or os.environ.get("SVB_TILE_TABLE", "1") == "0":
         return _TABLE_INFO
     raw = open(path, "rb").read()
     doc = json.loads(raw)
+    ncfg = len(_CFG_NAMES)
     for key, cfg in doc.get("choices", {}).items():
-        _TUNED[_sig_from_key(key)] = int(cfg)
-    _TABLE_INFO.update(path=os.path.basename(path), sha256_16=hashlib.sha256(raw).hexdigest()[:16], entries=len(_TUNED))
+        if not 1 <= int(cfg) <= ncfg:                 # (a table written for a library with more configurations than this one)
+            continue
+        sig = _sig_from_key(key)
+        _TUNED[sig] = int(cfg)
+        fam = _family(sig)
+        if fam is not None:
+            _FAMILIES.setdefault(fam[0], []).append((fam[1], fam[2], int(cfg), sig))
+    _TABLE_INFO.update(path=os.path.basename(path), sha256_16=hashlib.sha256(raw).hexdigest()[:16], entries=len(_TUNED),
+                       arch=doc.get("arch"))
     return _TABLE_INFO
 
 
 def tile_table_info():
-    """For bench.py's JSON line: which table this process ran with, and what it had to measure itself."""
-    return dict(_TABLE_INFO, online_tuned_signatures=len(_TUNED_ONLINE),
+    """For bench.py's JSON line: which table this process ran with, and what it had to resolve itself."""
+    return dict(_TABLE_INFO, online_tuned_signatures=len(_TUNED_ONLINE), nearest_bucket_signatures=len(_TUNED_NEAREST),
                 online_tuned=[{"sig": list(map(str, k)), "cfg": v} for k, v in list(_TUNED_ONLINE.items())[:24]])
 
 
+def _nearest_choice(sig):
+    """Choice of the nearest table entry of `sig`'s family (None: the table does not know the family)."""
+    hit = _TUNED_NEAREST.get(sig)
+    if hit is not None:
+        return hit[0]
+    fam = _family(sig)
+    entries = _FAMILIES.get(fam[0]) if fam is not None else None
+    if not entries:
+        return None
+    import math
+    lb, lt = math.log(max(fam[1], 1)), math.log(max(fam[2], 1))
+    best = min(entries, key=lambda e: (abs(math.log(e[0]) + math.log(e[1]) - lb - lt) + 0.5 * abs(math.log(e[1]) - lt), e[3]))
+    _TUNED_NEAREST[sig] = (best[2], best[3])
+    return best[2]
+
+
 def _tuned_cfg(sig, launch, ncfg=5):
-    """launch(force_cfg) enqueues the kernel once.  Returns the table's / the measured force_cfg (1..ncfg) or 0 (heuristic)."""
+    """launch(force_cfg) enqueues the kernel once.  Returns the table's force_cfg (1..ncfg) for `sig`, else the nearest table
+    entry's of its family, else 0 (heuristic); the tuner (AUTOTUNE_ONLINE) measures an unseen signature instead."""
     best = _TUNED.get(sig)
     if best is not None:
         return best
-    # (timing needs an event synchronise: never inside a hipGraph capture -> heuristic tile.  The capture query is a driver
-    # call: it is only made on a cache miss -- the step is host-bound enough for 250 of them per step to cost 3 ms.)
-    if not AUTOTUNE or PROFILE is not None or torch.cuda.is_current_stream_capturing():
+    if not AUTOTUNE or PROFILE is not None:
+        return 0
+    if not AUTOTUNE_ONLINE:
+        best = _nearest_choice(sig)
+        return best if best is not None and best <= ncfg else 0
+    # (timing needs an event synchronise: never inside a hipGraph capture -> heuristic tile)
+    if torch.cuda.is_current_stream_capturing():
         return 0
     for cfg in range(1, ncfg + 1):
         launch(cfg)                                   # warm (also validates the configuration)
@@ -399,12 +449,18 @@ def conv1d_transposed(x, pb, cout, tout, k, stride=1, pad=0, dil=1, groups=1, ou
 
 
 def tuned_choice(sig, on_gpu):
-    """Tile configuration the autotuner holds for `sig`; 0 (the library's heuristic) where nothing is ever tuned (CPU tensors,
-    autotuning off); None when the signature still has to be measured (the caller takes the per-launch path once)."""
+    """Tile configuration for `sig` without launching anything: the table's, else its family's nearest table entry's, else 0 (the
+    library's heuristic; also for CPU tensors and with autotuning off).  None only while the tuner measures on line
+    (AUTOTUNE_ONLINE): the caller then takes the per-launch path once."""
     best = _TUNED.get(sig)
     if best is not None:
         return best
-    return None if (AUTOTUNE and on_gpu and PROFILE is None) else 0
+    if not (AUTOTUNE and on_gpu and PROFILE is None):
+        return 0
+    if AUTOTUNE_ONLINE:
+        return None
+    best = _nearest_choice(sig)
+    return best if best is not None else 0
 
 
 # ---- the gated stack as one C-ABI call per direction (csrc/wn_stack.hip) ---------------------------------------------------

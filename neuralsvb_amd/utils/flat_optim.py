@@ -112,9 +112,19 @@ class FlatAdamW:
         saved = {}
         for i in skip:                                        # (a flat-backed zero view would make torch update it)
             saved[i], self.params[i].grad = self.params[i].grad, None
-        self.opt.step()
-        for i, gr in saved.items():
-            self.params[i].grad = gr
+        # the tasks build their optimizers with fused=True on the GPU, and this object keeps every state['step'] as a CPU tensor
+        # (the reference's state_dict layout): torch's fused kernel refuses that mix, its multi-tensor form takes it
+        flags = [(g, g.get("fused"), g.get("foreach")) for g in self.opt.param_groups]
+        for g, fused, _ in flags:
+            if fused:
+                g["fused"], g["foreach"] = False, True
+        try:
+            self.opt.step()
+        finally:
+            for g, fused, foreach in flags:
+                g["fused"], g["foreach"] = fused, foreach
+            for i, gr in saved.items():
+                self.params[i].grad = gr
         for i, p in enumerate(self.params):
             if i not in skip:
                 self.steps[i] += 1

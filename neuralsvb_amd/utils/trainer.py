@@ -105,19 +105,25 @@ class FlatGradSync:
     (optimizer, phase, critic plan): the graph is static under a key, so the recorded counts are exact; an announcement
     beyond the recorded count raises instead of silently reducing a half-accumulated bucket."""
 
-    def __init__(self, params, world_size, group=None, bucket_bytes=8 << 20, overlap=True, drop_autograd_grads=False):
+    def __init__(self, params, world_size, group=None, bucket_bytes=8 << 20, overlap=True, drop_autograd_grads=False,
+                 exchange=None):
         self.params = [p for p in params]
         self.world_size, self.group = world_size, group
+        # `exchange`: the collectives run (default: whenever there is more than one rank).  True with world_size == 1 is the
+        # `ddp_single_rank` form of the Trainer: one rank goes through the whole exchange path -- buckets announced from inside
+        # backward, all_reduce(async_op=True) on the launch stream, waits, averaging by 1 -- which is what a one-GPU box can
+        # exercise of RCCL (tests/test_ddp_gloo.py::test_rccl_single_rank_exchange_path_equals_the_plain_step)
+        self.exchange = (world_size > 1) if exchange is None else bool(exchange)
         # One process, eager launches: a parameter whose gradient only ever arrives through autograd (norm affines, biases of
         # torch ops, ...) gets `.grad = None` instead of a zeroed view after each optimizer step, so autograd hands it the
         # new gradient tensor as-is rather than launching `grad += new` (~50 launches per step).  Parameters whose gradient
         # a kernel accumulates in place (functional._gbuf marks them) keep their slice of the flat buffer.
-        self.drop_autograd_grads = bool(drop_autograd_grads) and world_size == 1
+        self.drop_autograd_grads = bool(drop_autograd_grads) and not self.exchange
         self._zeroed = 0
         n = sum((p.numel() + 3) // 4 * 4 for p in self.params)        # every view starts 16-byte aligned (vector kernels)
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.overlap = bool(overlap) and world_size > 1
+        self.overlap = bool(overlap) and self.exchange
         self.buckets, self._bucket_of = [], {}
         self._offsets = []               # element offset of every parameter's slice
         off = start = 0
@@ -241,7 +247,7 @@ class FlatGradSync:
 
     def finish(self):
         """After backward: exchange the buckets that did not complete during it (same descending order), wait, average."""
-        if self.world_size <= 1:
+        if not self.exchange:
             return
         if not self.overlap or self._counts is None:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
@@ -279,7 +285,7 @@ class FlatGradSync:
 
     def all_reduce(self):
         """Blocking exchange of the whole buffer (no overlap): kept for callers outside the Trainer's step."""
-        if self.world_size > 1:
+        if self.exchange:
             if self._counts is not None:
                 return self.finish()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
@@ -348,7 +354,10 @@ class Trainer:
         self.on_gpu = torch.cuda.is_available() and self.world_size > 0
         self.proc_rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        self.use_ddp = self.world_size > 1
+        # `ddp_single_rank: true` (a test / bring-up switch): a one-rank run takes the data-parallel path -- process group, start-up
+        # broadcast, bucketed gradient exchange overlapped with backward and the constraints that come with it (immediate
+        # weight-gradient reduces, every gradient a slice of the flat buffer) -- so RCCL executes on a one-GPU box
+        self.use_ddp = self.world_size > 1 or (self.world_size == 1 and bool(hparams.get("ddp_single_rank", False)))
         self.logger = _NullWriter()
 
     # ------------------------------------------------------------------ entry points
@@ -410,7 +419,7 @@ class Trainer:
             self.first_epoch = True
             self.grad_sync = [FlatGradSync([p for g in o.param_groups for p in g["params"]], self.world_size,
                                            bucket_bytes=int(hparams.get("ddp_bucket_mb", 8) * (1 << 20)),
-                                           overlap=hparams.get("ddp_overlap", True),
+                                           overlap=hparams.get("ddp_overlap", True), exchange=self.use_ddp,
                                            drop_autograd_grads=(not self.hip_graph and hparams.get("drop_autograd_grads", True)))
                               if o is not None else None for o in self.optimizers]
         if checkpoint is not None:
@@ -515,6 +524,20 @@ class Trainer:
             if self.global_step > self.max_updates:
                 break
         task.on_train_end()
+        self._write_tile_report()
+
+    def _write_tile_report(self):
+        """<work_dir>/tile_table_info.json: which tile table the run used and how many conv launch signatures it had to resolve through
+        the nearest table entry of their family (every batch shape of a token-budget loader) -- and that none was measured on line."""
+        if self.proc_rank != 0 or not self.work_dir:
+            return
+        try:
+            import json
+            from .. import kernels as _K
+            with open(os.path.join(self.work_dir, "tile_table_info.json"), "w") as f:
+                json.dump(dict(_K.tile_table_info(), global_step=int(self.global_step)), f)
+        except OSError:
+            pass
 
     def _static_batch(self, batch):
         """hipGraph mode: the batch lives in fixed device buffers (one set per distinct shape signature)."""
@@ -564,7 +587,7 @@ class Trainer:
                 # in a 48 MB arena per stream and one multi-tensor launch finishes them when it is full and at the end of the
                 # pass (with a gradient exchange they must be final when they are announced: immediate reduces there)
                 defer = (hparams.get("defer_wgrad_reduce", True) and _SF.GRAD_READY is None and not _SF.CAPTURING
-                         and self.world_size == 1 and not (self.hip_graph and self.on_gpu))
+                         and not self.use_ddp and not (self.hip_graph and self.on_gpu))
                 if defer:
                     _K.begin_deferred_reduces()
                 try:
@@ -714,7 +737,7 @@ class Trainer:
         # step returns (validation, user code, the next test) must get their results on the stream they launch from.
         prev_side = _K.WGRAD_STREAM
         graph_mode = self.hip_graph and self.on_gpu
-        step_graph = graph_mode and self.hip_graph_mode == "step" and self.world_size == 1 and self.accumulate_grad_batches == 1
+        step_graph = graph_mode and self.hip_graph_mode == "step" and not self.use_ddp and self.accumulate_grad_batches == 1
         want_side = self.on_gpu and (not graph_mode or step_graph) and hparams.get("wgrad_side_stream", True)
         if want_side and self._wgrad_stream is None:
             self._wgrad_stream = torch.cuda.Stream(self.device)
@@ -763,7 +786,7 @@ class Trainer:
                 self._fwd_done = self._prefetch
         pbar, tb = {}, {}
         multi = len(self.optimizers) > 1
-        if graph_mode and self.hip_graph_mode == "step" and self.world_size == 1 and self.accumulate_grad_batches == 1:
+        if graph_mode and self.hip_graph_mode == "step" and not self.use_ddp and self.accumulate_grad_batches == 1:
             task.critic_barrier = None
             self._graphed_step(task, batch, batch_idx, sig, multi, pbar, tb)
             if hasattr(task, "end_step"):

@@ -36,7 +36,6 @@ def _fresh_kernel_state():
     from neuralsvb_amd import functional as SF
     from neuralsvb_amd import kernels as K
 
-    K.TUNE_REPS = 3      # (signatures outside the committed tile table are measured on line: a short measurement is enough here)
 
     def reset():
         K.reset_runtime_state()

@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 import yaml
@@ -63,3 +64,36 @@ def test_run_py_train_resume_infer(gpu_only, tmp_path):
     for key in ("gt_a", "gt_p", "a2a", "p2p", "a2p"):
         assert glob.glob(os.path.join(gen[0], "wavs", f"{key}_wavout", "*.wav")), key
         assert glob.glob(os.path.join(gen[0], "mels", f"{key}_mel", "*.npy")), key
+
+
+@pytest.mark.gpu
+def test_run_py_variable_length_batches_never_measure_tiles(gpu_only, tmp_path):
+    """The reference's loader batches length-sorted clips by a token budget (utils/__init__.py:163-217, tasks/tts/tts.py:57-101):
+    every batch of a real run has its own (B, T).  `tasks/run.py` at the REAL channel dimensions on a synthetic set of 24 clips of
+    24 distinct lengths (0.7 ... 3.0 s), `max_tokens`-bounded batches, 50 optimizer steps: the conv launches of every batch shape
+    take their tiles from the committed table -- exact hits or the nearest entry of their launch family -- and NOTHING is measured
+    inside the run (round 5 measured 17 configurations x 11 launches with an event synchronise per unseen signature)."""
+    import json
+    sys.path.insert(0, ROOT)
+    from neuralsvb_amd.utils.hparams import set_hparams, hparams
+    from neuralsvb_amd.utils import synth
+    cfg = os.path.join(ROOT, "egs/datasets/audio/PopBuTFy/vae_global_mle_eng.yaml")
+    base_hp = ("max_sentences=6,max_tokens=900,ds_workers=0,num_sanity_val_steps=0,endless_ds=True,audio_sample_rate=24000,fmax=12000,"
+               "max_updates=50,val_check_interval=100000,phase_2_steps=100000,tb_log_interval=1000,max_valid_sentences=1,"
+               "conv_precision=bf16x3,sort_by_len=True")
+    set_hparams(config=cfg, exp_name="", hparams_str=base_hp, print_hparams=False)
+    data_dir, asr_dir = str(tmp_path / "data/binary/synth"), str(tmp_path / "checkpoints/asr")
+    secs = [0.7 + 0.1 * i for i in range(24)]
+    synth.write_binary_dataset(data_dir, hparams, synth.mel_fn_hip(hparams, gpu_only), n_train=24, n_valid=1, seconds=secs)
+    lens = np.load(os.path.join(data_dir, "train_lengths.npy"))
+    assert len(set(int(v) for v in lens)) >= 20
+    synth.write_fake_asr_ckpt(asr_dir, 70, hparams)
+    hp = base_hp + f",binary_data_dir={data_dir},pretrain_asr_ckpt={asr_dir}"
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="0", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tasks/run.py"), "--config", cfg, "--exp_name", "vl", "--reset",
+                        "--hparams", hp], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    info = json.load(open(tmp_path / "checkpoints/vl/tile_table_info.json"))
+    assert info["global_step"] > 50 and info["entries"] > 300
+    assert info["online_tuned_signatures"] == 0, info
+    assert info["nearest_bucket_signatures"] >= 40, info          # many batch shapes x ~30 conv signatures each, none in the table

@@ -272,3 +272,60 @@ def test_two_ranks_share_one_gpu_same_step_as_one_rank(tmp_path, gpu_only):
         assert sum(s["launched_in_backward"] for s in r["stats"]) > 0, r["stats"]
     assert r0["order"] == r1["order"]
     del probe
+
+
+def _rccl_single_rank_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import argparse
+    import sys
+    import tempfile
+    sys.path.insert(0, ROOT)
+    import bench
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1)          # "nccl" IS RCCL on ROCm
+    args = argparse.Namespace(batch=2, seconds=0.71, sample_rate=24000, bf16=False, precision="bf16x3", graph=False)
+    small = (",hidden_size=32,fvae_enc_dec_hidden=32,latent_size=16,fvae_enc_n_layers=2,fvae_dec_n_layers=2,"
+             "mel_disc_hidden_size=16,warmup_updates=4,ddp_bucket_mb=0.02")
+    res = {}
+    for name, extra in (("plain", ",defer_wgrad_reduce=False"), ("rccl", ",ddp_single_rank=True")):
+        with tempfile.TemporaryDirectory() as tmp:
+            task, trainer, batch, hp = bench.build_task(args, 0, 1, dev, tmp, extra_hparams=small + extra)
+            assert trainer.use_ddp == (name == "rccl") and trainer.world_size == 1 and trainer.on_gpu
+            syncs = [g for g in trainer.grad_sync if g is not None]
+            assert all(g.exchange == (name == "rccl") and g.overlap == (name == "rccl") for g in syncs)
+            bench.run_steps(trainer, task, batch, 3, 1)
+            trainer._join_critic_stream()
+            torch.cuda.synchronize()
+            res[name] = {"w": torch.cat([p.detach().flatten() for p in task.gen_params + task.disc_params]).cpu().numpy(),
+                         "stats": [dict(g.stats) for g in syncs], "order": [list(g.order) for g in syncs],
+                         "backend": dist.get_backend(), "comm_streams": sum(g._comm_stream is not None for g in syncs)}
+            del task, trainer, batch
+    np.save(os.path.join(out, "rccl1.npy"), res, allow_pickle=True)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_exchange_path_equals_the_plain_step(tmp_path, gpu_only):
+    """What a one-GPU box can exercise of RCCL (reference: torch DDP over NCCL, utils/trainer.py:441-466): `ddp_single_rank: true`
+    sends a ONE-rank run down the whole data-parallel path -- `nccl` process group, gradients as slices of the flat buffer,
+    immediate weight-gradient reduces, buckets announced from inside backward, `all_reduce(async_op=True)` issued by RCCL from the
+    launch stream that has joined the compute and weight-gradient streams, `work.wait()`, averaging (by 1).  A sum over one rank is
+    the identity, so three phase-2 steps must leave the weights BIT-identical to the same steps without the exchange; buckets must
+    have gone out from inside backward, in descending order."""
+    probe = torch.zeros(4, device="cuda")
+    mp.spawn(_rccl_single_rank_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "rccl1.npy", allow_pickle=True).item()
+    assert r["rccl"]["backend"] == "nccl"
+    assert np.isfinite(r["plain"]["w"]).all() and np.array_equal(r["plain"]["w"], r["rccl"]["w"])
+    st = r["rccl"]["stats"]
+    assert sum(s["launched_in_backward"] for s in st) > 0 and sum(s["passes"] for s in st) >= 6, st
+    assert r["rccl"]["comm_streams"] >= 2                                  # generator and critic exchanged on their launch streams
+    for order in r["rccl"]["order"]:
+        if not order:                     # (the latent-map optimizer has no pass in phase 2)
+            continue
+        top = max(order)                  # every pass exchanges its buckets top, top - 1, ..., 0
+        assert all(order[i + 1] == order[i] - 1 or (order[i] == 0 and order[i + 1] == top) for i in range(len(order) - 1)), order
+    assert all(s["launched_in_backward"] == 0 and s["passes"] == 0 for s in r["plain"]["stats"])
+    del probe

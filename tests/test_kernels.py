@@ -1012,7 +1012,37 @@ def test_tile_table_is_committed_and_well_formed():
         assert ("qf", 32, 192, 384, 1, 1124, 1, 1, 0, 1, False) in K._TUNED
         assert K.tuned_choice(("qf", 32, 192, 384, 1, 1124, 5, 1, 2, 1, False), True) == K._TUNED[("qf", 32, 192, 384, 1, 1124, 5, 1, 2, 1, False)]
         assert K.load_tile_table(None)["entries"] == 0 and not K._TUNED
-        assert K.tuned_choice(("qf", 1, 2, 3), True) is None          # unseen signature on the GPU: measured on line
+        assert K.tuned_choice(("qf", 1, 2, 3), True) == 0             # no table: the library's heuristic tile, nothing is measured
+    finally:
+        K.load_tile_table()
+
+
+def test_tile_choice_for_unseen_batch_shapes_is_the_nearest_table_entry_of_the_family():
+    """The reference batches length-sorted clips by a token budget (utils/__init__.py:163-217, tasks/tts/tts.py:57-101): B and T
+    change from batch to batch, so an exact-signature table misses on every batch of a real run.  A signature the table does not
+    hold takes the choice of the nearest entry (in log B T, log T) of its launch family -- the signature without its batch / length
+    fields -- and a family the table has never seen takes the heuristic tile; nothing is measured (no launch, no synchronise),
+    and `tile_table_info()` counts what was resolved this way."""
+    from neuralsvb_amd import kernels as K
+    K.load_tile_table()
+    try:
+        exact = ("qf", 32, 192, 384, 1, 1124, 5, 1, 2, 1, False)
+        short = ("qf", 32, 192, 384, 1, 281, 5, 1, 2, 1, False)
+        assert exact in K._TUNED and short in K._TUNED
+        launched = []
+        near_long = ("qf", 29, 192, 384, 1, 1180, 5, 1, 2, 1, False)           # a token-budget batch near the T = 1124 entry
+        assert K._tuned_cfg(near_long, launched.append, K._NCFG_Q) == K._TUNED[exact]
+        near_short = ("qf", 34, 192, 384, 1, 300, 5, 1, 2, 1, False)
+        assert K._tuned_cfg(near_short, launched.append, K._NCFG_Q) == K._TUNED[short]
+        assert K.tuned_choice(near_long, True) == K._TUNED[exact] and not launched
+        assert K._TUNED_NEAREST[near_long][1] == exact and K._TUNED_NEAREST[near_short][1] == short
+        tq = ("qt", 30, 384, 192, 1, 1200, 1200, 5, 1, 2, 1, False)              # transposed form: B, Tin, Tout are the size fields
+        assert K._tuned_cfg(tq, launched.append, K._NCFG_Q) == K._TUNED[("qt", 32, 384, 192, 1, 1124, 1124, 5, 1, 2, 1, False)]
+        unknown = ("qf", 32, 200, 392, 1, 1124, 5, 1, 2, 1, False)               # a family the table has never seen
+        assert K._tuned_cfg(unknown, launched.append, K._NCFG_Q) == 0 and K.tuned_choice(unknown, True) == 0
+        info = K.tile_table_info()
+        assert info["online_tuned_signatures"] == 0 and info["nearest_bucket_signatures"] == 3 and not launched
+        assert K._family(("qf", 2, 3, 4, 1, 50, 5, 1, 2, 1, False)) == (("qf", 3, 4, 1, 5, 1, 2, 1, False), 2, 50)
     finally:
         K.load_tile_table()
 

@@ -221,14 +221,19 @@ def test_flat_adamw_matches_torch_clip_and_adamw(dev):
     assert our_o.state[our_p[0]]["exp_avg"].data_ptr() == flat.m.data_ptr()
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("wd", [0.0, 0.01])
-def test_flat_adamw_parameter_without_gradient_is_left_alone_like_torch(dev, wd):
+def test_flat_adamw_parameter_without_gradient_is_left_alone_like_torch(dev, wd, fused):
     """torch.optim.AdamW skips a parameter whose `.grad` is None: no weight decay, no moment decay, its own `step` does not
     advance (reference tasks/singing/svb_vae_task.py:84-118 steps stock AdamW).  FlatAdamW + FlatGradSync(drop_autograd_grads)
     through `gather_adopted`: parameter 1 NEVER gets a gradient, parameter 3 gets one only in some passes (so it has history
     when it is skipped), parameter 0 is a kernel sink (always a flat view).  Weights, moments and per-parameter step counts
     must equal torch's after every step, with and without weight decay; the fast flat launch must still be the one that runs
-    while it is exact (wd = 0, only the never-updated parameter skipped)."""
+    while it is exact (wd = 0, only the never-updated parameter skipped).  `fused`: the optimizer as the tasks build it on the GPU
+    (`torch.optim.AdamW(..., fused=True)`, svb_vae_task.py / hifigan_task.py) -- the exact fallback must step it although this
+    object keeps the per-parameter `step` entries as CPU tensors."""
+    if fused and dev.type != "cuda":
+        pytest.skip("fused AdamW needs CUDA parameters")
     from neuralsvb_amd.utils.trainer import FlatGradSync
     from neuralsvb_amd.utils.flat_optim import FlatAdamW
     g = torch.Generator().manual_seed(11)
@@ -237,7 +242,7 @@ def test_flat_adamw_parameter_without_gradient_is_left_alone_like_torch(dev, wd)
     our_p = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref_p]
     our_p[0]._svb_sink = True                      # (what functional._gbuf marks: a kernel accumulates into its flat view)
     kw = dict(lr=2e-3, betas=(0.8, 0.99), eps=1e-8, weight_decay=wd)
-    ref_o, our_o = torch.optim.AdamW(ref_p, **kw), torch.optim.AdamW(our_p, **kw)
+    ref_o, our_o = torch.optim.AdamW(ref_p, **kw), torch.optim.AdamW(our_p, fused=fused, **kw)
     sync = FlatGradSync(our_p, 1, drop_autograd_grads=True)
     flat = FlatAdamW(our_o, sync)
     flat.set_clip(1.5)
@@ -283,6 +288,7 @@ def test_flat_adamw_parameter_without_gradient_is_left_alone_like_torch(dev, wd)
         else:
             assert float(sd[i]["exp_avg"].abs().max()) == 0.0 and float(sd[i]["exp_avg_sq"].abs().max()) == 0.0
     assert torch_steps >= 3                                       # passes 2..4: a parameter with history was skipped / steps diverged
+    assert all(bool(g.get("fused")) == fused for g in our_o.param_groups)      # the fallback restores the group's flags
     # an optimizer FlatAdamW cannot represent is reported as not eligible (Trainer.setup then keeps optimizer.step())
     assert not FlatAdamW.eligible(torch.optim.AdamW([torch.nn.Parameter(torch.zeros(2))], amsgrad=True))
     assert not FlatAdamW.eligible(torch.optim.AdamW([torch.nn.Parameter(torch.zeros(2))], maximize=True))
