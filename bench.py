@@ -559,7 +559,7 @@ def main():
                          "fp32 = fp32 MFMA, the exact parity mode; bf16 = ONE bf16 product per operand pair (plain bf16 arithmetic, "
                          "narrower than the reference: never the headline, see `bf16_single_product` on the default line)")
     ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = try 8/16/32 threads and report the fastest")
     ap.add_argument("--use-q", action="store_true", help="A/B switch: pre-split (Q image) activations inside the gated stacks")
     ap.add_argument("--no-side-stream", action="store_true",

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define SVB_ABI_VERSION 8
+#define SVB_ABI_VERSION 9
 int svb_abi_version(void);
 
 /* ---- fused conv epilogue / prologue description ------------------------------------------------------
@@ -133,7 +133,7 @@ int svb_conv1d_wgrad_bf16x3(const float* a, const float* b, float* part, int B, 
 /* Stage 2: reduce partials (+ WeightNorm backward: dv, dg from dW).  rows = d0, rowlen = d1*k.
  * bias_part/db (optional): also sum the [nsplit][rows] bias-gradient partials of stage 1 into db[rows].
  * accumulate: 1 = add into dv / dg / db instead of overwriting them (gradients written straight into `.grad` buffers; with
- * weight_norm this needs 16-byte aligned rows and rowlen <= 4096, SVB_ERR_UNSUPPORTED otherwise); 2 = add into db only. */
+ * weight_norm this needs 16-byte aligned rows and rowlen <= 8192, SVB_ERR_UNSUPPORTED otherwise); 2 = add into db only. */
 int svb_wgrad_reduce(const float* part, int nsplit, const float* v, const float* g, float* dv, float* dg, int rows,
                      int rowlen, int weight_norm, int accumulate, const float* bias_part, float* db, void* stream);
 /* Several stage-2 reduces in one launch per 24 descriptors (a backward pass can defer all of its reduces to its end): each
@@ -146,6 +146,19 @@ typedef struct SvbReduceDesc {
 int svb_wgrad_reduce_multi(const SvbReduceDesc* descs, int n, void* stream);
 /* db[c] = sum_{b,t} dy[b,c,t] * gate'(gate[b,c,t])                                                          */
 int svb_bias_grad(const float* dy, const float* gate, float slope, float* db, int B, int C, int T, void* stream);
+
+/* ---- GAN feature-matching loss as multi-tensor launches (reference modules/hifigan/hifigan.py:328-335 `feature_loss`:
+ * 2 * sum_p mean(|r_p - g_p|) over the discriminators' feature-map pairs).  fwd: out[0] (+)= sum_p scale_p * sum |a_p - b_p|
+ * (scale_p = 2 / n_p for the reference's loss); partials: floats of workspace, one per block (svb_l1_pairs_blocks).  bwd: for each
+ * pair  db = gout[0] * scale_p * sign(b - a),  da = -db  (either may be NULL).  At most SVB_L1_MAX_PAIRS pairs per call; the
+ * descriptors are HOST memory (they travel in the kernel-argument segment); block0 is filled in by the library.             */
+#define SVB_L1_MAX_PAIRS 32
+typedef struct SvbL1Pair {
+    const float* a; const float* b; float* da; float* db; long n; float scale; int block0;
+} SvbL1Pair;
+int svb_l1_pairs_blocks(const SvbL1Pair* pairs, int n);
+int svb_l1_pairs_fwd(const SvbL1Pair* pairs, int n, float* partials, float* out, int accumulate, void* stream);
+int svb_l1_pairs_bwd(const SvbL1Pair* pairs, int n, const float* gout, void* stream);
 
 /* ---- WaveNet-style gated layer pieces (reference modules/fastspeech/fs2_vae.py:10-16,61-91) ---------------
  * gate fwd: acts[b,c,t] = tanh(xin[b,c,t] + g[b,goff+c,t]) * sigmoid(xin[b,C+c,t] + g[b,goff+C+c,t])

@@ -54,6 +54,11 @@ class SvbReduceDesc(C.Structure):
                 ("weight_norm", C.c_int), ("accumulate", C.c_int), ("row_start", C.c_int)]
 
 
+class SvbL1Pair(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("da", C.c_void_p), ("db", C.c_void_p), ("n", C.c_long),
+                ("scale", C.c_float), ("block0", C.c_int)]
+
+
 I, F, P, SZ, I64 = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_int64
 
 # name -> (restype, argtypes)   -- must mirror include/svb_hip.h exactly
@@ -83,6 +88,9 @@ SIGNATURES = {
     "svb_conv1d_wgrad_bf16x3": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, P, F, P, F, I, P, P]),
     "svb_wgrad_reduce": (I, [P, I, P, P, P, P, I, I, I, I, P, P, P]),
     "svb_wgrad_reduce_multi": (I, [P, I, P]),
+    "svb_l1_pairs_blocks": (I, [P, I]),
+    "svb_l1_pairs_fwd": (I, [P, I, P, P, I, P]),
+    "svb_l1_pairs_bwd": (I, [P, I, P, P]),
     "svb_bias_grad": (I, [P, P, F, P, I, I, I, P]),
     "svb_wn_gate_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "svb_wn_gate_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),

@@ -430,7 +430,7 @@ __device__ __forceinline__ void svb_wgrad_reduce_row(const float* part, int nspl
     accumulate &= 1;
     const size_t base = (size_t)row * rowlen;
     float dot = 0.f, vv = 0.f;
-    float4 sreg[4];                                           // vec path: this thread's first 4 summed float4s of the row
+    float4 sreg[8];                                           // vec path: this thread's first 8 summed float4s of the row (8192 elements)
     // eight partials in flight per thread: a row is one float4 per thread and split, so the loop over the splits is a chain of
     // dependent HBM latencies (round 3: 28 splits two at a time = 14 round trips, 26 us per launch at 1.1 TB/s)
     auto sum_splits = [&](int e) {
@@ -455,7 +455,7 @@ __device__ __forceinline__ void svb_wgrad_reduce_row(const float* part, int nspl
     };
     if (vec) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                         // elements [0, 4096): kept in registers
+        for (int j = 0; j < 8; ++j) {                         // elements [0, 8192): kept in registers (1024 channels x 5 taps = 5120)
             const int e = threadIdx.x * 4 + j * 1024;
             sreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < rowlen) {
@@ -475,7 +475,7 @@ __device__ __forceinline__ void svb_wgrad_reduce_row(const float* part, int nspl
                 }
             }
         }
-        for (int e = threadIdx.x * 4 + 4096; e < rowlen; e += 1024) {      // longer rows: dv is the scratch (no accumulate with WN)
+        for (int e = threadIdx.x * 4 + 8192; e < rowlen; e += 1024) {      // longer rows: dv is the scratch (no accumulate with WN)
             float4 sv = sum_splits(e);
             float4* dst = reinterpret_cast<float4*>(dv + base + e);
             if (weight_norm) {
@@ -528,11 +528,11 @@ __device__ __forceinline__ void svb_wgrad_reduce_row(const float* part, int nspl
             *dst = o;
         };
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
             const int e = threadIdx.x * 4 + j * 1024;
             if (e < rowlen) finish(e, sreg[j]);
         }
-        for (int e = threadIdx.x * 4 + 4096; e < rowlen; e += 1024) finish(e, *reinterpret_cast<const float4*>(dv + base + e));
+        for (int e = threadIdx.x * 4 + 8192; e < rowlen; e += 1024) finish(e, *reinterpret_cast<const float4*>(dv + base + e));
     } else {
         for (int e = threadIdx.x; e < rowlen; e += 256) dv[base + e] = sa * dv[base + e] - sb * v[base + e];
     }
@@ -856,7 +856,7 @@ extern "C" int svb_wgrad_reduce(const float* part, int nsplit, const float* v, c
     // 16-byte loads when every row of every operand is 16-byte aligned
     const int vec = (rowlen & 3) == 0 && (((uintptr_t)part | (uintptr_t)dv | (uintptr_t)v) & 15) == 0;
     // accumulating into dv with WeightNorm needs the summed row in registers (dv is not free to be scratch)
-    if (weight_norm && accumulate && !(vec && rowlen <= 4096)) return SVB_ERR_UNSUPPORTED;
+    if (weight_norm && accumulate && !(vec && rowlen <= 8192)) return SVB_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(svb_wgrad_reduce_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, part, nsplit,
                        (size_t)rows * rowlen, v, g, dv, dg, rowlen, weight_norm, accumulate, bias_part, db, rows, vec);
     SVB_CHECK_LAUNCH();
@@ -875,7 +875,7 @@ extern "C" int svb_wgrad_reduce_multi(const SvbReduceDesc* descs, int n, void* s
             if (r.weight_norm && (!r.v || !r.g || !r.dg)) return SVB_ERR_ARG;
             if (r.bias_part && !r.db) return SVB_ERR_ARG;
             const int vec = (r.rowlen & 3) == 0 && (((uintptr_t)r.part | (uintptr_t)r.dv | (uintptr_t)r.v) & 15) == 0;
-            if (r.weight_norm && (r.accumulate & 1) && !(vec && r.rowlen <= 4096)) return SVB_ERR_UNSUPPORTED;
+            if (r.weight_norm && (r.accumulate & 1) && !(vec && r.rowlen <= 8192)) return SVB_ERR_UNSUPPORTED;
             r.row_start = rows;
             rows += r.rows;
             bt.d[i] = r;

@@ -1086,6 +1086,10 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
     }
     bool a_ok0, a_ok1, b_ok0, b_ok1, xk0[SVBQ_WG_NXIT], xk1[SVBQ_WG_NXIT];     // position validity of the staged chunk
 
+    // (Round 6 tried the two adjacent positions of a row as ONE 8-byte load at a dword-aligned address -- half the staging loads of
+    //  the tap-poor gradients, 48 dword loads per 24 MFMAs at one tap: the single-tap gradients got 25-50 % SLOWER (1536 x 256:
+    //  250 -> 373 us), the 5-tap ones did not move -- profiles/r06_wgrad_pair_loads.log.  Lanes of a load instruction walk ROWS here
+    //  (one 4-byte piece of 64 different rows per instruction); an 8-byte piece that is not 8-byte aligned is two requests.)
     auto load_tiles = [&](int chunk) {
         const int bb = chunk / a.chunks_per_b;
         const int q0 = (chunk - bb * a.chunks_per_b) * SVBQ_WG_QC;

@@ -53,8 +53,6 @@ struct SvbPwArgs {
 // s_waitcnt immediate: vmcnt(n) only (expcnt / lgkmcnt untouched)
 #define PW_VMCNT(n) ((((n) & 15) | 0x0F70 | (((n) >> 4) << 14)))
 
-typedef unsigned pw_u4 __attribute__((ext_vector_type(4)));
-
 // ---- epilogue of one wave: BF column blocks of 32 (first column n_first, consecutive blocks 32 apart) x AF row blocks from m_base:
 // v = act(acc + bias) [* gate'(out_gate)] [+ residual] [* mask]; a store is `uniform row offset + per-lane column offset` through
 // a buffer descriptor (columns outside the tensor carry an offset the bounds check drops)
@@ -116,22 +114,23 @@ __device__ __forceinline__ void pw_epilogue(const SvbPwArgs& a, f32x16 (&acc)[AF
     }
 }
 
-// ---- the x operand of one wave: BF column blocks of 32, chunk by chunk, PF chunks in flight.  fp32 source: 8 dword loads per block
-// and chunk (lane = position, channels 8 kb .. 8 kb + 7), split in registers one chunk ahead of its MFMAs.  QIN: the pre-split
-// planar image [chunk][hi h0, hi h1, lo h0, lo h1][column][8 bf16] -- a B fragment is ONE 16-byte load, no VALU work.
-template <int BF, int PF, bool QIN>
+// ---- the x operand of one wave: BF column blocks of 32, chunk by chunk, PF chunks in flight: 8 dword loads per block and chunk
+// (lane = position, channels 8 kb .. 8 kb + 7), split in registers one chunk ahead of its MFMAs.
+// (Round 6 also measured this kernel on a PRE-SPLIT planar image of x -- [chunk][hi h0, hi h1, lo h0, lo h1][column][8 bf16], a B
+//  fragment = ONE 16-byte load, no VALU work -- with timing-only data: 15-20 % per launch on the small tiles, 0.35 ms of a 12.5 ms
+//  step if every producer of a pointwise conv's input emitted that image for free; profiles/r06_pwbench_qin.log.  Not built: the
+//  producers are a dozen kernels on both sides of autograd, and the step does not see 0.35 ms of PPG-stream kernel time.)
+template <int BF, int PF>
 struct PwX {
-    float xr[QIN ? 1 : PF][BF][8];
+    float xr[PF][BF][8];
     uint4 bh[2][BF], bl[2][BF];
-    pw_u4 qh[QIN ? PF : 1][BF], ql[QIN ? PF : 1][BF];
     unsigned xv[BF];
-    unsigned t4, plane16;
+    unsigned t4;
     int last_slab;
     __amdgpu_buffer_rsrc_t rsrc;
 
     __device__ __forceinline__ void init(const SvbPwArgs& a, int nslab) {
         t4 = 4u * (unsigned)a.T;
-        plane16 = 16u * (unsigned)a.ncols;
         last_slab = nslab - 1;
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 4u * (unsigned)(a.B * a.Cin * a.T), 0x00020000);
     }
@@ -141,49 +140,33 @@ struct PwX {
 #pragma unroll
         for (int j = 0; j < BF; ++j) {
             const int n = n_first + 32 * j + l31;
-            if (QIN) {
-                xv[j] = n < a.ncols ? 16u * (unsigned)(kb * a.ncols + n) : 0x80000000u;
-            } else {
-                const int b = n / a.T, t = n - b * a.T;
-                xv[j] = n < a.ncols ? 4u * (unsigned)((b * a.Cin + 8 * kb) * a.T + t) : 0x80000000u;
-            }
+            const int b = n / a.T, t = n - b * a.T;
+            xv[j] = n < a.ncols ? 4u * (unsigned)((b * a.Cin + 8 * kb) * a.T + t) : 0x80000000u;
         }
     }
     __device__ __forceinline__ void load(int set, int sl) {        // chunk sl (clamped: a harmless re-read past the end) -> set
-        const int c = min(sl, last_slab);
-        if constexpr (QIN) {
-            const unsigned s0 = 4u * (unsigned)c * plane16;
+        const unsigned s0 = 16u * (unsigned)min(sl, last_slab) * t4;
 #pragma unroll
-            for (int j = 0; j < BF; ++j) {
-                qh[set][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, xv[j], s0, 0);
-                ql[set][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, xv[j], s0 + 2u * plane16, 0);
-            }
-        } else {
-            const unsigned s0 = 16u * (unsigned)c * t4;
+        for (int j = 0; j < BF; ++j)
 #pragma unroll
-            for (int j = 0; j < BF; ++j)
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    xr[set][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, xv[j], s0 + (unsigned)e * t4, 0));
-        }
+            for (int e = 0; e < 8; ++e)
+                xr[set][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, xv[j], s0 + (unsigned)e * t4, 0));
     }
     __device__ __forceinline__ void split(int bp, int set) {
-        if constexpr (!QIN) {
 #pragma unroll
-            for (int j = 0; j < BF; ++j) {
-                unsigned h[4], l[4];
+        for (int j = 0; j < BF; ++j) {
+            unsigned h[4], l[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) svbq_split2(xr[set][j][2 * e], xr[set][j][2 * e + 1], h[e], l[e]);
-                bh[bp][j] = make_uint4(h[0], h[1], h[2], h[3]);
-                bl[bp][j] = make_uint4(l[0], l[1], l[2], l[3]);
-            }
+            for (int e = 0; e < 4; ++e) svbq_split2(xr[set][j][2 * e], xr[set][j][2 * e + 1], h[e], l[e]);
+            bh[bp][j] = make_uint4(h[0], h[1], h[2], h[3]);
+            bl[bp][j] = make_uint4(l[0], l[1], l[2], l[3]);
         }
     }
 };
 
 // the 3 AF BF MFMAs of one chunk: products lo*hi, hi*lo, hi*hi per accumulator, in the family's order
-template <int AF, int BF, int PF, bool QIN>
-__device__ __forceinline__ void pw_mfma_slab(f32x16 (&acc)[AF][BF], const uint4 (&fa)[2 * AF], const PwX<BF, PF, QIN>& X, int bp, int set) {
+template <int AF, int BF, int PF>
+__device__ __forceinline__ void pw_mfma_slab(f32x16 (&acc)[AF][BF], const uint4 (&fa)[2 * AF], const PwX<BF, PF>& X, int bp) {
 #pragma unroll
     for (int prod = 0; prod < 3; ++prod)
 #pragma unroll
@@ -192,8 +175,8 @@ __device__ __forceinline__ void pw_mfma_slab(f32x16 (&acc)[AF][BF], const uint4 
             for (int n = 0; n < BF; ++n) {
                 const pw_bf16x8 ah = *reinterpret_cast<const pw_bf16x8*>(&fa[2 * i]);
                 const pw_bf16x8 al = *reinterpret_cast<const pw_bf16x8*>(&fa[2 * i + 1]);
-                const pw_bf16x8 xh = QIN ? *reinterpret_cast<const pw_bf16x8*>(&X.qh[set][n]) : *reinterpret_cast<const pw_bf16x8*>(&X.bh[bp][n]);
-                const pw_bf16x8 xl = QIN ? *reinterpret_cast<const pw_bf16x8*>(&X.ql[set][n]) : *reinterpret_cast<const pw_bf16x8*>(&X.bl[bp][n]);
+                const pw_bf16x8 xh = *reinterpret_cast<const pw_bf16x8*>(&X.bh[bp][n]);
+                const pw_bf16x8 xl = *reinterpret_cast<const pw_bf16x8*>(&X.bl[bp][n]);
                 if (prod == 0) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, acc[i][n], 0, 0, 0);
                 else if (prod == 1) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, acc[i][n], 0, 0, 0);
                 else acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc[i][n], 0, 0, 0);
@@ -203,9 +186,9 @@ __device__ __forceinline__ void pw_mfma_slab(f32x16 (&acc)[AF][BF], const uint4 
 // ==================================================================================================================
 // Phased form.  AF x BF: 32x32 accumulators per wave (workgroup tile 32 AF x 128 BF); PW_P: chunks per K phase; PF: chunks of x in
 // flight per wave (PF | PW_P; 8 BF registers per chunk).
-template <int AF, int BF, int PW_P, int PF, bool QIN>
+template <int AF, int BF, int PW_P, int PF>
 __global__ __launch_bounds__(256, 2) void svb_conv1d_pw_kernel(SvbPwArgs a) {
-    static_assert(PW_P % PF == 0 && PW_P % 2 == 0 && PF >= 2 && (QIN ? 2 : 8) * BF * PF <= 63,
+    static_assert(PW_P % PF == 0 && PW_P % 2 == 0 && PF >= 2 && 8 * BF * PF <= 63,
                   "register set of a chunk = chunk % PF; vmcnt counts to 63");
     constexpr int BM = 32 * AF, BN = 128 * BF;
     constexpr int SLAB16 = AF * 2 * 64;               // 16-byte units per weight slab image (AF blocks x hi|lo x 64 lanes)
@@ -227,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_pw_kernel(SvbPwArgs a) {
     const int mt = tile % a.m_tiles, nt = tile / a.m_tiles;
     const int m_base = mt * BM, n_first = nt * BN + wave * BF * 32;
 
-    PwX<BF, PF, QIN> X;
+    PwX<BF, PF> X;
     X.init(a, p_nph * PW_P);
     X.set_columns(a, n_first, lane);
 
@@ -274,31 +257,29 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_pw_kernel(SvbPwArgs a) {
 
     // Software pipeline over the chunks g = 0, 1, ...: while the MFMAs of chunk g run, the x registers of chunk g + 1 are split
     // (they were requested PF - 1 chunks ago), the A fragments of chunk g + 1 are read, and -- FIRST, pinned in front of the
-    // chunk's arithmetic -- the x loads of chunk g + PF (QIN: g + PF - 1) are issued into the register set that has just been
-    // vacated.  (Left to itself the scheduler sinks every load of a phase to its end and waits vmcnt(0) at the top of the next
+    // chunk's arithmetic -- the x loads of chunk g + PF are issued into the register set that has just been vacated.  (Left to itself the scheduler sinks every load of a phase to its end and waits vmcnt(0) at the top of the next
     // one; and the prologue's loads are pinned in chunk order, because the wait-count pass merges the loop header's state with
     // that block's: a set requested LAST there turns the first wait of every phase into a near-complete drain of the prefetch.)
     issue_w(0, 0);
 #pragma unroll
-    for (int s = 0; s < (QIN ? PF - 1 : PF); ++s) { X.load(s, s); __builtin_amdgcn_sched_barrier(0); }
+    for (int s = 0; s < PF; ++s) { X.load(s, s); __builtin_amdgcn_sched_barrier(0); }
     X.split(0, 0);
     for (int ph = 0; ph < p_nph; ++ph) {
         const int buf = ph & 1;
         // this wave's pieces of phase ph were requested a phase ago, BEFORE the x loads that may still be in flight (vmcnt retires
         // in order); after the barrier every wave's pieces have landed and nobody reads the other buffer any more
-        __builtin_amdgcn_s_waitcnt(PW_VMCNT(QIN ? 2 * BF * (PF - 1) : 8 * BF * PF));
+        __builtin_amdgcn_s_waitcnt(PW_VMCNT(8 * BF * PF));
         __builtin_amdgcn_s_barrier();
         if (ph + 1 < p_nph) issue_w(ph + 1, buf ^ 1);
         read_a(0, buf, 0);
 #pragma unroll
         for (int s = 0; s < PW_P; ++s) {
             const int par = s & 1;
-            if constexpr (QIN) X.load((s + PF - 1) % PF, ph * PW_P + s + PF - 1);    // (the set chunk g - 1 has just finished with)
-            else X.load(s % PF, ph * PW_P + s + PF);
+            X.load(s % PF, ph * PW_P + s + PF);
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < PW_P) read_a(par ^ 1, buf, s + 1);
             X.split(par ^ 1, (s + 1) % PF);
-            pw_mfma_slab<AF, BF, PF, QIN>(acc, fa[par], X, par, s % PF);
+            pw_mfma_slab<AF, BF, PF>(acc, fa[par], X, par);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -315,10 +296,10 @@ static const PwCfg kPwCfgs[SVB_PW_NVARIANTS] = {{4, 1, 2, 2}, {4, 2, 4, 2}, {2, 
 //  2-chunk phases.  A weight-stationary persistent form -- all of a row tile's weights in LDS once, waves walking column blocks with
 //  no barrier -- was 10-15 % SLOWER than the phased small tiles on every shape and is not in the tree.)
 
-template <int AF, int BF, int P, int PF, bool QIN>
+template <int AF, int BF, int P, int PF>
 static void pw_launch_kernel(const SvbPwArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)2 * P * AF * 2 * 64 * 16;
-    hipLaunchKernelGGL((svb_conv1d_pw_kernel<AF, BF, P, PF, QIN>), dim3(a.ntiles), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((svb_conv1d_pw_kernel<AF, BF, P, PF>), dim3(a.ntiles), dim3(256), lds, stream, a);
 }
 
 int svb_pw_launch(const SvbConvQArgs& q, const SvbConvPlan& p, int variant, hipStream_t stream) {
@@ -346,12 +327,12 @@ int svb_pw_launch(const SvbConvQArgs& q, const SvbConvPlan& p, int variant, hipS
     if (a.m_tiles * n_tiles >= (1L << 30)) return SVB_ERR_UNSUPPORTED;
     a.ntiles = (int)(a.m_tiles * n_tiles);
     switch (variant) {
-        case 0: pw_launch_kernel<4, 1, 2, 2, false>(a, stream); break;
-        case 1: pw_launch_kernel<4, 2, 4, 2, false>(a, stream); break;
-        case 2: pw_launch_kernel<2, 2, 4, 2, false>(a, stream); break;
-        case 3: pw_launch_kernel<2, 1, 4, 4, false>(a, stream); break;
-        case 4: pw_launch_kernel<3, 1, 4, 4, false>(a, stream); break;
-        default: pw_launch_kernel<3, 2, 4, 2, false>(a, stream); break;
+        case 0: pw_launch_kernel<4, 1, 2, 2>(a, stream); break;
+        case 1: pw_launch_kernel<4, 2, 4, 2>(a, stream); break;
+        case 2: pw_launch_kernel<2, 2, 4, 2>(a, stream); break;
+        case 3: pw_launch_kernel<2, 1, 4, 4>(a, stream); break;
+        case 4: pw_launch_kernel<3, 1, 4, 4>(a, stream); break;
+        default: pw_launch_kernel<3, 2, 4, 2>(a, stream); break;
     }
     if (hipGetLastError() != hipSuccess) return SVB_ERR_UNSUPPORTED;
     return SVB_OK;

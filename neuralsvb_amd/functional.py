@@ -620,7 +620,7 @@ def _wn_exec_backward(ctx, dout, xs, mask, G, dG, params, grads, need, need_x):
                 rowlen = v.shape[1] * kk
                 ok = sk[0] is not None and sk[2] is not None and (g is None or sk[1] is not None)
                 if ok and g is not None:
-                    ok = rowlen % 4 == 0 and rowlen <= 4096 and sk[0].data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
+                    ok = rowlen % 4 == 0 and rowlen <= 8192 and sk[0].data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
                 if not ok:
                     return False
             setattr(ly, names[0], K._ptr(v))
@@ -1545,3 +1545,35 @@ def conv2d_lrelu(x, weight, bias, stride, padding, lrelu_slope=None):
         y4 = _Conv2dS2Fn.apply(_S2DPadFn.apply(x), weight, bias, (N, C, H, W, lrelu_slope))
         return _CropDropNormFn.apply(y4, None, None, None, (N, weight.shape[0], H // 2, W // 2, 1e-5, False))
     return _Conv2dFn.apply(x, weight, bias, (int(stride), pad, lrelu_slope))
+
+
+
+# ---- GAN feature-matching loss (reference modules/hifigan/hifigan.py:328-335) as multi-tensor launches -----------------------
+FUSED_FEATURE_LOSS = True
+
+
+class _L1PairsFn(torch.autograd.Function):
+    """loss = sum_p scale_p * sum |a_p - b_p| over pairs of equally shaped fp32 tensors (K.l1_pairs_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, n, scales, *tensors):
+        a_list, b_list = [t.contiguous() for t in tensors[:n]], [t.contiguous() for t in tensors[n:]]
+        ctx.n, ctx.scales = n, scales
+        ctx.need = [t.requires_grad for t in tensors]
+        ctx.save_for_backward(*a_list, *b_list)
+        return K.l1_pairs_fwd(a_list, b_list, scales).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        a_list, b_list = list(saved[:n]), list(saved[n:])
+        da, db = K.l1_pairs_bwd(a_list, b_list, ctx.scales, g.reshape(1).contiguous().float(), ctx.need[:n], ctx.need[n:])
+        return (None, None) + tuple(da) + tuple(db)
+
+
+def l1_mean_pairs(a_list, b_list, weight=1.0):
+    """weight * sum_p mean(|a_p - b_p|): every pair in one multi-tensor launch per direction."""
+    n = len(a_list)
+    scales = tuple(float(weight) / a.numel() for a in a_list)
+    return _L1PairsFn.apply(n, scales, *a_list, *b_list)

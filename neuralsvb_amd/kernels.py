@@ -560,7 +560,7 @@ def conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.0
         all_sunk = sv is not None and (not wn or sg is not None) and (not want_bias or sb is not None)
         if all_sunk and wn:
             rowlen = (b.shape[1] // groups) * k
-            all_sunk = rowlen % 4 == 0 and rowlen <= 4096 and sv.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
+            all_sunk = rowlen % 4 == 0 and rowlen <= 8192 and sv.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
         if all_sunk and (bf16x3 if bf16x3 is not None else WGRAD_BF16X3):
             side.wait_stream(torch.cuda.current_stream(a.device))
             for t in (a, b, a_gate, b_gate, v, g):
@@ -699,7 +699,7 @@ def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.
         # every result goes into a gradient buffer: leave the partials in the arena, record the reduce, finish it later
         ok = sv is not None and accumulate_into is None and (not wn or sg is not None) and (not want_bias or sb is not None)
         if ok and wn:
-            ok = rowlen % 4 == 0 and rowlen <= 4096 and sv.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
+            ok = rowlen % 4 == 0 and rowlen <= 8192 and sv.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
         if ok and dfr["descs"] and (dfr["stream"] != st or dfr["dev"] != a.device):
             flush_deferred_reduces(end=False)            # (a different stream: finish what was recorded on the other one)
         if ok:
@@ -759,7 +759,7 @@ def _conv1d_wgrad(a, b, k, sx=1, pad=0, dil=1, groups=1, a_gate=None, a_slope=0.
     sink = (sv is not None and accumulate_into is None and (not wn or sg is not None)
             and (bias_part is None or sb is not None))
     if sink and wn:      # the accumulate-with-WeightNorm reduce needs 16-byte rows that fit the thread's registers
-        sink = rowlen % 4 == 0 and rowlen <= 4096 and sv.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
+        sink = rowlen % 4 == 0 and rowlen <= 8192 and sv.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0
     if sink:
         dw, dg, acc = sv, (sg if wn else None), 1
         db = sb if bias_part is not None else None
@@ -1030,6 +1030,51 @@ def gather_segments(srcs, offsets, dst):
     offs = (C.c_size_t * n)(*[int(o) for o in offsets])
     cnts = (C.c_size_t * n)(*[t.numel() for t in srcs])
     L.check(lib.svb_gather_segments(ptrs, offs, cnts, n, _ptr(dst), st), "svb_gather_segments")
+
+
+L1_MAX_PAIRS = 32
+
+
+def _l1_pairs(a_list, b_list, scales, da_list=None, db_list=None):
+    arr = (L.SvbL1Pair * len(a_list))()
+    for i, (a, b) in enumerate(zip(a_list, b_list)):
+        arr[i].a, arr[i].b, arr[i].n, arr[i].scale = a.data_ptr(), b.data_ptr(), a.numel(), float(scales[i])
+        arr[i].da = da_list[i].data_ptr() if da_list is not None and da_list[i] is not None else None
+        arr[i].db = db_list[i].data_ptr() if db_list is not None and db_list[i] is not None else None
+    return arr
+
+
+def l1_pairs_fwd(a_list, b_list, scales):
+    """sum_p scales[p] * sum |a_p - b_p| as a [1] tensor: one launch per 32 pairs + one finishing launch each (fixed order)."""
+    _f32(*a_list, *b_list)
+    lib, st = _prep(*a_list, *b_list)
+    out = torch.empty((1,), device=a_list[0].device, dtype=torch.float32)
+    for c0 in range(0, len(a_list), L1_MAX_PAIRS):
+        aa, bb = a_list[c0:c0 + L1_MAX_PAIRS], b_list[c0:c0 + L1_MAX_PAIRS]
+        arr = _l1_pairs(aa, bb, scales[c0:c0 + L1_MAX_PAIRS])
+        nblk = lib.svb_l1_pairs_blocks(arr, len(aa))
+        if nblk <= 0:
+            raise ValueError("svb_l1_pairs: bad pair list")
+        part = torch.empty((nblk,), device=out.device, dtype=torch.float32)
+        L.check(lib.svb_l1_pairs_fwd(arr, len(aa), _ptr(part), _ptr(out), int(c0 > 0), st), "svb_l1_pairs_fwd")
+    return out
+
+
+def l1_pairs_bwd(a_list, b_list, scales, gout, want_a, want_b):
+    """(da_list, db_list): db_p = gout * scales[p] * sign(b_p - a_p), da_p = -db_p; None where not wanted."""
+    _f32(gout)
+    lib, st = _prep(gout, *a_list, *b_list)
+    da = [torch.empty_like(a) if w else None for a, w in zip(a_list, want_a)]
+    db = [torch.empty_like(b) if w else None for b, w in zip(b_list, want_b)]
+    for c0 in range(0, len(a_list), L1_MAX_PAIRS):
+        sl = slice(c0, c0 + L1_MAX_PAIRS)
+        idx = [i for i in range(*sl.indices(len(a_list))) if da[i] is not None or db[i] is not None]
+        if not idx:
+            continue
+        arr = _l1_pairs([a_list[i] for i in idx], [b_list[i] for i in idx], [scales[i] for i in idx], [da[i] for i in idx],
+                        [db[i] for i in idx])
+        L.check(lib.svb_l1_pairs_bwd(arr, len(idx), _ptr(gout), st), "svb_l1_pairs_bwd")
+    return da, db
 
 
 def layernorm_bwd(x, gamma, dy, mean, rstd, n_part=128):

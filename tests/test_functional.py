@@ -783,3 +783,37 @@ def test_upsample_nearest_nct_matches_interpolate(dev, shape):
     assert torch.equal(y.detach().cpu(), yr.detach())
     y.backward(dy.to(dev))
     assert (xd.grad.cpu() - xr.grad).abs().max().item() <= 1e-6 * max(1.0, xr.grad.abs().max().item())
+
+
+def test_feature_loss_multi_tensor_launches_match_the_reference_formula(dev):
+    """`feature_loss` (reference modules/hifigan/hifigan.py:328-335: 2 * sum over the feature-map pairs of mean(|r - g|)) through the
+    multi-tensor kernels (csrc/loss_ops.hip): 37 pairs (two launches of <= 32), sizes that are and are not multiples of 4 / of a
+    workgroup's 4096 elements, exact zeros in r - g (torch's sign(0) = 0), gradients into the generated maps only (the generator
+    pass) and into both -- against the stock-torch formula; and the switch back to that formula gives the same numbers."""
+    from neuralsvb_amd.modules import hifigan as H
+    g_ = torch.Generator().manual_seed(5)
+    shapes = [(2, 3, 7), (1, 4, 1024), (2, 8, 300), (3, 5, 11, 2), (1, 1, 4097), (2, 16, 513)] * 6 + [(4, 4, 4)]
+    fr = [torch.randn(s, generator=g_) for s in shapes]
+    fg = [torch.randn(s, generator=g_) for s in shapes]
+    fg[1][0, :, :50] = fr[1][0, :, :50]                              # exact ties
+    groups = [slice(0, 12), slice(12, 30), slice(30, 37)]             # "discriminators" with 12 / 18 / 7 maps
+
+    def run(fused, r_grad):
+        SF.FUSED_FEATURE_LOSS = fused
+        r = [t.clone().to(dev).requires_grad_(r_grad) for t in fr]
+        g = [t.clone().to(dev).requires_grad_(True) for t in fg]
+        loss = H.feature_loss([r[s] for s in groups], [g[s] for s in groups])
+        (loss * 0.7).backward()
+        return loss.detach().cpu(), [t.grad.cpu() for t in g], [t.grad.cpu() if r_grad else None for t in r]
+    try:
+        for r_grad in (False, True):
+            l1, dg1, dr1 = run(True, r_grad)
+            l0, dg0, dr0 = run(False, r_grad)
+            assert abs(float(l1) - float(l0)) <= 2e-6 * abs(float(l0))
+            for a, b in zip(dg1, dg0):
+                assert torch.allclose(a, b, rtol=1e-6, atol=1e-9)
+            if r_grad:
+                for a, b in zip(dr1, dr0):
+                    assert torch.allclose(a, b, rtol=1e-6, atol=1e-9)
+    finally:
+        SF.FUSED_FEATURE_LOSS = True

@@ -524,6 +524,38 @@ def test_conv1d_wgrad_bias_sink_only(dev, bf16x3):
     assert rel_err(db0, dy.sum((0, 2))) < 1e-5
 
 
+@pytest.mark.parametrize("cin,k", [(1040, 5), (2064, 4)])
+def test_conv1d_wgrad_weight_norm_sinks_long_rows(dev, cin, k):
+    """WeightNorm backward accumulated straight into `.grad` sinks for rows longer than the old 4096-element register window
+    (the period discriminators' 1024 -> 1024 (5,1) convs: 5120 elements per row -- round 6 widened the window to 8192 so that these
+    gradients qualify for the side stream) and, beyond 8192, the refusal that sends the caller down the returned-tensor path."""
+    g_ = torch.Generator().manual_seed(cin)
+    B, Cout, T = 1, 4, 24
+    x = torch.randn(B, cin, T, generator=g_)
+    v = (torch.randn(Cout, cin, k, generator=g_) * 0.1).requires_grad_(True)
+    gn = (torch.rand(Cout, 1, 1, generator=g_) + 0.5).requires_grad_(True)
+    w = gn * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)
+    pad = (k - 1) // 2
+    y = oops.conv1d(x, w, None, 1, pad)
+    dy = torch.randn(y.shape, generator=g_)
+    y.backward(dy)
+    ta = y.shape[-1]
+    sk = (torch.full(v.shape, 0.25, device=dev), torch.full(gn.shape, -0.5, device=dev), torch.full((Cout,), 1.5, device=dev))
+    if cin * k <= 8192:
+        r = K.conv1d_wgrad(dy.to(dev), x.to(dev), k, 1, pad, 1, 1, v=v.detach().to(dev), g=gn.detach().to(dev), bf16x3=True,
+                           want_bias=True, sinks=sk)
+        assert all(t is None for t in r)
+        assert rel_err(sk[0] - 0.25, v.grad) < 1e-4 and rel_err(sk[1] + 0.5, gn.grad) < 1e-4
+        assert rel_err(sk[2] - 1.5, dy.sum((0, 2))) < 1e-5
+    else:
+        dv, dg, db = K.conv1d_wgrad(dy.to(dev), x.to(dev), k, 1, pad, 1, 1, v=v.detach().to(dev), g=gn.detach().to(dev), bf16x3=True,
+                                    want_bias=True, sinks=sk)
+        got_v = dv if dv is not None else sk[0] - 0.25
+        got_g = dg if dg is not None else sk[1] + 0.5
+        assert rel_err(got_v, v.grad) < 1e-4 and rel_err(got_g, gn.grad) < 1e-4
+    del ta
+
+
 def test_conv1d_wgrad_bf16x3_gates_and_weight_norm(dev):
     g_ = torch.Generator().manual_seed(11)
     B, Cin, Cout, T, k = 2, 10, 14, 145, 3

@@ -201,3 +201,54 @@ def test_infer_t1872_pipeline_matches_reference(gpu_only, precision):
             print(f"[{precision}] T=1872 waveform on the {tag}: max abs {max(err.max(), e_dense):.3e}, mean abs {err.mean():.3e} (|wav| mean {float(d['wav_abs_mean']):.3f})")
             soft(max(err.max(), e_dense) < tol["wav_max"] and err.mean() < tol["wav_mean"], tag)
     soft.done()
+
+
+def test_infer_b32_is_per_clip_bit_identical_to_the_b2_golden_run(gpu_only):
+    """configs[4] is quoted at B = 32 and its reference golden holds 2 clips (tests/golden/make_vocoder_shape_golden.py INF_B): tile
+    signatures contain B, so the bench runs tiles the golden test never ran.  Every kernel of the pipeline is batch-invariant -- each
+    output element is accumulated in the same order whatever the tile (bit-identity across the family's tiles) and nothing mixes clips
+    in eval mode -- so clips 0 and 1 of a B = 32 batch (30 more synthetic clips behind them) must come out BIT-identical to the B = 2
+    run the golden pins: mel of the three ways and the waveform, in the benchmarked arithmetic."""
+    from neuralsvb_amd import functional as SF
+    from neuralsvb_amd.modules.hifigan import HifiGanGenerator
+    from neuralsvb_amd.modules.svb_vae import MleSVBVAE
+    dev = gpu_only
+    HP = json.load(open(os.path.join(G, "ref_hparams_vae_global_mle_eng.json")))
+    d = np.load(os.path.join(G, "infer_t1872.npz"))
+    inp, f0 = MG.inputs_infer(), MG.infer_f0()
+    L = MG.INF_T * HIFIGAN_CFG["hop_size"]
+    ri, nz = MG.nsf_draws(MG.INF_B, L, 36)
+    B2, B32 = MG.INF_B, 32
+    g = torch.Generator().manual_seed(32)
+
+    def grow(t, noise_scale):
+        """[B2, ...] -> [32, ...]: the golden's clips first, then 30 perturbed copies (finite, same dtype / value range)."""
+        reps = [t[i % B2] for i in range(B32 - B2)]
+        if t.is_floating_point():
+            reps = [r + noise_scale * torch.randn(r.shape, generator=g) for r in reps]
+        return torch.cat([t, torch.stack(reps)], 0).contiguous()
+    with torch.no_grad():
+        SF.set_precision("bf16x3")
+        model = MleSVBVAE(70, HP)
+        _load(model, "MleSVBVAE", "model.")
+        model = model.to(dev).eval()
+        gen = _load(HifiGanGenerator(HIFIGAN_CFG), "HifiGanGenerator", "model_gen.")
+        gen.remove_weight_norm()
+        gen = gen.to(dev).eval()
+        eps = {k: torch.from_numpy(d[k]) for k in ("eps_a2a", "eps_p2p")}
+        res = {}
+        for name, B in (("b2", B2), ("b32", B32)):
+            x = {k: (v if B == B2 else grow(v, 0.05)).to(dev) for k, v in inp.items()}
+            e = {k: (v if B == B2 else grow(v, 0.1)).to(dev) for k, v in eps.items()}
+            out = model(amateur_mel=x["mels"], prof_mel=x["prof_mels"], amateur_pitch=x["pitch"], prof_pitch=x["prof_pitch"],
+                        amateur_spk_id=x["spk"], prof_spk_id=x["spk"], a2p_alignment=x["a2p_alignment"], p2a_alignment=None,
+                        infer=False, concurrent_ways=["a2a", "p2p", "a2p"], eps_a2a=e["eps_a2a"], eps_p2p=e["eps_p2p"])
+            mels = {w: out[w]["mel_out"][:B2].clone() for w in ("a2a", "p2p", "a2p")}
+            f0b = (f0 if B == B2 else grow(f0, 0.0)).to(dev)
+            rib, nzb = (ri, nz) if B == B2 else (grow(ri, 0.0), grow(nz, 0.0))
+            wav = gen(out["a2p"]["mel_out"].transpose(1, 2).contiguous(), f0b, rand_ini=rib.to(dev), noise=nzb.to(dev))
+            res[name] = (mels, wav[:B2].clone())
+    for w in ("a2a", "p2p", "a2p"):
+        assert torch.equal(res["b2"][0][w], res["b32"][0][w]), w
+    assert torch.equal(res["b2"][1], res["b32"][1])
+    assert torch.isfinite(res["b32"][1]).all()

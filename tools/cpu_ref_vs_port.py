@@ -29,7 +29,7 @@ def main():
     os.chdir(tmp)
     os.environ["CUDA_VISIBLE_DEVICES"] = ""
     os.environ["NUM_WORKERS"] = "0"
-    hp_str = ("audio_sample_rate=24000,fmax=12000,num_sanity_val_steps=0,max_updates=4,max_sentences=16,max_tokens=100000,"
+    hp_str = ("audio_sample_rate=24000,fmax=12000,num_sanity_val_steps=0,max_updates=6,max_sentences=16,max_tokens=100000,"
               "ds_workers=0,val_check_interval=100000,tb_log_interval=1000,endless_ds=False")
     sys.argv = ["tasks/run.py", "--config", "egs/datasets/audio/PopBuTFy/vae_global_mle_eng.yaml", "--exp_name", "cpuref",
                 "--reset", "--hparams", hp_str]
