@@ -32,6 +32,7 @@ DTYPE_NAMES = {"fp32": "f32", "bf16x3": "bf16x3 (fp32-class split, fp32 accumula
                "bf16": "bf16 single product (fp32 accumulate/storage; narrower than the reference -- secondary line only)"}
 PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA = 2.5e15    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak (no sparsity)
+PEAK_HBM_BPS = 8.0e12      # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s measured with a float4 copy)
 
 
 def build_task(args, rank, world, device, tmp, extra_hparams=""):
@@ -170,11 +171,23 @@ def conv_roofline(trainer, task, batch, steps, start_step, precision="fp32"):
         if nm == name:
             tags[tag] = tags.get(tag, 0) + 1
     traffic, traffic_src = pmc_traffic(tags)
-    return {"bound": "mfma", "kernel": name, "achieved": fl / sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-            "frac": fl / sec / peak, "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-            # the same kernel against the OTHER roof: PMC bytes per launch / live launch duration, of the 8 TB/s HBM peak
+    alg_bytes = sum(c * conv_alg_bytes(t) for t, c in tags.items()) / max(1, sum(tags.values()))
+    # Which roof bounds THIS kernel: its executed MFMA flops per algorithmic HBM byte against the ridge (dense MFMA peak / 8 TB/s).
+    # The pointwise (1-tap) kernel sits below it (K = 12 ... 64 chunks: ~260 executed FLOP/B against a ridge of 312): an HBM kernel;
+    # the multi-tap tiles sit above it: MFMA kernels.  `achieved` / `peak` / `frac` are the bounding roof's; the other roof's figures
+    # stay on the line (`mfma` / `hbm_*`).
+    ridge = peak / PEAK_HBM_BPS
+    hbm_bound = mult * (fl / cnt) / alg_bytes < ridge
+    mfma = {"achieved": fl / sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": fl / sec / peak}
+    hbm = {"achieved": alg_bytes / (sec / cnt) / 1e9, "peak": PEAK_HBM_BPS / 1e9, "unit": "GB/s", "frac": alg_bytes / (sec / cnt) / PEAK_HBM_BPS}
+    top = hbm if hbm_bound else mfma
+    return {"bound": "hbm" if hbm_bound else "mfma", "kernel": name, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
+            "frac": top["frac"], "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+            "executed_flop_per_algorithmic_byte": mult * (fl / cnt) / alg_bytes, "ridge_flop_per_byte": ridge,
+            "mfma": mfma, "hbm_algorithmic": hbm,
+            # the same kernel's PMC bytes per launch / live launch duration, of the 8 TB/s HBM peak
             "hbm_tbps": (traffic / (sec / cnt) / 1e12) if traffic else None, "hbm_frac": (traffic / (sec / cnt) / 8e12) if traffic else None,
-            "algorithmic_bytes_per_launch": sum(c * conv_alg_bytes(t) for t, c in tags.items()) / max(1, sum(tags.values())),
+            "algorithmic_bytes_per_launch": alg_bytes,
             "launches_per_step": cnt / steps,
             # which launch signatures (op, B, C_a, C_b, groups, T, k, stride, dil) the tile table sends to this kernel, launches per step
             "signatures": [{"sig": list(t), "launches_per_step": c / steps} for t, c in sorted(tags.items(), key=lambda kv: -kv[1])],
@@ -203,7 +216,7 @@ def pmc_traffic(tag_counts):
     tools/pmc_traffic.py on the MI355X: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, each calibrated
     on a launch of known traffic with the same access pattern).  Launch-weighted over the shapes the kernel ran in this
     step; (None, why) when the file does not cover at least 60 % of its launches."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (5, 4, 3, 2)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (6, 5, 4, 3, 2)) if os.path.exists(q)), None)
     if path is None:
         return None, "no PMC file"
     db = json.load(open(path)).get("shapes", {})
@@ -808,7 +821,7 @@ def main():
             #  issued, so the other ranks simply wait at the barrier below; `value` is final by now, and the replicas are not used again)
             for gs_ in trainer.grad_sync:
                 if gs_ is not None and world > 1:
-                    gs_.world_size, gs_.overlap = 1, False
+                    gs_.world_size, gs_.overlap, gs_.exchange = 1, False, False
             roof = conv_roofline(trainer, task, batch, 3, 1 + args.warmup + args.steps, args.precision)
             if roof is not None:
                 # the same launches with nothing beside them: in the benchmarked configuration weight gradients, the critic pass
@@ -831,9 +844,11 @@ def main():
                 if ser is not None:
                     roof["serial_streams"] = {
                         "note": "same step with weight gradients, critic pass and PPG encoder on the compute stream: the kernel's own duration",
-                        "kernel": ser["kernel"], "achieved": ser["achieved"], "frac": ser["frac"], "avg_launch_us": ser["avg_launch_us"],
+                        "kernel": ser["kernel"], "bound": ser["bound"], "achieved": ser["achieved"], "unit": ser["unit"], "frac": ser["frac"],
+                        "mfma": ser["mfma"], "hbm_algorithmic": ser["hbm_algorithmic"], "avg_launch_us": ser["avg_launch_us"],
                         "frac_executed": ser["frac_executed"], "all_conv_kernels": ser["all_conv_kernels"]}
-                    log(f"conv roofline with serial streams: {ser['achieved']:.1f} TFLOP/s = {ser['frac']:.4f} of bf16 peak")
+                    log(f"conv roofline with serial streams: {ser['kernel']}: {ser['achieved']:.1f} {ser['unit']} = {ser['frac']:.4f} of the "
+                        f"{ser['bound']} roof")
         if world > 1:
             dist.barrier()
         if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -453,6 +453,11 @@ int svb_upsample_nearest_nct(const float* x, float* y, long rows, int T, int sca
  *   img[plane][r][row][w] = x[plane][s*(row - lead) + r][w]   (zero outside the plane; `lead` zero rows in front, R rows in all)
  * (inverse != 0: the gather back, x[plane][h][w] = img[plane][h % s][lead + h / s][w] -- its gradient).  planes = B*C.        */
 int svb_period_s2d(const float* src, float* dst, long planes, int H, int p, int s, int lead, int R, int inverse, void* stream);
+/* The weight of that stride-1 conv: w2[co][ci*s + r][q] = v[co][ci][s*q + r + front] (0 outside [0,k); front <= 0, s*taps + front >= k).
+ * inverse = 0: w2 from v ([cout][cin][k] -> [cout][cin*s][taps]); inverse = 1: the gradient of v gathered from the gradient of w2,
+ * added to dst when `accumulate`.                                                                                      */
+int svb_period_weight(const float* src, float* dst, int cout, int cin, int k, int s, int taps, int front, int inverse,
+                      int accumulate, void* stream);
 
 /* ---- gradient clipping + AdamW of one optimizer over flat buffers (reference tasks/singing/svb_vae_task.py:84-118 torch.optim.AdamW,
  * :390-404 clip_grad_norm_): p, g, m, v are flat fp32 arrays of n elements (n % 4 == 0; parameters, gradients, first and second

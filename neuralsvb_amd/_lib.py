@@ -140,6 +140,7 @@ SIGNATURES = {
     "svb_embed_nct_fwd": (I, [P, P, P, I, I, I, I, P]),
     "svb_embed_nct_bwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "svb_period_s2d": (I, [P, P, C.c_long, I, I, I, I, I, I, P]),
+    "svb_period_weight": (I, [P, P, I, I, I, I, I, I, I, I, P]),
     "svb_upsample_nearest_nct": (I, [P, P, C.c_long, I, I, I, P]),
     "svb_conv_set_single_product": (None, [I]),
     "svb_conv_get_single_product": (I, []),

@@ -997,6 +997,9 @@ __device__ __forceinline__ unsigned svbq_funnel(unsigned hi, unsigned lo, unsign
 // (Round 5, measured: the general gated 3 / 4 / 5-tap instantiations spill 36 ... 200 bytes per lane at two workgroups per CU; at ONE per
 //  CU -- accumulators in AGPRs, no spills -- the vocoder step is 6 % SLOWER (118.8 / 119.3 against 112.0 ms): occupancy is worth more
 //  than the spills cost.  The self-gated variants (GATED 2) need neither.)
+// GATED 3 (round 6) = GATED 1 with the compile-time knowledge that only A carries a gate tensor (the discriminators' convs: the
+// activation sits in the producing conv's epilogue, so dy is gated by the saved OUTPUT and x is used as it is): the staging registers
+// of a second gate go away -- the 3-tap dilated instantiation no longer spills.
 template <int TGW, int DIL, int GATED, int AT, int BT>
 __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgradQArgs a) {
     HIP_DYNAMIC_SHARED(unsigned, wg_smem)
@@ -1048,7 +1051,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
 #pragma unroll
     for (int rr = 0; rr < RA; ++rr) bsum[rr] = 0.f;
     const float* a_base = a.a + (size_t)g * a.CA_g * a.TA;
-    const float* ag_base = GATED == 1 && a.a_gate ? a.a_gate + (size_t)g * a.CA_g * a.TA : nullptr;
+    const float* ag_base = (GATED == 1 || GATED == 3) && a.a_gate ? a.a_gate + (size_t)g * a.CA_g * a.TA : nullptr;
     const float* b_base = a.b + (size_t)g * a.CB_g * a.TB;
     const float* bg_base = GATED == 1 && a.b_gate ? a.b_gate + (size_t)g * a.CB_g * a.TB : nullptr;
 
@@ -1140,7 +1143,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_wgrad_bf16x3_kernel(SvbWgra
                     ar[rr][1] *= svb_gate(svbq_ld(gp, a_roff[rr] + ao1), a.a_slope);
                 }
             }
-            if (bg_base) {
+            if (GATED == 1 && bg_base) {
                 const float* gp = bg_base + (size_t)bb * a.CB * a.TB;
 #pragma unroll
                 for (int rr = 0; rr < RB; ++rr) {
@@ -1672,10 +1675,12 @@ static void wgq_launch_t(const SvbWgradQArgs& a, dim3 grid, size_t lds, hipStrea
     const bool self_b = !a.a_gate && a.b_gate && a.b_gate == a.b;
     if (a.dil == 1) {
         if (self_b) wgq_launch_kernel<TGW, 1, 2, AT, BT>(a, grid, lds, st);
+        else if (gated && !a.b_gate) wgq_launch_kernel<TGW, 1, 3, AT, BT>(a, grid, lds, st);
         else if (gated) wgq_launch_kernel<TGW, 1, 1, AT, BT>(a, grid, lds, st);
         else wgq_launch_kernel<TGW, 1, 0, AT, BT>(a, grid, lds, st);
     } else {
         if (self_b) wgq_launch_kernel<TGW, 0, 2, AT, BT>(a, grid, lds, st);
+        else if (gated && !a.b_gate) wgq_launch_kernel<TGW, 0, 3, AT, BT>(a, grid, lds, st);
         else if (gated) wgq_launch_kernel<TGW, 0, 1, AT, BT>(a, grid, lds, st);
         else wgq_launch_kernel<TGW, 0, 0, AT, BT>(a, grid, lds, st);
     }

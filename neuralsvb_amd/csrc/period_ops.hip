@@ -72,3 +72,42 @@ extern "C" int svb_period_s2d(const float* src, float* dst, long planes, int H, 
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
+
+// ---- the WEIGHT side of a strided period conv (round 6).  The stride-1 conv over the row space-to-depth image uses the kernel
+//   w2[co][ci * s + r][q] = v[co][ci][j],  j = s * q + r + front   (0 where j is outside [0, k): the slots no tap falls on),
+// `front` = padding + s * q_min <= 0.  forward (inverse = 0) writes w2 from v; inverse = 1 ADDS (accumulate) or writes the gradient
+// of v gathered from the gradient of w2 -- every element of v sits in exactly one slot.  Tiny tensors (<= 3 M elements): one
+// thread per element of the output side.
+__global__ __launch_bounds__(256) void svb_period_weight_kernel(const float* src, float* dst, int cout, int cin, int k, int s,
+                                                                int taps, int front, int inverse, int accumulate) {
+    const long total = inverse ? (long)cout * cin * k : (long)cout * cin * s * taps;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    if (inverse) {
+        const int j = (int)(i % k);
+        const long t = i / k;
+        const int ci = (int)(t % cin);
+        const long co = t / cin;
+        const int jj = j - front, q = jj / s, r = jj - q * s;
+        const float gv = src[(co * cin * s + (long)ci * s + r) * taps + q];
+        dst[i] = accumulate ? dst[i] + gv : gv;
+    } else {
+        const int q = (int)(i % taps);
+        const long t = i / taps;
+        const int cr = (int)(t % (cin * s));
+        const long co = t / (cin * s);
+        const int ci = cr / s, r = cr - ci * s;
+        const int j = s * q + r + front;
+        dst[i] = (j >= 0 && j < k) ? src[(co * cin + ci) * k + j] : 0.f;
+    }
+}
+
+extern "C" int svb_period_weight(const float* src, float* dst, int cout, int cin, int k, int s, int taps, int front, int inverse,
+                                 int accumulate, void* stream) {
+    if (!src || !dst || cout <= 0 || cin <= 0 || k <= 0 || s <= 0 || taps <= 0 || front > 0 || s * taps + front < k) return SVB_ERR_ARG;
+    const long total = inverse ? (long)cout * cin * k : (long)cout * cin * s * taps;
+    hipLaunchKernelGGL(svb_period_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       cout, cin, k, s, taps, front, inverse, accumulate);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}

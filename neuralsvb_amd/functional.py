@@ -155,12 +155,17 @@ def note_weights_updated(params=None):
             e.dirty = True
         for ent in _S2W.values():
             ent[3] = True
+        for ent in _PSW.values():
+            ent[3] = True
     else:
         ids = {id(p) for p in params}
         for e in _REG.values():
-            if e.vid in ids or e.gid in ids:
+            if e.vid in ids or e.gid in ids or e.src in ids:
                 e.dirty = True
         for k, ent in _S2W.items():
+            if k in ids:
+                ent[3] = True
+        for k, ent in _PSW.items():
             if k in ids:
                 ent[3] = True
 
@@ -219,6 +224,13 @@ def repack_registered(params):
             w = ent[0]()
             if w is not None:
                 K.s2_weight(w, out=ent[2])
+                torch.autograd.graph.increment_version(ent[2])
+                ent[1], ent[3] = (w._version, w.data_ptr()), False
+    for wid, ent in _PSW.items():
+        if wid in ids and ent[2] is not None and ent[3] and ent[4][0] > 1:
+            w = ent[0]()
+            if w is not None:
+                K.period_weight(w, *ent[4], out=ent[2])
                 torch.autograd.graph.increment_version(ent[2])
                 ent[1], ent[3] = (w._version, w.data_ptr()), False
     keys = tuple(k for k, e in _REG.items() if (e.vid in ids or e.gid in ids or e.src in ids) and e.alive() and (e.qa or e.qb))
@@ -1359,6 +1371,118 @@ class _PeriodS2DFn(torch.autograd.Function):
         return K.period_s2d(dimg.contiguous(), H, p, s, lead, R, inverse=True), None
 
 
+PERIOD_CONV_NODE = True  # the period discriminators' (k,1) convs as ONE autograd node on the 4-D parameters (see _PeriodConvFn)
+_PSW = {}                # id(weight_v) -> [weakref(weight_v), (version, data_ptr), kernel image, dirty, (s, taps, front), g view]
+
+
+def _period_kernel(weight_v, weight_g, s, taps, front):
+    """(w2, g1): the stride-1 kernel of a period conv as a PERSISTENT tensor -- for s = 1 the parameter's own storage seen as
+    [cout, cin, k], for s > 1 the slot image of svb_period_weight, refreshed when the parameter has changed (the same validity
+    rule as _s2_image) -- and weight_g seen as [cout].  Stable objects, so that the packed bf16x3 images can be registered on them."""
+    ent = _PSW.get(id(weight_v))
+    cout, cin, k = weight_v.shape[:3]
+    if ent is None or ent[0]() is not weight_v or ent[4] != (s, taps, front):
+        ent = _PSW[id(weight_v)] = [weakref.ref(weight_v), None, None, True, (s, taps, front), None]
+    ver = (weight_v._version, weight_v.data_ptr())
+    if s == 1:
+        if ent[2] is None or ent[1] != ver:
+            ent[2] = weight_v.detach().view(cout, cin, k)
+            ent[1], ent[3] = ver, False
+    else:
+        trainable = weight_v.requires_grad or weight_v.grad is not None
+        if ent[2] is None or ent[3] or ent[1] != ver or (trainable and (PACK_EPOCH is None or CAPTURING)):
+            if ent[2] is None:
+                ent[2] = K.period_weight(weight_v.detach(), s, taps, front)
+            else:
+                K.period_weight(weight_v.detach(), s, taps, front, out=ent[2])
+                torch.autograd.graph.increment_version(ent[2])
+            ent[1], ent[3] = ver, False
+    if weight_g is not None and (ent[5] is None or ent[5].data_ptr() != weight_g.data_ptr()):
+        ent[5] = weight_g.detach().view(-1)
+    return ent[2], (ent[5] if weight_g is not None else None)
+
+
+class _PeriodConvFn(torch.autograd.Function):
+    """weight_norm(Conv2d(cin, cout, (k,1), (s,1))) of the period discriminators (reference modules/hifigan/hifigan.py:202-221) on
+    the PARAMETERS themselves (weight_v [cout,cin,k,1], weight_g [cout,1,1,1]: leaves that own `.grad` buffers), x = the [B, C, H*p]
+    planes (s = 1) or their row space-to-depth image (s > 1).  Round 5 built the kernel of the stride-1 form with torch ops (pad /
+    view / permute per call) and handed views of the parameters to the generic conv node: the derived kernel was re-packed on every
+    call, its gradient went back through autograd's view / permute / pad nodes and an AccumulateGrad add, and -- a view owns no
+    gradient buffer -- every weight gradient of the five period discriminators ran on the compute stream (13 ms of the vocoder
+    step).  Here: the kernel image is persistent and refilled by one small launch per optimizer step, its packed bf16x3 images are
+    registered (refilled with the discriminators' other weights), and the weight / WeightNorm / bias gradients accumulate into the
+    parameters' buffers on the weight-gradient side stream (the slot gather of the strided form included)."""
+
+    @staticmethod
+    def forward(ctx, x, weight_v, weight_g, bias, cfg):
+        p, s, taps, front, pad, out_act, out_slope = cfg
+        cout, cin, k = weight_v.shape[:3]
+        x, bias = x.contiguous(), _c(bias)
+        w2, g1 = _period_kernel(weight_v, weight_g, s, taps, front)
+        trainable = weight_v.requires_grad or weight_v.grad is not None
+        if (PRECISION == "bf16x3" and PACK_REGISTRY and PACK_CACHE and PACK_EPOCH is not None and not CAPTURING
+                and (trainable or (id(w2), id(g1) if g1 is not None else 0, 1) in _REG)):
+            pa, pb = _pack_registered(w2, g1, 1, True, True, src=id(weight_v))
+            pb = pb if ctx.needs_input_grad[0] else None
+        else:
+            if PRECISION == "bf16x3":
+                pa, pb = K.weight_pack_q(w2, g1, 1, True, ctx.needs_input_grad[0])
+            else:
+                pa, pb = K.weight_pack(w2, g1, True, ctx.needs_input_grad[0])
+        y = K.conv1d_forward(x, pa, cout, taps, 1, pad, p, 1, bias=bias, out_act=out_act, out_slope=out_slope)
+        ctx.cfg, ctx.pb, ctx.has_bias = cfg, pb, bias is not None
+        ctx.save_for_backward(x, weight_v, weight_g, bias, y if out_act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, s, taps, front, pad, out_act, out_slope = ctx.cfg
+        x, weight_v, weight_g, bias, yact = ctx.saved_tensors
+        cout, cin, k = weight_v.shape[:3]
+        dy = dy.contiguous()
+        a_slope = 0.0 if out_act == ACT_RELU else out_slope
+        dx = dv = dg = db = None
+        if ctx.needs_input_grad[0]:
+            dx = K.conv1d_transposed(dy, ctx.pb, x.shape[1], x.shape[2], taps, 1, pad, p, 1, in_gate=yact, in_slope=a_slope)
+        want_b = ctx.has_bias and ctx.needs_input_grad[3]
+        if ctx.needs_input_grad[1]:
+            w2, g1 = _period_kernel(weight_v, weight_g, s, taps, front)
+            sv, sg, sb = _gbuf(weight_v), _gbuf(weight_g), (_gbuf(bias) if want_b else None)
+            sunk = sv is not None and (weight_g is None or sg is not None) and (not want_b or sb is not None)
+            if sunk:
+                with K.side_work(dy, x, yact, w2, g1):
+                    tmp = sv.view(cout, cin, k) if s == 1 else torch.zeros_like(w2)
+                    sg1 = sg.view(-1) if sg is not None else None
+                    r = K.conv1d_wgrad(dy, x, taps, 1, pad, p, 1, a_gate=yact, a_slope=a_slope, v=w2 if g1 is not None else None, g=g1,
+                                       want_bias=want_b, sinks=(tmp, sg1, sb))
+                    r = list(r) if isinstance(r, (tuple, list)) else [r]
+                    # (a gradient the reduce kernel could not add in place -- rows that are not a multiple of 4 floats: the
+                    #  first layer's single input channel -- comes back as a tensor: added here, still on the side stream)
+                    for got, sink in zip(r, [tmp] + ([sg1] if g1 is not None else []) + ([sb] if want_b else [])):
+                        if got is not None:
+                            sink.add_(got.view(sink.shape))
+                    if s > 1:
+                        # (inside a Trainer-managed pass the reduce that fills `tmp` may only be RECORDED so far: finish it first)
+                        K.flush_deferred_reduces(end=False)
+                        K.period_weight_bwd(tmp, cout, cin, k, s, taps, front, into=sv)
+                if GRAD_READY is not None:
+                    for prm in (weight_v, weight_g, bias if want_b else None):
+                        if prm is not None:
+                            GRAD_READY(prm)
+            else:
+                r = K.conv1d_wgrad(dy, x, taps, 1, pad, p, 1, a_gate=yact, a_slope=a_slope, v=w2 if g1 is not None else None, g=g1,
+                                   want_bias=want_b)
+                if want_b:
+                    r, db = r[:-1], r[-1]
+                    r = r if g1 is not None else r[0]
+                dw2, dg = (r if g1 is not None else (r, None))
+                dv = (dw2 if s == 1 else K.period_weight_bwd(dw2, cout, cin, k, s, taps, front)).view(weight_v.shape)
+                dg = dg.view(weight_g.shape) if dg is not None else None
+        elif want_b:
+            db = K.bias_grad(dy, yact, a_slope)
+        return dx, dv, dg, db, None
+
+
 def period_strided_conv(x, H, p, weight_v, weight_g, bias, stride, padding, out_act=ACT_NONE, out_slope=0.0):
     """weight_norm(Conv2d(cin, cout, (k,1), (stride,1), padding=(padding,0))) on x [B, Cin, H*p] = the reference's [B,Cin,H,p]
     planes (modules/hifigan/hifigan.py:202-221) -> ([B, Cout, H_out*p], H_out).  Stride 1: a dilation-p conv.  Stride s: a
@@ -1367,8 +1491,12 @@ def period_strided_conv(x, H, p, weight_v, weight_g, bias, stride, padding, out_
     v = weight_v.squeeze(-1) if weight_v.dim() == 4 else weight_v
     cout, cin, k = v.shape
     g = None if weight_g is None else weight_g.view(-1, 1, 1)
+    node = PERIOD_CONV_NODE and out_act != ACT_TANH and weight_v.is_leaf and (weight_g is None or weight_g.is_leaf)
     if stride == 1:
-        y = conv1d(x, v, bias, 1, padding * p, p, weight_g=g, out_act=out_act, out_slope=out_slope)
+        if node:
+            y = _PeriodConvFn.apply(x, weight_v, weight_g, bias, (p, 1, k, 0, padding * p, out_act, out_slope))
+        else:
+            y = conv1d(x, v, bias, 1, padding * p, p, weight_g=g, out_act=out_act, out_slope=out_slope)
         return y, y.shape[-1] // p
     s = int(stride)
     h_out = (H + 2 * padding - k) // s + 1
@@ -1379,6 +1507,8 @@ def period_strided_conv(x, H, p, weight_v, weight_g, bias, stride, padding, out_
     img = _PeriodS2DFn.apply(x, (H, p, s, lead, lead + h_out + q_max))      # rows [-lead, h_out + q_max) of the phase planes
     # weights: slot (q, r) <- tap j = s*q + r + padding  (F.pad supplies the empty slots in front / behind)
     front = padding + s * q_min                                           # j of slot (q_min, r = 0); <= 0
+    if node:
+        return _PeriodConvFn.apply(img, weight_v, weight_g, bias, (p, s, taps, front, 0, out_act, out_slope)), h_out
     v2 = torch.nn.functional.pad(v, (-front, s * taps + front - k))                         # [cout, cin, taps * s]
     v2 = v2.view(cout, cin, taps, s).permute(0, 1, 3, 2).reshape(cout, cin * s, taps)
     y = conv1d(img, v2, bias, 1, 0, p, weight_g=g, out_act=out_act, out_slope=out_slope)

@@ -126,9 +126,31 @@ def _nearest_choice(sig):
     return best[2]
 
 
+_ARCH_CHECKED = False
+
+
+def _check_table_arch():
+    """First use on a GPU: a table tuned on another architecture (its `arch` field against the device's gcnArchName) is dropped --
+    its choices would be applied silently, some of them to kernels that refuse to launch there; the heuristic tiles run instead."""
+    global _ARCH_CHECKED
+    _ARCH_CHECKED = True
+    want = _TABLE_INFO.get("arch")
+    if not want or not torch.cuda.is_available():
+        return
+    have = str(getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "gcnArchName", "")).split(":")[0]
+    if have and have != want:
+        import warnings
+        warnings.warn(f"tile table was tuned on {want}, this device is {have}: table ignored (heuristic tiles)")
+        _TUNED.clear()
+        _FAMILIES.clear()
+        _TABLE_INFO.update(entries=0, ignored_for_arch=have)
+
+
 def _tuned_cfg(sig, launch, ncfg=5):
     """launch(force_cfg) enqueues the kernel once.  Returns the table's force_cfg (1..ncfg) for `sig`, else the nearest table
     entry's of its family, else 0 (heuristic); the tuner (AUTOTUNE_ONLINE) measures an unseen signature instead."""
+    if not _ARCH_CHECKED:
+        _check_table_arch()
     best = _TUNED.get(sig)
     if best is not None:
         return best
@@ -1521,6 +1543,27 @@ def period_s2d(x, H, p, s, lead, R, inverse=False):
         planes = B * c
     L.check(lib.svb_period_s2d(_ptr(x), _ptr(out), planes, H, p, s, lead, R, int(inverse), st), "svb_period_s2d")
     return out
+
+
+def period_weight(v, s, taps, front, out=None):
+    """v [cout, cin, k] (any trailing unit dim) -> the strided period conv's stride-1 kernel [cout, cin*s, taps] (svb_period_weight)."""
+    _f32(v)
+    lib, st = _prep(v, out)
+    cout, cin, k = v.shape[:3]
+    if out is None:
+        out = torch.empty((cout, cin * s, taps), device=v.device, dtype=torch.float32)
+    L.check(lib.svb_period_weight(_ptr(v), _ptr(out), cout, cin, k, s, taps, front, 0, 0, st), "svb_period_weight")
+    return out
+
+
+def period_weight_bwd(dw2, cout, cin, k, s, taps, front, into=None):
+    """gradient of v from the gradient of the derived kernel; accumulated into `into` ([cout*cin*k] elements) when given."""
+    _f32(dw2, into)
+    lib, st = _prep(dw2, into)
+    dv = into if into is not None else torch.empty((cout, cin, k), device=dw2.device, dtype=torch.float32)
+    L.check(lib.svb_period_weight(_ptr(dw2), _ptr(dv), cout, cin, k, s, taps, front, 1, int(into is not None), st),
+            "svb_period_weight")
+    return None if into is not None else dv
 
 
 def f0_to_coarse(f0):

@@ -139,9 +139,7 @@ class MleSVBVAE(nn.Module):
         a shape runs eagerly -- lazy caches fill, tiles outside the table are measured --, the second captures; more than
         PPG_GRAPH_MAX_SHAPES shapes, or a capture that fails, fall back to eager launches for good).
 
-        The output buffer is overwritten by the NEXT replay: safe because the consumer's first op (the nearest upsampling /
-        smoothing conv of prepare_condition) has been enqueued on the compute stream before the next prefetch starts, and the
-        PPG stream waits for the compute stream before it replays."""
+        The graph's output buffer is overwritten by the NEXT replay; callers get a copy of it."""
         st = self.__dict__.setdefault("_ppg_graphs", {"seen": {}, "graphs": {}, "off": False})
         if st["off"] or self.vc_asr.training:
             return None
@@ -169,7 +167,10 @@ class MleSVBVAE(nn.Module):
         else:
             x_static.copy_(mels[0])
         g.replay()
-        return h_static
+        # (a copy, not the static buffer: two jobs of one prefetch may share a shape key -- `stack_ways: false` with equally long
+        #  amateur / professional mels -- and a consumer may save the tensor for its weight gradient; the next replay overwrites
+        #  the static one.  One 18 MB copy on the PPG stream.)
+        return h_static.clone()
 
     def _cached_content(self, key):
         cache = self.__dict__.get("_content_cache")

@@ -740,6 +740,9 @@ class Trainer:
         step_graph = graph_mode and self.hip_graph_mode == "step" and not self.use_ddp and self.accumulate_grad_batches == 1
         want_side = self.on_gpu and (not graph_mode or step_graph) and hparams.get("wgrad_side_stream", True)
         if want_side and self._wgrad_stream is None:
+            # (round 6 tried a CU-masked side stream -- hipExtStreamCreateWithCUMask on 50 / 75 / 87.5 % of every XCD's CUs, so that the
+            #  256-register weight-gradient workgroups cannot fill every SIMD's register file: 21.2 ms/step at every fraction against
+            #  12.3 with an ordinary stream, profiles/r06_ab_cu_mask.log)
             self._wgrad_stream = torch.cuda.Stream(self.device)
         _K.WGRAD_STREAM = self._wgrad_stream if want_side else None
         done = False

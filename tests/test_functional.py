@@ -725,6 +725,81 @@ def test_period_strided_conv_matches_conv2d(dev, case, precision):
         assert rel_err(got, ref) < 5 * tol
 
 
+@pytest.mark.parametrize("case", [(5, 12, 8, 12, 5, 3, 2), (3, 10, 1, 8, 5, 3, 2), (4, 9, 16, 12, 5, 1, 2), (2, 14, 4, 8, 7, 2, 3)])
+def test_period_conv_node_accumulates_into_gradient_buffers(dev, case):
+    """The period discriminators' convs as ONE autograd node on the 4-D parameters (functional._PeriodConvFn, round 6): inside a
+    Trainer-managed weight epoch, with `.grad` buffers in place, the weight / WeightNorm / bias gradients are ADDED into the buffers
+    (strided layers through the slot gather of svb_period_weight; a single input channel -- rows of 6 floats -- through the tensor
+    fallback), the kernel image and its packed forms persist across calls and follow an in-place weight update announced by
+    note_weights_updated(); results equal the round-5 composition (torch pad / view / permute + the generic conv node) and torch's
+    conv2d."""
+    p, H, cin, cout, k, stride, pad = case
+    g_ = torch.Generator().manual_seed(p * 10 + H)
+    B = 2
+    x = torch.randn(B, cin, H, p, generator=g_)
+    v = torch.randn(cout, cin, k, 1, generator=g_) * 0.3
+    gn = torch.rand(cout, 1, 1, 1, generator=g_) + 0.5
+    b = torch.randn(cout, generator=g_)
+
+    def reference(v_):
+        rl = [t.clone().requires_grad_(True) for t in (x, v_, gn, b)]
+        w = rl[2] * rl[1] / rl[1].flatten(1).norm(dim=1).view(-1, 1, 1, 1)
+        yr = F.leaky_relu(F.conv2d(rl[0], w, rl[3], (stride, 1), (pad, 0)), 0.1)
+        dy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(7))
+        yr.backward(dy)
+        return yr.detach(), dy, [t.grad for t in rl]
+    yr, dy, gr = reference(v)
+    xd, vd, gd, bd = (_leaf(t, dev) for t in (x, v, gn, b))
+    for t in (vd, gd, bd):
+        t.grad = torch.full_like(t, 0.25)
+
+    def run():
+        y, h_out = SF.period_strided_conv(xd.view(B, cin, H * p), H, p, vd, gd, bd, stride, pad, out_act=SF.ACT_LRELU, out_slope=0.1)
+        y.backward(dy.reshape(B, cout, -1).to(dev))
+        return y.detach()
+    with SF.precision_scope("bf16x3"):
+        SF.begin_weight_epoch()
+        try:
+            y = run()
+            assert rel_err(y.view(yr.shape), yr) < 6e-5
+            for got, ref in ((vd.grad - 0.25, gr[1]), (gd.grad - 0.25, gr[2]), (bd.grad - 0.25, gr[3])):
+                assert rel_err(got, ref) < 3e-4
+            assert rel_err(xd.grad, gr[0]) < 3e-4
+            n_reg = len(SF._REG)
+            run()                                                    # second call of the epoch: same persistent images, gradients add up
+            assert len(SF._REG) == n_reg and rel_err(vd.grad - 0.25, 2 * gr[1]) < 3e-4
+            # the Trainer's deferred stage-2 reduces (a pass only RECORDS them; one multi-tensor launch finishes them): the strided
+            # form's slot gather must see the finished gradient of the kernel image, not the zeros it was given
+            from neuralsvb_amd import kernels as K
+            K.begin_deferred_reduces()
+            try:
+                run()
+            finally:
+                K.flush_deferred_reduces()
+            assert rel_err(vd.grad - 0.25, 3 * gr[1]) < 3e-4 and rel_err(gd.grad - 0.25, 3 * gr[2]) < 3e-4
+            # an optimizer step the Trainer announces: the images follow the new weights
+            with torch.no_grad():
+                vd.mul_(1.5).add_(0.01)
+            SF.note_weights_updated([vd])
+            SF.repack_registered([vd, gd])
+            yr2, _, _ = reference(v * 1.5 + 0.01)
+            for t in (vd, gd, bd):
+                t.grad.fill_(0.0)
+            xd.grad = None
+            y2 = run()
+            assert rel_err(y2.view(yr2.shape), yr2) < 6e-5
+            # the round-5 composition on the same tensors
+            SF.PERIOD_CONV_NODE = False
+            v_ref = vd.grad.clone()
+            for t in (vd, gd, bd):
+                t.grad.fill_(0.0)
+            y3 = run()
+            assert rel_err(y3, y2) < 1e-6 and rel_err(vd.grad, v_ref) < 1e-5
+        finally:
+            SF.PERIOD_CONV_NODE = True
+            SF.end_weight_epoch()
+
+
 def test_period_s2d_index_walk(dev):
     """svb_period_s2d walks the element index as a mixed-radix counter advancing by the grid's stride (no division per element).
     Forward and inverse against index arithmetic in torch, bit for bit."""

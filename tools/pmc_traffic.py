@@ -1,4 +1,4 @@
-"""HBM-side traffic (rocprofv3 PMC) of the step's dominant conv kernel, per shape -> profiles/<round>_pmc_traffic.json (GPU box; round tag from SVB_ROUND, default r05).
+"""HBM-side traffic (rocprofv3 PMC) of the step's dominant conv kernel, per shape -> profiles/<round>_pmc_traffic.json (GPU box; round tag from SVB_ROUND, default r06).
 
 As MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (they do not fit one pass), nothing but
 --pmc on the rocprofv3 command line, units of KB, and -- because the gfx950 counters are only calibrated for 16-byte streaming
@@ -32,7 +32,7 @@ def run_pmc(counter, conv_args):
             raise RuntimeError(f"rocprofv3 failed ({r.returncode}): {r.stderr[-400:]}")
         vals, name = [], None
         for row in csv.DictReader(open(files[0])):
-            if row["Counter_Name"] == counter and "svb_conv1d_bf16x3_kernel" in row["Kernel_Name"]:
+            if row["Counter_Name"] == counter and "svb_conv1d_" in row["Kernel_Name"] and "wgrad" not in row["Kernel_Name"]:
                 vals.append(float(row["Counter_Value"]))
                 name = row["Kernel_Name"]
         if not vals:
@@ -69,8 +69,10 @@ def main():
     torch.cuda.empty_cache()
     cfg = 1 + [i for i, n in enumerate(K._CFG_NAMES) if n.split("(")[1] == dom.split("(")[1]][0]
     # ---- calibration: known traffic, same kernel, same access pattern
-    cb, ccin, ccout, cT = 32, 16, 128, 32768
-    known_fetch = 4.0 * cb * ccin * cT + 4.0 * ccout * 16
+    # (the pointwise kernel's domain is Cin % 64 == 0; its row tile is the first number of the configuration's "(MxN)")
+    pw = dom.startswith("svb_conv1d_pw")
+    cb, ccin, ccout, cT = 32, (64 if pw else 16), (int(dom.split("(")[1].split("x")[0]) if pw else 128), 32768
+    known_fetch = 4.0 * cb * ccin * cT + 4.0 * ccout * ccin
     known_write = 4.0 * cb * ccout * cT
     cal = {}
     for counter, known in (("FETCH_SIZE", known_fetch), ("WRITE_SIZE", known_write)):
@@ -95,7 +97,7 @@ def main():
         out["shapes"][json.dumps(list(tag))] = ent
         print(tag, ent, flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    rnd = os.environ.get("SVB_ROUND", "r05")
+    rnd = os.environ.get("SVB_ROUND", "r06")
     for path in (os.path.join(ROOT, "gpurun_out", f"{rnd}_pmc_traffic.json"), os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")):
         with open(path, "w") as f:
             json.dump(out, f, indent=1)
