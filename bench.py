@@ -600,6 +600,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries the ONE JSON line and nothing else: whatever the task / checkpoint utilities print goes to stderr
+    out, sys.stdout = sys.stdout, sys.stderr
     emu = os.environ.get("SVB_BENCH_EMU_LIB")      # TEST HARNESS ONLY (tests/test_ddp_gloo.py): the CPU lane emulator build of
     if emu:                                        # the kernel sources, so the launcher + N > 1 path run in a GPU-less container
         from neuralsvb_amd import _lib
@@ -626,7 +628,7 @@ def main():
         res.update({"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
                     "vs_baseline": None, "data": "synthetic",
                     "dtype": DTYPE_NAMES[args.precision]})
-        print(json.dumps(res))
+        print(json.dumps(res), file=out, flush=True)
         return
 
     if args.use_q:
@@ -917,7 +919,7 @@ def main():
                 "value_with_h2d": (args.batch * args.seconds * world / (ms_h2d * 1e-3)) if ms_h2d else None, "ms_per_step_with_h2d": ms_h2d,
                 "step_split": split, "n1_with_ddp_constraints_ms": n1_ddp, "phase3": phase3,
                 "comm": comm, "data_side": data_side, "roofline": roof, "cpu_baseline": cpu,
-                "bf16_single_product": single, "extra_workloads": extra_w}))
+                "bf16_single_product": single, "extra_workloads": extra_w}), file=out, flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -1,8 +1,8 @@
-// conv1d_pw.hip -- the "pointwise" member of the bf16x3 conv family (round 6): 1-tap, stride-1, ungrouped convs as a GEMM
+// conv1d_pw.hip -- the GEMM member of the bf16x3 conv family (round 6): stride-1, equal-length, ungrouped convs of 1 .. 16 taps as
 //
-//        Y[Cout x N] = W[Cout x Cin] . X[Cin x N],      N = B * T  (the batch's positions, flattened),
+//        Y[Cout x N] = sum_tap W_tap[Cout x Cin] . shift_tap(X)[Cin x N],      N = B * T  (the batch's positions, flattened),
 //
-// i.e. every nn.Linear / Conv1d(k=1) of the path and their data gradients (reference: modules/fastspeech/conformer/layers.py:182-258
+// first built for the 1-tap case -- every nn.Linear / Conv1d(k=1) of the path and their data gradients (reference: modules/fastspeech/conformer/layers.py:182-258
 // FFN / pointwise convs, modules/commons/espnet_transformer_attn.py:125-186 q/k/v/out projections, modules/fastspeech/fs2_vae.py:66-91
 // res_skip and cond layers, modules/voice_conversion/svb_vae.py:152-162 condition projection).  Same arithmetic as conv1d_bf16.hip --
 // operands split v = hi + lo into bf16, products lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate, K walked in
@@ -22,7 +22,15 @@
 //     (loads pinned in front of each chunk's arithmetic); the next phase's weight pieces are requested right behind the barrier
 //     and have a whole phase to land.
 //
-// Domain: one tap at offset 0, Tin == Tout, groups == 1, sx == out_stride == 1, Cin % 64 == 0 (% 32: the 2-chunk-phase tile), Cout % 8 == 0, no input gate.
+//   * taps: the K walk runs over (chunk, tap) slabs, tap fastest; a tap only moves the position a lane loads (its column + the
+//     tap's offset; outside the clip the buffer bounds check answers 0 = the conv's zero padding).  x is then fetched once per tap
+//     (L1 / L2 hits after the first) instead of staged once into LDS -- measured on the MI355X that is still 20-40 % faster than
+//     the tap-table tiles on the vocoder's k = 3 / 7 / 11 residual convs and their data gradients (profiles/r06_tile_tuner_taps.log);
+//   * an input gate (x * lrelu'(gate): the data gradients of the critic towers; gate == x: `conv(leaky_relu(x))` of the HifiGAN
+//     generator) is applied in registers before the split.
+//
+// Domain: 1 .. 16 taps in one phase with weight slabs in arithmetic progression, Tin == Tout, groups == 1, sx == out_stride == 1,
+// (Cin / 16) * taps a multiple of the tile's phase length (4; 2 for the 128x128 tile), Cin % 16 == 0, Cout % 8 == 0.
 // Everything else stays on conv1d_bf16.hip (svb_pw_launch returns SVB_ERR_UNSUPPORTED).
 #include "svb_common.h"
 #include "svb_q.h"
@@ -45,10 +53,23 @@ struct SvbPwArgs {
     int out_act;
     int B, Cin, Cout, T;
     int ncols;                  // B * T
-    int nph;                    // K phases (Cin / 64)
+    int nph;                    // K phases: (Cin / 16) * ntap slabs in groups of P
     int w_rows;                 // rows per packed weight slab
     int m_tiles, ntiles;
+    // taps (round 6b): slab g = chunk * ntap + tap reads x at position + tap_off(tap) (zero outside the clip) and the weight slab
+    // (tw0 + tap * tstep) * w_tap16 + chunk * 2 w_rows (16-byte units)
+    int ntap, tw0, tstep, rcp;  // rcp = ceil(2^16 / ntap): g / ntap == (g * rcp) >> 16 for g < 4096
+    unsigned w_tap16;
+    unsigned long long offs[4];               // sixteen signed 16-bit tap offsets
+    const float* in_gate;       // optional: x is multiplied by gate'(in_gate) (1 where in_gate > 0, else in_slope); == x: self-gated
+    float in_slope;
 };
+
+__device__ __forceinline__ int pw_tap_off(const SvbPwArgs& a, int tap) {
+    // (selects, not an indexed read: an indexed kernel argument becomes a scratch table)
+    const unsigned long long lo = (tap & 4) ? a.offs[1] : a.offs[0], hi = (tap & 4) ? a.offs[3] : a.offs[2];
+    return (int)(short)(unsigned short)(((tap & 8) ? hi : lo) >> (16 * (tap & 3)));
+}
 
 // s_waitcnt immediate: vmcnt(n) only (expcnt / lgkmcnt untouched)
 #define PW_VMCNT(n) ((((n) & 15) | 0x0F70 | (((n) >> 4) << 14)))
@@ -120,44 +141,65 @@ __device__ __forceinline__ void pw_epilogue(const SvbPwArgs& a, f32x16 (&acc)[AF
 //  fragment = ONE 16-byte load, no VALU work -- with timing-only data: 15-20 % per launch on the small tiles, 0.35 ms of a 12.5 ms
 //  step if every producer of a pointwise conv's input emitted that image for free; profiles/r06_pwbench_qin.log.  Not built: the
 //  producers are a dozen kernels on both sides of autograd, and the step does not see 0.35 ms of PPG-stream kernel time.)
-template <int BF, int PF>
+template <int BF, int PF, int GATE>
 struct PwX {
     float xr[PF][BF][8];
+    float gr[GATE == 1 ? PF : 1][BF][8];
     uint4 bh[2][BF], bl[2][BF];
-    unsigned xv[BF];
+    unsigned xv[BF];             // byte offset of (clip, channel 8 kb, position) of this lane's column; >= 2^31: no such column
+    int col_t[BF];               // its position inside the clip
     unsigned t4;
-    int last_slab;
-    __amdgpu_buffer_rsrc_t rsrc;
+    int T, last_chunk;
+    float slope;
+    __amdgpu_buffer_rsrc_t rsrc, grsrc;
 
-    __device__ __forceinline__ void init(const SvbPwArgs& a, int nslab) {
+    __device__ __forceinline__ void init(const SvbPwArgs& a, int nchunk) {
         t4 = 4u * (unsigned)a.T;
-        last_slab = nslab - 1;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 4u * (unsigned)(a.B * a.Cin * a.T), 0x00020000);
+        T = a.T;
+        last_chunk = nchunk - 1;
+        slope = a.in_slope;
+        const unsigned bytes = 4u * (unsigned)(a.B * a.Cin * a.T);
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, bytes, 0x00020000);
+        grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GATE == 1 ? a.in_gate : a.x), 0, bytes, 0x00020000);
     }
-    // per-lane byte offsets of the wave's columns n_first + 32 j + l31 (>= 2^31: outside the tensor, the load returns 0)
     __device__ __forceinline__ void set_columns(const SvbPwArgs& a, int n_first, int lane) {
         const int kb = lane >> 5, l31 = lane & 31;
 #pragma unroll
         for (int j = 0; j < BF; ++j) {
             const int n = n_first + 32 * j + l31;
             const int b = n / a.T, t = n - b * a.T;
+            col_t[j] = t;
             xv[j] = n < a.ncols ? 4u * (unsigned)((b * a.Cin + 8 * kb) * a.T + t) : 0x80000000u;
         }
     }
-    __device__ __forceinline__ void load(int set, int sl) {        // chunk sl (clamped: a harmless re-read past the end) -> set
-        const unsigned s0 = 16u * (unsigned)min(sl, last_slab) * t4;
+    // chunk c (clamped: a harmless re-read past the end) at tap offset `off` -> register set; positions outside the clip (the
+    // conv's zero padding) and columns outside the tensor get an offset the buffer's bounds check answers with 0
+    __device__ __forceinline__ void load(int set, int c, int off) {
+        const unsigned s0 = 16u * (unsigned)min(c, last_chunk) * t4;
 #pragma unroll
-        for (int j = 0; j < BF; ++j)
+        for (int j = 0; j < BF; ++j) {
+            const bool ok = xv[j] < 0x80000000u && (unsigned)(col_t[j] + off) < (unsigned)T;
+            const unsigned v = ok ? xv[j] + 4u * (unsigned)off : 0x80000000u;
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                xr[set][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, xv[j], s0 + (unsigned)e * t4, 0));
+            for (int e = 0; e < 8; ++e) {
+                xr[set][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, v, s0 + (unsigned)e * t4, 0));
+                if (GATE == 1) gr[set][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, v, s0 + (unsigned)e * t4, 0));
+            }
+        }
     }
     __device__ __forceinline__ void split(int bp, int set) {
 #pragma unroll
         for (int j = 0; j < BF; ++j) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = xr[set][j][e];
+                if (GATE == 1) v[e] *= svb_gate(gr[set][j][e], slope);
+                if (GATE == 2) v[e] *= svb_gate(v[e], slope);
+            }
             unsigned h[4], l[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) svbq_split2(xr[set][j][2 * e], xr[set][j][2 * e + 1], h[e], l[e]);
+            for (int e = 0; e < 4; ++e) svbq_split2(v[2 * e], v[2 * e + 1], h[e], l[e]);
             bh[bp][j] = make_uint4(h[0], h[1], h[2], h[3]);
             bl[bp][j] = make_uint4(l[0], l[1], l[2], l[3]);
         }
@@ -165,8 +207,8 @@ struct PwX {
 };
 
 // the 3 AF BF MFMAs of one chunk: products lo*hi, hi*lo, hi*hi per accumulator, in the family's order
-template <int AF, int BF, int PF>
-__device__ __forceinline__ void pw_mfma_slab(f32x16 (&acc)[AF][BF], const uint4 (&fa)[2 * AF], const PwX<BF, PF>& X, int bp) {
+template <int AF, int BF, int PF, int GATE>
+__device__ __forceinline__ void pw_mfma_slab(f32x16 (&acc)[AF][BF], const uint4 (&fa)[2 * AF], const PwX<BF, PF, GATE>& X, int bp) {
 #pragma unroll
     for (int prod = 0; prod < 3; ++prod)
 #pragma unroll
@@ -186,9 +228,9 @@ __device__ __forceinline__ void pw_mfma_slab(f32x16 (&acc)[AF][BF], const uint4 
 // ==================================================================================================================
 // Phased form.  AF x BF: 32x32 accumulators per wave (workgroup tile 32 AF x 128 BF); PW_P: chunks per K phase; PF: chunks of x in
 // flight per wave (PF | PW_P; 8 BF registers per chunk).
-template <int AF, int BF, int PW_P, int PF>
+template <int AF, int BF, int PW_P, int PF, int GATE>
 __global__ __launch_bounds__(256, 2) void svb_conv1d_pw_kernel(SvbPwArgs a) {
-    static_assert(PW_P % PF == 0 && PW_P % 2 == 0 && PF >= 2 && 8 * BF * PF <= 63,
+    static_assert(PW_P % PF == 0 && PW_P % 2 == 0 && PF >= 2 && (GATE == 1 ? 16 : 8) * BF * PF <= 63,
                   "register set of a chunk = chunk % PF; vmcnt counts to 63");
     constexpr int BM = 32 * AF, BN = 128 * BF;
     constexpr int SLAB16 = AF * 2 * 64;               // 16-byte units per weight slab image (AF blocks x hi|lo x 64 lanes)
@@ -210,30 +252,34 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_pw_kernel(SvbPwArgs a) {
     const int mt = tile % a.m_tiles, nt = tile / a.m_tiles;
     const int m_base = mt * BM, n_first = nt * BN + wave * BF * 32;
 
-    PwX<BF, PF> X;
-    X.init(a, p_nph * PW_P);
+    const int p_ntap = a.ntap;
+    PwX<BF, PF, GATE> X;
+    X.init(a, a.Cin / 16);
     X.set_columns(a, n_first, lane);
 
     // ---- weight pieces of a phase: piece q = slab * 2 AF + block * 2 + (hi|lo); lane L copies 16 bytes of row 32 block + (L & 31),
     // channel half L >> 5 -- the 64 lanes together one contiguous KiB of the packed weight -- to slot q * 64 + L ------------
     const uint4* const w_hi16 = reinterpret_cast<const uint4*>(a.wq_hi);
     const uint4* const w_lo16 = reinterpret_cast<const uint4*>(a.wq_lo);
-    unsigned w_src[PPW];         // 16-byte unit inside chunk 0 of this lane's source, per piece of this wave
-    const unsigned w_chunk16 = 2u * (unsigned)a.w_rows;
+    unsigned w_src[PPW];         // 16-byte unit of this lane's source inside a slab, per piece of this wave
+    const unsigned w_chunk16 = 2u * (unsigned)a.w_rows, w_tap16 = a.w_tap16;
+    const int p_rcp = a.rcp, p_tw0 = a.tw0, p_tstep = a.tstep;
 #pragma unroll
     for (int u = 0; u < PPW; ++u) {
         const int q = wave + 4 * u;
         const int sl = q / (2 * AF), rem = q - sl * 2 * AF, blk = rem >> 1;
         const int row = min(m_base + 32 * blk + l31, a.w_rows - 1);
-        w_src[u] = (unsigned)sl * w_chunk16 + 2u * (unsigned)row + (unsigned)kb;
+        w_src[u] = 2u * (unsigned)row + (unsigned)kb;
     }
     auto issue_w = [&](int ph, int buf) {
-        const unsigned ph16 = (unsigned)(ph * PW_P) * w_chunk16;
 #pragma unroll
         for (int u = 0; u < PPW; ++u) {
             const int q = wave + 4 * u;
             if (NPIECE % 4 == 0 || q < NPIECE) {
-                const uint4* src = ((q & 1) ? w_lo16 : w_hi16) + (size_t)(ph16 + w_src[u]);
+                const int g = ph * PW_P + q / (2 * AF);                       // slab -> (chunk, tap), tap fastest
+                const int c = (g * p_rcp) >> 16, t = g - c * p_ntap;
+                const unsigned slab16 = (unsigned)(p_tw0 + t * p_tstep) * w_tap16 + (unsigned)c * w_chunk16;
+                const uint4* src = ((q & 1) ? w_lo16 : w_hi16) + (size_t)(slab16 + w_src[u]);
                 svb_glds16(src, smem, 16u * (unsigned)(buf * PHASE16 + q * 64));
             }
         }
@@ -255,31 +301,37 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_pw_kernel(SvbPwArgs a) {
             fa[par][r] = *reinterpret_cast<const uint4*>(lds + 16 * (buf * PHASE16 + s * SLAB16 + r * 64));
     };
 
-    // Software pipeline over the chunks g = 0, 1, ...: while the MFMAs of chunk g run, the x registers of chunk g + 1 are split
-    // (they were requested PF - 1 chunks ago), the A fragments of chunk g + 1 are read, and -- FIRST, pinned in front of the
-    // chunk's arithmetic -- the x loads of chunk g + PF are issued into the register set that has just been vacated.  (Left to itself the scheduler sinks every load of a phase to its end and waits vmcnt(0) at the top of the next
+    // Software pipeline over the slabs g = 0, 1, ... (slab = (chunk, tap), tap fastest): while the MFMAs of slab g run, the x
+    // registers of slab g + 1 are split (they were requested PF - 1 slabs ago), the A fragments of slab g + 1 are read, and -- FIRST,
+    // pinned in front of the slab's arithmetic -- the x loads of slab g + PF are issued into the register set that has just been
+    // vacated.  (Left to itself the scheduler sinks every load of a phase to its end and waits vmcnt(0) at the top of the next
     // one; and the prologue's loads are pinned in chunk order, because the wait-count pass merges the loop header's state with
     // that block's: a set requested LAST there turns the first wait of every phase into a near-complete drain of the prefetch.)
+    int lc = 0, lt = 0;                               // (chunk, tap) of the next slab to request
+    auto load_next = [&](int set) {
+        X.load(set, lc, pw_tap_off(a, lt));
+        if (++lt == p_ntap) { lt = 0; ++lc; }
+    };
     issue_w(0, 0);
 #pragma unroll
-    for (int s = 0; s < PF; ++s) { X.load(s, s); __builtin_amdgcn_sched_barrier(0); }
+    for (int s = 0; s < PF; ++s) { load_next(s); __builtin_amdgcn_sched_barrier(0); }
     X.split(0, 0);
     for (int ph = 0; ph < p_nph; ++ph) {
         const int buf = ph & 1;
         // this wave's pieces of phase ph were requested a phase ago, BEFORE the x loads that may still be in flight (vmcnt retires
         // in order); after the barrier every wave's pieces have landed and nobody reads the other buffer any more
-        __builtin_amdgcn_s_waitcnt(PW_VMCNT(8 * BF * PF));
+        __builtin_amdgcn_s_waitcnt(PW_VMCNT((GATE == 1 ? 16 : 8) * BF * PF));
         __builtin_amdgcn_s_barrier();
         if (ph + 1 < p_nph) issue_w(ph + 1, buf ^ 1);
         read_a(0, buf, 0);
 #pragma unroll
         for (int s = 0; s < PW_P; ++s) {
             const int par = s & 1;
-            X.load(s % PF, ph * PW_P + s + PF);
+            load_next(s % PF);
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < PW_P) read_a(par ^ 1, buf, s + 1);
             X.split(par ^ 1, (s + 1) % PF);
-            pw_mfma_slab<AF, BF, PF>(acc, fa[par], X, par);
+            pw_mfma_slab<AF, BF, PF, GATE>(acc, fa[par], X, par);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -296,44 +348,72 @@ static const PwCfg kPwCfgs[SVB_PW_NVARIANTS] = {{4, 1, 2, 2}, {4, 2, 4, 2}, {2, 
 //  2-chunk phases.  A weight-stationary persistent form -- all of a row tile's weights in LDS once, waves walking column blocks with
 //  no barrier -- was 10-15 % SLOWER than the phased small tiles on every shape and is not in the tree.)
 
-template <int AF, int BF, int P, int PF>
+template <int AF, int BF, int P, int PF, int GATE>
 static void pw_launch_kernel(const SvbPwArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)2 * P * AF * 2 * 64 * 16;
-    hipLaunchKernelGGL((svb_conv1d_pw_kernel<AF, BF, P, PF>), dim3(a.ntiles), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((svb_conv1d_pw_kernel<AF, BF, P, PF, GATE>), dim3(a.ntiles), dim3(256), lds, stream, a);
+}
+
+template <int AF, int BF, int P, int PF>
+static int pw_launch_gate(const SvbPwArgs& a, hipStream_t stream) {
+    if (a.in_gate && a.in_gate == a.x) {
+        if constexpr (AF * BF < 8) pw_launch_kernel<AF, BF, P, PF, 2>(a, stream);
+        else return SVB_ERR_UNSUPPORTED;             // (128x256: the gate's temporaries spill)
+    } else if (a.in_gate) {
+        // a second operand stream: two register sets at most, 128-column tiles only
+        if constexpr (BF == 1) pw_launch_kernel<AF, BF, P, 2, 1>(a, stream);
+        else return SVB_ERR_UNSUPPORTED;
+    } else pw_launch_kernel<AF, BF, P, PF, 0>(a, stream);
+    return SVB_OK;
 }
 
 int svb_pw_launch(const SvbConvQArgs& q, const SvbConvPlan& p, int variant, hipStream_t stream) {
     if (variant < 0 || variant >= SVB_PW_NVARIANTS) return SVB_ERR_UNSUPPORTED;
-    if (p.n_phase != 1 || q.sx != 1 || q.out_stride != 1 || q.G != 1 || q.xq || q.in_gate) return SVB_ERR_UNSUPPORTED;
-    if (p.phase_start[1] - p.phase_start[0] != 1 || p.tap_off[p.phase_start[0]] != 0 || p.tap_w[p.phase_start[0]] != 0)
-        return SVB_ERR_UNSUPPORTED;
+    if (p.n_phase != 1 || q.sx != 1 || q.out_stride != 1 || q.G != 1 || q.xq) return SVB_ERR_UNSUPPORTED;
+    const int t0 = p.phase_start[0], ntap = p.phase_start[1] - t0;
+    if (ntap < 1 || ntap > 16) return SVB_ERR_UNSUPPORTED;
     if (p.phase_out_base[0] != 0 || p.phase_nq[0] != q.Tout || q.Tin != q.Tout) return SVB_ERR_UNSUPPORTED;
     const PwCfg c = kPwCfgs[variant];
-    if (q.Cin % (16 * c.P) || q.Cout % 8 || q.Cout < 32) return SVB_ERR_UNSUPPORTED;
+    const int nslab = (q.Cin / 16) * ntap;
+    if (q.Cin % 16 || nslab % c.P || q.Cout % 8 || q.Cout < 32 || nslab >= 4096) return SVB_ERR_UNSUPPORTED;
     // 32-bit byte offsets inside the kernel; an offset >= 2^31 marks a column outside the tensor
-    if ((long)q.B * q.Cin * q.Tin >= (1L << 29) || (long)q.B * q.Cout * q.Tout >= (1L << 29)) return SVB_ERR_UNSUPPORTED;
-    if ((long)q.w_slab_rows * 2 * (q.Cin / 16 + 1) >= (1L << 31)) return SVB_ERR_UNSUPPORTED;
+    if ((long)q.B * q.Cin * q.Tin >= (1L << 28) || (long)q.B * q.Cout * q.Tout >= (1L << 28)) return SVB_ERR_UNSUPPORTED;
+    if ((long)q.w_tap_slabs * q.w_slab_rows * 2 * (SVB_MAX_TAPS + 1) >= (1L << 31)) return SVB_ERR_UNSUPPORTED;
     SvbPwArgs a;
     memset(&a, 0, sizeof(a));
+    a.ntap = ntap;
+    a.tw0 = p.tap_w[t0];
+    a.tstep = ntap > 1 ? p.tap_w[t0 + 1] - p.tap_w[t0] : 0;
+    for (int t = 0; t < ntap; ++t) {
+        const int off = p.tap_off[t0 + t];
+        if (p.tap_w[t0 + t] != a.tw0 + t * a.tstep || off < -32768 || off > 32767) return SVB_ERR_UNSUPPORTED;
+        const unsigned long long v = (unsigned long long)(unsigned short)(short)off << (16 * (t & 3));
+        a.offs[t >> 2] |= v;
+    }
+    a.rcp = (65536 + ntap - 1) / ntap;
+    a.w_tap16 = (unsigned)q.w_tap_slabs * (unsigned)q.w_slab_rows * 2u;
     a.x = q.x; a.wq_hi = q.wq_hi; a.wq_lo = q.wq_lo; a.bias = q.bias; a.y = q.y;
+    a.in_gate = q.in_gate; a.in_slope = q.in_slope;
     a.out_gate = q.out_gate; a.mask = q.mask; a.residual = q.residual;
     a.out_slope = q.out_slope; a.out_gate_slope = q.out_gate_slope; a.out_act = q.out_act;
     a.B = q.B; a.Cin = q.Cin; a.Cout = q.Cout; a.T = q.Tin;
     a.ncols = q.B * q.Tin;
-    a.nph = q.Cin / (16 * c.P);
+    a.nph = nslab / c.P;
     a.w_rows = q.w_slab_rows;
     a.m_tiles = svb_cdiv(q.Cout, 32 * c.AF);
     const long n_tiles = ((long)a.ncols + 128 * c.BF - 1) / (128 * c.BF);
     if (a.m_tiles * n_tiles >= (1L << 30)) return SVB_ERR_UNSUPPORTED;
     a.ntiles = (int)(a.m_tiles * n_tiles);
+    int rc;
     switch (variant) {
-        case 0: pw_launch_kernel<4, 1, 2, 2>(a, stream); break;
-        case 1: pw_launch_kernel<4, 2, 4, 2>(a, stream); break;
-        case 2: pw_launch_kernel<2, 2, 4, 2>(a, stream); break;
-        case 3: pw_launch_kernel<2, 1, 4, 4>(a, stream); break;
-        case 4: pw_launch_kernel<3, 1, 4, 4>(a, stream); break;
-        default: pw_launch_kernel<3, 2, 4, 2>(a, stream); break;
+        case 0: rc = pw_launch_gate<4, 1, 2, 2>(a, stream); break;
+        case 1: rc = pw_launch_gate<4, 2, 4, 2>(a, stream); break;
+        case 2: rc = pw_launch_gate<2, 2, 4, 2>(a, stream); break;
+        case 3: rc = pw_launch_gate<2, 1, 4, 4>(a, stream); break;
+        case 4: rc = pw_launch_gate<3, 1, 4, 4>(a, stream); break;
+        default: rc = pw_launch_gate<3, 2, 4, 2>(a, stream); break;
     }
+    if (rc != SVB_OK) return rc;
     if (hipGetLastError() != hipSuccess) return SVB_ERR_UNSUPPORTED;
     return SVB_OK;
 }

@@ -35,7 +35,7 @@ struct SvbConvQArgs {
 #define SVB_TW_NVARIANTS 3
 int svb_tw_launch(const SvbConvQArgs& a, const SvbConvPlan& p, int variant, hipStream_t stream);
 
-// conv1d_pw.hip: the pointwise (1-tap) GEMM form.  variant = 0 .. SVB_PW_NVARIANTS-1 (128x128, 128x256, 64x256, 64x128, 96x128,
-// 96x256 output tiles); returns SVB_ERR_UNSUPPORTED outside its domain (taps, strides, groups, input gates, Cin % 64, Cout % 8).
+// conv1d_pw.hip: the GEMM form (1 .. 16 taps, stride 1, equal length).  variant = 0 .. SVB_PW_NVARIANTS-1 (128x128, 128x256, 64x256,
+// 64x128, 96x128, 96x256 output tiles); returns SVB_ERR_UNSUPPORTED outside its domain (strides, groups, Tin != Tout, Cin % 16, Cout % 8).
 #define SVB_PW_NVARIANTS 6
 int svb_pw_launch(const SvbConvQArgs& a, const SvbConvPlan& p, int variant, hipStream_t stream);

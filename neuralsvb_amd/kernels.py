@@ -57,6 +57,7 @@ _TUNED_NEAREST = {}       # signatures resolved through their family's nearest t
 _FAMILIES = {}            # family key -> [(B, T, choice, sig)] of the table
 _TUNE_LOG = None          # tools/tune_tiles.py: dict sig -> [median us per configuration]
 _TABLE_INFO = {"path": None, "sha256_16": None, "entries": 0}
+_ARCH_CHECKED = False     # the table's `arch` is compared with the device's on the first GPU lookup
 # positions of the batch / length fields per signature kind (everything else names the launch family)
 _SIZE_FIELDS = {"qf": (1, 5), "f": (1, 5), "qt": (1, 5, 6), "t": (1, 5, 6), "taps": (2, 5, 6)}
 
@@ -81,11 +82,14 @@ def _family(sig):
 
 def load_tile_table(path=TILE_TABLE_PATH):
     """Replace the in-process choices by the table at `path` (missing file: empty table)."""
+    global _ARCH_CHECKED
+    _ARCH_CHECKED = False
     _TUNED.clear()
     _TUNED_ONLINE.clear()
     _TUNED_NEAREST.clear()
     _FAMILIES.clear()
     _TABLE_INFO.update(path=None, sha256_16=None, entries=0)
+    _TABLE_INFO.pop("ignored_for_arch", None)
     if not path or not os.path.exists(path) or os.environ.get("SVB_TILE_TABLE", "1") == "0":
         return _TABLE_INFO
     raw = open(path, "rb").read()
@@ -124,9 +128,6 @@ def _nearest_choice(sig):
     best = min(entries, key=lambda e: (abs(math.log(e[0]) + math.log(e[1]) - lb - lt) + 0.5 * abs(math.log(e[1]) - lt), e[3]))
     _TUNED_NEAREST[sig] = (best[2], best[3])
     return best[2]
-
-
-_ARCH_CHECKED = False
 
 
 def _check_table_arch():

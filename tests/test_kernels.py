@@ -675,19 +675,69 @@ def test_conv1d_bf16x3_pointwise_gemm_kernel(dev, cfg, shape):
         assert torch.equal(dx, K.conv1d_transposed(dy.to(dev), qb, Cin, T, 1, 1, 0, 1, 1, force_cfg=4, **kw))
 
 
+def _taps_ref(x, w, offsets):
+    B, Cin, T = x.shape
+    y = torch.zeros(B, w.shape[0], T, dtype=torch.float64)
+    for t, off in enumerate(offsets):
+        xs = torch.zeros(B, Cin, T, dtype=torch.float64)
+        lo, hi = max(0, -off), min(T, T - off)
+        if hi > lo:
+            xs[:, :, lo:hi] = x[:, :, lo + off:hi + off].double()
+        y += torch.einsum("oc,bct->bot", w[:, :, t].double(), xs)
+    return y.float()
+
+
+@pytest.mark.parametrize("cfg", [18, 19, 20, 21, 22, 23])
+@pytest.mark.parametrize("shape", [(64, 72, (-1, 0, 1), 150), (32, 40, (-8, -4, 0, 4, 8), 97), (48, 64, (-43, -42, -1, 0), 61),
+                                   (64, 264, (0, 3), 40), (16, 32, (-70, -3, -2, -1, 0, 1, 2, 70), 45),
+                                   (32, 64, tuple(range(-15, 16, 3)), 130), (16, 40, tuple(range(-8, 8)), 33)])
+def test_conv1d_bf16x3_gemm_kernel_with_taps_and_input_gates(dev, cfg, shape):
+    """The same kernel over (chunk, tap) slabs: stride-1 equal-length convs of up to 16 taps with an arbitrary offset table
+    (dilated, one-sided as the period critics' slot convs are, offsets past the clip's length), the tap's shift applied to the
+    column's position with the zero padding answered by the buffer bounds check; the input gated by its own sign
+    (`conv(leaky_relu(x))`) and by a second tensor (the critic towers' data gradients); forward and transposed forms against the
+    oracle and a tap-table tile."""
+    Cin, Cout, offsets, T = shape
+    k = len(offsets)
+    g = torch.Generator().manual_seed(cfg * 131 + Cin + k)
+    B = 3
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) * 0.2
+    bias = torch.randn(Cout, generator=g)
+    qa, qb = K.weight_pack_q(w.to(dev), None, 1)
+    xd, bd = x.to(dev), bias.to(dev)
+    ref = _taps_ref(x, w, offsets) + bias[None, :, None]
+    y = K.conv1d_taps(xd, qa, Cout, offsets, bias=bd, force_cfg=cfg)
+    assert rel_err(y, ref) < 6e-5
+    assert rel_err(y, K.conv1d_taps(xd, qa, Cout, offsets, bias=bd, force_cfg=4).cpu()) < 2e-6
+    yg = K.conv1d_taps(xd, qa, Cout, offsets, bias=bd, in_gate=xd, in_slope=0.1, force_cfg=cfg)
+    assert rel_err(yg, _taps_ref(F.leaky_relu(x, 0.1), w, offsets) + bias[None, :, None]) < 6e-5
+    gate = torch.randn(B, Cin, T, generator=g)
+    yh = K.conv1d_taps(xd, qa, Cout, offsets, bias=bd, in_gate=gate.to(dev), in_slope=0.2, force_cfg=cfg)
+    assert rel_err(yh, _taps_ref(x * torch.where(gate > 0, 1.0, 0.2), w, offsets) + bias[None, :, None]) < 6e-5
+    if offsets == tuple(range(offsets[0], offsets[0] + (k - 1) * (offsets[1] - offsets[0]) + 1, offsets[1] - offsets[0])) \
+            and offsets[0] == -offsets[-1]:
+        dil, pad = offsets[1] - offsets[0], -offsets[0]
+        dy = torch.randn(B, Cout, T, generator=g)
+        gy = torch.randn(B, Cout, T, generator=g)
+        xr = x.clone().requires_grad_(True)
+        dref = torch.autograd.grad(oops.conv1d(xr, w, None, 1, pad, dil), xr, dy * torch.where(gy > 0, 1.0, 0.2))[0]
+        dx = K.conv1d_transposed(dy.to(dev), qb, Cin, T, k, 1, pad, dil, 1, in_gate=gy.to(dev), in_slope=0.2, force_cfg=cfg)
+        assert rel_err(dx, dref) < 6e-5
+
+
 @pytest.mark.parametrize("cfg", [18, 20])
 def test_conv1d_bf16x3_pointwise_gemm_falls_back_outside_its_domain(dev, cfg):
-    """Convs outside the pointwise kernel's domain (taps, input gates, Cin % 64 != 0, strides) run a tap-table tile of the family
-    when its configuration is forced -- same results as that tile."""
+    """Convs outside the kernel's domain (more than 16 taps, Cin % 16 != 0, strides, outputs longer than the input) run a tap-table
+    tile of the family when its configuration is forced -- same results as that tile."""
     g = torch.Generator().manual_seed(cfg)
     B, T = 2, 90
-    for Cin, Cout, k, s, gated in [(64, 64, 3, 1, False), (48, 64, 1, 1, False), (64, 64, 1, 1, True), (64, 64, 1, 2, False)]:
+    for Cin, Cout, k, s, pad in [(64, 64, 17, 1, 8), (40, 64, 1, 1, 0), (64, 64, 3, 1, 2), (64, 64, 1, 2, 0)]:
         x = torch.randn(B, Cin, T, generator=g).to(dev)
         w = torch.randn(Cout, Cin, k, generator=g) * 0.2
         qa, _ = K.weight_pack_q(w.to(dev), None, 1)
-        kw = dict(in_gate=x, in_slope=0.1) if gated else {}
-        y = K.conv1d_forward(x, qa, Cout, k, s, k // 2, 1, 1, force_cfg=cfg, **kw)
-        assert torch.equal(y, K.conv1d_forward(x, qa, Cout, k, s, k // 2, 1, 1, force_cfg=4, **kw))
+        y = K.conv1d_forward(x, qa, Cout, k, s, pad, 1, 1, force_cfg=cfg)
+        assert torch.equal(y, K.conv1d_forward(x, qa, Cout, k, s, pad, 1, 1, force_cfg=4))
 
 
 @pytest.mark.parametrize("cfg", [13, 14])

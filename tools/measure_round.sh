@@ -5,7 +5,7 @@
 # One-off A/B runs of step variants: tools/ab_bench.sh "<hparams overrides | bench flag>" ...   (both scripts are parameterised:
 # the 50 single-purpose scripts of round 3 are gone; git history has them)
 set -x
-TAG=${1:-r05}
+TAG=${1:-r06}
 O=gpurun_out/${TAG}_final
 mkdir -p $O
 export TMPDIR=/tmp
