@@ -28,6 +28,13 @@ typedef SvbDiv256 SsimDiv;        // (svb_common.h: division-free (row, column) 
 // 5 planes of rows x F), then along the frames per output pixel -- 11 + 11 taps per moment instead of 121.  (Round 3: the
 // full 2-D windows made these kernels VALU/LDS-bound -- ~1.2 k VALU ops and 242 LDS reads per pixel, 70 us per call at
 // [32, 1124, 80] for 23 MB of input -- the separable form needs ~150 and ~90.)
+// (Round 6: NOT LDS-instruction bound any more.  The same two passes with ds_read_b128 -- four adjacent bins per thread, 5x fewer
+// LDS instructions, bit-identical sums -- measured 98.8 us forward / 201 us backward against 96.8 / 151 for these scalar passes
+// (profiles/r06_streaming_kernels_3.log; with two output rows per thread the frames pass needed > 256 VGPRs and ran 2x slower,
+// r06_streaming_kernels_2.log).  Even the L1-only call, which touches no LDS, takes 34 us for 23 MB: a workgroup is a chain of
+// dependent round trips (stage -> barrier -> bins pass -> barrier -> frames pass -> block sums) over 1280 pixels, and the 60 KB of
+// LDS hold two workgroups per CU, 4.4 rounds of 2272 workgroups.  The next form is a strip walk -- one workgroup per clip and
+// 128-frame strip, the frames window kept in registers -- not a faster tile.)
 __device__ __forceinline__ void ssim_hpass5(const float* xs, const float* ys, int ld, int F, int rows, const SsimWin& w, float* hm) {
     const int n = rows * F;
     SsimDiv dv(F);

@@ -350,6 +350,8 @@ __global__ __launch_bounds__(256) void svb_layernorm_bwd_kernel(const float* x, 
 // LayerNorm over the channel dim of an NCT tensor.  Block = 32 time columns x 8 channel groups (a wave covers two
 // 128-byte row segments per load); each thread keeps its C/8 values in registers (all loads in flight at once, x is
 // read ONCE), the groups combine their shifted moments through LDS.  1 read + 1 write of x.
+// (Round 6: 3.0 TB/s at C = 256, T = 1124.  A 64-column x 4-group block -- 256-byte runs per load instruction, 64 values per
+// thread -- measured 2.47 TB/s, profiles/r06_streaming_kernels_2.log: not the run length; kept as is.)
 #define SVB_LN_MAXV 48          /* register-resident values per thread: C <= 384 (larger C re-reads x) */
 __global__ __launch_bounds__(256) void svb_layernorm_nct_fwd_kernel(const float* x, const float* gamma, const float* beta,
                                                                     float* y, int B, int C, int T, float eps) {
