@@ -25,7 +25,7 @@
 //   * taps: the K walk runs over (chunk, tap) slabs, tap fastest; a tap only moves the position a lane loads (its column + the
 //     tap's offset; outside the clip the buffer bounds check answers 0 = the conv's zero padding).  x is then fetched once per tap
 //     (L1 / L2 hits after the first) instead of staged once into LDS -- measured on the MI355X that is still 20-40 % faster than
-//     the tap-table tiles on the vocoder's k = 3 / 7 / 11 residual convs and their data gradients (profiles/r06_tile_tuner_taps.log);
+//     the tap-table tiles on the vocoder's k = 3 / 7 / 11 residual convs and their data gradients (profiles/r06_tile_tuner_taps16.log);
 //   * an input gate (x * lrelu'(gate): the data gradients of the critic towers; gate == x: `conv(leaky_relu(x))` of the HifiGAN
 //     generator) is applied in registers before the split.
 //
