@@ -957,30 +957,7 @@ extern "C" int svb_conv1d_transposed_bf16x3(const float* x, const unsigned short
 // are 2*odd dwords: the 8-byte-aligned ds_read_b64 of the dil == 1 path and the dword reads of the general path are
 // both bank-conflict free (each is serviced per 32-lane half, i.e. per kb).
 // ==================================================================================================================
-struct SvbWgradQArgs {
-    const float* a;
-    const float* b;
-    float* part;
-    float* bias_part;   // optional [nsplit][CA]: per-split sums of the (gated) A rows = bias-gradient partials when A = dy
-    const float* a_gate;
-    const float* b_gate;
-    float a_slope, b_slope;
-    int B, CA, CB, G, CA_g, CB_g, TA, TB;
-    int k, off0, dil, sx;
-    int n_tg, a_tiles, b_tiles, chunks_per_b, total_chunks, nsplit;
-    int at, bt;   // 32x32 accumulator tiles per wave along A / B rows (workgroup tile 64*at x 64*bt)
-    int gp_ca, gp_cb;   // group packing: G / CA_g / CB_g above describe `gp` real groups merged into one (their channels are
-                        // contiguous), so that a 64x64 tile holds gp diagonal blocks of gp_ca x gp_cb REAL per-group channels instead
-                        // of one (MSD's grouped k41 convs: 16 x 8 channels per group); only those blocks are stored.  0 = off.
-    int pa, pb;   // LDS row pitches in dwords (2 * odd)
-    int xcd_map;  // 1: XCD-aware work ids (the product's constant; the instrumentation build can switch it off for an A/B)
-    // tap groups.  Stride 1: group i = taps [i*TGW, ...), Bt position of tile index t: q0 + off0 + j0*dil + t.
-    // Stride s > 1 (dil 1): taps are grouped by phase r = (j - pad) mod s; within a phase the strided gather
-    // q*s + j - pad = (q + o_j)*s + r is a stride-1 walk over the phase-r subsequence of Bt, so a group is a stride-1
-    // problem on positions (q0 + o0 + t)*s + r with weight taps j0, j0 + s, j0 + 2s, ...
-    short tg_j0[SVB_MAX_TAPS], tg_ntap[SVB_MAX_TAPS], tg_r[SVB_MAX_TAPS], tg_o0[SVB_MAX_TAPS];
-};
-
+// (SvbWgradQArgs: conv1d_q.h -- shared with the direct-operand 1-tap kernel, conv1d_wgrad_pw.hip)
 #define SVBQ_WG_QC 64
 #define SVBQ_WG_NXIT 3
 
@@ -1606,6 +1583,7 @@ static const long g_svbq_wg_blocks = SVB_ENV_LONG("SVB_WG_BLOCKS", 512);   // sp
 // Group packing factor (see SvbWgradQArgs::gp_ca): the largest power of two m dividing `groups` with m*CA_g <= 64 and m*CB_g <= 64.
 static const bool g_svbq_wg_nopack = SVB_ENV_FLAG("SVB_WG_NO_GROUP_PACK");      // A/B switch
 static const bool g_svbq_wg_no_xcd = SVB_ENV_FLAG("SVB_WG_NO_XCD");             // A/B switch: identity block -> work map
+static const bool g_svbq_wg_no_pw = SVB_ENV_FLAG("SVB_WG_NO_PW");               // A/B switch: 1-tap gradients on the tap-group kernel
 static int wgq_pack(int groups, int CA_g, int CB_g) {
     int m = 1;
     if (g_svbq_wg_nopack) return 1;
@@ -1639,7 +1617,8 @@ extern "C" size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB
     groups /= gp;
     const int CA_g = CA / groups, CB_g = CB / groups;
     int at = 1, bt = 1;
-    wgq_tile(CA_g, CB_g, tgw, false, &at, &bt);
+    if (!(gp == 1 && !g_svbq_wg_no_pw && svb_wgrad_pw_plan(CA, CB, groups, k, sx, pad, dil, TA, &at, &bt)))
+        wgq_tile(CA_g, CB_g, tgw, false, &at, &bt);
     const long tiles = (long)groups * svb_cdiv(CA_g, 64 * at) * svb_cdiv(CB_g, 64 * bt) * n_tg;
     const long chunks = (long)B * svb_cdiv(TA, SVBQ_WG_QC);
     long ns_cap = g_svbq_wg_blocks / tiles;                      // one resident wave of blocks at 2 per CU
@@ -1743,6 +1722,7 @@ extern "C" int svb_conv1d_wgrad_bf16x3(const float* a_t, const float* b_t, float
     if (nsplit > a.total_chunks) return SVB_ERR_ARG;
     a.nsplit = nsplit;
     a.xcd_map = g_svbq_wg_no_xcd ? 0 : 1;
+    if (gp == 1 && !g_svbq_wg_no_pw && svb_wgrad_pw_launch(a, (hipStream_t)stream) == SVB_OK) return SVB_OK;   // 1-tap: direct operands
     a.pa = 34;
     a.pb = 32 + ((tgw - 1) * dil + 1) / 2 + 6;
     a.pb += a.pb & 1;

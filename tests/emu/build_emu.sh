@@ -6,6 +6,9 @@ ROOT="$(cd "$HERE/../.." && pwd)"
 CXX=${SVB_EMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}
 [ -x "$CXX" ] || CXX=clang++
 OUT="$HERE/libsvb_emu.so"
+mkdir -p "$HERE/build"
+exec 9> "$HERE/build/.lock"          # pytest-xdist workers build one at a time; the library appears by an atomic rename
+flock 9
 SRCS=$(ls "$ROOT"/neuralsvb_amd/csrc/*.hip)
 OBJS=""
 mkdir -p "$HERE/build"
@@ -17,6 +20,14 @@ for s in $SRCS; do
   OBJS="$OBJS $o"
 done
 wait
-"$CXX" -std=c++17 -O2 -fPIC -I"$HERE/include" -c "$HERE/emu_runtime.cpp" -o "$HERE/build/emu_runtime.o"
-"$CXX" -shared -o "$OUT" $OBJS "$HERE/build/emu_runtime.o"
+RT="$HERE/build/emu_runtime.o"
+if [ ! -f "$RT" ] || [ "$HERE/emu_runtime.cpp" -nt "$RT" ] || [ -n "$(find "$HERE/include" -name '*.h' -newer "$RT")" ]; then
+  "$CXX" -std=c++17 -O2 -fPIC -I"$HERE/include" -c "$HERE/emu_runtime.cpp" -o "$RT"
+fi
+NEWER=""
+for o in $OBJS "$RT"; do [ -f "$OUT" ] && [ ! "$o" -nt "$OUT" ] || NEWER=1; done
+if [ -n "$NEWER" ]; then
+  "$CXX" -shared -o "$OUT.tmp.$$" $OBJS "$RT"
+  mv -f "$OUT.tmp.$$" "$OUT"
+fi
 echo "$OUT"

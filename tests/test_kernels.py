@@ -509,6 +509,39 @@ def test_conv1d_wgrad_bf16x3(dev, case):
     assert rel_err(db, dy.sum((0, 2))) < 1e-5          # bias-gradient partials fused into the same two launches
 
 
+@pytest.mark.parametrize("gates", ["none", "a", "self_b", "both", "b"])
+@pytest.mark.parametrize("case", [(3, 64, 64, 53), (2, 130, 70, 281), (1, 256, 384, 130), (5, 96, 200, 16), (4, 64, 128, 1),
+                                  (2, 192, 64, 97)])
+def test_conv1d_wgrad_pointwise_direct_operands(dev, case, gates):
+    """Weight gradient of the 1-tap convs on the direct-operand kernel (csrc/conv1d_wgrad_pw.hip: both operands global -> VGPR -> split
+    -> MFMA, no LDS): clips whose length is not a multiple of the 16-position step (ragged last step, chunks with fewer than four
+    steps, T = 1), ragged row tiles on both sides, 64 x 64 / 64 x 32 / 32 x 64 wave tiles, every gate form (dy gated by the saved
+    output, x gated by itself, by a second tensor, both), bias partials -- against torch autograd."""
+    B, Cin, Cout, T = case
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + T + len(gates))
+    x = torch.randn(B, Cin, T, generator=g)
+    w = (torch.randn(Cout, Cin, 1, generator=g) * 0.2).requires_grad_(True)
+    gx = torch.randn(B, Cin, T, generator=g)
+    xin = x
+    kw = {}
+    if gates in ("self_b", "both"):
+        xin = F.leaky_relu(x, 0.1) if gates == "self_b" else x * torch.where(gx > 0, 1.0, 0.1)
+        kw.update(b_gate=(x if gates == "self_b" else gx).to(dev), b_slope=0.1)
+    if gates == "b":
+        xin = x * torch.where(gx > 0, 1.0, 0.3)
+        kw.update(b_gate=gx.to(dev), b_slope=0.3)
+    y = oops.conv1d(xin, w, None, 1, 0)
+    if gates in ("a", "both"):
+        y = F.leaky_relu(y, 0.2)
+        kw.update(a_gate=y.detach().to(dev), a_slope=0.2)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dw, db = K.conv1d_wgrad(dy.to(dev), x.to(dev), 1, 1, 0, 1, 1, bf16x3=True, want_bias=True, **kw)
+    assert rel_err(dw, w.grad) < 6e-5
+    dyg = dy * torch.where(y > 0, 1.0, 0.2) if gates in ("a", "both") else dy
+    assert rel_err(db, dyg.sum((0, 2))) < 1e-5
+
+
 @pytest.mark.parametrize("bf16x3", [True, False])
 def test_conv1d_wgrad_bias_sink_only(dev, bf16x3):
     """bias_sink: the bias gradient alone is accumulated into an existing buffer (svb_wgrad_reduce accumulate = 2) while the
