@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define SVB_ABI_VERSION 9
+#define SVB_ABI_VERSION 10
 int svb_abi_version(void);
 
 /* ---- fused conv epilogue / prologue description ------------------------------------------------------
@@ -228,6 +228,45 @@ typedef struct SvbWnBackward {
  * caller joins it.  Weight gradients whose d_*_v is NULL are skipped.  SVB_ERR_UNSUPPORTED: a weight gradient does not fit
  * the bf16x3 kernel's envelope or the arena (nothing has been launched for that gradient; earlier launches stand).        */
 int svb_wn_stack_backward(const SvbWnStack* s, const SvbWnBackward* b, void* stream, void* side_stream);
+
+/* ---- Host-side executor of one window's tower of the mel critic (reference modules/voice_conversion/multi_window_disc.py:14-64:
+ * blocks of [Conv2d 3x3 s2 + LeakyReLU -> Dropout2d -> InstanceNorm2d] chained through the conv's space-to-depth layout, then the
+ * Linear score layer): ONE call issues every launch of the forward / of the backward through the entry points above
+ * (svb_conv1d_taps_bf16x3, svb_crop_drop_inorm_*, svb_plane_score_*, svb_conv1d_wgrad_bf16x3 + svb_wgrad_reduce, svb_s2_weight_bwd).
+ * Layouts are those entry points': x4 = space-to-depth planes [4C][N][H/2+1][W/2+1] of the (N, C, H, W) input; block b's conv
+ * output y4 [cout][N][Ho+1][Wo+1]; `out` = the next block's x4, or [cout][N][Ho][Wo] for the last block.                          */
+#define SVB_CT_MAX_BLOCKS 4
+typedef struct SvbCtBlock {
+    const unsigned short *a_hi, *a_lo;   /* packed derived 2x2 kernel [cout][4C][4] (svb_s2_weight + svb_weight_pack_bf16x3), forward image */
+    const unsigned short *b_hi, *b_lo;   /* its data-gradient image (backward with dx4 only)                                           */
+    const float* bias;                   /* [cout] or NULL                                                                             */
+    const float* keep;                   /* Dropout2d factors [N][cout] or NULL                                                        */
+    const float *gamma, *beta;           /* InstanceNorm2d affine or NULL (no norm)                                                    */
+    float eps;
+    int cout, cfg_fwd, cfg_bwd;          /* tile configurations of the two convs (0 = the kernel's heuristic)                          */
+    float *y4, *out, *stats;             /* forward results (stats [cout][N][2] with gamma)                                            */
+    float *dy4, *dgb, *dx4;              /* backward: conv output gradient, per-plane sums [2][N][cout] (with gamma), input gradient (NULL:
+                                          * not needed -- block 0 only)                                                                 */
+    float *d_weight, *d_bias;            /* gradient buffers of the 3x3 weight [cout][C][3][3] / bias to ACCUMULATE into (NULL: skipped)  */
+} SvbCtBlock;
+typedef struct SvbCriticTower {
+    int nb, N, C, H, W;                  /* blocks; planes of the tower's input                                                        */
+    int has_slope; float slope;          /* LeakyReLU after every conv                                                                  */
+    const float* x4;
+    const float *score_w, *score_b;      /* [C_last * H_last * W_last], [1] or NULL                                                    */
+    float* score;                        /* [N]                                                                                         */
+    SvbCtBlock blk[SVB_CT_MAX_BLOCKS];
+} SvbCriticTower;
+int svb_critic_tower_forward(const SvbCriticTower* t, void* stream);
+typedef struct SvbCtBackward {
+    const float* ds; long ds_stride;     /* score cotangents ds[n * ds_stride]                                                         */
+    float* dh;                           /* [C_last][N][H_last][W_last] scratch: gradient of the last block's output                   */
+    float *d_score_w, *d_score_b;        /* outputs (overwritten) or NULL                                                               */
+    float* ws; size_t ws_floats;         /* workspace of the weight gradients (partials + two [cout][4C][2] results of the largest block) */
+} SvbCtBackward;
+/* side_stream (optional): the weight gradients, their reduces and the gather into d_weight are issued there after it has caught up
+ * with `stream` (one event per block); the caller joins it.  SVB_ERR_UNSUPPORTED: a weight gradient does not fit the workspace. */
+int svb_critic_tower_backward(const SvbCriticTower* t, const SvbCtBackward* g, void* stream, void* side_stream);
 
 /* ---- LayerNorm over the channel (last) dim of [rows, C] (reference modules/fastspeech/conformer/layers.py:160-170,
  * conformer.py:30; torch.nn.LayerNorm eps 1e-5).                                                             */

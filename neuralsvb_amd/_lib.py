@@ -42,6 +42,25 @@ class SvbWnBackward(C.Structure):
                 [("arena_floats", C.c_size_t), ("need_dx0", C.c_int)])
 
 
+SVB_CT_MAX_BLOCKS = 4
+
+
+class SvbCtBlock(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("a_hi", "a_lo", "b_hi", "b_lo", "bias", "keep", "gamma", "beta")] + [("eps", C.c_float)] +
+                [(n, C.c_int) for n in ("cout", "cfg_fwd", "cfg_bwd")] +
+                [(n, C.c_void_p) for n in ("y4", "out", "stats", "dy4", "dgb", "dx4", "d_weight", "d_bias")])
+
+
+class SvbCriticTower(C.Structure):
+    _fields_ = ([(n, C.c_int) for n in ("nb", "N", "C", "H", "W", "has_slope")] + [("slope", C.c_float)] +
+                [(n, C.c_void_p) for n in ("x4", "score_w", "score_b", "score")] + [("blk", SvbCtBlock * SVB_CT_MAX_BLOCKS)])
+
+
+class SvbCtBackward(C.Structure):
+    _fields_ = [("ds", C.c_void_p), ("ds_stride", C.c_long), ("dh", C.c_void_p), ("d_score_w", C.c_void_p),
+                ("d_score_b", C.c_void_p), ("ws", C.c_void_p), ("ws_floats", C.c_size_t)]
+
+
 class SvbPackDesc(C.Structure):
     _fields_ = [("v", C.c_void_p), ("g", C.c_void_p), ("qa_hi", C.c_void_p), ("qa_lo", C.c_void_p), ("qb_hi", C.c_void_p),
                 ("qb_lo", C.c_void_p), ("d0", C.c_int), ("d1", C.c_int), ("k", C.c_int), ("groups", C.c_int),
@@ -98,6 +117,8 @@ SIGNATURES = {
     "svb_wn_res_skip": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
     "svb_wn_stack_forward": (I, [P, P, P, P]),
     "svb_wn_stack_backward": (I, [P, P, P, P]),
+    "svb_critic_tower_forward": (I, [P, P]),
+    "svb_critic_tower_backward": (I, [P, P, P, P]),
     "svb_split_q": (I, [P, P, P, I, I, I, P]),
     "svb_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
     "svb_relpos_softmax": (I, [P, P, P, P, I, I, I, F, P]),

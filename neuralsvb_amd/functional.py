@@ -13,6 +13,7 @@ import weakref
 
 import torch
 
+from . import _lib as L_
 from . import kernels as K
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = K.ACT_NONE, K.ACT_RELU, K.ACT_LRELU, K.ACT_TANH
@@ -80,10 +81,10 @@ DIRECT_GRADS = True      # weight/bias gradients of leaf parameters that already
 def reset_runtime_state():
     """Arithmetic mode, optional fusions and the Trainer-set routing state back to their import-time values (see
     kernels.reset_runtime_state)."""
-    global USE_Q, DIRECT_GRADS, GRAD_READY, CAPTURING, PACK_CACHE, PACK_REGISTRY, PACK_EPOCH, STACK_EXECUTOR
+    global USE_Q, DIRECT_GRADS, GRAD_READY, CAPTURING, PACK_CACHE, PACK_REGISTRY, PACK_EPOCH, STACK_EXECUTOR, TOWER_EXECUTOR
     set_precision("fp32")
     USE_Q = False
-    DIRECT_GRADS = PACK_CACHE = PACK_REGISTRY = STACK_EXECUTOR = True
+    DIRECT_GRADS = PACK_CACHE = PACK_REGISTRY = STACK_EXECUTOR = TOWER_EXECUTOR = True
     GRAD_READY = PACK_EPOCH = None
     CAPTURING = False
 
@@ -1594,6 +1595,203 @@ class _OpCtx:
 FUSE_CRITIC_TOWER = True     # a whole critic tower (3 blocks + score layer) as ONE autograd node
 
 
+TOWER_EXECUTOR = True        # ... and its launches issued by ONE C-ABI call per direction (csrc/critic_tower.hip)
+_TOWER_CFG = {}              # (N, C, H, W, cout) -> (tile of the forward conv, tile of the data-gradient conv)
+
+
+def _tower_tiles(N, C, H, W, cout, on_gpu):
+    key = (N, C, H, W, cout)
+    t = _TOWER_CFG.get(key)
+    if t is None:
+        P = W // 2 + 1
+        L = N * (H // 2 + 1) * P
+        f = K.tuned_choice(("taps", True, 1, 4 * C, cout, L, L, (-P - 1, -P, -1, 0)), on_gpu)
+        b = K.tuned_choice(("taps", True, 1, cout, 4 * C, L, L, (P + 1, P, 1, 0)), on_gpu)
+        if f is None or b is None:
+            return None                      # (the offline tuner is measuring: the per-op path launches every signature once)
+        t = _TOWER_CFG[key] = (f, b)
+    return t
+
+
+def _tower_exec_forward(ctx, x4, cfg, params, need):
+    """The tower's forward through the C executor.  Fills the same private tape the per-op forward bodies would (so the per-op
+    backward can still run on it) and returns the scores; None = not applicable here (nothing launched)."""
+    (N, C, H, W), slope, drops, epss = cfg
+    nb = len(drops)
+    if not (TOWER_EXECUTOR and PRECISION == "bf16x3" and nb <= L_.SVB_CT_MAX_BLOCKS and K.PROFILE is None and not CAPTURING
+            and x4.dtype == torch.float32):
+        return None
+    dev = x4.device
+    on_gpu = x4.is_cuda
+    h_, w_, c_ = H, W, C
+    for b in range(nb):
+        if h_ % 2 or w_ % 2:
+            return None
+        h_, w_, c_ = h_ // 2, w_ // 2, params[4 * b].shape[0]
+    d = L_.SvbCriticTower()
+    d.nb, d.N, d.C, d.H, d.W = nb, N, C, H, W
+    d.has_slope, d.slope = int(slope is not None), float(slope if slope is not None else 0.0)
+    x4 = x4.contiguous()
+    d.x4 = x4.data_ptr()
+    tape, keepalive, live = [], [], []
+    x_need = need[0]
+    h_, w_, c_ = H, W, C
+    xin = x4.view(1, 4 * C, -1)
+    for b in range(nb):
+        w, bias, gamma, beta = params[4 * b:4 * b + 4]
+        nw = need[2 + 4 * b:6 + 4 * b]
+        cout = w.shape[0]
+        ho, wo = h_ // 2, w_ // 2
+        last = b + 1 == nb
+        tiles = _tower_tiles(N, c_, h_, w_, cout, on_gpu)
+        if tiles is None:
+            return None
+        wc = w.contiguous()
+        img = _s2_image(wc)
+        if (S2_REGISTERED and PACK_REGISTRY and PACK_CACHE and PACK_EPOCH is not None
+                and (wc.requires_grad or wc.grad is not None or (id(img), 0, 1) in _REG)):
+            pa, pb = _pack_registered(img, None, 1, True, True, src=id(wc))
+            pb = pb if x_need else None
+        else:
+            pa, pb = _pack(img, None, 1, want_a=True, want_b=x_need)
+        L4 = N * (ho + 1) * (wo + 1)
+        y4 = torch.empty((1, cout, L4), device=dev, dtype=torch.float32)
+        keep = dropout2d_keep(N, cout, drops[b], dev) if drops[b] else None
+        out = torch.empty(((cout, N, ho, wo) if last else (4 * cout, N, ho // 2 + 1, wo // 2 + 1)), device=dev, dtype=torch.float32)
+        gm, bt = _c(gamma), _c(beta)
+        stats = torch.empty((cout, N, 2), device=dev, dtype=torch.float32) if gm is not None else None
+        bc = _c(bias)
+        k = d.blk[b]
+        k.a_hi, k.a_lo = pa.hi.data_ptr(), pa.lo.data_ptr()
+        if pb is not None:
+            k.b_hi, k.b_lo = pb.hi.data_ptr(), pb.lo.data_ptr()
+        k.bias, k.keep, k.gamma, k.beta = K._ptr(bc), K._ptr(keep), K._ptr(gm), K._ptr(bt)
+        k.eps, k.cout, k.cfg_fwd, k.cfg_bwd = float(epss[b]), cout, tiles[0], tiles[1]
+        k.y4, k.out, k.stats = y4.data_ptr(), out.data_ptr(), K._ptr(stats)
+        keepalive += [pa, pb, bc, gm, bt]
+        live += [y4, out, stats, keep]       # (until the call below has issued the launches that write / read them)
+        # the tape entries of the per-op forward bodies (_Conv2dS2Fn.forward / _CropDropNormFn.forward)
+        c1 = _OpCtx((x_need, nw[0], nw[1], False))
+        c1.dims, c1.slope, c1.pb, c1.has_bias = (N, c_, h_, w_, cout), slope, pb, bias is not None
+        c1.offsets = (-(wo + 1) - 1, -(wo + 1), -1, 0)
+        c1.bias_ref = weakref.ref(bias) if bias is not None else None
+        c1.save_for_backward(xin if nw[0] else None, y4 if slope is not None else None, wc)
+        c2 = _OpCtx((True, False, nw[2], nw[3], False))
+        c2.dims = (N, cout, ho, wo, epss[b], not last)
+        c2.save_for_backward(y4, keep, gamma, stats)
+        tape.append((c1, c2))
+        xin = out.view(1, 4 * cout, -1) if not last else out
+        x_need = True
+        h_, w_, c_ = ho, wo, cout
+    sw, sb = params[4 * nb], params[4 * nb + 1]
+    swf = sw.contiguous().view(-1)
+    sbc = _c(sb)
+    score = torch.empty((N, 1), device=dev, dtype=torch.float32)
+    d.score_w, d.score_b, d.score = swf.data_ptr(), K._ptr(sbc), score.data_ptr()
+    K.critic_tower_forward(d, x4)
+    del live
+    hview = xin.permute(1, 0, 2, 3)
+    c3 = _OpCtx((True, need[2 + 4 * nb], need[3 + 4 * nb]))
+    c3.save_for_backward(hview, swf)
+    c3.wshape, c3.has_bias = sw.shape, sb is not None
+    ctx.tape, ctx.score_ctx, ctx.nb = tape, c3, nb
+    ctx.exec = (d, x4, cfg, params, keepalive, sbc)
+    return score
+
+
+def _tower_exec_backward(ctx, ds):
+    """The tower's backward through the C executor: data-gradient chain on the current stream, weight gradients (reduced in-stream,
+    gathered into `.grad`) on the side stream.  None = a gradient this pass needs cannot go that way (nothing launched): the caller
+    runs the per-op bodies on the same tape."""
+    d, x4, cfg, params, keepalive, sbc = ctx.exec
+    (N, C, H, W), slope, drops, epss = cfg
+    nb = ctx.nb
+    need = ctx.needs_input_grad
+    dev = x4.device
+    sinks, with_bias, any_w = [], False, False
+    for b in range(nb):
+        w, bias, gamma, beta = params[4 * b:4 * b + 4]
+        nw = need[2 + 4 * b:6 + 4 * b]
+        if nw[0]:
+            sw_ = _gbuf(w) if w.is_contiguous() else None
+            sb_ = _gbuf(bias) if (bias is not None and nw[1]) else None
+            if sw_ is None or (bias is not None and nw[1] and sb_ is None):
+                return None
+            sinks.append((sw_, sb_))
+            with_bias = with_bias or sb_ is not None
+            any_w = True
+        elif bias is not None and nw[1]:
+            return None
+        else:
+            sinks.append((None, None))
+        if b > 0 and ctx.tape[b][0].pb is None:
+            return None
+    if need[0] and ctx.tape[0][0].pb is None:
+        return None
+    side = K.WGRAD_STREAM if (any_w and x4.is_cuda) else None
+    ws = None
+    if any_w:
+        n = K.critic_tower_ws_floats(N, C, H, W, [params[4 * b].shape[0] for b in range(nb)], with_bias)
+        if not n:
+            return None
+        dfr = K._DEFERRED
+        if dfr is not None and dfr["descs"]:
+            mine = {t.data_ptr() for pair in sinks for t in pair if t is not None}
+            if mine & dfr["sinks"]:
+                K.flush_deferred_reduces(end=False)        # (a recorded reduce into the same rows: finish it first)
+        ws = K._side_ws(side, dev, 2, n) if side is not None else torch.empty((n,), device=dev, dtype=torch.float32)
+    ds = ds.reshape(-1)
+    bw = L_.SvbCtBackward()
+    bw.ds, bw.ds_stride = ds.data_ptr(), ds.stride(0)
+    c3 = ctx.score_ctx
+    hview, swf = c3.saved_tensors
+    dh = torch.empty_strided(hview.shape, hview.stride(), device=dev, dtype=torch.float32)
+    dsw = torch.empty_like(swf) if need[2 + 4 * nb] else None
+    dsb = torch.empty((1,), device=dev, dtype=torch.float32) if (c3.has_bias and need[3 + 4 * nb]) else None
+    bw.dh, bw.d_score_w, bw.d_score_b = dh.data_ptr(), K._ptr(dsw), K._ptr(dsb)
+    bw.ws, bw.ws_floats = K._ptr(ws), (ws.numel() if ws is not None else 0)
+    h_, w_, c_ = H, W, C
+    held, dgbs, dx0 = [dh, ds, ws], [], None
+    for b in range(nb):
+        w, bias, gamma, beta = params[4 * b:4 * b + 4]
+        cout = w.shape[0]
+        ho, wo = h_ // 2, w_ // 2
+        k = d.blk[b]
+        dy4 = torch.empty((cout, N, ho + 1, wo + 1), device=dev, dtype=torch.float32)
+        dgb = torch.empty((2, N, cout), device=dev, dtype=torch.float32) if gamma is not None else None
+        want_dx = b > 0 or need[0]
+        dx4 = torch.empty((1, 4 * c_, N * (ho + 1) * (wo + 1)), device=dev, dtype=torch.float32) if want_dx else None
+        k.dy4, k.dgb, k.dx4 = dy4.data_ptr(), K._ptr(dgb), K._ptr(dx4)
+        k.d_weight, k.d_bias = K._ptr(sinks[b][0]), K._ptr(sinks[b][1])
+        held += [dy4, dx4]
+        dgbs.append(dgb)
+        if b == 0:
+            dx0 = dx4
+        h_, w_, c_ = ho, wo, cout
+    if side is not None:
+        # tensors the side stream reads: keep the caching allocator from recycling them while it still runs
+        for c1, c2 in ctx.tape:
+            for t in c1.saved_tensors[:2] + (c2.saved_tensors[0],):
+                if t is not None:
+                    t.record_stream(side)
+        for t in held:
+            if t is not None and t.is_cuda:
+                t.record_stream(side)
+    K.critic_tower_backward(d, bw, x4, side)
+    grads = [None] * (4 * nb + 2)
+    grads[4 * nb] = dsw.view(c3.wshape) if dsw is not None else None
+    grads[4 * nb + 1] = dsb
+    for b in range(nb):
+        w, bias, gamma, beta = params[4 * b:4 * b + 4]
+        nw = need[2 + 4 * b:6 + 4 * b]
+        if dgbs[b] is not None and (nw[2] or nw[3]):
+            dg, dbeta = dgbs[b].sum(1).unbind(0)
+            grads[4 * b + 2], grads[4 * b + 3] = (dg if nw[2] else None), (dbeta if nw[3] else None)
+        if sinks[b][0] is not None:
+            _notify(sinks[b], (w, bias), (None, None))
+    return (dx0.view(x4.shape) if (need[0] and dx0 is not None) else None, None) + tuple(grads)
+
+
 class _CriticTowerFn(torch.autograd.Function):
     """One window's tower of the mel critic -- three [Conv2d 3x3 s2 + LeakyReLU -> Dropout2d -> InstanceNorm2d] blocks chained
     through the conv's space-to-depth layout, then the score layer (reference multi_window_disc.py:14-64) -- as ONE autograd
@@ -1608,6 +1806,10 @@ class _CriticTowerFn(torch.autograd.Function):
         (N, C, H, W), slope, drops, epss = cfg
         nb = len(drops)
         need = ctx.needs_input_grad
+        ctx.exec = None
+        y = _tower_exec_forward(ctx, x4, cfg, params, need)
+        if y is not None:
+            return y
         tape = []
         h, planes = x4, (N, C, H, W)
         x_need = need[0]
@@ -1636,6 +1838,11 @@ class _CriticTowerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ds):
         nb = ctx.nb
+        if ctx.exec is not None:
+            r = _tower_exec_backward(ctx, ds)
+            if r is not None:
+                ctx.tape = ctx.score_ctx = ctx.exec = None
+                return r
         grads = [None] * (4 * nb + 2)
         dh, dsw, dsb = _PlaneScoreFn.backward(ctx.score_ctx, ds)
         grads[4 * nb], grads[4 * nb + 1] = dsw, dsb
@@ -1644,7 +1851,7 @@ class _CriticTowerFn(torch.autograd.Function):
             dy4, _, dg, dbeta, _ = _CropDropNormFn.backward(c2, dh)
             dh, dw, dbias, _ = _Conv2dS2Fn.backward(c1, dy4)
             grads[4 * b:4 * b + 4] = [dw, dbias, dg, dbeta]
-        ctx.tape = ctx.score_ctx = None
+        ctx.tape = ctx.score_ctx = ctx.exec = None
         return (dh, None) + tuple(grads)
 
 

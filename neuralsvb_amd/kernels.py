@@ -535,6 +535,47 @@ def wn_stack_backward(desc, bw, x, side):
             "svb_wn_stack_backward")
 
 
+def critic_tower_forward(desc, x4):
+    lib, st = _prep(x4)
+    L.check(lib.svb_critic_tower_forward(C.byref(desc), st), "svb_critic_tower_forward")
+
+
+def critic_tower_backward(desc, bw, x4, side):
+    lib, st = _prep(x4)
+    L.check(lib.svb_critic_tower_backward(C.byref(desc), C.byref(bw), st, side.cuda_stream if side is not None else None),
+            "svb_critic_tower_backward")
+
+
+_CT_WS = {}               # (N, C, H, W, couts, with bias) -> floats of weight-gradient workspace the tower's backward needs
+
+
+def critic_tower_ws_floats(N, Cc, H, W, couts, with_bias):
+    key = (N, Cc, H, W, tuple(couts), bool(with_bias))
+    n = _CT_WS.get(key)
+    if n is None:
+        lib = L.get_lib()
+        n, c, h, w = 0, Cc, H, W
+        for cout in couts:
+            ho, wo = h // 2, w // 2
+            P, Ltot = wo + 1, N * (ho + 1) * (wo + 1)
+            res = 2 * ((cout * 4 * c * 2 + 15) & ~15)
+            worst = 0
+            for pad in (P + 1, 1):
+                ns = C.c_int(0)
+                nfl = lib.svb_conv1d_wgrad_bf16x3_workspace_floats(1, cout, 4 * c, 1, Ltot, 2, 1, pad, 1, C.byref(ns))
+                if not nfl:
+                    worst = None
+                    break
+                worst = max(worst, ((nfl + 15) & ~15) + (((ns.value * cout + 15) & ~15) if with_bias else 0))
+            if worst is None:
+                n = 0
+                break
+            n = max(n, res + worst)
+            c, h, w = cout, ho, wo
+        _CT_WS[key] = n
+    return n
+
+
 WGRAD_BF16X3 = False      # set by functional.set_precision: stride-1 weight gradients on the bf16x3 kernel
 
 

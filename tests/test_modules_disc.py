@@ -91,6 +91,56 @@ def test_fused_tower_node_equals_per_op_nodes(dev):
             assert torch.equal(a, b)
 
 
+def test_tower_executor_equals_python_issue_order(dev):
+    """The tower's C executor (csrc/critic_tower.hip: one ABI call per direction) against the per-op Python bodies on the same
+    tape, bf16x3: scores and input gradients bit for bit; parameter gradients accumulated into existing `.grad` buffers (the
+    executor's weight gradients: partials reduced in-stream, gathered into the 3x3 kernels' buffers) bit for bit as well; with the
+    critic frozen (the generator's pass: data gradients only); and the fall-back when there are no `.grad` buffers to
+    accumulate into (torch.autograd.grad): the executor's forward tape must serve the per-op backward."""
+    from neuralsvb_amd import functional as SF
+    from neuralsvb_amd.modules.mel_disc import Discriminator
+    torch.manual_seed(0)
+    disc = Discriminator(time_lengths=[32, 64], freq_length=80, hidden_size=16, kernel=(3, 3), cond_size=0,
+                         norm_type="in", reduction="stack").to(dev)
+    disc.train()
+    g = torch.Generator().manual_seed(5)
+    xs0 = [torch.randn(2, 90, 80, generator=g).to(dev) for _ in range(2)]
+    starts = [[[5, 5], [11, 11]], [[40, 40], [0, 0]]]
+    SF.set_precision("bf16x3")
+    try:
+        res = {}
+        for mode in ("grad_buffers", "frozen", "autograd_grad"):
+            for p in disc.parameters():
+                p.requires_grad_(mode != "frozen")
+            for ex in (True, False):
+                SF.TOWER_EXECUTOR = ex
+                torch.manual_seed(7)          # the Dropout2d draws
+                xs = [x.clone().requires_grad_(True) for x in xs0]
+                for p in disc.parameters():
+                    p.grad = torch.full_like(p, 0.125) if mode == "grad_buffers" else None
+                outs = disc.forward_many([(x, [list(s) for s in st], None, 90) for x, st in zip(xs, starts)], want_fmaps=False)
+                loss = sum(((o["y"] - 1) ** 2).mean() * (i + 1) for i, o in enumerate(outs))
+                if mode == "autograd_grad":
+                    grads = torch.autograd.grad(loss, xs + list(disc.parameters()))
+                else:
+                    loss.backward()
+                    grads = [x.grad for x in xs] + ([p.grad.clone() for p in disc.parameters()] if mode == "grad_buffers" else [])
+                res[(mode, ex)] = ([o["y"].detach().clone() for o in outs], grads)
+            (ya, ga), (yb, gb) = res[(mode, True)], res[(mode, False)]
+            for a, b in zip(ya, yb):
+                assert torch.equal(a, b), mode
+            assert len(ga) == len(gb)
+            for i, (a, b) in enumerate(zip(ga, gb)):
+                assert torch.equal(a, b), (mode, i, (a - b).abs().max().item())
+            if mode == "grad_buffers":
+                assert any((gr - 0.125).abs().max().item() > 1e-3 for gr in ga[2:])     # the buffers did receive gradients
+    finally:
+        SF.TOWER_EXECUTOR = True
+        SF.set_precision("fp32")
+        for p in disc.parameters():
+            p.grad = None
+
+
 def test_critic_general_shapes_match_stock_torch(dev):
     """Reference-legal critic configurations outside the fast path (multi_window_disc.py:14-65): a number of mel bins whose
     halvings turn odd (60 -> 30 -> 15 -> 8) and a 5x5 kernel.  Both used to raise inside SF.critic_block; they now take the

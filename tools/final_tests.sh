@@ -1,6 +1,6 @@
 #!/bin/bash
-# the round's closing GPU call: full suite with -x, then smoke()      usage: bash tools/final_tests.sh [round tag, default r05]
-R=${1:-r05}
+# the round's closing GPU call: full suite with -x, then smoke()      usage: bash tools/final_tests.sh [round tag, default r06]
+R=${1:-r06}
 O=gpurun_out/${R}_final_tests
 mkdir -p $O
 export TMPDIR=/tmp

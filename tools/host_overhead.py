@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--aten", action="store_true", help="list the torch (ATen) ops a step issues next to the library's kernels, by call site")
     ap.add_argument("--extra-hparams", default="")
     ap.add_argument("--no-stack-executor", action="store_true")
+    ap.add_argument("--no-tower-executor", action="store_true", help="A/B: the critic towers through the per-op Python bodies")
     a = ap.parse_args()
     from neuralsvb_amd import _lib
     _lib._LIB, _lib._LIB_IS_EMU = null_library(), True
@@ -95,6 +96,9 @@ def main():
     if a.no_stack_executor:
         from neuralsvb_amd import functional as SF
         SF.STACK_EXECUTOR = False
+    if a.no_tower_executor:
+        from neuralsvb_amd import functional as SF
+        SF.TOWER_EXECUTOR = False
     import bench
     args = argparse.Namespace(batch=2, seconds=0.71, sample_rate=24000, bf16=False, precision="bf16x3", graph=False)
     extra = ",ds_workers=0" + (("," + a.extra_hparams) if a.extra_hparams else "")
