@@ -100,6 +100,7 @@ class SVBVAEMleTask(BaseTask):
     def build_model(self):
         SF.set_precision(hparams.get("conv_precision", "fp32"))
         SF.STACK_EXECUTOR = bool(hparams.get("wn_stack_executor", True))
+        SF.TOWER_EXECUTOR = bool(hparams.get("tower_executor", True))       # (A/B switch: the critic towers as one C-ABI call per direction)
         SF.S2_REGISTERED = bool(hparams.get("critic_s2_registered", True))
         from ..modules import vc_asr as _va
         _va.FUSE_QKV = bool(hparams.get("ppg_fuse_qkv", True))
