@@ -300,7 +300,8 @@ int svb_relpos_attn_fwd(const float* q, const float* k, const float* v, long qkv
  * bf16 hi + lo (p = hi + lo to fp32 class; constant for a frozen encoder and a given T: prepared once by the host).
  * Each key block computes the 63-column band of (q + pos_v) . p it needs as one MFMA product and skews it through LDS.      */
 int svb_relpos_attn_pos_fwd(const float* q, const float* k, const float* v, long qkv_sb, const float* pos_u, const float* pos_v,
-                            const unsigned short* pt_hi, const unsigned short* pt_lo, const float* keep, float* out, int B, int H,
+                            const unsigned short* pt_hi, const unsigned short* pt_lo, const unsigned short* pt_lo2, const float* keep,
+                            float* out, int B, int H,
                             int dk, int T, float scale, void* stream);
 
 /* ---- Conformer convolution module between its pointwise convs, eval mode (reference
@@ -480,6 +481,13 @@ int svb_embed_nct_bwd(const int64_t* idx, const float* dy, float* part, float* d
  * is that arithmetic, reported as a secondary line only (it is narrower than the reference's fp32).                            */
 void svb_conv_set_single_product(int on);
 int svb_conv_get_single_product(void);
+/* Arithmetic of svb_relpos_attn_fwd / svb_relpos_attn_pos_fwd (ABI v10).  on: operands split three ways into bf16 parts (24 mantissa
+ * bits), six products per operand pair, ~2^-23 per product -- the `conv_precision: fp32` mode, whose reference evaluates this
+ * attention in fp32 (modules/commons/espnet_transformer_attn.py:125-186); the position table then needs its third part (pt_lo2 of
+ * svb_relpos_attn_pos_fwd; NULL: that call runs two-way).  off: hi + lo, three products (2^-16 per product), the bf16x3 / bf16 modes.
+ * Process-wide, like the switch above; default ON (the host side's default precision is fp32).                                  */
+void svb_attn_set_split3(int on);
+int svb_attn_get_split3(void);
 
 /* ---- nearest-neighbour upsampling along time, conv layout (reference modules/voice_conversion/svb_vae.py:39-45:
  * nn.Upsample(scale_factor=s, mode='nearest') of the content features; ABI v8).  adjoint == 0: x [rows][T] -> y [rows][T*scale],

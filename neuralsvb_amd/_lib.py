@@ -123,7 +123,7 @@ SIGNATURES = {
     "svb_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, F, P]),
     "svb_relpos_softmax": (I, [P, P, P, P, I, I, I, F, P]),
     "svb_relpos_attn_fwd": (I, [P, P, P, C.c_long, P, P, C.c_long, C.c_long, C.c_long, P, P, I, I, I, I, F, P]),
-    "svb_relpos_attn_pos_fwd": (I, [P, P, P, C.c_long, P, P, P, P, P, P, I, I, I, I, F, P]),
+    "svb_relpos_attn_pos_fwd": (I, [P, P, P, C.c_long, P, P, P, P, P, P, P, I, I, I, I, F, P]),
     "svb_glu_dwconv_bn_swish": (I, [P, P, P, P, P, P, P, F, P, I, I, I, I, P]),
     "svb_layernorm_nct_fwd": (I, [P, P, P, P, I, I, I, F, P]),
     "svb_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
@@ -164,6 +164,8 @@ SIGNATURES = {
     "svb_period_weight": (I, [P, P, I, I, I, I, I, I, I, I, P]),
     "svb_upsample_nearest_nct": (I, [P, P, C.c_long, I, I, I, P]),
     "svb_conv_set_single_product": (None, [I]),
+    "svb_attn_set_split3": (None, [I]),
+    "svb_attn_get_split3": (I, []),
     "svb_conv_get_single_product": (I, []),
 }
 

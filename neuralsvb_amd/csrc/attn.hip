@@ -166,6 +166,49 @@ __device__ __forceinline__ void svba_split8(const float* v, svba_bf16x8& hi, svb
     __builtin_memcpy(&lo, l, 16);
 }
 
+// three-way split v = p0 + p1 + p2 (each bf16, 24 mantissa bits together): the exact-parity mode's operands
+__device__ __forceinline__ void svba_split8x3(const float* v, svba_bf16x8& p0, svba_bf16x8& p1, svba_bf16x8& p2) {
+    unsigned a[4], b[4], c[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const svbq_f2 x = {v[2 * e], v[2 * e + 1]};
+        const svbq_bf2 h = __builtin_convertvector(x, svbq_bf2);
+        const svbq_f2 r1 = x - __builtin_convertvector(h, svbq_f2);
+        const svbq_bf2 m = __builtin_convertvector(r1, svbq_bf2);
+        const svbq_f2 r2 = r1 - __builtin_convertvector(m, svbq_f2);
+        const svbq_bf2 l = __builtin_convertvector(r2, svbq_bf2);
+        __builtin_memcpy(&a[e], &h, 4);
+        __builtin_memcpy(&b[e], &m, 4);
+        __builtin_memcpy(&c[e], &l, 4);
+    }
+    __builtin_memcpy(&p0, a, 16);
+    __builtin_memcpy(&p1, b, 16);
+    __builtin_memcpy(&p2, c, 16);
+}
+template <int NS>
+__device__ __forceinline__ void svba_split(const float* v, svba_bf16x8 (&p)[NS]) {
+    if constexpr (NS == 3) svba_split8x3(v, p[0], p[1], p[2]);
+    else svba_split8(v, p[0], p[1]);
+}
+// acc += A . B over the parts: NS = 2: lo*hi + hi*lo + hi*hi (+ lo*lo first with LL); NS = 3: the six products down to 2^-16 of the
+// largest (p2*q0 + p0*q2 + p1*q1 + p1*q0 + p0*q1 + p0*q0), smallest first
+template <int NS, bool LL>
+__device__ __forceinline__ void svba_mma(f32x16& acc, const svba_bf16x8 (&a)[NS], const svba_bf16x8 (&b)[NS]) {
+    if constexpr (NS == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    } else {
+        if (LL) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    }
+}
+
 #define SVB_ATTN_DK 64
 #define SVB_ATTN_SKEW_P 34      // row pitch (floats) of the skew buffer: lane il reads row jl + 31 - il -> word stride 33, conflict-free
 
@@ -178,17 +221,22 @@ __device__ __forceinline__ void svba_split8(const float* v, svba_bf16x8& hi, svb
 // row jl + 31 - il: the accumulators go through a per-wave LDS buffer once (written [cl][il], read skewed, conflict-free with a
 // pitch of 34 floats).  The second form uses the frags of the queries i + 1.  +24 MFMAs per block against 36, and neither the
 // 4 B per score element of HBM traffic nor the rocBLAS GEMM that wrote them.
-template <bool POS>
-__global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float* q, const float* k, const float* v, const float* pos_u,
+// NS (round 6): parts of the operand split.  2 = hi + lo, three products per pair (bf16x3: 2^-16 per product); 3 = the exact-parity
+// mode (`conv_precision: fp32`, whose reference evaluates this attention in fp32: svb_attn_set_split3): three bf16 parts, six products,
+// ~2^-23 per product -- the q fragments then take 1.5x the LDS, so a workgroup is ONE wave.
+template <bool POS, int NS>
+__global__ __launch_bounds__(NS == 3 ? 64 : 128, 2) void svb_relpos_attn_fwd_kernel(const float* q, const float* k, const float* v, const float* pos_u,
                                                                   const float* bd, long bd_sb, long bd_sh, long bd_sr,
                                                                   const float* keep, float* out, int B, int H, int T,
                                                                   float scale, long qkv_sb, const float* pos_v,
-                                                                  const unsigned short* pt_hi, const unsigned short* pt_lo) {
+                                                                  const unsigned short* pt_hi, const unsigned short* pt_lo,
+                                                                  const unsigned short* pt_lo2) {
+    constexpr int NW = NS == 3 ? 1 : 2;              // waves per workgroup
     constexpr int DK = SVB_ATTN_DK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kb = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, hh = bh - b * H;
-    const int i0 = (blockIdx.x * 2 + wave) * 32;
+    const int i0 = (blockIdx.x * NW + wave) * 32;
     if (i0 >= T) return;                                            // (waves are independent: no barrier below)
     const int i = i0 + l31;
     const bool iv = i < T;
@@ -204,7 +252,7 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
     // ---- B operand of the score product: Qu[i][d], d = 16s + 8kb + e.  The 8 fragments are this lane's alone; they live in a
     // private LDS slot (conflict-free 16-byte rows, no barrier) rather than in 32 registers: the kernel is bound by memory
     // latency, i.e. by how many waves fit on a SIMD.
-    __shared__ uint4 q_frag[2][8][64];
+    __shared__ uint4 q_frag[NW][4 * NS][64];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         float t[8];
@@ -213,14 +261,14 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
             const int d = 16 * s + 8 * kb + e;
             t[e] = qh[(size_t)d * T + ic] + pos_u[hh * DK + d];
         }
-        svba_bf16x8 fh, fl;
-        svba_split8(t, fh, fl);
-        __builtin_memcpy(&q_frag[wave][2 * s][lane], &fh, 16);
-        __builtin_memcpy(&q_frag[wave][2 * s + 1][lane], &fl, 16);
+        svba_bf16x8 f[NS];
+        svba_split<NS>(t, f);
+#pragma unroll
+        for (int u = 0; u < NS; ++u) __builtin_memcpy(&q_frag[wave][NS * s + u][lane], &f[u], 16);
     }
     // POS: Qv[i][d] = q[i][d] + pos_v[d] of this lane's query and of the next one (the j > i + 1 form reads row i + 1 of bd)
-    __shared__ uint4 qv_frag[POS ? 2 : 1][POS ? 2 : 1][POS ? 8 : 1][POS ? 64 : 1];       // [wave][query i / i+1][fragment][lane]
-    __shared__ float m_skew[POS ? 2 : 1][POS ? 64 * SVB_ATTN_SKEW_P : 1];
+    __shared__ uint4 qv_frag[POS ? NW : 1][POS ? 2 : 1][POS ? 4 * NS : 1][POS ? 64 : 1];       // [wave][query i / i+1][fragment][lane]
+    __shared__ float m_skew[POS ? NW : 1][POS ? 64 * SVB_ATTN_SKEW_P : 1];
     if (POS) {
         const int i1 = i + 1 < T ? i + 1 : T - 1;
 #pragma unroll
@@ -233,10 +281,10 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
                     const int d = 16 * s + 8 * kb + e;
                     t[e] = qh[(size_t)d * T + (w1 ? i1 : ic)] + pos_v[hh * DK + d];
                 }
-                svba_bf16x8 fh, fl;
-                svba_split8(t, fh, fl);
-                __builtin_memcpy(&qv_frag[POS ? wave : 0][POS ? w1 : 0][POS ? 2 * s : 0][POS ? lane : 0], &fh, 16);
-                __builtin_memcpy(&qv_frag[POS ? wave : 0][POS ? w1 : 0][POS ? 2 * s + 1 : 0][POS ? lane : 0], &fl, 16);
+                svba_bf16x8 f[NS];
+                svba_split<NS>(t, f);
+#pragma unroll
+                for (int u = 0; u < NS; ++u) __builtin_memcpy(&qv_frag[POS ? wave : 0][POS ? w1 : 0][POS ? NS * s + u : 0][POS ? lane : 0], &f[u], 16);
             }
     }
     // the band product + skew (see the header of the kernel): sh[r] = position score of key j0 + 8*(r>>2) + 4*kb + (r&3) for this
@@ -251,22 +299,19 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
             for (int r = 0; r < 16; ++r) m[r] = 0.f;
             int rc = cb + 32 * tt + l31;
             rc = rc < 0 ? 0 : (rc > T - 1 ? T - 1 : rc);                 // (columns outside [0, T) are never selected below)
-            const unsigned short* ph = pt_hi + ((size_t)hh * T + rc) * DK + 8 * kb;
-            const unsigned short* pl = pt_lo + ((size_t)hh * T + rc) * DK + 8 * kb;
+            const size_t prow = ((size_t)hh * T + rc) * DK + 8 * kb;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                svba_bf16x8 ah, al, qh8, ql8;
-                __builtin_memcpy(&ah, ph + 16 * s, 16);
-                __builtin_memcpy(&al, pl + 16 * s, 16);
-                __builtin_memcpy(&qh8, &qv_frag[POS ? wave : 0][POS ? which : 0][POS ? 2 * s : 0][POS ? lane : 0], 16);
-                __builtin_memcpy(&ql8, &qv_frag[POS ? wave : 0][POS ? which : 0][POS ? 2 * s + 1 : 0][POS ? lane : 0], 16);
-                // four products, not three: the position scores used to come from an fp32 GEMM, and the exact-parity mode's
+                svba_bf16x8 a[NS], qv[NS];
+                __builtin_memcpy(&a[0], pt_hi + prow + 16 * s, 16);
+                __builtin_memcpy(&a[1], pt_lo + prow + 16 * s, 16);
+                if constexpr (NS == 3) __builtin_memcpy(&a[2], pt_lo2 + prow + 16 * s, 16);
+#pragma unroll
+                for (int u = 0; u < NS; ++u) __builtin_memcpy(&qv[u], &qv_frag[POS ? wave : 0][POS ? which : 0][POS ? NS * s + u : 0][POS ? lane : 0], 16);
+                // NS = 2: four products, not three: the position scores used to come from an fp32 GEMM, and the exact-parity mode's
                 // gradient check at the bench shape (1e-4 on norms) sees a three-term band (2^-16 per product) as 1.6e-4 on the
                 // first layer behind the encoder
-                m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ql8, m, 0, 0, 0);
-                m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh8, m, 0, 0, 0);
-                m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql8, m, 0, 0, 0);
-                m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh8, m, 0, 0, 0);
+                svba_mma<NS, true>(m, a, qv);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -307,13 +352,11 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
             float t[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) t[e] = kh[(size_t)(16 * s + 8 * kb + e) * T + jr];
-            svba_bf16x8 ah, al, quh, qul;
-            svba_split8(t, ah, al);
-            __builtin_memcpy(&quh, &q_frag[wave][2 * s][lane], 16);
-            __builtin_memcpy(&qul, &q_frag[wave][2 * s + 1][lane], 16);
-            s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, quh, s_acc, 0, 0, 0);
-            s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qul, s_acc, 0, 0, 0);
-            s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, quh, s_acc, 0, 0, 0);
+            svba_bf16x8 a[NS], qu[NS];
+            svba_split<NS>(t, a);
+#pragma unroll
+            for (int u = 0; u < NS; ++u) __builtin_memcpy(&qu[u], &q_frag[wave][NS * s + u][lane], 16);
+            svba_mma<NS, false>(s_acc, a, qu);
         }
         // ---- + shifted position scores, scale, key mask; block maximum per query
         float p[16];
@@ -394,8 +437,8 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
         // ---- O^T += V . P^T
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            svba_bf16x8 ph, pl;
-            svba_split8(p + 8 * s2, ph, pl);
+            svba_bf16x8 pp[NS];
+            svba_split<NS>(p + 8 * s2, pp);
             const int ja = j0 + 16 * s2 + 4 * kb;                   // slots 0-3: ja .. ja+3, slots 4-7: ja+8 .. ja+11
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
@@ -413,11 +456,9 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
                         t[e] = j < T ? vr[j] : 0.f;
                     }
                 }
-                svba_bf16x8 ah, al;
-                svba_split8(t, ah, al);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ph, o[db], 0, 0, 0);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, pl, o[db], 0, 0, 0);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ph, o[db], 0, 0, 0);
+                svba_bf16x8 a[NS];
+                svba_split<NS>(t, a);
+                svba_mma<NS, false>(o[db], a, pp);
             }
         }
     };
@@ -445,27 +486,49 @@ __global__ __launch_bounds__(128, 2) void svb_relpos_attn_fwd_kernel(const float
     }
 }
 
+// process-wide arithmetic mode of the attention products (see NS above); the host side sets it with `conv_precision`
+static int g_svb_attn_split3 = 1;      // (default = the host side's default precision, fp32)
+extern "C" void svb_attn_set_split3(int on) { g_svb_attn_split3 = on ? 1 : 0; }
+extern "C" int svb_attn_get_split3(void) { return g_svb_attn_split3; }
+
+template <bool POS, int NS>
+static void attn_launch(const float* q, const float* k, const float* v, const float* pos_u, const float* bd, long bd_sb, long bd_sh,
+                        long bd_sr, const float* keep, float* out, int B, int H, int T, float scale, long qkv_sb, const float* pos_v,
+                        const unsigned short* pt_hi, const unsigned short* pt_lo, const unsigned short* pt_lo2, void* stream) {
+    constexpr int NW = NS == 3 ? 1 : 2;
+    hipLaunchKernelGGL((svb_relpos_attn_fwd_kernel<POS, NS>), dim3((T + 32 * NW - 1) / (32 * NW), B * H), dim3(64 * NW), 0,
+                       (hipStream_t)stream, q, k, v, pos_u, bd, bd_sb, bd_sh, bd_sr, keep, out, B, H, T, scale, qkv_sb, pos_v, pt_hi, pt_lo,
+                       pt_lo2);
+}
+
 extern "C" int svb_relpos_attn_fwd(const float* q, const float* k, const float* v, long qkv_sb, const float* pos_u, const float* bd,
                                    long bd_sb, long bd_sh, long bd_sr, const float* keep, float* out, int B, int H, int dk, int T,
                                    float scale, void* stream) {
     if (!q || !k || !v || !pos_u || !bd || !keep || !out || B <= 0 || H <= 0 || T <= 0) return SVB_ERR_ARG;
     if (dk != SVB_ATTN_DK || (long)B * H > 65535) return SVB_ERR_UNSUPPORTED;
     if (qkv_sb < (long)H * dk * T) return SVB_ERR_ARG;
-    hipLaunchKernelGGL(svb_relpos_attn_fwd_kernel<false>, dim3((T + 63) / 64, B * H), dim3(128), 0, (hipStream_t)stream, q, k, v, pos_u,
-                       bd, bd_sb, bd_sh, bd_sr, keep, out, B, H, T, scale, qkv_sb, (const float*)nullptr,
-                       (const unsigned short*)nullptr, (const unsigned short*)nullptr);
+    if (g_svb_attn_split3)
+        attn_launch<false, 3>(q, k, v, pos_u, bd, bd_sb, bd_sh, bd_sr, keep, out, B, H, T, scale, qkv_sb, nullptr, nullptr, nullptr, nullptr,
+                              stream);
+    else
+        attn_launch<false, 2>(q, k, v, pos_u, bd, bd_sb, bd_sh, bd_sr, keep, out, B, H, T, scale, qkv_sb, nullptr, nullptr, nullptr, nullptr,
+                              stream);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
 
 extern "C" int svb_relpos_attn_pos_fwd(const float* q, const float* k, const float* v, long qkv_sb, const float* pos_u,
                                        const float* pos_v, const unsigned short* pt_hi, const unsigned short* pt_lo,
-                                       const float* keep, float* out, int B, int H, int dk, int T, float scale, void* stream) {
+                                       const unsigned short* pt_lo2, const float* keep, float* out, int B, int H, int dk, int T,
+                                       float scale, void* stream) {
     if (!q || !k || !v || !pos_u || !pos_v || !pt_hi || !pt_lo || !keep || !out || B <= 0 || H <= 0 || T <= 0) return SVB_ERR_ARG;
     if (dk != SVB_ATTN_DK || (long)B * H > 65535) return SVB_ERR_UNSUPPORTED;
     if (qkv_sb < (long)H * dk * T) return SVB_ERR_ARG;
-    hipLaunchKernelGGL(svb_relpos_attn_fwd_kernel<true>, dim3((T + 63) / 64, B * H), dim3(128), 0, (hipStream_t)stream, q, k, v, pos_u,
-                       (const float*)nullptr, 0L, 0L, 0L, keep, out, B, H, T, scale, qkv_sb, pos_v, pt_hi, pt_lo);
+    // (the three-way form needs the table's third part; a two-part table runs the two-way kernel whatever the mode)
+    if (g_svb_attn_split3 && pt_lo2)
+        attn_launch<true, 3>(q, k, v, pos_u, nullptr, 0L, 0L, 0L, keep, out, B, H, T, scale, qkv_sb, pos_v, pt_hi, pt_lo, pt_lo2, stream);
+    else
+        attn_launch<true, 2>(q, k, v, pos_u, nullptr, 0L, 0L, 0L, keep, out, B, H, T, scale, qkv_sb, pos_v, pt_hi, pt_lo, nullptr, stream);
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }

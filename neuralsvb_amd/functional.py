@@ -41,6 +41,12 @@ def set_precision(mode):
         from . import _lib as _L
         (_L._LIB if _L._LIB is not None else _L.get_lib()).svb_conv_set_single_product(int(single))
     SINGLE_PRODUCT = single
+    # the PPG encoder's attention: three-way operand split (six products, fp32-class) in the exact-parity mode -- the library's
+    # default --, hi + lo with three products otherwise
+    from . import _lib as _L4
+    lib4 = _L4._LIB if _L4._LIB is not None else _L4.get_lib()
+    if bool(lib4.svb_attn_get_split3()) != (mode == "fp32"):
+        lib4.svb_attn_set_split3(int(mode == "fp32"))
     PRECISION = "bf16x3" if single else mode
     K.WGRAD_BF16X3 = PRECISION == "bf16x3"
 

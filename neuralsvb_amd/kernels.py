@@ -976,13 +976,16 @@ def relpos_attention(q, k, v, pos_u, bd, keep, scale, n_head):
 
 
 def relpos_pos_table(p, n_head):
-    """p = linear_pos(pos_emb) [1, H*dk, T] -> (pt_hi, pt_lo) int16 [H, T, dk]: transposed, split into bf16 hi + lo (the operand
-    layout of relpos_attention_pos; computed once per length for a frozen encoder)."""
+    """p = linear_pos(pos_emb) [1, H*dk, T] -> (pt_hi, pt_lo): transposed [H, T, dk] and split into bf16 parts (the operand layout of
+    relpos_attention_pos; computed once per length for a frozen encoder).  pt_hi int16 [H, T, dk]; pt_lo int16 [2, H, T, dk]: the
+    second and the third part of the three-way split (the two-way kernel reads pt_lo[0] only)."""
     D, T = p.shape[-2], p.shape[-1]
     pt = p.reshape(n_head, D // n_head, T).transpose(1, 2).contiguous().float()
     hi = pt.to(torch.bfloat16)
-    lo = (pt - hi.float()).to(torch.bfloat16)
-    return hi.view(torch.int16).contiguous(), lo.view(torch.int16).contiguous()
+    r1 = pt - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    return hi.view(torch.int16).contiguous(), torch.stack([mid, lo]).view(torch.int16).contiguous()
 
 
 def relpos_attention_pos(q, k, v, pos_u, pos_v, pt_hi, pt_lo, keep, scale, n_head):
@@ -996,11 +999,14 @@ def relpos_attention_pos(q, k, v, pos_u, pos_v, pt_hi, pt_lo, keep, scale, n_hea
     for t in (q, k, v):
         if tuple(t.shape) != (B, D, T) or t.stride(2) != 1 or t.stride(1) != T or t.stride(0) != sb or t.device != q.device:
             raise ValueError("q, k, v must be [B, D, T] with contiguous [D, T] blocks and one common batch pitch")
-    if tuple(pt_hi.shape) != (n_head, T, dk) or tuple(pt_lo.shape) != (n_head, T, dk) or pt_hi.dtype != torch.int16:
-        raise ValueError("pt_hi / pt_lo must be int16 [H, T, dk] (relpos_pos_table)")
+    three = tuple(pt_lo.shape) == (2, n_head, T, dk)
+    if (tuple(pt_hi.shape) != (n_head, T, dk) or not (three or tuple(pt_lo.shape) == (n_head, T, dk)) or pt_hi.dtype != torch.int16
+            or not pt_lo.is_contiguous()):
+        raise ValueError("pt_hi / pt_lo must be int16 [H, T, dk] / [2, H, T, dk] (relpos_pos_table)")
     out = torch.empty((B, D, T), device=q.device, dtype=torch.float32)
-    L.check(lib.svb_relpos_attn_pos_fwd(_ptr(q), _ptr(k), _ptr(v), sb, _ptr(pos_u), _ptr(pos_v), _ptr(pt_hi), _ptr(pt_lo), _ptr(keep),
-                                        _ptr(out), B, n_head, dk, T, float(scale), st), "svb_relpos_attn_pos_fwd")
+    lo2 = pt_lo.data_ptr() + 2 * n_head * T * dk if three else None
+    L.check(lib.svb_relpos_attn_pos_fwd(_ptr(q), _ptr(k), _ptr(v), sb, _ptr(pos_u), _ptr(pos_v), _ptr(pt_hi), _ptr(pt_lo), lo2,
+                                        _ptr(keep), _ptr(out), B, n_head, dk, T, float(scale), st), "svb_relpos_attn_pos_fwd")
     return out
 
 

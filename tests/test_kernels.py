@@ -894,6 +894,53 @@ def test_relpos_attention_fused_matches_espnet(dev, T):
     assert rel_err(out2, ref) < 5e-5
 
 
+def test_relpos_attention_three_way_split_in_the_fp32_mode(dev):
+    """`conv_precision: fp32` evaluates the PPG encoder's attention with a THREE-way bf16 operand split (24 mantissa bits, six
+    products per pair; svb_attn_set_split3, set by SF.set_precision; the position table carries its third part): against an fp64
+    evaluation of the reference's op sequence it must be fp32-class -- within 4x the error of the reference's own fp32 op sequence (stock torch) and at
+    least 8x closer than the hi + lo / three-product form of bf16x3 -- for both entry points (position scores handed over / computed in the kernel)."""
+    from neuralsvb_amd import functional as SF
+    g = torch.Generator().manual_seed(31)
+    B, H, dk, T = 2, 2, 64, 130
+    q, k, v = (torch.randn(B, H, dk, T, generator=g) for _ in range(3))
+    pu, pv = torch.randn(H, dk, generator=g) * 0.5, torch.randn(H, dk, generator=g) * 0.5
+    pe = torch.randn(1, H, dk, T, generator=g)
+    keep = torch.ones(B, T)
+    keep[1, T - 9:] = 0
+    qd, kd, vd, ped = q.double(), k.double(), v.double(), pe.double()
+    ac = torch.matmul((qd + pu.double()[None, :, :, None]).transpose(-1, -2), kd)
+    bd = torch.matmul((qd + pv.double()[None, :, :, None]).transpose(-1, -2), ped)
+    x = F.pad(bd, (1, 0)).view(B, H, T + 1, T)[:, :, 1:].reshape(B, H, T, T)
+    drop = ~(keep.bool())[:, None, None, :]
+    attn = torch.softmax(((ac + x) / dk ** 0.5).masked_fill(drop, -1e300), -1).masked_fill(drop, 0.0)
+    ref = torch.matmul(vd, attn.transpose(-1, -2)).reshape(B, H * dk, T)
+    D = H * dk
+    qkv = torch.cat([q.reshape(B, D, T), k.reshape(B, D, T), v.reshape(B, D, T)], 1).to(dev)
+    pt_hi, pt_lo = K.relpos_pos_table(pe.reshape(1, D, T).to(dev), H)
+    err = {}
+    try:
+        for mode in ("bf16x3", "fp32"):
+            SF.set_precision(mode)
+            out = K.relpos_attention_pos(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], pu.to(dev), pv.to(dev), pt_hi, pt_lo,
+                                         keep.to(dev), 1.0 / dk ** 0.5, H)
+            err[mode] = ((out.cpu().double() - ref).abs().mean() / ref.abs().mean()).item()
+            out = K.relpos_attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], pu.to(dev), bd.float().to(dev), keep.to(dev),
+                                     1.0 / dk ** 0.5, H)
+            err[mode + "/bd"] = ((out.cpu().double() - ref).abs().mean() / ref.abs().mean()).item()
+    finally:
+        SF.set_precision("fp32")
+    # the yardstick: the reference's own op sequence in fp32 (stock torch) against the same fp64 evaluation
+    ac32 = torch.matmul((q + pu[None, :, :, None]).transpose(-1, -2), k)
+    bd32 = torch.matmul((q + pv[None, :, :, None]).transpose(-1, -2), pe)
+    x32 = F.pad(bd32, (1, 0)).view(B, H, T + 1, T)[:, :, 1:].reshape(B, H, T, T)
+    a32 = torch.softmax(((ac32 + x32) / dk ** 0.5).masked_fill(drop, torch.finfo(torch.float32).min), -1).masked_fill(drop, 0.0)
+    e32 = ((torch.matmul(v, a32.transpose(-1, -2)).reshape(B, D, T).double() - ref).abs().mean() / ref.abs().mean()).item()
+    err["torch fp32"] = e32
+    assert err["fp32"] < 4 * e32 and err["fp32"] * 8 < err["bf16x3"], err
+    assert err["fp32/bd"] < 4 * e32 and err["fp32/bd"] * 8 < err["bf16x3/bd"], err
+    print(err)
+
+
 @pytest.mark.parametrize("T", [37, 130])
 def test_relpos_softmax_matches_espnet_rel_shift(dev, T):
     """svb_relpos_softmax against the reference's op sequence (espnet_transformer_attn.py:125-186): legacy rel_shift via
