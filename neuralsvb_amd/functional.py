@@ -1605,18 +1605,20 @@ TOWER_EXECUTOR = True        # ... and its launches issued by ONE C-ABI call per
 _TOWER_CFG = {}              # (N, C, H, W, cout) -> (tile of the forward conv, tile of the data-gradient conv)
 
 
-def _tower_tiles(N, C, H, W, cout, on_gpu):
+def _tower_tiles(N, C, H, W, cout, on_gpu, want_bwd):
     key = (N, C, H, W, cout)
     t = _TOWER_CFG.get(key)
     if t is None:
-        P = W // 2 + 1
-        L = N * (H // 2 + 1) * P
-        f = K.tuned_choice(("taps", True, 1, 4 * C, cout, L, L, (-P - 1, -P, -1, 0)), on_gpu)
-        b = K.tuned_choice(("taps", True, 1, cout, 4 * C, L, L, (P + 1, P, 1, 0)), on_gpu)
-        if f is None or b is None:
-            return None                      # (the offline tuner is measuring: the per-op path launches every signature once)
-        t = _TOWER_CFG[key] = (f, b)
-    return t
+        t = _TOWER_CFG[key] = [None, None]
+    P = W // 2 + 1
+    L = N * (H // 2 + 1) * P
+    if t[0] is None:
+        t[0] = K.tuned_choice(("taps", True, 1, 4 * C, cout, L, L, (-P - 1, -P, -1, 0)), on_gpu)
+    if want_bwd and t[1] is None:     # (asked for only where the data gradient runs: an unused signature would count as a table miss)
+        t[1] = K.tuned_choice(("taps", True, 1, cout, 4 * C, L, L, (P + 1, P, 1, 0)), on_gpu)
+    if t[0] is None or (want_bwd and t[1] is None):
+        return None                          # (the offline tuner is measuring: the per-op path launches every signature once)
+    return t[0], (t[1] if want_bwd else 0)
 
 
 def _tower_exec_forward(ctx, x4, cfg, params, need):
@@ -1649,7 +1651,7 @@ def _tower_exec_forward(ctx, x4, cfg, params, need):
         cout = w.shape[0]
         ho, wo = h_ // 2, w_ // 2
         last = b + 1 == nb
-        tiles = _tower_tiles(N, c_, h_, w_, cout, on_gpu)
+        tiles = _tower_tiles(N, c_, h_, w_, cout, on_gpu, bool(x_need))
         if tiles is None:
             return None
         wc = w.contiguous()

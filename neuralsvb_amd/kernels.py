@@ -111,7 +111,8 @@ def load_tile_table(path=TILE_TABLE_PATH):
 def tile_table_info():
     """For bench.py's JSON line: which table this process ran with, and what it had to resolve itself."""
     return dict(_TABLE_INFO, online_tuned_signatures=len(_TUNED_ONLINE), nearest_bucket_signatures=len(_TUNED_NEAREST),
-                online_tuned=[{"sig": list(map(str, k)), "cfg": v} for k, v in list(_TUNED_ONLINE.items())[:24]])
+                online_tuned=[{"sig": list(map(str, k)), "cfg": v} for k, v in list(_TUNED_ONLINE.items())[:24]],
+                nearest_bucket=[{"sig": list(map(str, k)), "cfg": v[0]} for k, v in list(_TUNED_NEAREST.items())[:8]])
 
 
 def _nearest_choice(sig):
