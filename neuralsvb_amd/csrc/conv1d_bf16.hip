@@ -904,10 +904,6 @@ extern "C" int svb_conv1d_taps_bf16x3(const float* x, const unsigned short* q_hi
         if (tap_off[j] > mx) mx = tap_off[j];
     }
     p.phase_nq[0] = Tout; p.phase_out_base[0] = 0; p.phase_min_off[0] = mn; p.phase_span_off[0] = mx - mn;
-    if (!g_svbq_single && (Cin == 4 || Cout == 4)) {       // the mel critic's first block: streaming kernels (critic_c4.hip)
-        if (svb_c4_fwd_launch(a, p, (hipStream_t)stream) == SVB_OK) return SVB_OK;
-        if (svb_c4_bwd_launch(a, p, (hipStream_t)stream) == SVB_OK) return SVB_OK;
-    }
     return q_dispatch(a, p, (hipStream_t)stream);
 }
 
@@ -1605,11 +1601,6 @@ extern "C" size_t svb_conv1d_wgrad_bf16x3_workspace_floats(int B, int CA, int CB
     const int n_tg = wgq_groups(k, sx, pad, dil, &tgw, nullptr, nullptr, nullptr, nullptr);
     if (n_tg <= 0) return 0;
     const long slab = (long)CA * (CB / groups) * k;
-    if (svb_c4_wgrad_applies(B, CA, CB, groups, k, sx, dil)) {          // critic_c4.hip: its own split count
-        const int ns4 = svb_c4_wgrad_nsplit(TA);
-        if (nsplit_out) *nsplit_out = ns4;
-        return (size_t)ns4 * slab;
-    }
     if (wgq_g16_njt(groups, CA / groups, CB / groups, k, sx, dil)) {       // grouped 16-row kernel: one workgroup per 16 output channels
         const long tiles16 = ((long)CA / 16) * (CB / groups > 16 ? 2 : 1);
         const long chunks16 = (long)B * svb_cdiv(TA, 64);
@@ -1689,8 +1680,6 @@ extern "C" int svb_conv1d_wgrad_bf16x3(const float* a_t, const float* b_t, float
     if (!a_t || !b_t || !part || B <= 0 || groups <= 0 || CA % groups || CB % groups || k <= 0 || k > SVB_MAX_TAPS ||
         dil <= 0 || nsplit <= 0 || sx <= 0)
         return SVB_ERR_ARG;
-    if (svb_c4_wgrad_applies(B, CA, CB, groups, k, sx, dil) && !b_gate && TA == TB && nsplit <= TA)
-        return svb_c4_wgrad_launch(a_t, b_t, part, CA, TA, pad, a_gate, a_slope, nsplit, bias_part, (hipStream_t)stream);
     if (const int njt = wgq_g16_njt(groups, CA / groups, CB / groups, k, sx, dil)) {
         SvbWgradG16Args q;
         q.a = a_t; q.b = b_t; q.part = part; q.bias_part = bias_part; q.a_gate = a_gate; q.b_gate = b_gate;

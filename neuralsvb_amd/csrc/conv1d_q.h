@@ -70,12 +70,3 @@ struct SvbWgradQArgs {
 int svb_wgrad_pw_launch(const SvbWgradQArgs& a, hipStream_t stream);
 // its domain test and wave tile (at x bt accumulator tiles per wave, workgroup tile 64 at x 64 bt) -- also sizes the split count
 bool svb_wgrad_pw_plan(int CA, int CB, int groups, int k, int sx, int pad, int dil, int TA, int* at, int* bt);
-
-// critic_c4.hip: the mel critic's first block (4 input planes) as streaming kernels: forward (Cin == 4), data gradient (Cout == 4),
-// weight gradient (CB == 4, two taps).  The launchers return SVB_ERR_UNSUPPORTED outside their shapes.
-int svb_c4_fwd_launch(const SvbConvQArgs& a, const SvbConvPlan& p, hipStream_t stream);
-int svb_c4_bwd_launch(const SvbConvQArgs& a, const SvbConvPlan& p, hipStream_t stream);
-bool svb_c4_wgrad_applies(int B, int CA, int CB, int groups, int k, int sx, int dil);
-int svb_c4_wgrad_nsplit(int L);
-int svb_c4_wgrad_launch(const float* a_t, const float* b_t, float* part, int CA, int L, int pad, const float* a_gate, float a_slope,
-                        int nsplit, float* bias_part, hipStream_t stream);

@@ -759,42 +759,6 @@ def test_conv1d_bf16x3_gemm_kernel_with_taps_and_input_gates(dev, cfg, shape):
         assert rel_err(dx, dref) < 6e-5
 
 
-@pytest.mark.parametrize("L,P", [(700, 11), (2600, 41), (97, 5)])
-def test_critic_first_block_streaming_kernels(dev, L, P):
-    """The mel critic's first block in its space-to-depth form (csrc/critic_c4.hip): 4 planes -> 72 / 128 channels over L positions
-    with the 2x2 kernel's offsets (-P-1, -P, -1, 0), bias + LeakyReLU (forward, Cin == 4); its data gradient with the activation
-    gate (Cout == 4); its weight gradient as two 2-tap gradients with the gate and the bias partials (CB == 4) -- positions near
-    both ends read zeros, L not a multiple of the 256-position workgroup.  Against fp64 evaluations."""
-    g = torch.Generator().manual_seed(L + P)
-    offs = (-P - 1, -P, -1, 0)
-    for cout in (72, 128):
-        x = torch.randn(1, 4, L, generator=g)
-        w = torch.randn(cout, 4, 4, generator=g) * 0.3
-        bias = torch.randn(cout, generator=g)
-        qa, qb = K.weight_pack_q(w.to(dev), None, 1)
-        ref = F.leaky_relu(_taps_ref(x, w, offs) + bias[None, :, None], 0.2)
-        y = K.conv1d_taps(x.to(dev), qa, cout, offs, bias=bias.to(dev), out_act=K.ACT_LRELU, out_slope=0.2)
-        assert rel_err(y, ref) < 2e-5
-        # data gradient: dx = sum_t w[:, :, t]^T (dy * gate'(y)) shifted by -off
-        dy = torch.randn(1, cout, L, generator=g)
-        gdy = dy * torch.where(ref > 0, 1.0, 0.2)
-        noffs = tuple(-o for o in offs)
-        dref = _taps_ref(gdy, w.transpose(0, 1).contiguous(), noffs)
-        dx = K.conv1d_taps(dy.to(dev), qb, 4, noffs, in_gate=y, in_slope=0.2)
-        assert rel_err(dx, dref) < 2e-5
-        # weight gradient, tap pairs {0, 1} (pad P + 1) and {2, 3} (pad 1)
-        for pad, taps in ((P + 1, (0, 1)), (1, (2, 3))):
-            dw, db = K.conv1d_wgrad(dy.to(dev), x.to(dev), 2, 1, pad, 1, 1, a_gate=y, a_slope=0.2, bf16x3=True, want_bias=True)
-            wref = torch.zeros(cout, 4, 2, dtype=torch.float64)
-            for j, t in enumerate(taps):
-                xs = torch.zeros(4, L, dtype=torch.float64)
-                lo, hi = max(0, -offs[t]), min(L, L - offs[t])
-                xs[:, lo:hi] = x[0, :, lo + offs[t]:hi + offs[t]].double()
-                wref[:, :, j] = gdy[0].double() @ xs.t()
-            assert rel_err(dw, wref.float()) < 2e-5
-            assert rel_err(db, gdy.sum((0, 2))) < 1e-5
-
-
 @pytest.mark.parametrize("cfg", [18, 20])
 def test_conv1d_bf16x3_pointwise_gemm_falls_back_outside_its_domain(dev, cfg):
     """Convs outside the kernel's domain (more than 16 taps, Cin % 16 != 0, strides, outputs longer than the input) run a tap-table
