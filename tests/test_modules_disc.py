@@ -100,12 +100,12 @@ def test_tower_executor_equals_python_issue_order(dev):
     from neuralsvb_amd import functional as SF
     from neuralsvb_amd.modules.mel_disc import Discriminator
     torch.manual_seed(0)
-    disc = Discriminator(time_lengths=[32, 64], freq_length=80, hidden_size=16, kernel=(3, 3), cond_size=0,
+    disc = Discriminator(time_lengths=[32], freq_length=80, hidden_size=16, kernel=(3, 3), cond_size=0,
                          norm_type="in", reduction="stack").to(dev)
     disc.train()
     g = torch.Generator().manual_seed(5)
-    xs0 = [torch.randn(2, 90, 80, generator=g).to(dev) for _ in range(2)]
-    starts = [[[5, 5], [11, 11]], [[40, 40], [0, 0]]]
+    xs0 = [torch.randn(2, 60, 80, generator=g).to(dev) for _ in range(2)]
+    starts = [[[5, 5]], [[22, 22]]]
     SF.set_precision("bf16x3")
     try:
         res = {}
@@ -118,7 +118,7 @@ def test_tower_executor_equals_python_issue_order(dev):
                 xs = [x.clone().requires_grad_(True) for x in xs0]
                 for p in disc.parameters():
                     p.grad = torch.full_like(p, 0.125) if mode == "grad_buffers" else None
-                outs = disc.forward_many([(x, [list(s) for s in st], None, 90) for x, st in zip(xs, starts)], want_fmaps=False)
+                outs = disc.forward_many([(x, [list(s) for s in st], None, 60) for x, st in zip(xs, starts)], want_fmaps=False)
                 loss = sum(((o["y"] - 1) ** 2).mean() * (i + 1) for i, o in enumerate(outs))
                 if mode == "autograd_grad":
                     grads = torch.autograd.grad(loss, xs + list(disc.parameters()))
