@@ -32,9 +32,10 @@ SVB_BENCH_MARKERS=1 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_vo
 python $R/tools/trace_summary.py /tmp/prof_voc/${TAG}_kernel_trace.csv 4 60 > $R/$O/kernel_summary_vocoder.txt
 (cd $R && timeout 100 python tools/ewbench.py > $O/streaming_kernels.log 2>&1)
 C="SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
-for shp in "32 192 384 1124 5" "32 192 384 281 5"; do
-  nm=$(echo $shp | tr ' ' '_')
-  rm -rf /tmp/pmc1; timeout 200 rocprofv3 --pmc $C -d /tmp/pmc1 --output-format csv -- python $R/tools/pmc_conv.py $shp fwd 2 > /dev/null 2>&1
+# (shape + direction + forced tile: 2 = the 128x96 tap-table tile of the k5 layers, 21 = the 64x128 GEMM-form tile of the 1-tap convs)
+for shp in "32 192 384 1124 5 fwd 2" "32 192 384 281 5 fwd 2" "32 256 256 562 1 fwd 21" "32 192 384 281 1 fwd 21"; do
+  nm=$(echo $shp | cut -d' ' -f1-5 | tr ' ' '_')
+  rm -rf /tmp/pmc1; timeout 200 rocprofv3 --pmc $C -d /tmp/pmc1 --output-format csv -- python $R/tools/pmc_conv.py $shp > /dev/null 2>&1
   python $R/tools/pmc_summary.py $(find /tmp/pmc1 -name "*counter_collection.csv" | head -1) svb_conv1d > $R/$O/pmc_sq_conv_$nm.txt 2>&1
 done
 cd $R
