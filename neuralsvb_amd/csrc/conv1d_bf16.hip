@@ -1564,6 +1564,8 @@ static int wgq_groups(int k, int sx, int pad, int dil, int* tgw_out, short* j0, 
 // convs, whose 64x64 tile has only 12 MFMAs per wave and staged chunk; the staging registers of wider tiles, of gated
 // operands or of more taps do not fit 256 VGPRs (measured: spills), so those keep the 64x64 tile.  A side is doubled only
 // when that leaves no fully empty 64-row block.
+// (Round 6, measured: the 64x128 tile for TWO taps with only the A operand gated -- the mel critic's towers; 36 bytes of scratch per
+//  lane -- is 10-25 % SLOWER than the 64x64 tile on every tower shape (profiles/r06_conv_per_shape_bt2.log): not enabled.)
 static void wgq_tile(int CA_g, int CB_g, int tgw, bool gated, int* at, int* bt) {
     *at = *bt = 1;
     if (tgw != 1 || gated || g_svbq_wg_narrow) return;

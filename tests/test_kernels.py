@@ -542,6 +542,30 @@ def test_conv1d_wgrad_pointwise_direct_operands(dev, case, gates):
     assert rel_err(db, dyg.sum((0, 2))) < 1e-5
 
 
+@pytest.mark.parametrize("case", [(1, 200, 72, 700, 12), (1, 512, 128, 333, 1), (2, 130, 40, 150, 3)])
+def test_conv1d_wgrad_two_taps_a_gated(dev, case):
+    """Two-tap weight gradients whose A operand alone is gated (the mel critic's towers: dy gated by the saved conv output, the
+    space-to-depth input as it is; one-sided tap pairs, pad = P + 1 or 1), wide B sides with ragged blocks and ragged A rows, with the
+    bias partials -- against fp64."""
+    B, CB, CA, T, pad = case
+    g = torch.Generator().manual_seed(CB + CA + T)
+    x = torch.randn(B, CB, T, generator=g)
+    dy = torch.randn(B, CA, T, generator=g)
+    yact = torch.randn(B, CA, T, generator=g)
+    gdy = (dy * torch.where(yact > 0, 1.0, 0.2)).double()
+    ref = torch.zeros(CA, CB, 2, dtype=torch.float64)
+    for j in range(2):
+        off = j - pad
+        xs = torch.zeros(B, CB, T, dtype=torch.float64)
+        lo, hi = max(0, -off), min(T, T - off)
+        if hi > lo:
+            xs[:, :, lo:hi] = x[:, :, lo + off:hi + off].double()
+        ref[:, :, j] = torch.einsum("bat,bct->ac", gdy, xs)
+    dw, db = K.conv1d_wgrad(dy.to(dev), x.to(dev), 2, 1, pad, 1, 1, a_gate=yact.to(dev), a_slope=0.2, bf16x3=True, want_bias=True)
+    assert rel_err(dw, ref.float()) < 6e-5
+    assert rel_err(db, gdy.sum((0, 2)).float()) < 1e-5
+
+
 @pytest.mark.parametrize("bf16x3", [True, False])
 def test_conv1d_wgrad_bias_sink_only(dev, bf16x3):
     """bias_sink: the bias gradient alone is accumulated into an existing buffer (svb_wgrad_reduce accumulate = 2) while the
