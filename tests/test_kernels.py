@@ -1297,3 +1297,74 @@ def test_self_gated_conv_and_wgrad_variants_equal_the_general_gate(dev, k, dil, 
     wr = w.cpu().clone().requires_grad_(True)
     oops.conv1d(F.leaky_relu(xr, 0.1), wr, None, 1, pad, dil).backward(dy.cpu())
     assert rel_err(d_self[0], wr.grad) < 1e-4
+
+
+# ---- the round-6 kernels at the bench step's own sizes (BASELINE configs[1]: 16 clips x 2 ways = 32 rows of T = 1124 / 562 / 281) -----
+BENCH_PW_SHAPES = [(32, 256, 256, 562, 1, 1), (32, 192, 384, 281, 1, 1), (32, 1024, 256, 562, 1, 1), (32, 256, 1536, 1124, 1, 1),
+                   (32, 192, 384, 1124, 5, 1), (32, 256, 256, 1124, 3, 2)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", BENCH_PW_SHAPES)
+def test_gemm_conv_at_bench_sizes_properties(gpu_only, shape):
+    """The GEMM-form conv kernel (configurations 18..23) at the train step's own shapes, through properties that do not need an
+    oracle run of that size: every tile configuration agrees with the tap-table tile 4 (bit for bit for one tap, 2e-6 otherwise);
+    linearity in x to rounding; a time shift of the input inside the clip shifts the output; and 64 sampled output elements against
+    an fp64 dot product of the same inputs."""
+    dev = gpu_only
+    B, Cin, Cout, T, k, dil = shape
+    g = torch.Generator().manual_seed(Cin + Cout + T + k)
+    x = torch.randn(B, Cin, T, generator=g).to(dev)
+    x2 = torch.randn(B, Cin, T, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, k, generator=g) * 0.05).to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    qa, _ = K.weight_pack_q(w, None, 1)
+    pad = dil * (k - 1) // 2
+    run = lambda inp, cfg, **kw: K.conv1d_forward(inp, qa, Cout, k, 1, pad, dil, 1, force_cfg=cfg, **kw)
+    ref = run(x, 4, bias=bias)
+    for cfg in range(18, 24):
+        y = run(x, cfg, bias=bias)
+        if k == 1:
+            assert torch.equal(y, ref), cfg
+        else:
+            assert rel_err(y.cpu(), ref.cpu()) < 2e-6, cfg
+    y1, y2, y12 = run(x, 21), run(x2, 21), run(x + x2, 21)
+    assert rel_err((y1 + y2).cpu(), y12.cpu()) < 2e-5
+    # shift by 3 positions: away from the clip's ends the outputs move with the input
+    xs = torch.zeros_like(x)
+    xs[:, :, 3:] = x[:, :, :-3]
+    ys = run(xs, 21)
+    m = pad + 3
+    assert rel_err(ys[:, :, m + 3:T - m].cpu(), y1[:, :, m:T - m - 3].cpu()) < 1e-6
+    # sampled elements against fp64
+    idx = torch.randint(0, B * Cout * (T - 2 * pad), (64,), generator=g)
+    xc, wc = x.cpu().double(), w.cpu().double()
+    for i in idx.tolist():
+        b, r = divmod(i, Cout * (T - 2 * pad))
+        co, t = divmod(r, T - 2 * pad)
+        t += pad
+        want = sum((wc[co, :, j] * xc[b, :, t + (j * dil - pad)]).sum() for j in range(k)).item()
+        got = y1[b, co, t].item()
+        assert abs(got - want) <= 3e-5 * max(1.0, abs(want)), (b, co, t, got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(32, 1536, 256, 1124), (32, 3072, 256, 281), (32, 192, 384, 281), (32, 256, 256, 1124)])
+def test_pointwise_weight_gradient_at_bench_sizes(gpu_only, shape):
+    """The direct-operand 1-tap weight gradient at the step's own shapes: against an fp64 GEMM of the same operands (whole matrix),
+    its bias partials against the row sums, and additivity over a split of the batch (two halves sum to the whole, to rounding)."""
+    dev = gpu_only
+    B, Cin, Cout, T = shape
+    g = torch.Generator().manual_seed(Cin + Cout + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    dy = torch.randn(B, Cout, T, generator=g)
+    ref = torch.einsum("bot,bit->oi", dy.double(), x.double())
+    xd, dyd = x.to(dev), dy.to(dev)
+    dw, db = K.conv1d_wgrad(dyd, xd, 1, 1, 0, 1, 1, bf16x3=True, want_bias=True)
+    assert rel_err(dw[:, :, 0].cpu(), ref.float()) < 2e-5
+    assert rel_err(db.cpu(), dy.sum((0, 2))) < 1e-5
+    h = B // 2
+    da = K.conv1d_wgrad(dyd[:h].contiguous(), xd[:h].contiguous(), 1, 1, 0, 1, 1, bf16x3=True)
+    dbb = K.conv1d_wgrad(dyd[h:].contiguous(), xd[h:].contiguous(), 1, 1, 0, 1, 1, bf16x3=True)
+    assert rel_err((da + dbb).cpu(), dw.cpu()) < 2e-5
+
