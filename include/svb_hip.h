@@ -82,7 +82,7 @@ int svb_conv1d_transposed(const float* x, const float* wp, float* y, int B, int 
  * svb_weight_pack_bf16x3 writes bf16 hi/lo weights in the two operand layouts
  *   qa: [k][ceil(d1/16)][d0][16]  (Conv1d forward, ConvTranspose1d data-gradient)
  *   qb: [k][groups][ceil((d0/groups)/16)][d1][16]  (ConvTranspose1d forward, Conv1d data-gradient);
- * buffers must be zero-filled by the caller when d1 or d0/groups is not a multiple of 16 (padding is never written). */
+ * padding entries (d1 or d0/groups not a multiple of 16) are written as zeros by the pack itself (ABI v10): buffers need no prior fill. */
 int svb_weight_pack_bf16x3(const float* v, const float* g, unsigned short* qa_hi, unsigned short* qa_lo,
                            unsigned short* qb_hi, unsigned short* qb_lo, int d0, int d1, int k, int groups, int weight_norm,
                            void* stream);
@@ -155,6 +155,8 @@ int svb_bias_grad(const float* dy, const float* gate, float slope, float* db, in
 #define SVB_L1_MAX_PAIRS 32
 typedef struct SvbL1Pair {
     const float* a; const float* b; float* da; float* db; long n; float scale; int block0;
+    int mode; float target;      /* mode 1 (ABI v10): the term is sum (a - target)^2 (b, db unused) -- the LS-GAN terms of
+                                  * discriminator_loss / generator_loss, modules/hifigan/hifigan.py:338-365; da = g * scale * 2 (a - target) */
 } SvbL1Pair;
 int svb_l1_pairs_blocks(const SvbL1Pair* pairs, int n);
 int svb_l1_pairs_fwd(const SvbL1Pair* pairs, int n, float* partials, float* out, int accumulate, void* stream);

@@ -75,7 +75,7 @@ class SvbReduceDesc(C.Structure):
 
 class SvbL1Pair(C.Structure):
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("da", C.c_void_p), ("db", C.c_void_p), ("n", C.c_long),
-                ("scale", C.c_float), ("block0", C.c_int)]
+                ("scale", C.c_float), ("block0", C.c_int), ("mode", C.c_int), ("target", C.c_float)]
 
 
 I, F, P, SZ, I64 = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_int64

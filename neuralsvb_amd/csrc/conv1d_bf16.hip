@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void svb_conv1d_bf16x3_kernel(SvbConvQArgs 
 // Weight pack: v [d0][d1][k] (reference layout, WeightNorm over dim-0 rows) -> bf16 hi/lo in the two operand layouts
 //   qa[tap][ceil(d1/16)][d0][16]            (k-dim = d1: Conv1d forward, ConvTranspose1d data-gradient)
 //   qb[tap][G][ceil(d0g/16)][d1][16]        (k-dim = d0 within its group: ConvTranspose1d forward, Conv1d data-gradient)
-// Padding entries are never written: the caller zero-fills the buffers once.
+// Padding entries are written as zeros by the block of the row (qa) / of the group's last row (qb): buffers need no prior fill.
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void svbq_pack_row(const float* v, const float* gnorm, unsigned short* qa_hi, unsigned short* qa_lo,
                                               unsigned short* qb_hi, unsigned short* qb_lo, int d0, int d1, int k, int G,
@@ -636,6 +636,23 @@ __device__ __forceinline__ void svbq_pack_row(const float* v, const float* gnorm
             qb_hi[ib] = (unsigned short)hi; qb_lo[ib] = (unsigned short)lo;
         }
     }
+    // padding (round 6: written here, so a fresh buffer needs no zero fill -- the per-call packs of the spectral-normalised convs paid a
+    // memset launch each): qa's channels d1 .. 16 kcha - 1 of this row; qb's rows d0g .. 16 kchb - 1 of this row's group (its last row's block)
+    const int pad_a = 16 * kcha - d1;
+    if (qa_hi && pad_a)
+        for (int e = threadIdx.x; e < pad_a * k; e += 256) {
+            const int c1 = d1 + e / k, j = e - (e / k) * k;
+            const size_t ia = (((size_t)j * kcha + (c1 >> 4)) * d0 + row) * 16 + (c1 & 15);
+            qa_hi[ia] = 0; qa_lo[ia] = 0;
+        }
+    const int pad_b = 16 * kchb - d0g;
+    if (qb_hi && pad_b && rl == d0g - 1)
+        for (int e = threadIdx.x; e < pad_b * rowlen; e += 256) {
+            const int r2 = d0g + e / rowlen, e2 = e - (e / rowlen) * rowlen;
+            const int c1 = e2 / k, j = e2 - c1 * k;
+            const size_t ib = ((((size_t)j * G + gq) * kchb + (r2 >> 4)) * d1 + c1) * 16 + (r2 & 15);
+            qb_hi[ib] = 0; qb_lo[ib] = 0;
+        }
 }
 
 __global__ __launch_bounds__(256) void svb_weight_pack_bf16x3_kernel(const float* v, const float* gnorm, unsigned short* qa_hi,

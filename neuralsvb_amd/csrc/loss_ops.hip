@@ -6,6 +6,8 @@
 // critical stream.  Here: ONE launch sums |a - b| of up to 32 pairs (descriptors in the kernel-argument segment: no device table,
 // no upload), one per-block partial each, and a one-workgroup launch finishes them in a fixed order (deterministic, no atomics);
 // the backward is ONE launch per batch of pairs that writes  d b = scale_p * g * sign(b - a)  (and d a = - d b where asked).
+// mode 1 terms (same launches): sum (a - target)^2 -- the LS-GAN terms `mean((1 - D(x))^2)`, `mean(D(G)^2)` of discriminator_loss /
+// generator_loss (hifigan.py:338-365) over the 8 discriminators' outputs: ~60 stock launches per call and as many in backward.
 #include "svb_common.h"
 #include "../../include/svb_hip.h"
 
@@ -33,7 +35,13 @@ __global__ __launch_bounds__(256) void svb_l1_pairs_fwd_kernel(SvbL1Batch b, flo
     const long n = b.p[i].n;
     const long e0 = (long)(blk - b.p[i].block0) * L1_CHUNK;
     float s = 0.f;
-    if ((n & 3) == 0 && (((size_t)pa | (size_t)pb) & 15) == 0) {
+    if (b.p[i].mode == 1) {                          // squared distance to a constant (LS-GAN term): short tensors, scalar loads
+        const float c = b.p[i].target;
+        for (int j = 0; j < 16; ++j) {
+            const long e = e0 + j * 256 + threadIdx.x;
+            if (e < n) { const float d = pa[e] - c; s = fmaf(d, d, s); }
+        }
+    } else if ((n & 3) == 0 && (((size_t)pa | (size_t)pb) & 15) == 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long e = e0 + (long)(j * 256 + threadIdx.x) * 4;
@@ -78,6 +86,14 @@ __global__ __launch_bounds__(256) void svb_l1_pairs_bwd_kernel(SvbL1Batch b, con
     const long e0 = (long)(blk - b.p[i].block0) * L1_CHUNK;
     const float g = gout[0] * b.p[i].scale;
     auto sgn = [](float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); };       // torch's abs backward: sign(0) = 0
+    if (b.p[i].mode == 1) {
+        const float c = b.p[i].target, g2 = 2.f * g;
+        for (int j = 0; j < 16; ++j) {
+            const long e = e0 + j * 256 + threadIdx.x;
+            if (e < n && da) da[e] = g2 * (pa[e] - c);
+        }
+        return;
+    }
     if ((n & 3) == 0 && (((size_t)pa | (size_t)pb | (size_t)da | (size_t)db) & 15) == 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -106,7 +122,7 @@ static int l1_fill(SvbL1Batch& b, const SvbL1Pair* pairs, int n) {
     int blocks = 0;
     b.n = n;
     for (int i = 0; i < n; ++i) {
-        if (!pairs[i].a || !pairs[i].b || pairs[i].n <= 0) return -1;
+        if (!pairs[i].a || (!pairs[i].b && pairs[i].mode != 1) || pairs[i].n <= 0 || (pairs[i].mode != 0 && pairs[i].mode != 1)) return -1;
         b.p[i] = pairs[i];
         b.p[i].block0 = blocks;
         const long nb = (pairs[i].n + L1_CHUNK - 1) / L1_CHUNK;

@@ -1917,6 +1917,33 @@ class _L1PairsFn(torch.autograd.Function):
         return (None, None) + tuple(da) + tuple(db)
 
 
+FUSED_GAN_LOSS = True
+
+
+class _SqTermsFn(torch.autograd.Function):
+    """loss = sum_p scale_p * sum (x_p - target_p)^2 over fp32 tensors (K.sq_terms_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, targets, scales, *tensors):
+        xs = [t.contiguous() for t in tensors]
+        ctx.targets, ctx.scales = targets, scales
+        ctx.save_for_backward(*xs)
+        return K.sq_terms_fwd(xs, targets, scales).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        xs = list(ctx.saved_tensors)
+        dx = K.sq_terms_bwd(xs, ctx.targets, ctx.scales, g.reshape(1).contiguous().float(), ctx.needs_input_grad[2:])
+        return (None, None) + tuple(dx)
+
+
+def mean_sq_to_targets(tensors, targets, weight=1.0):
+    """weight * sum_p mean((x_p - targets[p])^2): every term in one multi-tensor launch per direction (the LS-GAN terms of the
+    vocoder step: reference modules/hifigan/hifigan.py:338-365)."""
+    scales = tuple(float(weight) / x.numel() for x in tensors)
+    return _SqTermsFn.apply(tuple(float(t) for t in targets), scales, *tensors)
+
+
 def l1_mean_pairs(a_list, b_list, weight=1.0):
     """weight * sum_p mean(|a_p - b_p|): every pair in one multi-tensor launch per direction."""
     n = len(a_list)

@@ -296,8 +296,7 @@ def weight_pack_q(v, g=None, groups=1, want_a=True, want_b=True):
     d0, d1, k = v.shape
     d0g = d0 // groups
     def buf(n, padded):
-        f = torch.zeros if padded else torch.empty
-        return f((n,), device=v.device, dtype=torch.int16)
+        return torch.empty((n,), device=v.device, dtype=torch.int16)      # (the pack kernel writes the padding entries itself)
     qa = qb = None
     if want_a:
         n = k * (-(-d1 // 16)) * d0 * 16
@@ -1146,6 +1145,41 @@ def l1_pairs_bwd(a_list, b_list, scales, gout, want_a, want_b):
                         [db[i] for i in idx])
         L.check(lib.svb_l1_pairs_bwd(arr, len(idx), _ptr(gout), st), "svb_l1_pairs_bwd")
     return da, db
+
+
+def sq_terms_fwd(tensors, targets, scales):
+    """sum_p scales[p] * sum (x_p - targets[p])^2 as a [1] tensor (mode-1 terms of the multi-tensor loss launches; <= 32 per launch)."""
+    _f32(*tensors)
+    lib, st = _prep(*tensors)
+    out = torch.empty((1,), device=tensors[0].device, dtype=torch.float32)
+    for c0 in range(0, len(tensors), L1_MAX_PAIRS):
+        xs = tensors[c0:c0 + L1_MAX_PAIRS]
+        arr = (L.SvbL1Pair * len(xs))()
+        for i, x in enumerate(xs):
+            arr[i].a, arr[i].n, arr[i].scale, arr[i].mode, arr[i].target = (x.data_ptr(), x.numel(), float(scales[c0 + i]), 1,
+                                                                            float(targets[c0 + i]))
+        nblk = lib.svb_l1_pairs_blocks(arr, len(xs))
+        if nblk <= 0:
+            raise ValueError("svb_l1_pairs: bad term list")
+        part = torch.empty((nblk,), device=out.device, dtype=torch.float32)
+        L.check(lib.svb_l1_pairs_fwd(arr, len(xs), _ptr(part), _ptr(out), int(c0 > 0), st), "svb_l1_pairs_fwd")
+    return out
+
+
+def sq_terms_bwd(tensors, targets, scales, gout, want):
+    """dx_p = gout * scales[p] * 2 (x_p - targets[p]); None where not wanted."""
+    _f32(gout)
+    lib, st = _prep(gout, *tensors)
+    dx = [torch.empty_like(x) if w_ else None for x, w_ in zip(tensors, want)]
+    idx = [i for i, d in enumerate(dx) if d is not None]
+    for c0 in range(0, len(idx), L1_MAX_PAIRS):
+        ii = idx[c0:c0 + L1_MAX_PAIRS]
+        arr = (L.SvbL1Pair * len(ii))()
+        for j, i in enumerate(ii):
+            arr[j].a, arr[j].da, arr[j].n, arr[j].scale, arr[j].mode, arr[j].target = (tensors[i].data_ptr(), dx[i].data_ptr(),
+                                                                                      tensors[i].numel(), float(scales[i]), 1, float(targets[i]))
+        L.check(lib.svb_l1_pairs_bwd(arr, len(ii), _ptr(gout), st), "svb_l1_pairs_bwd")
+    return dx
 
 
 def layernorm_bwd(x, gamma, dy, mean, rstd, n_part=128):

@@ -333,12 +333,24 @@ def feature_loss(fmap_r, fmap_g):
     return loss * 2
 
 
+def _fused_gan_terms(outs):
+    return SF.FUSED_GAN_LOSS and outs and all(o.dtype == torch.float32 and o.numel() > 0 for o in outs)
+
+
 def discriminator_loss(disc_real_outputs, disc_generated_outputs):
+    """(mean over discriminators of mean((1 - D(x))^2), ... of mean(D(G(s))^2))  (hifigan.py:338-353)."""
     n = len(disc_real_outputs)
+    if _fused_gan_terms(list(disc_real_outputs) + list(disc_generated_outputs)):
+        # one multi-tensor launch per term list and direction (4 stock launches per discriminator and term otherwise)
+        return (SF.mean_sq_to_targets(list(disc_real_outputs), [1.0] * n, 1.0 / n),
+                SF.mean_sq_to_targets(list(disc_generated_outputs), [0.0] * len(disc_generated_outputs), 1.0 / n))
     r = sum(torch.mean((1 - dr) ** 2) for dr in disc_real_outputs) / n
     g = sum(torch.mean(dg ** 2) for dg in disc_generated_outputs) / n
     return r, g
 
 
 def generator_loss(disc_outputs):
+    """mean over discriminators of mean((1 - D(G(s)))^2)  (hifigan.py:356-365)."""
+    if _fused_gan_terms(list(disc_outputs)):
+        return SF.mean_sq_to_targets(list(disc_outputs), [1.0] * len(disc_outputs), 1.0 / len(disc_outputs))
     return sum(torch.mean((1 - dg) ** 2) for dg in disc_outputs) / len(disc_outputs)

@@ -860,6 +860,35 @@ def test_upsample_nearest_nct_matches_interpolate(dev, shape):
     assert (xd.grad.cpu() - xr.grad).abs().max().item() <= 1e-6 * max(1.0, xr.grad.abs().max().item())
 
 
+def test_lsgan_terms_multi_tensor_launches_match_the_reference_formula(dev):
+    """`discriminator_loss` / `generator_loss` (reference modules/hifigan/hifigan.py:338-365: means over the discriminators of
+    mean((1 - D(x))^2), mean(D(G)^2)) through the mode-1 terms of the multi-tensor launches: 8 discriminator outputs of different
+    sizes (one longer than a workgroup's 4096 elements, slices of stacked real / generated outputs as the task hands them over),
+    value and gradients against the stock-torch formula, and the switch back gives the same numbers."""
+    from neuralsvb_amd.modules import hifigan as H
+    g_ = torch.Generator().manual_seed(8)
+    shapes = [(2, 1, 37), (2, 1, 19), (2, 1, 5000), (2, 1, 64), (2, 1, 1), (2, 1, 130), (2, 1, 77), (2, 1, 512)]
+    stacked = [torch.randn((2 * s[0],) + s[1:], generator=g_) for s in shapes]
+
+    def run(fused):
+        SF.FUSED_GAN_LOSS = fused
+        outs = [t.clone().to(dev).requires_grad_(True) for t in stacked]
+        real, gen = [o[:2] for o in outs], [o[2:] for o in outs]
+        r, g = H.discriminator_loss(real, gen)
+        a = H.generator_loss(gen)
+        (r * 0.5 + g * 1.5 + a * 0.25).backward()
+        return [float(r), float(g), float(a)], [o.grad.cpu() for o in outs]
+    try:
+        v1, g1 = run(True)
+        v0, g0 = run(False)
+        for a, b in zip(v1, v0):
+            assert abs(a - b) <= 3e-6 * max(1.0, abs(b))
+        for a, b in zip(g1, g0):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-9)
+    finally:
+        SF.FUSED_GAN_LOSS = True
+
+
 def test_feature_loss_multi_tensor_launches_match_the_reference_formula(dev):
     """`feature_loss` (reference modules/hifigan/hifigan.py:328-335: 2 * sum over the feature-map pairs of mean(|r - g|)) through the
     multi-tensor kernels (csrc/loss_ops.hip): 37 pairs (two launches of <= 32), sizes that are and are not multiples of 4 / of a

@@ -566,6 +566,33 @@ def test_conv1d_wgrad_two_taps_a_gated(dev, case):
     assert rel_err(db, gdy.sum((0, 2)).float()) < 1e-5
 
 
+@pytest.mark.parametrize("case", [(24, 10, 3, 1), (36, 24, 5, 3), (16, 40, 1, 1), (48, 12, 2, 4)])
+def test_weight_pack_bf16x3_writes_its_padding(dev, case):
+    """The bf16x3 weight pack fills the padding entries of both layouts itself (channel counts that are not multiples of 16, grouped
+    convs): packed into buffers pre-filled with a NaN bit pattern, forward and data gradient must come out as from zero-filled
+    buffers (a stale padding entry would put NaN into every output)."""
+    d0, d1g, k, G = case
+    g = torch.Generator().manual_seed(d0 + d1g + k + G)
+    w = (torch.randn(d0, d1g, k, generator=g) * 0.3).to(dev)
+    x = torch.randn(2, d1g * G, 50, generator=g).to(dev)
+    dy = torch.randn(2, d0, 50, generator=g).to(dev)
+    qa0, qb0 = K.weight_pack_q(w, None, G)
+    qa, qb = K.weight_pack_q_alloc(w, G, True, True)
+    for t in (qa.hi, qa.lo, qb.hi, qb.lo):
+        t.fill_(0x7FC1)                                   # bf16 NaN
+    K.weight_pack_q_into(w, None, G, qa, qb)
+    pad = (k - 1) // 2
+    y0 = K.conv1d_forward(x, qa0, d0, k, 1, pad, 1, G)
+    y1 = K.conv1d_forward(x, qa, d0, k, 1, pad, 1, G)
+    assert torch.equal(y0, y1) and torch.isfinite(y1).all()
+    tout = x.shape[-1]
+    dx0 = K.conv1d_transposed(dy[:, :, :y0.shape[-1]].contiguous(), qb0, d1g * G, tout, k, 1, pad, 1, G)
+    dx1 = K.conv1d_transposed(dy[:, :, :y0.shape[-1]].contiguous(), qb, d1g * G, tout, k, 1, pad, 1, G)
+    assert torch.equal(dx0, dx1) and torch.isfinite(dx1).all()
+    ref = oops.conv1d(x.cpu(), w.cpu(), None, 1, pad, 1, G)
+    assert rel_err(y1, ref) < 6e-5
+
+
 @pytest.mark.parametrize("bf16x3", [True, False])
 def test_conv1d_wgrad_bias_sink_only(dev, bf16x3):
     """bias_sink: the bias gradient alone is accumulated into an existing buffer (svb_wgrad_reduce accumulate = 2) while the

@@ -34,7 +34,7 @@ def null_library():
     lib = Lib()
     n_calls = {"n": 0}
     for name, (res, args) in _lib.SIGNATURES.items():
-        if any(s in name for s in ("workspace", "abi_version", "pick_cfg", "_floats", "_bytes", "debug")):
+        if any(s in name for s in ("workspace", "abi_version", "pick_cfg", "_floats", "_bytes", "_blocks", "debug", "get_")):
             setattr(lib, name, getattr(real, name))
             continue
         proto = C.CFUNCTYPE(res, *args)
@@ -80,12 +80,43 @@ def aten_ops(run, steps):
         print(f"  {n / steps:6.1f}  {nm:34s} {site}")
 
 
+def vocoder_aten():
+    """The torch ops of one NSF-HifiGAN training step (B = 2 segments of 8192 samples, no-op kernels), by call site."""
+    import numpy as np
+    from neuralsvb_amd.tasks.hifigan_task import HifiGanTask, default_hparams
+    from neuralsvb_amd.utils.hparams import hparams
+    from neuralsvb_amd.utils.trainer import Trainer
+    hparams.clear()
+    hparams.update(default_hparams())
+    hparams["conv_precision"] = "bf16x3"
+    B, L = 2, 8192
+    trainer = Trainer(work_dir="", num_sanity_val_steps=0)
+    torch.manual_seed(0)
+    task = trainer.setup(HifiGanTask())
+    task.train()
+    g = torch.Generator().manual_seed(0)
+    f0 = 150 + 200 * torch.rand(B, L // 128, generator=g)
+    batch = {"mels": torch.randn(B, 80, L // 128, generator=g), "wavs": torch.randn(B, 1, L, generator=g) * 0.1, "f0": f0}
+    for o in trainer.optimizers:
+        if o is not None:
+            o.step = lambda *a, **k: None
+    torch.nn.utils.clip_grad_norm_ = lambda *a, **k: torch.zeros(())
+
+    def steps(n, s0):
+        for i in range(n):
+            task.global_step = trainer.global_step = s0 + i
+            trainer.run_training_batch(i, batch)
+    steps(2, 1)
+    aten_ops(lambda: steps(2, 3), 2)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--aten", action="store_true", help="list the torch (ATen) ops a step issues next to the library's kernels, by call site")
     ap.add_argument("--extra-hparams", default="")
+    ap.add_argument("--workload", default="train", choices=["train", "vocoder"], help="vocoder: the NSF-HifiGAN step (G + MPD + MSD), --aten only")
     ap.add_argument("--no-stack-executor", action="store_true")
     ap.add_argument("--no-tower-executor", action="store_true", help="A/B: the critic towers through the per-op Python bodies")
     a = ap.parse_args()
@@ -100,6 +131,9 @@ def main():
         from neuralsvb_amd import functional as SF
         SF.TOWER_EXECUTOR = False
     import bench
+    if a.workload == "vocoder":
+        vocoder_aten()
+        return
     args = argparse.Namespace(batch=2, seconds=0.71, sample_rate=24000, bf16=False, precision="bf16x3", graph=False)
     extra = ",ds_workers=0" + (("," + a.extra_hparams) if a.extra_hparams else "")
     with tempfile.TemporaryDirectory() as tmp:
