@@ -161,6 +161,9 @@ typedef struct SvbL1Pair {
 int svb_l1_pairs_blocks(const SvbL1Pair* pairs, int n);
 int svb_l1_pairs_fwd(const SvbL1Pair* pairs, int n, float* partials, float* out, int accumulate, void* stream);
 int svb_l1_pairs_bwd(const SvbL1Pair* pairs, int n, const float* gout, void* stream);
+/* out = scale * (a + b [+ c]) over n contiguous floats (c may be NULL; ABI v10): the HifiGAN generator's mean over its parallel
+ * ResBlocks (reference modules/hifigan/hifigan.py:157-163) in one pass instead of two adds and a division.                       */
+int svb_sum_scale(const float* a, const float* b, const float* c, float scale, float* out, long n, void* stream);
 
 /* ---- WaveNet-style gated layer pieces (reference modules/fastspeech/fs2_vae.py:10-16,61-91) ---------------
  * gate fwd: acts[b,c,t] = tanh(xin[b,c,t] + g[b,goff+c,t]) * sigmoid(xin[b,C+c,t] + g[b,goff+C+c,t])

@@ -110,6 +110,7 @@ SIGNATURES = {
     "svb_l1_pairs_blocks": (I, [P, I]),
     "svb_l1_pairs_fwd": (I, [P, I, P, P, I, P]),
     "svb_l1_pairs_bwd": (I, [P, I, P, P]),
+    "svb_sum_scale": (I, [P, P, P, F, P, C.c_long, P]),
     "svb_bias_grad": (I, [P, P, F, P, I, I, I, P]),
     "svb_wn_gate_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "svb_wn_gate_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),

@@ -155,3 +155,31 @@ extern "C" int svb_l1_pairs_bwd(const SvbL1Pair* pairs, int n, const float* gout
     SVB_CHECK_LAUNCH();
     return SVB_OK;
 }
+
+// ---- out = scale * (a + b [+ c]): the HifiGAN generator's mean over its parallel ResBlocks (reference modules/hifigan/hifigan.py:157-163:
+// `xs = xs + resblocks[...](x)` twice, then `x = xs / num_kernels`: three stock launches over the widest tensors of the step) in one pass.
+__global__ __launch_bounds__(256) void svb_sum_scale_kernel(const float* a, const float* b, const float* c, float scale, float* out, long n4,
+                                                            long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c) z = reinterpret_cast<const float4*>(c)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4((x.x + y.x + z.x) * scale, (x.y + y.y + z.y) * scale, (x.z + y.z + z.z) * scale,
+                                                        (x.w + y.w + z.w) * scale);
+    } else {
+        const long e = 4 * n4 + (i - n4);
+        if (e < n) out[e] = (a[e] + b[e] + (c ? c[e] : 0.f)) * scale;
+    }
+}
+
+extern "C" int svb_sum_scale(const float* a, const float* b, const float* c, float scale, float* out, long n, void* stream) {
+    if (!a || !b || !out || n <= 0) return SVB_ERR_ARG;
+    const bool vec = ((((size_t)a | (size_t)b | (size_t)c | (size_t)out) & 15) == 0);
+    const long n4 = vec ? n / 4 : 0, items = n4 + (n - 4 * n4);
+    if ((items + 255) / 256 > (1L << 30)) return SVB_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(svb_sum_scale_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, scale, out, n4, n);
+    SVB_CHECK_LAUNCH();
+    return SVB_OK;
+}
+

@@ -1920,6 +1920,32 @@ class _L1PairsFn(torch.autograd.Function):
 FUSED_GAN_LOSS = True
 
 
+class _MeanOfFn(torch.autograd.Function):
+    """(a + b [+ c]) / n of equally shaped tensors in one pass (K.sum_scale); every input's gradient is dy / n -- one scaled copy
+    shared by all of them."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        ctx.n = len(xs)
+        xs = [x.contiguous() for x in xs]
+        return K.sum_scale(xs[0], xs[1], xs[2] if len(xs) > 2 else None, 1.0 / len(xs))
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = dy * (1.0 / ctx.n)
+        return (g,) * ctx.n
+
+
+def mean_of(xs):
+    """Mean of 2 or 3 equally shaped fp32 tensors (the HifiGAN generator's `xs / num_kernels`, reference hifigan.py:157-163)."""
+    if len(xs) in (2, 3) and all(x.dtype == torch.float32 and x.shape == xs[0].shape for x in xs):
+        return _MeanOfFn.apply(*xs)
+    s = xs[0]
+    for x in xs[1:]:
+        s = s + x
+    return s / len(xs)
+
+
 class _SqTermsFn(torch.autograd.Function):
     """loss = sum_p scale_p * sum (x_p - target_p)^2 over fp32 tensors (K.sq_terms_fwd / _bwd)."""
 

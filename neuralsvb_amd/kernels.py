@@ -1147,6 +1147,15 @@ def l1_pairs_bwd(a_list, b_list, scales, gout, want_a, want_b):
     return da, db
 
 
+def sum_scale(a, b, c, scale):
+    """scale * (a + b [+ c]) of equally shaped contiguous fp32 tensors, one pass."""
+    _f32(a, b, c)
+    lib, st = _prep(a, b, c)
+    out = torch.empty_like(a)
+    L.check(lib.svb_sum_scale(_ptr(a), _ptr(b), _ptr(c), float(scale), _ptr(out), a.numel(), st), "svb_sum_scale")
+    return out
+
+
 def sq_terms_fwd(tensors, targets, scales):
     """sum_p scales[p] * sum (x_p - targets[p])^2 as a [1] tensor (mode-1 terms of the multi-tensor loss launches; <= 32 per launch)."""
     _f32(*tensors)

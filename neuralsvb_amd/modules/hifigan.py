@@ -138,11 +138,8 @@ class HifiGanGenerator(nn.Module):
             x = self.ups[i](x, in_slope=LRELU_SLOPE)                       # ups(leaky_relu(x))
             if har is not None:
                 x = self.noise_convs[i](har, residual=x)                   # x + noise_conv(har_source)
-            xs = None
-            for j in range(self.num_kernels):
-                r = self.resblocks[i * self.num_kernels + j](x)
-                xs = r if xs is None else xs + r
-            x = xs / self.num_kernels
+            rs = [self.resblocks[i * self.num_kernels + j](x) for j in range(self.num_kernels)]
+            x = SF.mean_of(rs) if len(rs) > 1 else rs[0]                  # (xs + ...) / num_kernels, one pass
         x = self.conv_post(x, in_slope=0.01)                               # F.leaky_relu default slope (:165)
         return torch.tanh(x)
 

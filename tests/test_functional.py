@@ -860,6 +860,21 @@ def test_upsample_nearest_nct_matches_interpolate(dev, shape):
     assert (xd.grad.cpu() - xr.grad).abs().max().item() <= 1e-6 * max(1.0, xr.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("n,shape", [(3, (2, 8, 333)), (2, (1, 4, 4096)), (3, (3, 5, 7))])
+def test_mean_of_parallel_resblocks_one_pass(dev, n, shape):
+    """SF.mean_of (the HifiGAN generator's `xs / num_kernels`, reference hifigan.py:157-163) in one pass against the stock
+    sequence of adds and a division: value to one rounding, every input's gradient dy / n."""
+    g_ = torch.Generator().manual_seed(n + shape[-1])
+    xs = [torch.randn(shape, generator=g_).to(dev).requires_grad_(True) for _ in range(n)]
+    y = SF.mean_of(xs)
+    ref = sum(x.detach().cpu().double() for x in xs) / n
+    assert rel_err(y.detach(), ref.float()) < 2e-7
+    dy = torch.randn(shape, generator=g_).to(dev)
+    y.backward(dy)
+    for x in xs:
+        assert torch.allclose(x.grad.cpu(), dy.cpu() / n, rtol=3e-7, atol=0)
+
+
 def test_lsgan_terms_multi_tensor_launches_match_the_reference_formula(dev):
     """`discriminator_loss` / `generator_loss` (reference modules/hifigan/hifigan.py:338-365: means over the discriminators of
     mean((1 - D(x))^2), mean(D(G)^2)) through the mode-1 terms of the multi-tensor launches: 8 discriminator outputs of different
