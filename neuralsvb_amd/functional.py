@@ -1065,6 +1065,41 @@ class _SplitStackedFn(torch.autograd.Function):
         return dx, None
 
 
+class _SplitBatchFn(torch.autograd.Function):
+    """x [2B, ...] -> (x[:B], x[B:]) as views.  Backward assembles the two gradients in ONE buffer -- stock slicing gives, per half, a
+    zero-filled full-size gradient + a copy, and an add of the two (the stacked real / generated discriminator outputs of the
+    vocoder step: 5 launches per discriminator and pass become 2)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        ctx.set_materialize_grads(False)
+        B = x.shape[0] // 2
+        return x[:B], x[B:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        B = ctx.shape[0] // 2
+        ref = ga if ga is not None else gb
+        if ref is None:
+            return None
+        dx = torch.empty(ctx.shape, device=ref.device, dtype=ref.dtype)
+        for half, g in ((dx[:B], ga), (dx[B:], gb)):
+            if g is None:
+                half.zero_()
+            else:
+                half.copy_(g)
+        return dx
+
+
+def split_batch_halves(x):
+    """(x[:B], x[B:]) of a [2B, ...] tensor with a one-buffer backward (see _SplitBatchFn)."""
+    if x.requires_grad and torch.is_grad_enabled() and x.shape[0] % 2 == 0:
+        return _SplitBatchFn.apply(x)
+    B = x.shape[0] // 2
+    return x[:B], x[B:]
+
+
 def split_stacked_ways(x, n):
     """x [n*B, C, T] -> tuple of n [B, T, C] views (see _SplitStackedFn)."""
     return _SplitStackedFn.apply(x, int(n))

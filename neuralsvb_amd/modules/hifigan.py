@@ -215,7 +215,8 @@ class MultiPeriodDiscriminator(nn.Module):
         mel2 = None if mel is None else torch.cat([mel, mel], 0)
         for d in self.discriminators:
             o, fm = d(both, mel2)
-            y_d_rs.append(o[:B]); y_d_gs.append(o[B:])
+            r, g = SF.split_batch_halves(o)
+            y_d_rs.append(r); y_d_gs.append(g)
             fmap_rs.append([f[:B] for f in fm]); fmap_gs.append([f[B:] for f in fm])
         return y_d_rs, y_d_gs, fmap_rs, fmap_gs
 
@@ -312,7 +313,7 @@ class MultiScaleDiscriminator(nn.Module):
                 g, fg = d(y_hat.contiguous(), mel)
             else:   # weight-normalised scales: real and generated stacked into one batch (per-clip layers only)
                 o, fm = d(torch.cat([y, y_hat], 0), None if mel is None else torch.cat([mel, mel], 0))
-                r, g = o[:B], o[B:]
+                r, g = SF.split_batch_halves(o)
                 fr, fg = [f[:B] for f in fm], [f[B:] for f in fm]
             y_d_rs.append(r); fmap_rs.append(fr); y_d_gs.append(g); fmap_gs.append(fg)
         return y_d_rs, y_d_gs, fmap_rs, fmap_gs

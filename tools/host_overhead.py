@@ -60,7 +60,12 @@ def aten_ops(run, steps):
         def __torch_dispatch__(self, func, types, args=(), kwargs=None):
             nm = "aten::" + func.__name__.split(".")[0] if not str(func).startswith("aten") else str(func)
             nm = "aten::" + str(func).split(".")[1] if str(func).startswith("aten.") else nm
-            if not nm.startswith(_NO_KERNEL):
+            base = nm.split(".")[0]
+            hidden = base in _NO_KERNEL or any(base.startswith(p_) for p_ in ("aten::is_", "aten::new_", "aten::lift", "aten::broadcast_",
+                                                                              "aten::_local_scalar", "aten::size", "aten::stride"))
+            if base in ("aten::zeros_like", "aten::new_zeros", "aten::ones_like"):
+                hidden = False                       # (an allocation AND a fill launch)
+            if not hidden:
                 f = sys._getframe(1)
                 site = "(autograd engine: backward of a torch op)"
                 while f is not None:
