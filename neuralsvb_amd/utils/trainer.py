@@ -255,6 +255,15 @@ class FlatGradSync:
             return
         if self._expected is None:
             self._profiles[self._key] = list(self._counts)
+            # the recording step of a pass key also tells which parameters the pass does not reach: they keep a ZERO gradient in the
+            # flat buffer and AdamW steps them (the reference leaves `.grad = None` and skips them) -- say so once instead of
+            # differing silently (never the case for the three optimizers of SVBVAEMleTask)
+            n_req = sum(1 for p in self.params if p.requires_grad)
+            if sum(self._counts) < n_req:
+                import warnings
+                warnings.warn(f"{n_req - sum(self._counts)} of {n_req} parameters of this optimizer received no gradient in pass {self._key}: "
+                              f"in the flat gradient buffer they keep a zero gradient and the optimizer still steps them (moments decay, "
+                              f"weight decay acts), where the reference's zero_grad() -> None would skip them", RuntimeWarning)
         while self._next >= 0:
             self._launch(self._next, False)
             self._next -= 1

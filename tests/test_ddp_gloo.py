@@ -142,6 +142,40 @@ def test_flat_grad_allreduce_two_ranks_gloo(tmp_path, _emu_lib):
     assert np.abs(r0["div_grad"] - r0["div_ref"]).max() < 2e-5 * max(1.0, np.abs(r0["div_ref"]).max())
 
 
+def _unreached_worker(port, out):
+    import warnings
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from neuralsvb_amd.utils.trainer import FlatGradSync
+    a, b, c = (torch.nn.Parameter(torch.randn(8, 3)) for _ in range(3))
+    gs = FlatGradSync([a, b, c], 1, bucket_bytes=64, overlap=True, exchange=True)
+    msgs = []
+    for step in range(2):
+        gs.begin_pass(("opt0", "phase"))
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            (a.sum() * 2 + (b * b).sum()).backward()          # c is never reached
+            gs.finish()
+        msgs.append([str(x.message) for x in w if issubclass(x.category, RuntimeWarning)])
+    torch.save({"msgs": msgs, "ga": a.grad.clone(), "gc": c.grad.clone()}, out)
+    dist.destroy_process_group()
+
+
+def test_pass_that_leaves_a_parameter_without_gradient_says_so(tmp_path):
+    """The flat gradient buffer keeps a ZERO gradient for a parameter a pass does not reach (the reference's zero_grad() -> None would
+    make the optimizer skip it): the recording step of the pass key says so once -- a RuntimeWarning naming the count -- instead of
+    differing silently; the exchange itself is unaffected."""
+    out = str(tmp_path / "r.pt")
+    ctx = mp.get_context("spawn")
+    pr = ctx.Process(target=_unreached_worker, args=(_free_port(), out))
+    pr.start()
+    pr.join(120)
+    assert pr.exitcode == 0
+    r = torch.load(out)
+    assert len(r["msgs"][0]) == 1 and "1 of 3 parameters" in r["msgs"][0][0] and r["msgs"][1] == []
+    assert torch.equal(r["ga"], torch.full((8, 3), 4.0)) and float(r["gc"].abs().max()) == 0.0     # (two steps accumulated: no zeroing here)
+
+
 def test_batch_sharding_rule():
     """build_dataloader: global batches of max_sentences*world clips, rank r takes every world-th item."""
     from neuralsvb_amd.utils.batching import batch_by_size
