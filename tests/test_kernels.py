@@ -810,6 +810,26 @@ def test_conv1d_bf16x3_gemm_kernel_with_taps_and_input_gates(dev, cfg, shape):
         assert rel_err(dx, dref) < 6e-5
 
 
+@pytest.mark.parametrize("cfg", [18, 21, 23])
+def test_conv1d_bf16x3_gemm_kernel_edge_shapes(dev, cfg):
+    """Edges of the GEMM-form kernel's domain: a single position per clip (T = 1), clips shorter than one 32-column block with many
+    clips per tile, the smallest channel counts it takes (Cin = 16, Cout = 32), a single clip, tap tables whose every offset points
+    outside the clip (the output is the bias) and offsets at the 16-bit limit's order of magnitude -- against the oracle."""
+    g = torch.Generator().manual_seed(cfg)
+    for B, Cin, Cout, T, offs in [(5, 16, 32, 1, (0,)), (40, 32, 40, 3, (-1, 0, 1)), (1, 64, 32, 700, (-2, 0, 2, 5)),
+                                  (3, 16, 72, 9, (-20, 30)), (2, 48, 64, 50, (-3000, 0, 3000, 1)), (7, 32, 32, 33, (0, 1))]:
+        x = torch.randn(B, Cin, T, generator=g)
+        w = torch.randn(Cout, Cin, len(offs), generator=g) * 0.2
+        bias = torch.randn(Cout, generator=g)
+        qa, _ = K.weight_pack_q(w.to(dev), None, 1)
+        ref = _taps_ref(x, w, offs) + bias[None, :, None]
+        y = K.conv1d_taps(x.to(dev), qa, Cout, offs, bias=bias.to(dev), force_cfg=cfg)
+        assert y.shape == ref.shape
+        if all(abs(o) >= T for o in offs):
+            assert torch.allclose(y.cpu(), bias[None, :, None].expand_as(ref), rtol=0, atol=0)
+        assert rel_err(y, ref) < 6e-5, (B, Cin, Cout, T, offs)
+
+
 @pytest.mark.parametrize("cfg", [18, 20])
 def test_conv1d_bf16x3_pointwise_gemm_falls_back_outside_its_domain(dev, cfg):
     """Convs outside the kernel's domain (more than 16 taps, Cin % 16 != 0, strides, outputs longer than the input) run a tap-table
