@@ -69,6 +69,29 @@ for g, (d, c) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
 print(f"{'ms/step':>9} {'calls/step':>10} {'avg us':>8}  kernel")
 for nm, (d, c) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:top]:
     print(f"{d / 1e6 / steps:9.3f} {c / steps:10.1f} {d / c / 1e3:8.1f}  {nm[:110]}")
+# how many kernels are in flight, as a share of the span (a sweep over the interval endpoints): where the step runs on ONE kernel the
+# chip is as full as that kernel's grid makes it; the streams only help where the count is >= 2
+ev = sorted([(a_, 1) for a_, _ in iv] + [(b_, -1) for _, b_ in iv])
+depth, last, hist = 0, ev[0][0], defaultdict(int)
+for t_, d_ in ev:
+    hist[min(depth, 4)] += t_ - last
+    last = t_
+    depth += d_
+print("kernels in flight (share of the span): " + ", ".join(f"{k if k < 4 else '4+'}: {100.0 * hist[k] / wall:.1f} %" for k in sorted(hist)))
+# ... and the same restricted to the time the LONGEST-running class of kernels is alone: which kernels run without company
+solo = defaultdict(int)
+act, last = [], ev[0][0]
+ev2 = sorted([(int(r["Start_Timestamp"]), 1, r["Kernel_Name"]) for r in rows] + [(int(r["End_Timestamp"]), -1, r["Kernel_Name"]) for r in rows],
+             key=lambda e_: (e_[0], e_[1]))
+for t_, d_, nm in ev2:
+    if len(act) == 1:
+        solo[act[0]] += t_ - last
+    last = t_
+    if d_ == 1:
+        act.append(nm)
+    else:
+        act.remove(nm)
+print("alone on the device, ms/step (top 8): " + "; ".join(f"{v / 1e6 / steps:.2f} {k.split('(')[0][-48:]}" for k, v in sorted(solo.items(), key=lambda kv: -kv[1])[:8]))
 # per-queue view (a HIP stream maps to a hardware queue): busy time, launches, idle gaps inside the queue's own span
 qcol = next((c for c in ("Queue_Id", "Stream_Id", "queue_id") if c in rows[0]), None)
 if qcol:
